@@ -1,0 +1,133 @@
+"""Pins the CPU oracle (oracle/epa_oracle.c) against (a) the independent brute-force golden
+vectors of tests/gen_golden.py and (b) the reference's own literal vectors for this path
+(edge numbering, test/src/pll_util.cpp:134-143).  CPU only."""
+import numpy as np
+import pytest
+
+from golden_util import CASES, load_case
+from oracle_lib import Oracle, gamma_rates, lib
+
+
+def make_oracle(g):
+    labels = [a for a, _ in g["msa"]]
+    seqs = [b for _, b in g["msa"]]
+    return Oracle(g["newick"], labels, seqs, g["states"], g["subst"], g["freqs"],
+                  g["gamma_rates"])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_gamma_rates(case):
+    g = load_case(case)
+    r = gamma_rates(g["alpha"], 4)
+    assert np.allclose(r, g["gamma_rates"], rtol=1e-11, atol=0)
+    assert abs(r.mean() - 1.0) < 1e-12
+
+
+def test_gamma_alpha1_known_values():
+    # closed form for alpha = 1 (exponential): SURVEY.md section 8c quotes these
+    r = gamma_rates(1.0, 4)
+    assert np.allclose(r, [0.13695378, 0.47675186, 1.0, 2.38629436], atol=5e-9)
+
+
+def test_edge_numbering_reference_literal():
+    # literal from the reference's test/src/pll_util.cpp:134-137 (ref.tre with all lengths 1.0)
+    g = load_case("dna8_gtr_g_default")
+    import re
+    nw = re.sub(r":[0-9.]+", ":1.0", g["newick"])
+    labels = [a for a, _ in g["msa"]]
+    seqs = [b for _, b in g["msa"]]
+    o = Oracle(nw, labels, seqs, 4, g["subst"], g["freqs"], g["gamma_rates"])
+    assert o.numbered_newick(2) == (
+        "(A:1.00{0},(B:1.00{1},(C:1.00{2},(D:1.00{3},(E:1.00{4},(F:1.00{5},G:1.00{6}):"
+        "1.00{7}):1.00{8}):1.00{9}):1.00{10}):1.00{11},H:1.00{12});")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_tree_lnl_all_edges(case):
+    # invariant (i) of the reference's test/src/epa_pll_util.cpp:82-121 + golden value
+    g = load_case(case)
+    o = make_oracle(g)
+    assert o.B == len(g["branch_lengths"])
+    assert o.numbered_newick(2) == g["numbered_newick_p2"]
+    for b in range(o.B):
+        assert abs(o.tree_lnl(b) - g["tree_lnl"]) < 1e-8
+        assert abs(o.branch_info(b)[0] - g["branch_lengths"][b]) < 1e-15
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_preplace_matches_bruteforce(case):
+    g = load_case(case)
+    o = make_oracle(g)
+    qs = [q["seq"] for q in g["queries"]]
+    got = o.preplace(qs)
+    exp = np.array(g["preplace"])
+    assert got.shape == exp.shape
+    assert np.max(np.abs(got - exp)) < 1e-8
+    # lookup-sum == direct edge lnL (SURVEY 8c invariant)
+    for qi in (0, len(qs) - 1):
+        for b in (0, o.B // 2, o.B - 1):
+            assert abs(o.direct_default_lnl(b, qs[qi]) - got[qi, b]) < 1e-9
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_thorough_matches_bruteforce(case):
+    g = load_case(case)
+    o = make_oracle(g)
+    qs = [q["seq"] for q in g["queries"]]
+    pb, ps = [], []
+    for b in range(o.B):
+        for qi in range(len(qs)):
+            pb.append(b)
+            ps.append(qi)
+    lnl, pen, dis = o.thorough(pb, ps, qs)
+    nrev = 0
+    for i, (b, qi) in enumerate(zip(pb, ps)):
+        e = g["thorough"][qi][b]
+        assert abs(lnl[i] - e["lnl"]) < 1e-7, (b, qi, lnl[i], e)
+        # lengths: relative (flat optima at pendant ~ 40 are only tol-determined)
+        assert abs(pen[i] - e["pendant"]) < 1e-7 * max(1.0, e["pendant"]), (b, qi, pen[i], e)
+        assert abs(dis[i] - e["distal"]) < 1e-7, (b, qi, dis[i], e)
+        nrev += e["reverted"]
+    assert o.last_stats["reverts"] == nrev
+    assert o.last_stats["rounds"] == sum(e["rounds"] for row in g["thorough"] for e in row)
+    # sanity ranges of the reference's test/src/Tiny_Tree.cpp:39-48
+    for i, b in enumerate(pb):
+        assert np.isfinite(lnl[i]) and lnl[i] != 0.0
+        assert 0.0 < dis[i] < g["branch_lengths"][b]
+        assert pen[i] > 0.0
+
+
+def test_derivatives_match_finite_differences():
+    g = load_case("dna8_gtr_fu_g4")
+    o = make_oracle(g)
+    q = g["queries"][0]["seq"]
+    t, h = 0.07, 1e-5
+    f, df, l0 = o.pendant_derivatives(3, q, t)
+    _, _, lp = o.pendant_derivatives(3, q, t + h)
+    _, _, lm = o.pendant_derivatives(3, q, t - h)
+    assert abs(f - (-(lp - lm) / (2 * h))) < 1e-5 * max(1.0, abs(f))
+    assert abs(df - (-(lp - 2 * l0 + lm) / (h * h))) < 2e-3 * max(1.0, abs(df))
+
+
+def test_windowed_equals_full_when_outside_is_gap():
+    # reference property test/src/pll_util.cpp:325-335
+    g = load_case("dna8_gtr_g_default")
+    o = make_oracle(g)
+    q = g["queries"][2]["seq"]           # window 100..250
+    a = o.preplace([q], premask=True)
+    full = o.preplace([q], premask=False)
+    # outside the window the query is all-gap: those sites add the reference-only site lnL
+    ref_only = o.preplace(["-" * (o.W - 1) + "A"], premask=False)  # not used for equality
+    assert a.shape == full.shape and np.all(full < a)
+    assert ref_only.shape == a.shape
+
+
+def test_error_codes():
+    g = load_case("dna8_gtr_g_default")
+    o = make_oracle(g)
+    with pytest.raises(RuntimeError):
+        o.preplace(["-" * o.W])
+    with pytest.raises(RuntimeError):
+        o.preplace(["!" + "A" * (o.W - 1)])
+    assert lib().orc_char_column(4, b"u", 0) == 1 and lib().orc_char_column(4, b"x", 0) == 0
+    assert lib().orc_char_column(20, b"X", 1) == 11 and lib().orc_char_column(20, b"X", 0) == 21
