@@ -1,0 +1,238 @@
+"""Host-side Python surface of the MI355X placement evaluator.
+
+Thin ctypes binding over the C-ABI of include/epa_dev.h (libepa_dev.so, hand-written HIP for
+gfx950).  There is NO CPU fallback: if the shared library is missing or no GPU is visible the
+calls raise.  Names mirror the reference's operators for this path:
+    Evaluator.preplace   <-> place()           src/core/place.cpp:41-95
+    Evaluator.thorough   <-> place_thorough()  src/core/place.cpp:97-171
+    Evaluator.select     <-> apply_heuristic() src/core/heuristics.hpp:119-127 (dynamic)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEV_SO = os.path.join(HERE, "libepa_dev.so")
+
+__all__ = ["EpaError", "dev_lib", "device_count", "encode_queries", "Evaluator", "PAIR_DTYPE",
+           "RESULT_DTYPE", "DEV_SO"]
+
+PAIR_DTYPE = np.dtype([("branch_id", np.uint32), ("seq_id", np.uint32)])
+RESULT_DTYPE = np.dtype([("lnl", np.float64), ("pendant_length", np.float64),
+                         ("distal_length", np.float64)])
+
+
+class EpaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("epa_dev error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _RefDesc(C.Structure):
+    _fields_ = [("states", C.c_uint32), ("rate_cats", C.c_uint32), ("sites", C.c_uint32),
+                ("branches", C.c_uint32),
+                ("eigenvals", C.c_void_p), ("eigenvecs_u", C.c_void_p),
+                ("eigenvecs_uinv", C.c_void_p), ("freqs", C.c_void_p), ("rates", C.c_void_p),
+                ("rate_weights", C.c_void_p), ("prop_invar", C.c_double),
+                ("prox_clv", C.c_void_p), ("prox_scaler", C.c_void_p), ("dist_clv", C.c_void_p),
+                ("dist_tipchars", C.c_void_p), ("dist_scaler", C.c_void_p),
+                ("branch_length", C.c_void_p),
+                ("tipmap", C.c_void_p), ("tipmap_size", C.c_uint32),
+                ("blo_min_branch", C.c_double), ("blo_max_branch", C.c_double),
+                ("blo_default_branch", C.c_double), ("blo_epsilon", C.c_double),
+                ("pendant_default", C.c_double), ("blo_max_rounds", C.c_uint32),
+                ("blo_max_newton", C.c_uint32), ("flags", C.c_uint32), ("aa_x_as_n", C.c_uint32)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("pairs", C.c_uint64), ("rounds", C.c_uint64), ("newton_evals", C.c_uint64),
+                ("reverts", C.c_uint64)]
+
+
+_LIB = None
+
+
+def dev_lib():
+    """Loads libepa_dev.so (fails loudly when the HIP extension has not been built)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(DEV_SO):
+            raise ImportError("libepa_dev.so is missing: run `python __graft_entry__.py` "
+                              "(build()) -- the HIP extension is the only compute path")
+        L = C.CDLL(DEV_SO)
+        L.epa_dev_device_count.restype = C.c_int
+        L.epa_dev_create.argtypes = [C.POINTER(_RefDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.epa_dev_destroy.argtypes = [C.c_void_p]
+        L.epa_dev_last_error.restype = C.c_char_p
+        L.epa_dev_last_error.argtypes = [C.c_void_p]
+        L.epa_dev_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.epa_dev_build_lookup.argtypes = [C.c_void_p]
+        L.epa_encode_queries.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.epa_dev_preplace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                       C.c_void_p]
+        L.epa_dev_thorough.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(_Stats)]
+        L.epa_dev_select_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double,
+                                                C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.epa_dev_last_kernel_ms.restype = C.c_double
+        L.epa_dev_last_kernel_ms.argtypes = [C.c_void_p, C.c_char_p]
+        _LIB = L
+    return _LIB
+
+
+def device_count():
+    return dev_lib().epa_dev_device_count()
+
+
+def _ptr(a):
+    """numpy array -> host pointer; torch tensor / int -> raw (device) pointer"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data
+    if isinstance(a, int):
+        return a
+    return a.data_ptr()  # torch tensor
+
+
+def encode_queries(states, seqs, premasking=True, aa_x_as_n=False):
+    """ASCII query rows -> (codes uint8 [Q][W], win_begin uint32 [Q], win_span uint32 [Q])."""
+    Q = len(seqs)
+    W = len(seqs[0])
+    arr = (C.c_char_p * Q)()
+    arr[:] = [s if isinstance(s, bytes) else s.encode() for s in seqs]
+    for s in arr:
+        if len(s) != W:
+            raise EpaError(-4, "Query sequence length not same as reference alignment!")
+    codes = np.zeros((Q, W), np.uint8)
+    wb = np.zeros(Q, np.uint32)
+    ws = np.zeros(Q, np.uint32)
+    bad = C.c_uint32(0)
+    rc = dev_lib().epa_encode_queries(states, W, Q, arr, int(premasking), int(aa_x_as_n),
+                                      codes.ctypes.data, wb.ctypes.data, ws.ctypes.data,
+                                      C.byref(bad))
+    if rc:
+        raise EpaError(rc, "query %d: %s" % (bad.value, "char is invalid!" if rc == -6 else
+                                             "does not appear to have any non-gap sites!"))
+    return codes, wb, ws
+
+
+class Evaluator:
+    """One epa_ctx (one GPU).  Reference-side inputs per branch, libpll layouts:
+    prox_clv[b], dist_clv[b]: float64 [W][c][s] (dist_clv[b] may be None when dist_tip[b] is a
+    uint8 [W] tip-code row), prox_scaler[b] / dist_scaler[b]: uint32 [W] or None."""
+
+    def __init__(self, states, rates, weights, eigenvals, u, uinv, freqs, branch_length,
+                 prox_clv, dist_clv, prox_scaler=None, dist_scaler=None, dist_tip=None,
+                 tipmap=None, device=0, aa_x_as_n=False):
+        L = dev_lib()
+        B = len(branch_length)
+        self.B, self.s, self.c = B, states, len(rates)
+        W = None
+        for a in list(prox_clv):
+            W = a.shape[0]
+            break
+        self.W = W
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        keep = [f64(eigenvals), f64(u), f64(uinv), f64(freqs), f64(rates), f64(weights),
+                f64(branch_length)]
+
+        def ptr_array(items, dtype):
+            arr = (C.c_void_p * B)()
+            held = []
+            for i, it in enumerate(items if items is not None else [None] * B):
+                if it is None:
+                    arr[i] = None
+                else:
+                    a = np.ascontiguousarray(it, dtype=dtype)
+                    held.append(a)
+                    arr[i] = a.ctypes.data
+            return arr, held
+
+        pc, h1 = ptr_array(prox_clv, np.float64)
+        dc, h2 = ptr_array(dist_clv, np.float64)
+        ps, h3 = ptr_array(prox_scaler, np.uint32)
+        ds, h4 = ptr_array(dist_scaler, np.uint32)
+        dt, h5 = ptr_array(dist_tip, np.uint8)
+        tm = np.ascontiguousarray(tipmap, dtype=np.uint32) if tipmap is not None else None
+        d = _RefDesc()
+        d.states, d.rate_cats, d.sites, d.branches = states, self.c, W, B
+        d.eigenvals, d.eigenvecs_u, d.eigenvecs_uinv = (keep[0].ctypes.data, keep[1].ctypes.data,
+                                                       keep[2].ctypes.data)
+        d.freqs, d.rates, d.rate_weights = keep[3].ctypes.data, keep[4].ctypes.data, keep[5].ctypes.data
+        d.prop_invar = 0.0
+        d.prox_clv = C.cast(pc, C.c_void_p)
+        d.prox_scaler = C.cast(ps, C.c_void_p)
+        d.dist_clv = C.cast(dc, C.c_void_p)
+        d.dist_tipchars = C.cast(dt, C.c_void_p) if dist_tip is not None else None
+        d.dist_scaler = C.cast(ds, C.c_void_p)
+        d.branch_length = keep[6].ctypes.data
+        if tm is not None:
+            d.tipmap, d.tipmap_size = tm.ctypes.data, len(tm)
+        d.aa_x_as_n = int(aa_x_as_n)
+        h = C.c_void_p()
+        rc = L.epa_dev_create(C.byref(d), device, C.byref(h))
+        if rc:
+            raise EpaError(rc, L.epa_dev_last_error(None).decode())
+        self.h = h
+        self.L = L
+        self.last_stats = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.epa_dev_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc:
+            raise EpaError(rc, self.L.epa_dev_last_error(self.h).decode())
+
+    def set_stream(self, stream_ptr):
+        self._check(self.L.epa_dev_set_stream(self.h, stream_ptr))
+
+    def build_lookup(self):
+        self._check(self.L.epa_dev_build_lookup(self.h))
+
+    def preplace(self, codes, win_begin, win_span, Q=None, out=None):
+        """-> lnl [Q][B].  Inputs numpy (host) or torch cuda tensors (HBM-resident)."""
+        Q = len(win_begin) if Q is None else Q
+        if out is None:
+            out = np.empty((Q, self.B), np.float64)
+        self._check(self.L.epa_dev_preplace(self.h, _ptr(codes), _ptr(win_begin), _ptr(win_span),
+                                            Q, _ptr(out)))
+        return out
+
+    def thorough(self, pairs, codes, win_begin, win_span, Q=None, n_pairs=None, out=None):
+        """pairs: structured PAIR_DTYPE array (or device buffer) -> RESULT_DTYPE array."""
+        Q = len(win_begin) if Q is None else Q
+        n = len(pairs) if n_pairs is None else n_pairs
+        if out is None:
+            out = np.empty(n, RESULT_DTYPE)
+        st = _Stats()
+        self._check(self.L.epa_dev_thorough(self.h, _ptr(pairs), n, _ptr(codes), _ptr(win_begin),
+                                            _ptr(win_span), Q, _ptr(out), C.byref(st)))
+        self.last_stats = {"pairs": st.pairs, "rounds": st.rounds,
+                           "newton_evals": st.newton_evals, "reverts": st.reverts}
+        return out
+
+    def select(self, lnl, Q, threshold=0.99999, max_pairs=None, out=None):
+        """dynamic heuristic -> branch-major sorted PAIR_DTYPE array"""
+        if max_pairs is None:
+            max_pairs = Q * self.B
+        host_out = out is None
+        if host_out:
+            out = np.empty(max_pairs, PAIR_DTYPE)
+        n = C.c_uint64(0)
+        self._check(self.L.epa_dev_select_candidates(self.h, _ptr(lnl), Q, threshold, _ptr(out),
+                                                     max_pairs, C.byref(n)))
+        return out[:n.value] if host_out else n.value
+
+    def kernel_ms(self, which):
+        return self.L.epa_dev_last_kernel_ms(self.h, which.encode())

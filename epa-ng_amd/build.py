@@ -1,0 +1,51 @@
+"""Builds the in-tree native libraries for gfx950 (no JIT cache: the .so travels with the repo).
+
+  libepa_dev.so   HIP kernels + C-ABI (include/epa_dev.h)
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+DEV_SOURCES = ["epa_dev.hip", "preplace.hip", "thorough_dna.hip", "thorough_aa.hip"]
+DEV_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+             "-I", CSRC, "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_dev(force=False, verbose=False):
+    out = os.path.join(HERE, "libepa_dev.so")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, "epa_dev_internal.hpp"), os.path.join(ROOT, "include", "epa_dev.h")]
+    objs, procs = [], []
+    for src in DEV_SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or _newer(op, [sp] + hdrs):
+            cmd = [HIPCC] + DEV_FLAGS + ["-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on " + src)
+    if force or procs or _newer(out, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+        subprocess.check_call(cmd)
+    return out
+
+
+if __name__ == "__main__":
+    print(build_dev(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,606 @@
+// libepa_dev.so -- host side of the C-ABI (include/epa_dev.h) plus the reference-data setup
+// kernels.  MI355X / gfx950 only; there is deliberately no CPU fallback anywhere in this file:
+// with no device every entry point fails with EPA_ERR_NO_DEVICE.
+#include "epa_dev_internal.hpp"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <numeric>
+
+static thread_local std::string g_create_err;
+
+int epa_fail(epa_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg; else g_create_err = msg;
+  return code;
+}
+
+void* epa_scratch(epa_ctx* ctx, int slot, size_t bytes) {
+  if (bytes <= ctx->scratch_sz[slot]) return ctx->scratch[slot];
+  if (ctx->scratch[slot]) (void)hipFree(ctx->scratch[slot]);
+  ctx->scratch[slot] = nullptr;
+  ctx->scratch_sz[slot] = 0;
+  size_t want = bytes + bytes / 4 + 256;
+  if (hipMalloc(&ctx->scratch[slot], want) != hipSuccess) return nullptr;
+  ctx->scratch_sz[slot] = want;
+  return ctx->scratch[slot];
+}
+
+bool epa_is_device_ptr(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+const void* epa_to_device(epa_ctx* ctx, int slot, const void* p, size_t bytes) {
+  if (epa_is_device_ptr(p)) return p;
+  void* d = epa_scratch(ctx, slot, bytes + 1024);  // slack: kernels may over-read a few words
+  if (!d) return nullptr;
+  if (hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return nullptr;
+  return d;
+}
+
+void epa_timer_start(epa_ctx* ctx, EvTimer& t) {
+  if (!t.a) { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
+  (void)hipEventRecord(t.a, ctx->stream);
+}
+void epa_timer_stop(epa_ctx* ctx, EvTimer& t) {
+  (void)hipEventRecord(t.b, ctx->stream);
+  t.valid = true;
+}
+
+// =============================================================================================
+// Setup kernel 1: eigen-transform one reference CLV (or tip row) into component-major layout.
+//   dst[(k*s + x) * W + site] = sum_i Ui[x][i] * clv[site][k][i]
+// Replaces the borrow of Tree::get_clv() pointers in make_tiny_partition
+// (src/tree/tiny_util.cpp:165-181); the transform is exact-arithmetic-equivalent to what
+// pll_update_sumtable / pll_update_prob_matrices apply per use (U^-1 is folded in once).
+// Coalescing: reads are [site][c*s] rows (one 128 B / 640 B row per thread, consecutive threads
+// consecutive rows); writes are lane-consecutive per component.
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_transform(const ModelDev* __restrict__ m,
+                                                   const double* __restrict__ clv,
+                                                   const uint8_t* __restrict__ tip,
+                                                   const uint32_t* __restrict__ tipmap,
+                                                   uint32_t W, double* __restrict__ dst) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* Ui = reinterpret_cast<double*>(smem);
+  const int s = m->s, c = m->c;
+  for (int i = threadIdx.x; i < s * s; i += blockDim.x) Ui[i] = m->Ui[i];
+  __syncthreads();
+  const uint32_t site = blockIdx.x * blockDim.x + threadIdx.x;
+  if (site >= W) return;
+  uint32_t mask = 0;
+  if (tip) mask = tipmap[tip[site]];
+  for (int k = 0; k < c; ++k) {
+    for (int x = 0; x < s; ++x) {
+      double acc = 0.0;
+      if (tip) {
+        for (int i = 0; i < s; ++i)
+          if ((mask >> i) & 1u) acc += Ui[x * s + i];
+      } else {
+        const double* v = clv + ((size_t)site * c + k) * s;
+        for (int i = 0; i < s; ++i) acc = fma(Ui[x * s + i], v[i], acc);
+      }
+      dst[(size_t)(k * s + x) * W + site] = acc;
+    }
+  }
+}
+
+int launch_transform(epa_ctx* ctx, const double* d_clv, const uint8_t* d_tip,
+                     const uint32_t* d_tipmap, uint32_t, double* dst) {
+  dim3 grid((ctx->W + 255) / 256);
+  size_t lds = sizeof(double) * ctx->s * ctx->s;
+  hipLaunchKernelGGL(k_transform, grid, dim3(256), lds, ctx->stream, ctx->dmodel, d_clv, d_tip,
+                     d_tipmap, ctx->W, dst);
+  EPA_HIP(ctx, hipGetLastError());
+  return EPA_OK;
+}
+
+// =============================================================================================
+// Setup kernel 2: per-branch per-site lookup table (K1 + K2 of SURVEY.md section 7.1).
+// Replaces, for every branch at once, the Tiny_Tree constructor's
+//   pll_update_prob_matrices(3) + pll_update_partials(inner <- distal (x) proximal)
+//   (src/tree/Tiny_Tree.cpp:88-112) and precompute_sites_static() x |char map| +
+//   Lookup_Store::init_branch (:18-46,114-128; src/core/Lookup_Store.hpp:73-81).
+// One thread per (branch, site); the inner CLV never leaves registers.
+// HBM-bound: reads 2*c*s*8 B + 4 B, writes ncols*8 B per site.
+// =============================================================================================
+template <int S>
+__global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict__ m,
+                                                      const double* __restrict__ refT,
+                                                      const uint32_t* __restrict__ scSum,
+                                                      const double* __restrict__ blen,
+                                                      double pendant, uint32_t W,
+                                                      double* __restrict__ lookup) {
+  __shared__ double U[S * S], Ui[S * S];
+  __shared__ double Eh[EPA_MAX_CATS * S], Ep[EPA_MAX_CATS * S];  // exp tables: half branch, pendant
+  const int c = m->c, ncols = m->ncols;
+  const uint32_t b = blockIdx.y;
+  const double half = blen[b] * 0.5;
+  for (int i = threadIdx.x; i < S * S; i += blockDim.x) { U[i] = m->U[i]; Ui[i] = m->Ui[i]; }
+  for (int i = threadIdx.x; i < c * S; i += blockDim.x) {
+    const int k = i / S, x = i % S;
+    Eh[i] = exp(m->lam[x] * m->rate[k] * half);     // proximal == distal == orig/2
+    Ep[i] = exp(m->lam[x] * m->rate[k] * pendant);  // reset_triplet_lengths, pll_util.cpp:354-374
+  }
+  __syncthreads();
+  const uint32_t site = blockIdx.x * blockDim.x + threadIdx.x;
+  if (site >= W) return;
+  const double* Xt = refT + (size_t)(2 * b) * c * S * W + site;
+  const double* Dt = refT + (size_t)(2 * b + 1) * c * S * W + site;
+  double I[EPA_MAX_CATS][S];
+  double mx = 0.0;
+  for (int k = 0; k < c; ++k) {
+    double dv[S], xv[S];
+#pragma unroll
+    for (int x = 0; x < S; ++x) {
+      dv[x] = Dt[(size_t)(k * S + x) * W] * Eh[k * S + x];
+      xv[x] = Xt[(size_t)(k * S + x) * W] * Eh[k * S + x];
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      double a = 0.0, bb = 0.0;
+#pragma unroll
+      for (int x = 0; x < S; ++x) {
+        a = fma(U[i * S + x], dv[x], a);
+        bb = fma(U[i * S + x], xv[x], bb);
+      }
+      const double v = a * bb;
+      I[k][i] = v;
+      mx = fmax(mx, v);
+    }
+  }
+  uint32_t sc = scSum[(size_t)b * W + site];
+  // per-site scaling of pll_update_partials: every entry below 2^-256 -> multiply by 2^256
+  const bool resc = mx < 0x1p-256;
+  if (resc) sc += 1;
+  const double mult = resc ? 0x1p+256 : 1.0;
+  // g[k][i] = pi_i * (P_pendant I)_i  via the eigenbasis: P I = U (e o (Ui I))
+  double g[EPA_MAX_CATS][S];
+  for (int k = 0; k < c; ++k) {
+    double it[S];
+#pragma unroll
+    for (int x = 0; x < S; ++x) {
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < S; ++i) acc = fma(Ui[x * S + i], I[k][i] * mult, acc);
+      it[x] = acc * Ep[k * S + x];
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      double acc = 0.0;
+#pragma unroll
+      for (int x = 0; x < S; ++x) acc = fma(U[i * S + x], it[x], acc);
+      g[k][i] = m->pi[i] * acc;
+    }
+  }
+  const double log_thr = -256.0 * 0.6931471805599453094;  // log(2^-256)
+  double* out = lookup + ((size_t)b * W + site) * ncols;
+  for (int col = 0; col < ncols; ++col) {
+    const uint32_t mask = m->colmask[col];
+    double terma = 0.0;
+    for (int k = 0; k < c; ++k) {
+      double tr = 0.0;
+#pragma unroll
+      for (int i = 0; i < S; ++i)
+        if ((mask >> i) & 1u) tr += g[k][i];
+      terma += tr * m->w[k];
+    }
+    double v = log(terma);
+    if (sc) v += sc * log_thr;
+    out[col] = v;
+  }
+}
+
+int launch_build_lookup(epa_ctx* ctx) {
+  dim3 grid((ctx->W + 255) / 256, ctx->B);
+  epa_timer_start(ctx, ctx->t_lookup);
+  if (ctx->s == 4)
+    hipLaunchKernelGGL(k_build_lookup<4>, grid, dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT,
+                       ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup);
+  else
+    hipLaunchKernelGGL(k_build_lookup<20>, grid, dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT,
+                       ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup);
+  epa_timer_stop(ctx, ctx->t_lookup);
+  EPA_HIP(ctx, hipGetLastError());
+  return EPA_OK;
+}
+
+__global__ void k_add_scaler(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                             uint32_t W) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < W) dst[i] += src[i];
+}
+
+// =============================================================================================
+// character maps (src/util/maps.hpp:9-31, src/core/Lookup_Store.hpp:33-68, pll_map_nt/_aa)
+// =============================================================================================
+static const char NT_COLS[16] = {'-', 'T', 'G', 'K', 'C', 'Y', 'S', 'B',
+                                 'A', 'W', 'R', 'D', 'M', 'H', 'V', 'N'};
+static const char AA_COLS[24] = {'A', 'C', 'D', 'E', 'F', 'G', 'H', 'I', 'K', 'L', 'M', 'N',
+                                 'P', 'Q', 'R', 'S', 'T', 'V', 'W', 'Y', '-', 'X', 'B', 'Z'};
+static const char AA_STATE_ORDER[21] = "ARNDCQEGHILKMFPSTWYV";
+
+static uint32_t column_mask(int s, int col) {
+  if (s == 4) {  // column index bits: A=8 C=4 G=2 T=1 -> state bits A=1 C=2 G=4 T=8
+    if (col == 0) return 15u;  // '-' == any
+    uint32_t m = 0;
+    if (col & 8) m |= 1u;
+    if (col & 4) m |= 2u;
+    if (col & 2) m |= 4u;
+    if (col & 1) m |= 8u;
+    return m;
+  }
+  const char ch = AA_COLS[col];
+  const char* p = strchr(AA_STATE_ORDER, ch);
+  if (p) return 1u << (p - AA_STATE_ORDER);
+  if (ch == 'B') return (1u << 2) | (1u << 3);
+  if (ch == 'Z') return (1u << 5) | (1u << 6);
+  return (1u << 20) - 1;  // '-' and 'X'
+}
+
+extern "C" int epa_encode_queries(uint32_t states, uint32_t sites, uint32_t Q,
+                                  const char* const* seqs, int premasking, int aa_x_as_n,
+                                  uint8_t* codes, uint32_t* win_begin, uint32_t* win_span,
+                                  uint32_t* bad_query) {
+  int8_t map[256];
+  memset(map, -1, sizeof(map));
+  const bool dna = states == 4;
+  const char* cols = dna ? NT_COLS : AA_COLS;
+  const int n = dna ? 16 : 24;
+  for (int i = 0; i < n; ++i) {
+    map[(unsigned char)cols[i]] = (int8_t)i;
+    map[(unsigned char)tolower(cols[i])] = (int8_t)i;
+  }
+  if (dna) {
+    map['U'] = map['u'] = map['T'];
+    map['X'] = map['x'] = map['O'] = map['o'] = map['.'] = map['-'];
+  } else if (aa_x_as_n) {
+    map['X'] = map['x'] = map['N'];
+  }
+  map['?'] = map['-'];
+  for (uint32_t q = 0; q < Q; ++q) {
+    const char* sq = seqs[q];
+    uint8_t* out = codes + (size_t)q * sites;
+    for (uint32_t w = 0; w < sites; ++w) {
+      const int8_t v = map[(unsigned char)sq[w]];
+      if (v < 0) { if (bad_query) *bad_query = q; return EPA_ERR_INVALID_CHAR; }
+      out[w] = (uint8_t)v;
+    }
+    uint32_t lo = 0, hi = sites;
+    if (premasking) {  // get_valid_range, src/util/Range.hpp:34-49: only the literal '-'
+      while (lo < hi && sq[lo] == '-') ++lo;
+      while (hi > lo && sq[hi - 1] == '-') --hi;
+      if (hi == lo) { if (bad_query) *bad_query = q; return EPA_ERR_QUERY_ALL_GAP; }
+    }
+    win_begin[q] = lo;
+    win_span[q] = hi - lo;
+  }
+  return EPA_OK;
+}
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" int epa_dev_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+extern "C" const char* epa_dev_last_error(const epa_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+extern "C" int epa_dev_set_stream(epa_ctx* ctx, void* s) {
+  if (!ctx) return EPA_ERR_INVALID_ARG;
+  ctx->stream = (hipStream_t)s;
+  return EPA_OK;
+}
+
+extern "C" void epa_dev_destroy(epa_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < 8; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+  if (ctx->refT) (void)hipFree(ctx->refT);
+  if (ctx->scSum) (void)hipFree(ctx->scSum);
+  if (ctx->blen) (void)hipFree(ctx->blen);
+  if (ctx->lookup) (void)hipFree(ctx->lookup);
+  if (ctx->dmodel) (void)hipFree(ctx->dmodel);
+  EvTimer* ts[4] = {&ctx->t_lookup, &ctx->t_preplace, &ctx->t_thorough, &ctx->t_select};
+  for (auto* t : ts) { if (t->a) (void)hipEventDestroy(t->a); if (t->b) (void)hipEventDestroy(t->b); }
+  delete ctx;
+}
+
+static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx) {
+  const int s = (int)d->states, c = (int)d->rate_cats;
+  if (!(s == 4 || s == 20)) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "states must be 4 or 20");
+  if (c < 1 || c > EPA_MAX_CATS) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "rate_cats out of range");
+  if (!d->sites || !d->branches) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "empty reference");
+  if (d->prop_invar != 0.0)
+    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "prop_invar > 0 (+I) is not implemented yet");
+  if (!d->eigenvals || !d->eigenvecs_u || !d->eigenvecs_uinv || !d->freqs || !d->rates ||
+      !d->rate_weights || !d->prox_clv || !d->branch_length)
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "null model / reference pointer in descriptor");
+  if (!d->dist_clv && !d->dist_tipchars)
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "descriptor has neither dist_clv nor dist_tipchars");
+  ctx->device = device;
+  ctx->s = s; ctx->c = c; ctx->W = d->sites; ctx->B = d->branches;
+  ctx->ncols = s == 4 ? 16 : 24;
+  ctx->aa_x_as_n = (int)d->aa_x_as_n;
+  EPA_HIP(ctx, hipSetDevice(device));
+
+  ModelDev& m = ctx->hmodel;
+  memset(&m, 0, sizeof(m));
+  m.s = s; m.c = c; m.ncols = ctx->ncols;
+  for (int i = 0; i < s * s; ++i) { m.U[i] = d->eigenvecs_u[i]; m.Ui[i] = d->eigenvecs_uinv[i]; }
+  for (int i = 0; i < s; ++i) { m.lam[i] = d->eigenvals[i]; m.pi[i] = d->freqs[i]; }
+  for (int k = 0; k < c; ++k) { m.rate[k] = d->rates[k]; m.w[k] = d->rate_weights[k]; }
+  for (int col = 0; col < ctx->ncols; ++col) {
+    m.colmask[col] = column_mask(s, col);
+    for (int x = 0; x < s; ++x) {
+      double acc = 0.0;
+      for (int i = 0; i < s; ++i)
+        if ((m.colmask[col] >> i) & 1u) acc += m.Ui[x * s + i];
+      m.qt[col * s + x] = acc;
+    }
+  }
+  if (s == 4 && c == 4) {
+    for (int i = 0; i < 16; ++i) { ctx->dna.U[i] = m.U[i]; ctx->dna.Ui[i] = m.Ui[i]; }
+    for (int i = 0; i < 4; ++i) {
+      ctx->dna.lam[i] = m.lam[i]; ctx->dna.rate[i] = m.rate[i]; ctx->dna.w[i] = m.w[i];
+      ctx->dna.pi[i] = m.pi[i];
+    }
+  }
+  ctx->blo.min_branch = d->blo_min_branch > 0 ? d->blo_min_branch : 1e-4;
+  ctx->blo.max_branch = d->blo_max_branch > 0 ? d->blo_max_branch : 100.0;
+  ctx->blo.default_branch = d->blo_default_branch > 0 ? d->blo_default_branch : 0.1;
+  ctx->blo.epsilon = d->blo_epsilon > 0 ? d->blo_epsilon : 0.1;
+  ctx->blo.pendant_default = d->pendant_default > 0 ? d->pendant_default : -log(0.9);
+  ctx->blo.max_rounds = d->blo_max_rounds ? d->blo_max_rounds : 32;
+  ctx->blo.max_newton = d->blo_max_newton ? d->blo_max_newton : 30;
+  const uint32_t flags = d->flags ? d->flags : EPA_FLAG_SLIDING_BLO;
+  ctx->blo.sliding = (flags & EPA_FLAG_SLIDING_BLO) ? 1 : 0;
+  if (!ctx->blo.sliding)
+    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "--raxml-blo (non-sliding BLO) is not implemented");
+
+  EPA_HIP(ctx, hipMalloc(&ctx->dmodel, sizeof(ModelDev)));
+  EPA_HIP(ctx, hipMemcpy(ctx->dmodel, &m, sizeof(ModelDev), hipMemcpyHostToDevice));
+
+  const size_t W = ctx->W, B = ctx->B, cs = (size_t)c * s;
+  EPA_HIP(ctx, hipMalloc(&ctx->refT, sizeof(double) * 2 * B * cs * W));
+  EPA_HIP(ctx, hipMalloc(&ctx->scSum, sizeof(uint32_t) * B * W));
+  EPA_HIP(ctx, hipMemset(ctx->scSum, 0, sizeof(uint32_t) * B * W));
+  EPA_HIP(ctx, hipMalloc(&ctx->blen, sizeof(double) * B));
+  EPA_HIP(ctx, hipMalloc(&ctx->lookup, sizeof(double) * B * W * ctx->ncols));
+  ctx->h_blen.assign(d->branch_length, d->branch_length + B);
+  EPA_HIP(ctx, hipMemcpy(ctx->blen, d->branch_length, sizeof(double) * B, hipMemcpyHostToDevice));
+
+  uint32_t* d_tipmap = nullptr;
+  if (d->tipmap && d->tipmap_size) {
+    d_tipmap = (uint32_t*)epa_scratch(ctx, 2, sizeof(uint32_t) * d->tipmap_size);
+    if (!d_tipmap) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(tipmap)");
+    EPA_HIP(ctx, hipMemcpy(d_tipmap, d->tipmap, sizeof(uint32_t) * d->tipmap_size,
+                           hipMemcpyHostToDevice));
+  }
+  // upload + transform, one CLV at a time through two alternating staging buffers
+  for (size_t b = 0; b < B; ++b) {
+    for (int side = 0; side < 2; ++side) {
+      const double* clv = side == 0 ? d->prox_clv[b] : (d->dist_clv ? d->dist_clv[b] : nullptr);
+      const uint8_t* tip = (side == 1 && d->dist_tipchars) ? d->dist_tipchars[b] : nullptr;
+      const uint32_t* sc = side == 0 ? (d->prox_scaler ? d->prox_scaler[b] : nullptr)
+                                     : (d->dist_scaler ? d->dist_scaler[b] : nullptr);
+      if (side == 0 && !clv) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "prox_clv[b] is NULL");
+      if (side == 1 && !clv && !tip)
+        return epa_fail(ctx, EPA_ERR_INVALID_ARG, "branch has neither dist_clv nor dist_tipchars");
+      if (tip && !clv && !d_tipmap)
+        return epa_fail(ctx, EPA_ERR_INVALID_ARG, "dist_tipchars given without tipmap");
+      double* dst = ctx->refT + (2 * b + side) * cs * W;
+      const int slot = side;  // staging slots 0/1
+      if (clv) {
+        const double* dclv = (const double*)epa_to_device(ctx, slot, clv, sizeof(double) * W * cs);
+        if (!dclv) return epa_fail(ctx, EPA_ERR_HIP, "staging copy of CLV failed");
+        int rc = launch_transform(ctx, dclv, nullptr, nullptr, 0, dst);
+        if (rc) return rc;
+      } else {
+        const uint8_t* dtip = (const uint8_t*)epa_to_device(ctx, slot, tip, W);
+        if (!dtip) return epa_fail(ctx, EPA_ERR_HIP, "staging copy of tipchars failed");
+        int rc = launch_transform(ctx, nullptr, dtip, d_tipmap, d->tipmap_size, dst);
+        if (rc) return rc;
+      }
+      if (sc) {
+        const uint32_t* dsc = (const uint32_t*)epa_to_device(ctx, 3 + side, sc, sizeof(uint32_t) * W);
+        if (!dsc) return epa_fail(ctx, EPA_ERR_HIP, "staging copy of scaler failed");
+        hipLaunchKernelGGL(k_add_scaler, dim3((W + 255) / 256), dim3(256), 0, ctx->stream, dsc,
+                           ctx->scSum + b * W, (uint32_t)W);
+      }
+      // staging buffers are reused by the next branch: pageable H2D copies are synchronous
+      // with respect to the host buffer but the kernel must finish before the slot is reused
+      EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  }
+  EPA_HIP(ctx, hipGetLastError());
+  return EPA_OK;
+}
+
+extern "C" int epa_dev_create(const epa_ref_desc* desc, int device, epa_ctx** out) {
+  if (!desc || !out) return epa_fail(nullptr, EPA_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  if (epa_dev_device_count() <= 0)
+    return epa_fail(nullptr, EPA_ERR_NO_DEVICE,
+                    "no HIP device visible: libepa_dev has no CPU fallback by design");
+  epa_ctx* ctx = new epa_ctx();
+  int rc = create_impl(desc, device, ctx);
+  if (rc != EPA_OK) {
+    g_create_err = ctx->err;
+    epa_dev_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return EPA_OK;
+}
+
+extern "C" int epa_dev_build_lookup(epa_ctx* ctx) {
+  if (!ctx) return EPA_ERR_INVALID_ARG;
+  if (ctx->lookup_built) return EPA_OK;
+  EPA_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = launch_build_lookup(ctx);
+  if (rc) return rc;
+  ctx->lookup_built = true;
+  return EPA_OK;
+}
+
+// fetch a small u32 array to the host if it lives on the device
+static const uint32_t* host_view(const uint32_t* p, size_t n, std::vector<uint32_t>& buf,
+                                 hipStream_t st) {
+  if (!epa_is_device_ptr(p)) return p;
+  buf.resize(n);
+  (void)hipStreamSynchronize(st);
+  if (hipMemcpy(buf.data(), p, n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+    return nullptr;
+  return buf.data();
+}
+
+static int check_windows(epa_ctx* ctx, const uint32_t* hb, const uint32_t* hs, uint32_t Q,
+                         uint32_t* max_span) {
+  uint32_t mx = 0;
+  for (uint32_t q = 0; q < Q; ++q) {
+    if (hs[q] == 0)
+      return epa_fail(ctx, EPA_ERR_QUERY_ALL_GAP,
+                      "Sequence " + std::to_string(q) + " does not appear to have any non-gap sites!");
+    if ((uint64_t)hb[q] + hs[q] > ctx->W)
+      return epa_fail(ctx, EPA_ERR_QUERY_WIDTH,
+                      "Query sequence length not same as reference alignment!");
+    mx = std::max(mx, hs[q]);
+  }
+  *max_span = mx;
+  return EPA_OK;
+}
+
+extern "C" int epa_dev_preplace(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_begin,
+                                const uint32_t* win_span, uint32_t Q, double* lnl) {
+  if (!ctx || !q_codes || !win_begin || !win_span || !lnl)
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "null argument");
+  if (Q == 0) return EPA_OK;
+  EPA_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = epa_dev_build_lookup(ctx);
+  if (rc) return rc;
+  std::vector<uint32_t> hb_buf, hs_buf;
+  const uint32_t* hb = host_view(win_begin, Q, hb_buf, ctx->stream);
+  const uint32_t* hs = host_view(win_span, Q, hs_buf, ctx->stream);
+  if (!hb || !hs) return epa_fail(ctx, EPA_ERR_HIP, "cannot read window arrays");
+  uint32_t max_span = 0;
+  rc = check_windows(ctx, hb, hs, Q, &max_span);
+  if (rc) return rc;
+  const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * ctx->W);
+  const uint32_t* d_begin = (const uint32_t*)epa_to_device(ctx, 1, win_begin, sizeof(uint32_t) * Q);
+  const uint32_t* d_span = (const uint32_t*)epa_to_device(ctx, 2, win_span, sizeof(uint32_t) * Q);
+  if (!d_codes || !d_begin || !d_span) return epa_fail(ctx, EPA_ERR_HIP, "query upload failed");
+  const bool out_dev = epa_is_device_ptr(lnl);
+  double* d_lnl = out_dev ? lnl : (double*)epa_scratch(ctx, 3, sizeof(double) * (size_t)Q * ctx->B);
+  if (!d_lnl) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(lnl)");
+  rc = launch_preplace(ctx, d_codes, hb, hs, d_begin, d_span, Q, d_lnl);
+  if (rc) return rc;
+  if (!out_dev) {
+    EPA_HIP(ctx, hipMemcpyAsync(lnl, d_lnl, sizeof(double) * (size_t)Q * ctx->B,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return EPA_OK;
+}
+
+extern "C" int epa_dev_thorough(epa_ctx* ctx, const epa_pair* pairs, uint64_t n_pairs,
+                                const uint8_t* q_codes, const uint32_t* win_begin,
+                                const uint32_t* win_span, uint32_t Q, epa_result* out,
+                                epa_thorough_stats* stats) {
+  if (!ctx || !q_codes || !win_begin || !win_span || (n_pairs && (!pairs || !out)))
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "null argument");
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n_pairs == 0) return EPA_OK;
+  EPA_HIP(ctx, hipSetDevice(ctx->device));
+  if (!(ctx->s == 4 && ctx->c == 4) && !(ctx->s == 20))
+    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "thorough: DNA needs 4 rate categories");
+  std::vector<uint32_t> hb_buf, hs_buf;
+  const uint32_t* hb = host_view(win_begin, Q, hb_buf, ctx->stream);
+  const uint32_t* hs = host_view(win_span, Q, hs_buf, ctx->stream);
+  if (!hb || !hs) return epa_fail(ctx, EPA_ERR_HIP, "cannot read window arrays");
+  uint32_t max_span = 0;
+  int rc = check_windows(ctx, hb, hs, Q, &max_span);
+  if (rc) return rc;
+  if (!epa_is_device_ptr(pairs)) {
+    for (uint64_t i = 0; i < n_pairs; ++i)
+      if (pairs[i].branch_id >= ctx->B || pairs[i].seq_id >= Q)
+        return epa_fail(ctx, EPA_ERR_INVALID_ARG, "pair index out of range");
+  }
+  const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * ctx->W);
+  const uint32_t* d_begin = (const uint32_t*)epa_to_device(ctx, 1, win_begin, sizeof(uint32_t) * Q);
+  const uint32_t* d_span = (const uint32_t*)epa_to_device(ctx, 2, win_span, sizeof(uint32_t) * Q);
+  const epa_pair* d_pairs = (const epa_pair*)epa_to_device(ctx, 4, pairs, sizeof(epa_pair) * n_pairs);
+  if (!d_codes || !d_begin || !d_span || !d_pairs)
+    return epa_fail(ctx, EPA_ERR_HIP, "thorough input upload failed");
+  const bool out_dev = epa_is_device_ptr(out);
+  epa_result* d_out = out_dev ? out : (epa_result*)epa_scratch(ctx, 5, sizeof(epa_result) * n_pairs);
+  unsigned long long* d_stats = (unsigned long long*)epa_scratch(ctx, 6, 64);
+  if (!d_out || !d_stats) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(thorough out)");
+  EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 64, ctx->stream));
+  rc = launch_thorough(ctx, d_pairs, n_pairs, d_codes, d_begin, d_span, max_span, d_out, d_stats);
+  if (rc) return rc;
+  unsigned long long hst[8];
+  if (!out_dev)
+    EPA_HIP(ctx, hipMemcpyAsync(out, d_out, sizeof(epa_result) * n_pairs, hipMemcpyDeviceToHost,
+                                ctx->stream));
+  if (!out_dev || stats) {
+    EPA_HIP(ctx, hipMemcpyAsync(hst, d_stats, 64, hipMemcpyDeviceToHost, ctx->stream));
+    EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->last_stats.pairs = n_pairs;
+    ctx->last_stats.rounds = hst[0];
+    ctx->last_stats.newton_evals = hst[1];
+    ctx->last_stats.reverts = hst[2];
+    if (stats) *stats = ctx->last_stats;
+    if (hst[3])  // pairs whose lnL came out -inf / NaN
+      return epa_fail(ctx, EPA_ERR_NEG_INF,
+                      "-INF logl at branch " + std::to_string((uint32_t)(hst[4] >> 32)) +
+                          " with sequence " + std::to_string((uint32_t)(hst[4] & 0xffffffffu)));
+  }
+  return EPA_OK;
+}
+
+extern "C" int epa_dev_select_candidates(epa_ctx* ctx, const double* lnl, uint32_t Q,
+                                         double threshold, epa_pair* pairs, uint64_t max_pairs,
+                                         uint64_t* n_pairs) {
+  if (!ctx || !lnl || !pairs || !n_pairs) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "null argument");
+  *n_pairs = 0;
+  if (Q == 0) return EPA_OK;
+  EPA_HIP(ctx, hipSetDevice(ctx->device));
+  const double* d_lnl = (const double*)epa_to_device(ctx, 3, lnl, sizeof(double) * (size_t)Q * ctx->B);
+  if (!d_lnl) return epa_fail(ctx, EPA_ERR_HIP, "lnl upload failed");
+  const bool out_dev = epa_is_device_ptr(pairs);
+  epa_pair* d_pairs = out_dev ? pairs : (epa_pair*)epa_scratch(ctx, 4, sizeof(epa_pair) * max_pairs);
+  if (!d_pairs) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(pairs)");
+  int rc = launch_select(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, n_pairs);
+  if (rc) return rc;
+  if (!out_dev && *n_pairs) {
+    EPA_HIP(ctx, hipMemcpy(pairs, d_pairs, sizeof(epa_pair) * (*n_pairs), hipMemcpyDeviceToHost));
+  }
+  return EPA_OK;
+}
+
+extern "C" double epa_dev_last_kernel_ms(const epa_ctx* ctx, const char* which) {
+  if (!ctx || !which) return -1.0;
+  const EvTimer* t = nullptr;
+  if (!strcmp(which, "preplace")) t = &ctx->t_preplace;
+  else if (!strcmp(which, "thorough")) t = &ctx->t_thorough;
+  else if (!strcmp(which, "lookup")) t = &ctx->t_lookup;
+  else if (!strcmp(which, "select")) t = &ctx->t_select;
+  if (!t || !t->valid) return -1.0;
+  if (hipEventSynchronize(t->b) != hipSuccess) return -1.0;
+  float ms = -1.f;
+  if (hipEventElapsedTime(&ms, t->a, t->b) != hipSuccess) return -1.0;
+  return (double)ms;
+}

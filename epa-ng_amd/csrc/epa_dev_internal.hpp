@@ -1,0 +1,112 @@
+// Internal declarations shared by the HIP translation units of libepa_dev.so.
+// gfx950 (MI355X) only: wave64, 160 KiB LDS/CU, fp64 VALU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "epa_dev.h"
+
+#define EPA_MAX_STATES 20
+#define EPA_MAX_CATS 8
+#define EPA_MAX_COLS 24
+
+// Model constants handed to kernels by value (kernarg -> SGPRs via s_load).
+struct ModelDNA {
+  double U[16];     // [i][x]
+  double Ui[16];    // [x][i]
+  double lam[4];
+  double rate[4];   // r_k (prop_invar == 0)
+  double w[4];
+  double pi[4];
+};
+
+struct BloConsts {
+  double min_branch, max_branch, default_branch, epsilon, pendant_default;
+  uint32_t max_rounds, max_newton;
+  uint32_t sliding;
+};
+
+// Generic model block in HBM (used by the setup kernels and the 20-state path)
+struct ModelDev {
+  int s, c, ncols;
+  double U[EPA_MAX_STATES * EPA_MAX_STATES];
+  double Ui[EPA_MAX_STATES * EPA_MAX_STATES];
+  double lam[EPA_MAX_STATES];
+  double pi[EPA_MAX_STATES];
+  double rate[EPA_MAX_CATS];
+  double w[EPA_MAX_CATS];
+  uint32_t colmask[EPA_MAX_COLS];  // lookup column -> state set
+  // eigen-space image of each column's 0/1 tip vector: qt[col][x] = sum_{m in mask} Ui[x][m]
+  double qt[EPA_MAX_COLS * EPA_MAX_STATES];
+};
+
+struct EvTimer {
+  hipEvent_t a = nullptr, b = nullptr;
+  bool valid = false;
+};
+
+struct epa_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  int s = 0, c = 0, ncols = 0;
+  uint32_t W = 0, B = 0;
+  ModelDev hmodel;          // host copy
+  ModelDev* dmodel = nullptr;
+  ModelDNA dna;             // valid when s == 4 && c == 4
+  BloConsts blo;
+  int aa_x_as_n = 0;
+
+  // HBM-resident reference data
+  //   refT   [2B][c*s][W]  eigen-transformed CLVs, component-major (side 0 proximal, 1 distal)
+  //   scSum  [B][W]        prox + dist per-site scaler counts
+  //   blen   [B]
+  //   lookup [B][W][ncols]
+  double* refT = nullptr;
+  uint32_t* scSum = nullptr;
+  double* blen = nullptr;
+  double* lookup = nullptr;
+  bool lookup_built = false;
+  std::vector<double> h_blen;
+
+  // per-call scratch (grown on demand)
+  void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t scratch_sz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  EvTimer t_lookup, t_preplace, t_thorough, t_select;
+  epa_thorough_stats last_stats{};
+};
+
+// ---- helpers (epa_dev.hip)
+int epa_fail(epa_ctx* ctx, int code, const std::string& msg);
+void* epa_scratch(epa_ctx* ctx, int slot, size_t bytes);
+bool epa_is_device_ptr(const void* p);
+// returns a device pointer holding `bytes` of *p (copying into scratch slot if p is on the host)
+const void* epa_to_device(epa_ctx* ctx, int slot, const void* p, size_t bytes);
+void epa_timer_start(epa_ctx* ctx, EvTimer& t);
+void epa_timer_stop(epa_ctx* ctx, EvTimer& t);
+
+#define EPA_HIP(ctx, call)                                                               \
+  do {                                                                                    \
+    hipError_t e__ = (call);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      return epa_fail(ctx, EPA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+// ---- kernel launchers
+int launch_transform(epa_ctx* ctx, const double* d_clv_or_null, const uint8_t* d_tip_or_null,
+                     const uint32_t* d_tipmap, uint32_t tipmap_size, double* dst);
+int launch_build_lookup(epa_ctx* ctx);
+int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* h_begin,
+                    const uint32_t* h_span, const uint32_t* d_begin, const uint32_t* d_span,
+                    uint32_t Q, double* d_lnl);
+int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
+                    const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
+                    epa_result* d_out, unsigned long long* d_stats);
+int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshold,
+                  epa_pair* d_pairs, uint64_t max_pairs, uint64_t* n_pairs);

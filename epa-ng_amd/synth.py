@@ -1,0 +1,157 @@
+"""Deterministic synthetic workloads for the benchmark / parity configs of BASELINE.json
+(SURVEY.md section 8d): random-join reference tree, MSA simulated down that tree under the
+model (so multi-round branch-length optimisation is exercised), and short reads cut from tip
+sequences with substitutions.  Pure numpy; data generation only, no likelihood code."""
+import math
+
+import numpy as np
+
+DNA = "ACGT"
+AA = "ARNDCQEGHILKMFPSTWYV"
+
+# model string pinned by the reference's test/src/parse_model.cpp:10-11
+CFG2_SUBST = [0.787874, 1.821672, 1.294006, 0.698421, 3.034135, 1.0]
+CFG2_FREQS = [0.256465, 0.222535, 0.308594, 0.212406]
+CFG2_ALPHA = 0.478218
+
+
+def rate_matrix(subst, freqs):
+    s = len(freqs)
+    f = np.asarray(freqs, float)
+    R = np.zeros((s, s))
+    R[np.triu_indices(s, 1)] = subst
+    R = R + R.T
+    Q = R * f[None, :]
+    np.fill_diagonal(Q, 0.0)
+    np.fill_diagonal(Q, -Q.sum(1))
+    Q /= -(f * np.diag(Q)).sum()
+    return Q
+
+
+def pmatrix(Q, freqs, t):
+    """exp(Qt) through the symmetrised eigen-decomposition (data generation only)."""
+    sq = np.sqrt(np.asarray(freqs, float))
+    A = Q * sq[:, None] / sq[None, :]
+    A = 0.5 * (A + A.T)
+    w, V = np.linalg.eigh(A)
+    P = (V * np.exp(w * t)[None, :]) @ V.T
+    P = P * sq[None, :] / sq[:, None]
+    P = np.clip(P, 0.0, None)
+    return P / P.sum(1, keepdims=True)
+
+
+class Node:
+    __slots__ = ("kids", "label", "length")
+
+    def __init__(self, label=None):
+        self.kids, self.label, self.length = [], label, 0.0
+
+
+def random_tree(n_tips, seed, mean_bl=0.05, lo=1e-4, hi=1.0):
+    """random-join topology; branch lengths Exp(mean) clamped to [lo, hi]; top trifurcation."""
+    rng = np.random.RandomState(seed)
+    pool = [Node("t%d" % i) for i in range(n_tips)]
+    for nd in pool:
+        nd.length = float(min(max(rng.exponential(mean_bl), lo), hi))
+    while len(pool) > 3:
+        i, j = sorted(rng.choice(len(pool), 2, replace=False))
+        b = pool.pop(j)
+        a = pool.pop(i)
+        p = Node()
+        p.kids = [a, b]
+        p.length = float(min(max(rng.exponential(mean_bl), lo), hi))
+        pool.append(p)
+    root = Node()
+    root.kids = pool
+    return root
+
+
+def newick(root):
+    out = []
+
+    def rec(n):
+        if n.kids:
+            out.append("(")
+            for i, k in enumerate(n.kids):
+                if i:
+                    out.append(",")
+                rec(k)
+            out.append(")")
+        else:
+            out.append(n.label)
+        if n is not root:
+            out.append(":%r" % n.length)
+
+    import sys
+    sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
+    rec(root)
+    out.append(";")
+    return "".join(out)
+
+
+def simulate_msa(root, W, subst, freqs, cat_rates, seed):
+    """-> (labels, sequences) for the tips, simulated down the tree."""
+    rng = np.random.RandomState(seed)
+    s = len(freqs)
+    alphabet = DNA if s == 4 else AA
+    Q = rate_matrix(subst, freqs)
+    cats = rng.randint(0, len(cat_rates), W)
+    root_states = rng.choice(s, W, p=np.asarray(freqs) / np.sum(freqs))
+    labels, seqs = [], []
+    stack = [(root, root_states)]
+    while stack:
+        node, st = stack.pop()
+        if not node.kids:
+            labels.append(node.label)
+            seqs.append("".join(alphabet[i] for i in st))
+            continue
+        for k in node.kids:
+            child = np.empty(W, np.int64)
+            u = rng.random_sample(W)
+            for c, r in enumerate(cat_rates):
+                idx = np.nonzero(cats == c)[0]
+                if not len(idx):
+                    continue
+                cdf = np.cumsum(pmatrix(Q, freqs, k.length * r), axis=1)
+                child[idx] = (u[idx, None] > cdf[st[idx]]).sum(1).clip(0, s - 1)
+            stack.append((k, child))
+    order = np.argsort([int(l[1:]) for l in labels])
+    return [labels[i] for i in order], [seqs[i] for i in order]
+
+
+def make_reads(seqs, n_reads, read_len, sub_rate, seed, states=4):
+    """reads = read_len consecutive columns of a random tip sequence, sub_rate random
+    substitutions, every other column '-'."""
+    rng = np.random.RandomState(seed)
+    alphabet = DNA if states == 4 else AA
+    W = len(seqs[0])
+    tips = rng.randint(0, len(seqs), n_reads)
+    starts = rng.randint(0, W - read_len + 1, n_reads)
+    arr = np.frombuffer("".join(seqs).encode(), dtype=np.uint8).reshape(len(seqs), W)
+    out = np.full((n_reads, W), ord("-"), np.uint8)
+    alpha = np.frombuffer(alphabet.encode(), dtype=np.uint8)
+    cols = starts[:, None] + np.arange(read_len)[None, :]
+    frag = arr[tips[:, None], cols]
+    mut = rng.random_sample(frag.shape) < sub_rate
+    frag = np.where(mut, alpha[rng.randint(0, len(alpha), frag.shape)], frag)
+    out[np.arange(n_reads)[:, None], cols] = frag
+    return [row.tobytes().decode() for row in out], starts
+
+
+def gamma_rates(alpha, k=4):
+    """Yang-1994 mean discretisation (scipy; data generation only)."""
+    from scipy.stats import gamma as g
+    d, d1 = g(alpha, scale=1.0 / alpha), g(alpha + 1.0, scale=1.0 / alpha)
+    cuts = [0.0] + [d.ppf(i / k) for i in range(1, k)] + [math.inf]
+    return np.array([k * (d1.cdf(cuts[i + 1]) - d1.cdf(cuts[i])) for i in range(k)])
+
+
+def dna_workload(n_tips=512, W=1500, n_reads=100000, read_len=150, seeds=(1, 2, 3)):
+    """cfg2 of BASELINE.json."""
+    root = random_tree(n_tips, seeds[0])
+    rates = gamma_rates(CFG2_ALPHA)
+    labels, seqs = simulate_msa(root, W, CFG2_SUBST, CFG2_FREQS, rates, seeds[1])
+    reads, _ = make_reads(seqs, n_reads, read_len, 0.03, seeds[2])
+    return {"newick": newick(root), "labels": labels, "seqs": seqs, "reads": reads,
+            "states": 4, "subst": CFG2_SUBST, "freqs": CFG2_FREQS, "rates": rates,
+            "weights": np.full(4, 0.25)}

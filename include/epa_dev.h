@@ -1,0 +1,198 @@
+/*
+ * epa_dev.h -- C-ABI of the MI355X placement evaluator (libepa_dev.so).
+ *
+ * This is the drop-in boundary for EPA-ng's placement hot path.  The reference has no FFI for
+ * this path; the seam is the pair of static templates called from the chunk loop
+ *     place(chunk, tree, branches, preplace, options, lookups)            src/core/place.cpp:41-95,221
+ *     place_thorough(blo_work, chunk, tree, branches, blo_sample, ...)    src/core/place.cpp:97-171,234
+ * and, below them, the per-branch evaluator
+ *     Tiny_Tree::Tiny_Tree(edge, branch_id, Tree&, opt_branches, ...)     src/tree/Tiny_Tree.cpp:48-129
+ *     Placement Tiny_Tree::place(const Sequence&)                         src/tree/Tiny_Tree.cpp:131-218
+ * together with the libpll / pll-modules calls they wrap.
+ * Paths are relative to the reference checkout.  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types; every `const T*` data argument may be a host pointer or a
+ *    device (HBM) pointer -- the library inspects it (hipPointerGetAttributes) and copies only
+ *    when it lives on the host.  Outputs follow the same rule.
+ *  - all likelihood arithmetic is fp64.
+ *  - every entry point returns EPA_OK or a negative epa_status; epa_dev_last_error() returns
+ *    the message the reference would have thrown (std::runtime_error text) where one exists.
+ *  - one epa_ctx per GPU; a ctx is thread-compatible (one caller at a time), entry points are
+ *    called once per chunk, outside any OpenMP region.
+ */
+#ifndef EPA_DEV_H
+#define EPA_DEV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct epa_ctx epa_ctx;
+
+typedef enum {
+  EPA_OK = 0,
+  EPA_ERR_INVALID_ARG = -1,   /* bad descriptor / null pointer / unsupported shape            */
+  EPA_ERR_HIP = -2,           /* HIP runtime failure (message carries hipGetErrorString)       */
+  EPA_ERR_NO_DEVICE = -3,     /* no gfx950 device visible: there is NO CPU fallback            */
+  EPA_ERR_QUERY_WIDTH = -4,   /* "Query sequence length not same as reference alignment!"      *
+                               *   Tiny_Tree.cpp:145-147                                       */
+  EPA_ERR_QUERY_ALL_GAP = -5, /* "... does not appear to have any non-gap sites!" :153-156     */
+  EPA_ERR_INVALID_CHAR = -6,  /* "char is invalid!" Lookup_Store.hpp:100-108 (quirk D5: the     *
+                               *   reference does not validate; this library does on ingest)   */
+  EPA_ERR_NEG_INF = -7,       /* "-INF logl at branch ..." Tiny_Tree.cpp:209-212               */
+  EPA_ERR_UNSUPPORTED = -8    /* feature marked "next" in SURVEY.md section 8f                 */
+} epa_status;
+
+/* flags of epa_ref_desc.flags */
+#define EPA_FLAG_SLIDING_BLO 0x1u  /* Options::sliding_blo (default on, src/util/Options.hpp:16) */
+
+/*
+ * Reference-side inputs: what Tiny_Tree's constructor pulls out of `Tree` per branch
+ * (Tree::get_clv for the proximal and distal node, their scalers, the branch length:
+ * src/tree/tiny_util.cpp:72-199) plus the model arrays the tiny partition shares by pointer
+ * (:109-163).  Arrays use libpll's layouts: CLV [site][rate_cat][state] fp64, scaler
+ * uint32[site] (per-site scaling; per-rate scalers = PLL_ATTRIB_RATE_SCALERS are "next").
+ * Branch b is EPA-ng's branch_id == jplace edge_num (utree_query_branches order,
+ * src/core/pll/pll_util.cpp:182-205).  Orientation is the caller's job exactly as in
+ * Tiny_Tree.cpp:64-74: when one end of the branch is a tip it is passed as the DISTAL side.
+ */
+typedef struct {
+  uint32_t states;     /* 4 (DNA) or 20 (AA)                                                   */
+  uint32_t rate_cats;  /* number of rate categories c                                          */
+  uint32_t sites;      /* alignment width W after column pre-masking                           */
+  uint32_t branches;   /* B = 2n-3                                                             */
+
+  /* eigen system of the (single) rate matrix:  P(t) = U diag(exp(eigenvals r_k t)) U^-1.
+   * libpll stores U as `inv_eigenvecs` and U^-1 as `eigenvecs` (pll_update_eigen).           */
+  const double* eigenvals;   /* [states]                                                       */
+  const double* eigenvecs_u; /* [states*states] row-major U                                    */
+  const double* eigenvecs_uinv; /* [states*states] row-major U^-1                              */
+  const double* freqs;       /* [states] stationary frequencies                                */
+  const double* rates;       /* [rate_cats]                                                    */
+  const double* rate_weights;/* [rate_cats]                                                    */
+  double prop_invar;         /* must be 0.0 (+I is "next")                                     */
+
+  /* per branch: B pointers each */
+  const double* const* prox_clv;       /* [B] -> [W][c][s]                                     */
+  const uint32_t* const* prox_scaler;  /* [B] -> [W], entry or whole array may be NULL (= 0)   */
+  const double* const* dist_clv;       /* [B] -> [W][c][s]; NULL where dist_tipchars[b] is set */
+  const uint8_t* const* dist_tipchars; /* [B] -> [W] tip codes (index into tipmap); may be NULL */
+  const uint32_t* const* dist_scaler;  /* [B] -> [W], NULL for tips                            */
+  const double* branch_length;         /* [B] original branch length                           */
+
+  /* tip code -> state set (pll_map_nt / pll_map_aa semantics): bit i = state i allowed.
+   * Used for dist_tipchars only; query codes are lookup columns, see epa_dev_preplace.        */
+  const uint32_t* tipmap;
+  uint32_t tipmap_size;
+
+  /* constants of the branch-length optimiser.  They live in headers absent from the reference
+   * tree (pll_optimize.h), hence runtime parameters; 0 selects the default in brackets.       */
+  double blo_min_branch;     /* PLLMOD_OPT_MIN_BRANCH_LEN      [1e-4]  optimize.hpp:11          */
+  double blo_max_branch;     /* PLLMOD_OPT_MAX_BRANCH_LEN      [100]   optimize.hpp:12          */
+  double blo_default_branch; /* PLLMOD_OPT_DEFAULT_BRANCH_LEN  [0.1]   optimize.cpp:143         */
+  double blo_epsilon;        /* OPT_BRANCH_EPSILON             [0.1]   optimize.hpp:9           */
+  double pendant_default;    /* DEFAULT_BRANCH_LENGTH          [-ln 0.9] util/constants.hpp:12  */
+  uint32_t blo_max_rounds;   /* smoothings                     [32]    optimize.cpp:269         */
+  uint32_t blo_max_newton;   /* max_iters                      [30]    optimize.cpp:62          */
+  uint32_t flags;            /* EPA_FLAG_*; 0 selects EPA_FLAG_SLIDING_BLO                     */
+  uint32_t aa_x_as_n;        /* 1: reproduce quirk D4 (AA 'X' preplaced in the 'N' column,      *
+                              *    Lookup_Store.hpp:63-66); 0 (default): 'X' = any             */
+} epa_ref_desc;
+
+/* one unit of Work (src/core/Work.hpp:31-34 Work_Pair) */
+typedef struct {
+  uint32_t branch_id;
+  uint32_t seq_id; /* index into the chunk's queries */
+} epa_pair;
+
+/* one Placement minus the LWR (src/sample/Placement.hpp:48-53) */
+typedef struct {
+  double lnl;
+  double pendant_length;
+  double distal_length;
+} epa_result;
+
+/* Counters of the last epa_dev_thorough call (optional diagnostics). */
+typedef struct {
+  uint64_t pairs;
+  uint64_t rounds;       /* outer pplacer rounds over all pairs                               */
+  uint64_t newton_evals; /* derivative evaluations over all pairs                             */
+  uint64_t reverts;      /* pairs that hit the "worse -> restore" exit, optimize.cpp:224-232  */
+} epa_thorough_stats;
+
+/* Number of GPUs visible (0 => every other entry point fails with EPA_ERR_NO_DEVICE). */
+int epa_dev_device_count(void);
+
+/*
+ * Replaces: Tree::get_clv + make_tiny_partition + make_tiny_tree_structure for every branch
+ * (src/tree/tiny_util.cpp:72-306) -- copies the reference data to HBM once, transformed into the
+ * eigenbasis of the model -- and the per-branch part of Tiny_Tree::Tiny_Tree + Lookup_Store
+ * (src/tree/Tiny_Tree.cpp:88-128, src/core/Lookup_Store.hpp:73-81): the per-branch per-site
+ * lookup tables are built on device by epa_dev_build_lookup (called lazily by preplace).
+ */
+int epa_dev_create(const epa_ref_desc* desc, int device, epa_ctx** out);
+void epa_dev_destroy(epa_ctx* ctx);
+const char* epa_dev_last_error(const epa_ctx* ctx); /* ctx may be NULL: last create() error */
+
+/* Optional: run all kernels of `ctx` on this hipStream_t (passed as void*). Default stream 0. */
+int epa_dev_set_stream(epa_ctx* ctx, void* hip_stream);
+
+/* Builds T[b][site][col] for all branches (idempotent).  Replaces precompute_sites_static x C
+ * + Lookup_Store::init_branch (Tiny_Tree.cpp:18-46,114-128). */
+int epa_dev_build_lookup(epa_ctx* ctx);
+
+/*
+ * Query encoding (one byte per site, Q x W row-major): the lookup-column index of the
+ * character, i.e. the position in NT_MAP / AA_MAP (src/util/maps.hpp:9-31; for DNA this is the
+ * 4-bit code of the .bfast format, src/io/encoding.hpp) after the normalisation of
+ * Lookup_Store's constructor (Lookup_Store.hpp:33-68).  epa_encode_queries() produces it from
+ * ASCII.  win_begin/win_span = get_valid_range() per query (src/util/Range.hpp:34-49), or
+ * (0, W) when premasking is off.
+ */
+
+/* ASCII -> column codes + windows on the host.  seqs: Q pointers to W characters each.
+ * Returns EPA_OK, EPA_ERR_INVALID_CHAR or EPA_ERR_QUERY_ALL_GAP (first offender in *bad_query). */
+int epa_encode_queries(uint32_t states, uint32_t sites, uint32_t Q, const char* const* seqs,
+                       int premasking, int aa_x_as_n, uint8_t* codes, uint32_t* win_begin,
+                       uint32_t* win_span, uint32_t* bad_query);
+
+/*
+ * Replaces place() (src/core/place.cpp:41-95): lnl[q*B + b] = sum over the query's window of
+ * T[b][site][code(q,site)]  (Lookup_Store::sum_precomputed_sitelk, Lookup_Store.hpp:110-141,
+ * same summation order).  pendant = pendant_default and distal = branch_length/2 are implied.
+ */
+int epa_dev_preplace(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_begin,
+                     const uint32_t* win_span, uint32_t Q, double* lnl);
+
+/*
+ * Replaces place_thorough() (src/core/place.cpp:97-171) = Tiny_Tree::place with opt_branches
+ * (Tiny_Tree.cpp:159-204) -> call_focused(optimize_branch_triplet) -> opt_branch_lengths_pplacer
+ * (src/core/pll/optimize.cpp:60-286).  One result per pair, in pair order.  `stats` may be NULL.
+ */
+int epa_dev_thorough(epa_ctx* ctx, const epa_pair* pairs, uint64_t n_pairs,
+                     const uint8_t* q_codes, const uint32_t* win_begin, const uint32_t* win_span,
+                     uint32_t Q, epa_result* out, epa_thorough_stats* stats);
+
+/*
+ * Replaces apply_heuristic() for the default dynamic heuristic (src/core/heuristics.hpp:119-127,
+ * until_accumulated_reached src/set_manipulators.cpp:90-114) on device, so the Q x B table never
+ * leaves HBM: per query, branches in descending LWR order until the accumulated LWR reaches
+ * `threshold` (the crossing element included).  lnl is the Q x B table of epa_dev_preplace.
+ * Writes at most max_pairs pairs, branch-major sorted (Work iteration order); *n_pairs receives
+ * the number selected (if larger than max_pairs the call fails with EPA_ERR_INVALID_ARG).
+ */
+int epa_dev_select_candidates(epa_ctx* ctx, const double* lnl, uint32_t Q, double threshold,
+                              epa_pair* pairs, uint64_t max_pairs, uint64_t* n_pairs);
+
+/* duration in milliseconds of the last launch of the named kernel family on ctx's stream,
+ * measured with HIP events ("preplace", "thorough", "lookup", "select"); < 0 if never run. */
+double epa_dev_last_kernel_ms(const epa_ctx* ctx, const char* which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EPA_DEV_H */

@@ -1,0 +1,170 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI of libepa_dev.so) against the CPU
+oracle on the same inputs, and against the committed golden vectors.
+Tolerances: per-branch lnL |delta| <= 1e-6 (BASELINE.json north_star); lengths 1e-6 relative."""
+import numpy as np
+import pytest
+
+import epa_ng_amd as epa
+from golden_util import CASES, load_case
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+
+LNL_TOL = 1e-6
+TIPMAP_NT = np.arange(16, dtype=np.uint32)
+
+
+def oracle_of(g):
+    labels = [a for a, _ in g["msa"]]
+    seqs = [b for _, b in g["msa"]]
+    return Oracle(g["newick"], labels, seqs, g["states"], g["subst"], g["freqs"], g["gamma_rates"])
+
+
+def evaluator_from_oracle(o, rates, freqs):
+    """feeds the device with the oracle's reference-side CLVs (tests the kernels in isolation;
+    test_gpu_pipeline.py feeds it from the product's own host precompute instead)"""
+    ev, u, ui = o.eigen()
+    pc, ps, dc, ds, bl = [], [], [], [], []
+    for b in range(o.B):
+        cp, sp, cd, sd = o.branch_sides(b)
+        pc.append(cp); ps.append(sp); dc.append(cd); ds.append(sd)
+        bl.append(o.branch_info(b)[0])
+    return epa.Evaluator(o.s, rates, np.full(len(rates), 1.0 / len(rates)), ev, u, ui, freqs, bl,
+                         pc, dc, ps, ds)
+
+
+def all_pairs(B, Q):
+    p = np.zeros(B * Q, epa.PAIR_DTYPE)
+    p["branch_id"] = np.repeat(np.arange(B), Q)
+    p["seq_id"] = np.tile(np.arange(Q), B)
+    return p
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c.startswith("dna")])
+def test_golden_dna(case):
+    g = load_case(case)
+    o = oracle_of(g)
+    e = evaluator_from_oracle(o, g["gamma_rates"], g["freqs"])
+    qs = [q["seq"] for q in g["queries"]]
+    codes, wb, ws = epa.encode_queries(4, qs)
+    lnl = e.preplace(codes, wb, ws)
+    exp = np.array(g["preplace"])
+    assert np.max(np.abs(lnl - exp)) < LNL_TOL
+    assert np.max(np.abs(lnl - o.preplace(qs))) < LNL_TOL
+    pairs = all_pairs(o.B, len(qs))
+    res = e.thorough(pairs, codes, wb, ws)
+    olnl, open_, odis = o.thorough(pairs["branch_id"], pairs["seq_id"], qs)
+    assert np.max(np.abs(res["lnl"] - olnl)) < LNL_TOL
+    assert np.max(np.abs(res["pendant_length"] - open_) / np.maximum(1.0, open_)) < 1e-6
+    assert np.max(np.abs(res["distal_length"] - odis)) < 1e-6
+    for i, p in enumerate(pairs):
+        gold = g["thorough"][p["seq_id"]][p["branch_id"]]
+        assert abs(res["lnl"][i] - gold["lnl"]) < LNL_TOL
+    assert e.last_stats["reverts"] == o.last_stats["reverts"]
+    assert e.last_stats["rounds"] == o.last_stats["rounds"]
+    assert e.last_stats["newton_evals"] == o.last_stats["newton_evals"]
+
+
+def synth_case(n_tips, W, n_reads, read_len, seeds=(1, 2, 3)):
+    from epa_ng_amd import synth
+    return synth.dna_workload(n_tips, W, n_reads, read_len, seeds)
+
+
+def test_synthetic_64tips_preplace_thorough_select():
+    w = synth_case(64, 600, 700, 150, seeds=(5, 6, 7))
+    o = Oracle(w["newick"], w["labels"], w["seqs"], 4, w["subst"], w["freqs"], w["rates"])
+    e = evaluator_from_oracle(o, w["rates"], w["freqs"])
+    reads = w["reads"]
+    codes, wb, ws = epa.encode_queries(4, reads)
+    lnl = e.preplace(codes, wb, ws)
+    olnl = o.preplace(reads)
+    assert np.max(np.abs(lnl - olnl)) < LNL_TOL
+    # bit-exact: the kernel sums in the reference's association order from the same table
+    # only if the table is bit-identical, which it is not required to be; report the max ulp
+    # candidate selection == numpy restatement of the dynamic heuristic on the SAME table
+    pairs = e.select(lnl, len(reads), 0.99999)
+    exp_pairs = []
+    for q in range(len(reads)):
+        row = lnl[q]
+        lw = np.exp(row - row.max())
+        lw /= lw.sum()
+        order = np.lexsort((np.arange(len(row)), -row))
+        s = 0.0
+        for b in order:
+            if not s < 0.99999:
+                break
+            s += lw[b]
+            exp_pairs.append((b, q))
+    exp_pairs.sort()
+    got = sorted((int(p["branch_id"]), int(p["seq_id"])) for p in pairs)
+    assert got == exp_pairs
+    assert np.all(np.diff(pairs["branch_id"].astype(np.int64)) >= 0)  # branch-major order
+    res = e.thorough(pairs, codes, wb, ws)
+    tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
+    assert np.max(np.abs(res["lnl"] - tl)) < LNL_TOL
+    assert np.max(np.abs(res["pendant_length"] - tp) / np.maximum(1.0, tp)) < 1e-6
+    assert np.max(np.abs(res["distal_length"] - td)) < 1e-6
+    assert e.last_stats["rounds"] == o.last_stats["rounds"]
+    assert e.last_stats["reverts"] == o.last_stats["reverts"]
+    # reference sanity ranges (test/src/Tiny_Tree.cpp:39-48)
+    bl = np.array([o.branch_info(int(b))[0] for b in pairs["branch_id"]])
+    assert np.all(np.isfinite(res["lnl"])) and np.all(res["pendant_length"] > 0)
+    assert np.all(res["distal_length"] > 0) and np.all(res["distal_length"] < bl)
+
+
+def test_ragged_windows_and_tails():
+    # windows of every length 1..200 (exercises the group-of-4 / singles tail and NCH 1..4)
+    w = synth_case(16, 400, 8, 100, seeds=(11, 12, 13))
+    o = Oracle(w["newick"], w["labels"], w["seqs"], 4, w["subst"], w["freqs"], w["rates"])
+    e = evaluator_from_oracle(o, w["rates"], w["freqs"])
+    base = w["seqs"][3]
+    W = len(base)
+    qs = []
+    for n in list(range(1, 40)) + [63, 64, 65, 127, 128, 129, 160, 161, 191, 192, 193, 255, 256, 400]:
+        st = (n * 7) % (W - n + 1)
+        qs.append("-" * st + base[st:st + n] + "-" * (W - st - n))
+    codes, wb, ws = epa.encode_queries(4, qs)
+    lnl = e.preplace(codes, wb, ws)
+    assert np.max(np.abs(lnl - o.preplace(qs))) < LNL_TOL
+    pairs = all_pairs(o.B, len(qs))
+    res = e.thorough(pairs, codes, wb, ws)
+    tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], qs)
+    assert np.max(np.abs(res["lnl"] - tl)) < LNL_TOL
+    assert np.max(np.abs(res["distal_length"] - td)) < 1e-6
+
+
+def test_errors_are_loud():
+    w = synth_case(8, 100, 2, 50, seeds=(21, 22, 23))
+    o = Oracle(w["newick"], w["labels"], w["seqs"], 4, w["subst"], w["freqs"], w["rates"])
+    e = evaluator_from_oracle(o, w["rates"], w["freqs"])
+    with pytest.raises(epa.EpaError):
+        epa.encode_queries(4, ["-" * 100])
+    with pytest.raises(epa.EpaError):
+        epa.encode_queries(4, ["J" + "A" * 99])
+    codes, wb, ws = epa.encode_queries(4, w["reads"])
+    ws_bad = ws.copy(); ws_bad[0] = 0
+    with pytest.raises(epa.EpaError):
+        e.preplace(codes, wb, ws_bad)
+    bad = np.zeros(1, epa.PAIR_DTYPE); bad["branch_id"] = 10 ** 6
+    with pytest.raises(epa.EpaError):
+        e.thorough(bad, codes, wb, ws)
+
+
+def test_scaling_deep_tree():
+    # 300 tips with long branches: CLV entries underflow 2^-256 -> per-site scalers are live
+    from epa_ng_amd import synth
+    root = synth.random_tree(300, 31, mean_bl=0.6, hi=3.0)
+    rates = synth.gamma_rates(0.5)
+    labels, seqs = synth.simulate_msa(root, 200, synth.CFG2_SUBST, synth.CFG2_FREQS, rates, 32)
+    reads, _ = synth.make_reads(seqs, 40, 120, 0.05, 33)
+    o = Oracle(synth.newick(root), labels, seqs, 4, synth.CFG2_SUBST, synth.CFG2_FREQS, rates)
+    nsc = sum(int(o.branch_sides(b)[1].sum() + o.branch_sides(b)[3].sum()) for b in range(0, o.B, 50))
+    assert nsc > 0, "test is vacuous: no scaling happened"
+    e = evaluator_from_oracle(o, rates, synth.CFG2_FREQS)
+    codes, wb, ws = epa.encode_queries(4, reads)
+    lnl = e.preplace(codes, wb, ws)
+    assert np.max(np.abs(lnl - o.preplace(reads))) < LNL_TOL
+    pairs = e.select(lnl, len(reads), 0.99999)
+    res = e.thorough(pairs, codes, wb, ws)
+    tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
+    assert np.max(np.abs(res["lnl"] - tl)) < LNL_TOL
