@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Benchmark of the placement hot path on MI355X (contract: see the task's bench.py section).
+
+Metric (BASELINE.json): query placements/sec, 512-tip GTR+G4 DNA reference, preplace + thorough.
+Workload = cfg2 of SURVEY.md section 8d: 512-tip random-join tree (seed 1), 1500-column MSA
+simulated on that tree (seed 2), 150 bp reads with 3 % substitutions (seed 3 + 1000*rank),
+dynamic heuristic 0.99999.  A "step" is one chunk of --chunk reads through
+    preplace (Q x B lookup sums) -> candidate selection -> thorough NR placement
+with the encoded reads already resident in HBM; every rank works on its own reads (weak
+scaling, no data-path collective) and rank 0 gathers the per-pair results over RCCL.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps 5 --warmup 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == matrix peak (spec); the kernel is fp64 VALU
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--chunk", type=int, default=20000, help="reads per step (EPA-ng --chunk-size)")
+    p.add_argument("--tips", type=int, default=512)
+    p.add_argument("--width", type=int, default=1500)
+    p.add_argument("--read-len", type=int, default=150)
+    p.add_argument("--cpu-sample", type=int, default=1500, help="reads timed on the CPU baseline")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    import epa_ng_amd as epa
+    from epa_ng_amd import hostlib, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path is the only compute path")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+
+    # ---------------- workload (identical reference on every rank, rank-private reads)
+    n_chunks = a.steps + a.warmup
+    root = synth.random_tree(a.tips, 1)
+    rates = synth.gamma_rates(synth.CFG2_ALPHA)
+    labels, seqs = synth.simulate_msa(root, a.width, synth.CFG2_SUBST, synth.CFG2_FREQS, rates, 2)
+    newick = synth.newick(root)
+    reads, _ = synth.make_reads(seqs, n_chunks * a.chunk, a.read_len, 0.03, 3 + 1000 * rank)
+    ref = hostlib.Reference(newick, labels, seqs, states=4, subst=synth.CFG2_SUBST,
+                            freqs=synth.CFG2_FREQS, rates=rates)
+    ev = ref.evaluator(device=local)
+    t0 = time.time()
+    ev.build_lookup()
+    torch.cuda.synchronize()
+    lookup_ms = ev.kernel_ms("lookup")
+    B, W, Q = ref.B, ref.W, a.chunk
+
+    chunks = []
+    for c in range(n_chunks):
+        codes, wb, ws = epa.encode_queries(4, reads[c * Q:(c + 1) * Q])
+        chunks.append((torch.from_numpy(codes).to(dev), torch.from_numpy(wb.view(np.int32)).to(dev),
+                       torch.from_numpy(ws.view(np.int32)).to(dev), codes, wb, ws))
+    cap = Q * 64   # pair capacity per step (dynamic heuristic selects a handful per read)
+    d_lnl = torch.empty((Q, B), dtype=torch.float64, device=dev)
+    d_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+    d_res = torch.zeros((cap, 3), dtype=torch.float64, device=dev)
+    gather_list = None
+    if world > 1 and rank == 0:
+        gather_list = [torch.empty_like(d_res) for _ in range(world)]
+
+    th_ms, th_pairs, th_rounds, th_evals, pre_ms, sel_ms = [], [], [], [], [], []
+
+    def step(i, record):
+        dc, dwb, dws = chunks[i][0], chunks[i][1], chunks[i][2]
+        ev.preplace(dc, dwb, dws, Q=Q, out=d_lnl)
+        n = ev.select(d_lnl, Q, 0.99999, max_pairs=cap, out=d_pairs)
+        ev.thorough(d_pairs, dc, dwb, dws, Q=Q, n_pairs=n, out=d_res)
+        if world > 1:
+            dist.gather(d_res, gather_list, dst=0)   # the path's only exchange: results -> rank 0
+        if record:
+            th_ms.append(ev.kernel_ms("thorough")); pre_ms.append(ev.kernel_ms("preplace"))
+            sel_ms.append(ev.kernel_ms("select"))
+            th_pairs.append(n); th_rounds.append(ev.last_stats["rounds"])
+            th_evals.append(ev.last_stats["newton_evals"])
+        return n
+
+    for i in range(a.warmup):
+        step(i, False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, n_chunks):
+        step(i, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_reads = world * a.steps * Q
+    value = total_reads / elapsed
+    # ---------------- roofline of the dominant kernel (thorough NR), per launch
+    pairs = float(np.mean(th_pairs))
+    R = float(np.sum(th_rounds)) / float(np.sum(th_pairs))
+    kbar = float(np.sum(th_evals)) / max(1.0, 2.0 * float(np.sum(th_rounds)))
+    nq = a.read_len
+    flops_pair = nq * (884.0 + R * (1258.0 + 240.0 * kbar))
+    bytes_pair = 2 * nq * 16 * 8 + 2 * nq * 4 + nq + 24
+    t_th = float(np.mean(th_ms)) * 1e-3
+    ach_tflops = pairs * flops_pair / t_th / 1e12
+    roof = {"bound": "mfma", "kernel": "k_thorough_dna", "achieved": round(ach_tflops, 3),
+            "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tflops / FP64_PEAK_TFLOPS, 4),
+            "traffic": None,
+            "note": "fp64 VALU kernel priced against the fp64 vector=matrix peak (78.6 TF spec)",
+            "pairs_per_launch": pairs, "rounds_per_pair": round(R, 3), "newton_iters_per_solve": round(kbar, 3),
+            "flops_per_pair": round(flops_pair), "ms_per_launch": round(t_th * 1e3, 4),
+            "hbm_algorithmic_GBs": round(pairs * bytes_pair / t_th / 1e9, 1),
+            "hbm_frac": round(pairs * bytes_pair / t_th / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # ---------------- CPU baseline: the oracle's OpenMP restatement on a bounded sample
+    cpu = None
+    parity = None
+    if not a.no_cpu_baseline:
+        from oracle_lib import Oracle, lib as orc_lib
+        ns = min(a.cpu_sample, Q)
+        sample = reads[a.warmup * Q: a.warmup * Q + ns]
+        o = Oracle(newick, labels, seqs, 4, synth.CFG2_SUBST, synth.CFG2_FREQS, rates)
+        o.preplace(sample[:8])                      # builds the per-branch lookups (one-off)
+        codes, wb, ws = epa.encode_queries(4, sample)
+        lnl_gpu = ev.preplace(codes, wb, ws)
+        prs = ev.select(lnl_gpu, ns, 0.99999)
+        res_gpu = ev.thorough(prs, codes, wb, ws)
+        c0 = time.perf_counter()
+        lnl_cpu = o.preplace(sample)
+        tl, tp, td = o.thorough(prs["branch_id"], prs["seq_id"], sample)
+        cpu_t = time.perf_counter() - c0
+        cores = orc_lib().orc_max_threads()
+        cpu = {"value": round(ns / cpu_t, 2), "unit": "placements/s", "cores": cores, "kind": "port",
+               "sample": "%d reads of step 0 through the oracle's OpenMP preplace (B=%d) + thorough "
+                         "(%d pairs), lookups prebuilt" % (ns, B, len(prs))}
+        parity = {"preplace_max_abs_dlnl": float(np.max(np.abs(lnl_gpu - lnl_cpu))),
+                  "thorough_max_abs_dlnl": float(np.max(np.abs(res_gpu["lnl"] - tl))),
+                  "pairs_checked": int(len(prs))}
+
+    out = {"metric": "query placements/sec (whole node), 512-tip GTR+G4 DNA ref, preplace+thorough",
+           "value": round(value, 2), "unit": "placements/s", "n_gpus": world, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "data": "synthetic",
+           "config": {"workload": "cfg2: %d-tip DNA GTR+G4 ref, W=%d, %d bp reads, dyn-heur 0.99999, "
+                                  "preplace+thorough" % (a.tips, a.width, a.read_len),
+                      "reads_per_step_per_gpu": Q, "branches": B, "parallelism": "query-shard x%d" % world,
+                      "lookup_build_ms_once": round(lookup_ms, 3),
+                      "kernel_ms_per_step": {"preplace": round(float(np.mean(pre_ms)), 3),
+                                             "select": round(float(np.mean(sel_ms)), 3),
+                                             "thorough": round(float(np.mean(th_ms)), 3)}},
+           "roofline": roof, "cpu_baseline": cpu, "parity": parity}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,5 +47,32 @@ def build_dev(force=False, verbose=False):
     return out
 
 
+HOST_SOURCES = ["model.cpp", "tree.cpp", "place.cpp", "io.cpp", "capi.cpp"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-fopenmp", "-Wall", "-Wextra", "-Wno-unused-parameter",
+              "-I", os.path.join(ROOT, "include")]
+
+
+def build_host(force=False, verbose=False):
+    """libepa_host.so (C++ host pipeline above the C-ABI) and the epa-ng-amd CLI."""
+    hdir = os.path.join(CSRC, "host")
+    out = os.path.join(HERE, "libepa_host.so")
+    exe = os.path.join(HERE, "epa-ng-amd")
+    srcs = [os.path.join(hdir, s) for s in HOST_SOURCES]
+    deps = srcs + [os.path.join(hdir, "epa_host.hpp"), os.path.join(ROOT, "include", "epa_dev.h")]
+    link = ["-L", HERE, "-lepa_dev", "-Wl,-rpath,$ORIGIN"]
+    if force or _newer(out, deps):
+        cmd = ["g++"] + HOST_FLAGS + ["-shared", "-o", out] + srcs + link
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    main = os.path.join(hdir, "main.cpp")
+    if force or _newer(exe, deps + [main, out]):
+        cmd = ["g++"] + HOST_FLAGS + ["-o", exe, main, "-L", HERE, "-lepa_host", "-lepa_dev",
+                                      "-Wl,-rpath,$ORIGIN"]
+        subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build_dev(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

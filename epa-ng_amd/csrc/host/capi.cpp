@@ -1,0 +1,160 @@
+// C API of libepa_host.so for the Python harness (tests / bench): reference precompute and the
+// full chunk loop, without any likelihood code in Python.
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "epa_host.hpp"
+
+using namespace epa;
+
+namespace {
+thread_local std::string g_err;
+struct Ref {
+  std::unique_ptr<Tree> tree;
+  Options opt;
+};
+template <class F>
+int guarded(F&& f) {
+  try { f(); return 0; }
+  catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+}  // namespace
+
+extern "C" {
+
+const char* epa_host_last_error() { return g_err.c_str(); }
+
+// model given either as descriptor string (model_desc != NULL) or explicit arrays
+void* epa_host_ref_create(const char* newick, int n_seqs, const char* const* labels,
+                          const char* const* seqs, const char* model_desc, int states,
+                          const double* subst, const double* freqs, int cats, const double* rates,
+                          const double* weights) {
+  Ref* r = nullptr;
+  if (guarded([&] {
+        MSA msa;
+        for (int i = 0; i < n_seqs; ++i) msa.emplace_back(labels[i], seqs[i]);
+        Model m = model_desc ? Model(std::string(model_desc))
+                             : Model(states, std::vector<double>(subst, subst + states * (states - 1) / 2),
+                                     std::vector<double>(freqs, freqs + states),
+                                     std::vector<double>(rates, rates + cats),
+                                     weights ? std::vector<double>(weights, weights + cats)
+                                             : std::vector<double>());
+        r = new Ref();
+        r->tree.reset(new Tree(newick, msa, m, r->opt));
+      }))
+    return nullptr;
+  return r;
+}
+
+void epa_host_ref_destroy(void* h) { delete static_cast<Ref*>(h); }
+
+void epa_host_ref_dims(void* h, uint32_t* states, uint32_t* cats, uint32_t* sites, uint32_t* branches) {
+  const Tree& t = *static_cast<Ref*>(h)->tree;
+  *states = t.model().num_states(); *cats = t.model().num_ratecats();
+  *sites = (uint32_t)t.num_sites(); *branches = (uint32_t)t.num_branches();
+}
+
+double epa_host_ref_tree_logl(void* h, uint32_t branch) {
+  return static_cast<Ref*>(h)->tree->ref_tree_logl(branch);
+}
+
+int epa_host_ref_numbered_newick(void* h, unsigned precision, char* out, size_t cap) {
+  const std::string s = static_cast<Ref*>(h)->tree->numbered_newick(precision);
+  if (s.size() + 1 > cap) return -(int)s.size();
+  std::memcpy(out, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+
+void epa_host_ref_model(void* h, double* eigenvals, double* u, double* uinv, double* freqs,
+                        double* rates, double* weights) {
+  const Model& m = static_cast<Ref*>(h)->tree->model();
+  const int s = m.num_states(), c = m.num_ratecats();
+  std::memcpy(eigenvals, m.eigenvals().data(), sizeof(double) * s);
+  std::memcpy(u, m.eigenvecs_u().data(), sizeof(double) * s * s);
+  std::memcpy(uinv, m.eigenvecs_uinv().data(), sizeof(double) * s * s);
+  std::memcpy(freqs, m.base_freqs().data(), sizeof(double) * s);
+  std::memcpy(rates, m.ratecat_rates().data(), sizeof(double) * c);
+  std::memcpy(weights, m.ratecat_weights().data(), sizeof(double) * c);
+}
+
+// borrowed pointers into the tree for branch b (for parity tests against the oracle)
+void epa_host_ref_branch(void* h, uint32_t b, const double** prox_clv, const uint32_t** prox_sc,
+                         const double** dist_clv, const uint8_t** dist_tip, const uint32_t** dist_sc,
+                         double* length) {
+  const Tree::Branch br = static_cast<Ref*>(h)->tree->branch(b);
+  *prox_clv = br.prox_clv; *prox_sc = br.prox_scaler; *dist_clv = br.dist_clv;
+  *dist_tip = br.dist_tipchars; *dist_sc = br.dist_scaler; *length = br.length;
+}
+
+uint32_t epa_host_ref_tipmap(void* h, uint32_t* out, uint32_t cap) {
+  const auto& tm = static_cast<Ref*>(h)->tree->tipmap();
+  for (uint32_t i = 0; i < tm.size() && i < cap; ++i) out[i] = tm[i];
+  return (uint32_t)tm.size();
+}
+
+// creates the device context straight from the host tree (what simple_mpi does internally)
+int epa_host_dev_create(void* h, int device, int aa_x_as_n, epa_ctx** out) {
+  const Tree& t = *static_cast<Ref*>(h)->tree;
+  epa_ref_desc d;
+  std::vector<const double*> pc, dc;
+  std::vector<const uint32_t*> ps, ds;
+  std::vector<const uint8_t*> dt;
+  std::vector<double> bl;
+  t.fill_desc(d, pc, ps, dc, dt, ds, bl);
+  d.aa_x_as_n = aa_x_as_n;
+  const int rc = epa_dev_create(&d, device, out);
+  if (rc) g_err = epa_dev_last_error(nullptr);
+  return rc;
+}
+
+// the whole pipeline: query fasta -> <outdir>/epa_result.jplace
+int epa_host_place_file(void* h, const char* query_file, const char* outdir, uint32_t chunk_size,
+                        int prescoring, double prescoring_threshold, int premasking, int device,
+                        const char* invocation, uint64_t* n_queries, uint64_t* n_pairs) {
+  return guarded([&] {
+    Ref* r = static_cast<Ref*>(h);
+    Options o = r->opt;
+    if (chunk_size) o.chunk_size = chunk_size;
+    o.prescoring = prescoring != 0;
+    if (prescoring_threshold > 0) o.prescoring_threshold = prescoring_threshold;
+    o.premasking = premasking != 0;
+    const Run_Stats st = simple_mpi(*r->tree, query_file, outdir, o, invocation ? invocation : "epa_host_place_file", device);
+    if (n_queries) *n_queries = st.queries;
+    if (n_pairs) *n_pairs = st.pairs;
+  });
+}
+
+// host-side set operations exposed for unit tests with literal vectors
+// (the reference's test/src/set_manipulators.cpp:340-443)
+int epa_host_filter(const double* lwr, uint32_t n, double thresh, int acc, uint32_t mn, uint32_t mx,
+                    uint32_t* kept_branch_ids, uint32_t* n_kept) {
+  return guarded([&] {
+    Sample s(1);
+    for (uint32_t i = 0; i < n; ++i) { s[0].emplace_back(i, 0.0, 0.0, 0.0); s[0][i].lwr(lwr[i]); }
+    Options o;
+    o.support_threshold = thresh; o.acc_threshold = acc != 0; o.filter_min = mn; o.filter_max = mx;
+    filter(s, o);
+    *n_kept = (uint32_t)s[0].size();
+    for (uint32_t i = 0; i < *n_kept; ++i) kept_branch_ids[i] = (uint32_t)s[0][i].branch_id();
+  });
+}
+
+int epa_host_heuristic(const double* lnl, uint32_t Q, uint32_t B, int mode, double thresh,
+                       uint32_t* pair_branch, uint32_t* pair_seq, uint64_t cap, uint64_t* n) {
+  return guarded([&] {
+    Options o;
+    o.prescoring_threshold = thresh;
+    o.prescoring_by_percentage = mode == 1;
+    o.baseball = mode == 2;
+    std::vector<double> v(lnl, lnl + (size_t)Q * B);
+    const Work w = apply_heuristic(v, Q, B, o);
+    *n = w.size();
+    for (size_t i = 0; i < w.size() && i < cap; ++i) {
+      pair_branch[i] = (uint32_t)w[i].branch_id;
+      pair_seq[i] = (uint32_t)w[i].sequence_id;
+    }
+  });
+}
+
+}  // extern "C"

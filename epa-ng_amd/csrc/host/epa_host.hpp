@@ -1,0 +1,238 @@
+// Host side of the MI355X placement evaluator: the C++ mirror of the reference's operator
+// interface for the placement path, sitting directly above the C-ABI of include/epa_dev.h.
+// Class / function names follow the reference (paths relative to the reference checkout):
+//   Options            src/util/Options.hpp:6-35
+//   Sequence / MSA     src/seq/Sequence.hpp, src/seq/MSA.hpp
+//   Placement/PQuery/Sample  src/sample/
+//   Work               src/core/Work.hpp
+//   Model              src/core/raxml/Model.hpp (subset: GTR / PROTGTR + FU/FE + G, see model.cpp)
+//   Tree               src/tree/Tree.hpp (owns all directional CLVs of the reference tree)
+//   place / place_thorough / simple_mpi   src/core/place.cpp
+//   apply_heuristic    src/core/heuristics.hpp
+//   compute_and_set_lwr / filter          src/set_manipulators.cpp
+//   jplace output      src/io/jplace_util.cpp, src/io/jplace_writer.hpp
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "epa_dev.h"
+
+namespace epa {
+
+struct Options {  // defaults: src/util/Options.hpp:13-34
+  bool prescoring = true;
+  bool sliding_blo = true;
+  double support_threshold = 0.01;
+  bool acc_threshold = false;
+  unsigned int filter_min = 1;
+  unsigned int filter_max = 7;
+  bool prescoring_by_percentage = false;
+  double prescoring_threshold = 0.99999;
+  unsigned int chunk_size = 5000;
+  unsigned int num_threads = 0;
+  bool premasking = true;
+  bool baseball = false;
+  unsigned int precision = 10;
+  bool aa_x_as_n = false;   // quirk D4 switch
+  bool device_select = true;  // run the dynamic heuristic on the GPU (default heuristic only)
+};
+
+class Sequence {
+public:
+  Sequence() = default;
+  Sequence(std::string header, std::string sequence)
+      : header_(std::move(header)), sequence_(std::move(sequence)) {}
+  const std::string& header() const { return header_; }
+  const std::string& sequence() const { return sequence_; }
+private:
+  std::string header_, sequence_;
+};
+
+using MSA = std::vector<Sequence>;
+
+class Placement {  // src/sample/Placement.hpp:7-54
+public:
+  Placement() = default;
+  Placement(size_t branch_id, double likelihood, double pendant_length, double distal_length)
+      : branch_id_(branch_id), likelihood_(likelihood), lwr_(0.0),
+        pendant_length_(pendant_length), distal_length_(distal_length) {}
+  double lwr() const { return lwr_; }
+  double likelihood() const { return likelihood_; }
+  double pendant_length() const { return pendant_length_; }
+  double distal_length() const { return distal_length_; }
+  size_t branch_id() const { return branch_id_; }
+  void lwr(double v) { lwr_ = v; }
+private:
+  size_t branch_id_ = 0;
+  double likelihood_ = 0, lwr_ = 0, pendant_length_ = 0, distal_length_ = 0;
+};
+
+class PQuery {  // src/sample/PQuery.hpp:12-92
+public:
+  PQuery() = default;
+  PQuery(size_t seq_id, std::string header) : sequence_id_(seq_id), header_(std::move(header)) {}
+  size_t sequence_id() const { return sequence_id_; }
+  const std::string& header() const { return header_; }
+  std::vector<Placement>& placements() { return placements_; }
+  const std::vector<Placement>& placements() const { return placements_; }
+  auto begin() { return placements_.begin(); }
+  auto end() { return placements_.end(); }
+  auto begin() const { return placements_.begin(); }
+  auto end() const { return placements_.end(); }
+  size_t size() const { return placements_.size(); }
+  Placement& operator[](size_t i) { return placements_[i]; }
+  template <class... A> void emplace_back(A&&... a) { placements_.emplace_back(std::forward<A>(a)...); }
+private:
+  size_t sequence_id_ = 0;
+  std::string header_;
+  std::vector<Placement> placements_;
+};
+
+using Sample = std::vector<PQuery>;
+
+struct Work_Pair {  // src/core/Work.hpp:31-34
+  size_t branch_id;
+  size_t sequence_id;
+};
+using Work = std::vector<Work_Pair>;  // kept branch-major sorted (the reference's map order)
+
+class Model {
+public:
+  Model() = default;
+  // raxml-ng style descriptor, subset (src/core/raxml/Model.cpp:123-538):
+  //   GTR | PROTGTR  [{r1/r2/...}]  [+FU{f1/..} | +FE | +FO(->equal)]  [+G[n][{alpha}]]
+  explicit Model(const std::string& descriptor);
+  Model(int states, std::vector<double> subst, std::vector<double> freqs, std::vector<double> rates,
+        std::vector<double> weights);
+  int num_states() const { return states_; }
+  int num_ratecats() const { return (int)rates_.size(); }
+  const std::vector<double>& subst_rates() const { return subst_; }
+  const std::vector<double>& base_freqs() const { return freqs_; }
+  const std::vector<double>& ratecat_rates() const { return rates_; }
+  const std::vector<double>& ratecat_weights() const { return weights_; }
+  double alpha() const { return alpha_; }
+  const std::vector<double>& eigenvals() const { return eigenvals_; }
+  const std::vector<double>& eigenvecs_u() const { return u_; }       // libpll inv_eigenvecs
+  const std::vector<double>& eigenvecs_uinv() const { return uinv_; }  // libpll eigenvecs
+  // state bitmask of a character (pll_map_nt / pll_map_aa); 0 = invalid
+  uint32_t char_mask(char c) const;
+  // P(t) for rate category k, row-major states x states
+  void pmatrix(double t, int k, double* P) const;
+  std::string to_string() const;
+private:
+  void update_eigen();
+  int states_ = 4;
+  double alpha_ = 1.0;
+  std::vector<double> subst_, freqs_, rates_, weights_, eigenvals_, u_, uinv_;
+};
+
+std::vector<double> compute_gamma_cats(double alpha, int k);  // mean mode (pll_compute_gamma_cats)
+
+struct Tree_Numbers {  // src/tree/Tree_Numbers.hpp
+  unsigned int tip_nodes = 0, inner_nodes = 0, nodes = 0, branches = 0;
+};
+
+// Reference tree with all 3(n-2) directional CLVs precomputed (Tree::Tree src/tree/Tree.cpp:16-56,
+// precompute_clvs src/core/pll/epa_pll_util.cpp:62-107).
+class Tree {
+public:
+  Tree(const std::string& newick, const MSA& ref_msa, const Model& model, const Options& options);
+  const Tree_Numbers& nums() const { return nums_; }
+  const Model& model() const { return model_; }
+  size_t num_sites() const { return sites_; }
+  size_t num_branches() const { return nums_.branches; }
+  double ref_tree_logl(size_t branch = 0) const;  // edge lnL (Tree::ref_tree_logl :119-131)
+  // numbered newick, edge ids in utree_query_branches order (pll_util.cpp:182-259)
+  std::string numbered_newick(unsigned int precision) const;
+
+  // the two sides of branch b after the tip-is-distal orientation of Tiny_Tree.cpp:64-74
+  struct Branch {
+    const double* prox_clv;
+    const uint32_t* prox_scaler;
+    const double* dist_clv;        // nullptr when the distal end is a tip
+    const uint8_t* dist_tipchars;  // tip codes (state bitmask index into tipmap) or nullptr
+    const uint32_t* dist_scaler;   // nullptr for a tip
+    double length;
+  };
+  Branch branch(size_t b) const;
+  const std::vector<uint32_t>& tipmap() const { return tipmap_; }
+  // fills an epa_ref_desc that borrows this tree's buffers (valid while *this lives)
+  void fill_desc(epa_ref_desc& d, std::vector<const double*>& pc, std::vector<const uint32_t*>& ps,
+                 std::vector<const double*>& dc, std::vector<const uint8_t*>& dt,
+                 std::vector<const uint32_t*>& ds, std::vector<double>& bl) const;
+
+private:
+  struct Rec { int next = -1, back = -1, tip = -1; double length = 0.0; };
+  int new_rec();
+  int parse_subtree(const char*& p, double& len);
+  void compute_clv(int rec);
+  void side(int rec, const double*& clv, const uint8_t*& tip, const uint32_t*& sc) const;
+
+  Model model_;
+  Tree_Numbers nums_;
+  size_t sites_ = 0;
+  std::vector<Rec> recs_;
+  std::vector<std::string> labels_;
+  int vroot_ = -1;
+  std::vector<int> branch_rec_;
+  std::vector<std::vector<uint8_t>> tipchars_;   // per tip
+  std::vector<std::vector<double>> clv_;         // per record (empty for tips)
+  std::vector<std::vector<uint32_t>> scaler_;    // per record
+  std::vector<uint32_t> tipmap_;
+};
+
+// ---- readers / writers
+MSA read_fasta(const std::string& path);
+void write_jplace(std::ostream& os, const std::vector<Sample>& chunks, const std::string& newick,
+                  const std::string& invocation, unsigned int precision);
+
+// ---- device-backed evaluator: one epa_ctx, RAII
+class Device_Evaluator {
+public:
+  Device_Evaluator(const Tree& tree, const Options& options, int device = 0);
+  ~Device_Evaluator();
+  Device_Evaluator(const Device_Evaluator&) = delete;
+  epa_ctx* ctx() const { return ctx_; }
+private:
+  epa_ctx* ctx_ = nullptr;
+};
+
+// encoded chunk of queries (what crosses the C-ABI)
+struct Encoded_Chunk {
+  std::vector<uint8_t> codes;
+  std::vector<uint32_t> win_begin, win_span;
+};
+Encoded_Chunk encode_chunk(const MSA& chunk, const Tree& tree, const Options& options);
+
+// Hot loop 1: dense Q x B preplacement table (src/core/place.cpp:41-95).  lnl is Q x B row-major;
+// sample[q][b] = Placement{b, lnl, pendant = -ln 0.9, distal = len/2} is materialised lazily by
+// the heuristics below, not here (the reference's 40-byte-per-cell Sample is never built).
+void place(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, Device_Evaluator& dev,
+           std::vector<double>& lnl, const Options& options);
+
+// Candidate selection (src/core/heuristics.hpp:119-127): dynamic (default), fixed-%, baseball.
+Work apply_heuristic(const std::vector<double>& lnl, size_t num_sequences, size_t num_branches,
+                     const Options& options);
+
+// Hot loop 2 (src/core/place.cpp:97-171): one PQuery per query with its candidate placements.
+void place_thorough(const Work& to_place, const MSA& chunk, const Encoded_Chunk& enc,
+                    const Tree& tree, Device_Evaluator& dev, Sample& sample, const Options& options,
+                    size_t seq_id_offset = 0);
+
+void compute_and_set_lwr(Sample& sample);            // src/set_manipulators.cpp:43-69
+void filter(Sample& sample, const Options& options);  // :192-204
+
+// The chunk loop (src/core/place.cpp:173-251): reads `query_file` in chunks, writes
+// <outdir>/epa_result.jplace.  rank/world: contiguous query sharding as local_seq_package
+// (src/net/epa_mpi_util.cpp:10-30); every rank returns its own samples, rank 0 writes.
+struct Run_Stats { size_t queries = 0, pairs = 0; double seconds_place = 0, seconds_thorough = 0; };
+Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std::string& outdir,
+                     const Options& options, const std::string& invocation, int device = 0);
+
+}  // namespace epa

@@ -1,0 +1,89 @@
+// epa-ng-amd: command-line front end keeping EPA-ng's flags for the placement path
+// (src/main.cpp:96-270).  Flags outside the hot path (binary dump, bfast conversion, --split,
+// rooted-tree preservation, model files) are rejected with a message, not silently ignored.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "epa_host.hpp"
+
+using namespace epa;
+
+static void usage() {
+  std::cout <<
+      "epa-ng-amd - Evolutionary Placement Algorithm, MI355X placement evaluator\n"
+      "  -t,--tree FILE        reference tree (newick, unrooted)\n"
+      "  -s,--ref-msa FILE     reference MSA (fasta)\n"
+      "  -q,--query FILE       query MSA (fasta, aligned to the reference)\n"
+      "  -m,--model STR        model descriptor, e.g. GTR{..}+FU{..}+G4{a} (default GTR+G)\n"
+      "  -w,--outdir DIR       output directory (default ./)\n"
+      "  -g,--dyn-heur X       accumulated-LWR preplacement threshold (default 0.99999)\n"
+      "  -G,--fix-heur X       fixed fraction of branches\n"
+      "  --baseball-heur       baseball heuristic\n"
+      "  --no-heur             thorough placement on every branch\n"
+      "  --filter-acc-lwr X | --filter-min-lwr X | --filter-min N | --filter-max N\n"
+      "  --precision N         output digits (default 10)\n"
+      "  --chunk-size N        queries per chunk (default 5000)\n"
+      "  --no-pre-mask         evaluate all sites of every query\n"
+      "  --device N            GPU ordinal (default 0)\n";
+}
+
+int main(int argc, char** argv) {
+  const auto start = std::chrono::steady_clock::now();
+  std::string invocation;
+  for (int i = 0; i < argc; ++i) { invocation += argv[i]; invocation += " "; }
+  std::string tree_file, ref_file, query_file, outdir = "./", model_desc = "GTR+G";
+  Options opt;
+  int device = 0;
+  auto need = [&](int& i) -> std::string {
+    if (i + 1 >= argc) { std::cerr << "missing value for " << argv[i] << "\n"; std::exit(1); }
+    return argv[++i];
+  };
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    if (a == "-t" || a == "--tree") tree_file = need(i);
+    else if (a == "-s" || a == "--ref-msa" || a == "--msa") ref_file = need(i);
+    else if (a == "-q" || a == "--query") query_file = need(i);
+    else if (a == "-m" || a == "--model") model_desc = need(i);
+    else if (a == "-w" || a == "--outdir" || a == "--out-dir") outdir = need(i);
+    else if (a == "-g" || a == "--dyn-heur") { opt.prescoring_threshold = std::stod(need(i)); opt.prescoring_by_percentage = false; }
+    else if (a == "-G" || a == "--fix-heur") { opt.prescoring_threshold = std::stod(need(i)); opt.prescoring_by_percentage = true; }
+    else if (a == "--baseball-heur") opt.baseball = true;
+    else if (a == "--no-heur") opt.prescoring = false;
+    else if (a == "--filter-acc-lwr") { opt.support_threshold = std::stod(need(i)); opt.acc_threshold = true; }
+    else if (a == "--filter-min-lwr") { opt.support_threshold = std::stod(need(i)); opt.acc_threshold = false; }
+    else if (a == "--filter-min") opt.filter_min = (unsigned)std::stoul(need(i));
+    else if (a == "--filter-max") opt.filter_max = (unsigned)std::stoul(need(i));
+    else if (a == "--precision") opt.precision = (unsigned)std::stoul(need(i));
+    else if (a == "--chunk-size") opt.chunk_size = (unsigned)std::stoul(need(i));
+    else if (a == "--no-pre-mask") opt.premasking = false;
+    else if (a == "-T" || a == "--threads") opt.num_threads = (unsigned)std::stoul(need(i));
+    else if (a == "--device") device = std::stoi(need(i));
+    else if (a == "--redo" || a == "--verbose") {}
+    else if (a == "-h" || a == "--help") { usage(); return 0; }
+    else { std::cerr << "option " << a << " is outside the placement hot path of this build\n"; return 1; }
+  }
+  if (tree_file.empty() || ref_file.empty() || query_file.empty()) { usage(); return 1; }
+  try {
+    std::ifstream tf(tree_file);
+    if (!tf) throw std::runtime_error{"file_check failed: " + tree_file};
+    std::stringstream ss;
+    ss << tf.rdbuf();
+    const MSA ref = read_fasta(ref_file);
+    const Model model(model_desc);
+    std::cout << "Using model parameters: " << model.to_string() << std::endl;
+    const Tree tree(ss.str(), ref, model, opt);
+    std::cout << "Reference tree log-likelihood: " << tree.ref_tree_logl() << std::endl;
+    const Run_Stats st = simple_mpi(tree, query_file, outdir, opt, invocation, device);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+    std::cout << st.queries << " Sequences done! (" << st.pairs << " thorough pairs)\n"
+              << "Elapsed Time: " << secs << "s" << std::endl;
+  } catch (const std::exception& e) {
+    std::cerr << e.what() << "\nAborting with a failure." << std::endl;
+    return 1;
+  }
+  return 0;
+}

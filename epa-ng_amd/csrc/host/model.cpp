@@ -1,0 +1,285 @@
+// Substitution model: descriptor parsing (subset), eigen system, discrete-Gamma rates.
+// Mirrors what raxml::Model + raxml::assign hand to libpll (src/core/raxml/Model.cpp:123-538,
+// 711-733): the device only ever sees eigenvalues, U, U^-1, frequencies, rates and weights.
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstring>
+#include <sstream>
+
+#include "epa_host.hpp"
+
+namespace epa {
+
+namespace {
+
+const char* AA_STATE_ORDER = "ARNDCQEGHILKMFPSTWYV";  // libpll / PAML state order
+
+// regularised lower incomplete gamma P(a, x)
+double gamma_p(double a, double x) {
+  if (x <= 0) return 0.0;
+  const double lg = std::lgamma(a);
+  if (x < a + 1.0) {  // power series
+    double term = 1.0 / a, sum = term, ap = a;
+    for (int i = 0; i < 100000; ++i) {
+      ap += 1.0;
+      term *= x / ap;
+      sum += term;
+      if (std::fabs(term) < std::fabs(sum) * 1e-17) break;
+    }
+    return sum * std::exp(a * std::log(x) - x - lg);
+  }
+  // modified Lentz continued fraction for Q(a, x)
+  const double tiny = 1e-300;
+  double b = x + 1.0 - a, c = 1.0 / tiny, d = 1.0 / b, h = d;
+  for (int i = 1; i < 100000; ++i) {
+    const double an = -i * (i - a);
+    b += 2.0;
+    d = an * d + b;
+    if (std::fabs(d) < tiny) d = tiny;
+    c = b + an / c;
+    if (std::fabs(c) < tiny) c = tiny;
+    d = 1.0 / d;
+    const double del = d * c;
+    h *= del;
+    if (std::fabs(del - 1.0) < 1e-16) break;
+  }
+  return 1.0 - std::exp(a * std::log(x) - x - lg) * h;
+}
+
+// symmetric eigen-decomposition, cyclic Jacobi; v columns are eigenvectors
+void jacobi(int n, std::vector<double>& a, std::vector<double>& w, std::vector<double>& v) {
+  v.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) v[(size_t)i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 200; ++sweep) {
+    double off = 0;
+    for (int i = 0; i < n; ++i)
+      for (int j = i + 1; j < n; ++j) off += a[(size_t)i * n + j] * a[(size_t)i * n + j];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = a[(size_t)p * n + q];
+        if (std::fabs(apq) < 1e-300) continue;
+        const double theta = (a[(size_t)q * n + q] - a[(size_t)p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) {
+          const double x = a[(size_t)k * n + p], y = a[(size_t)k * n + q];
+          a[(size_t)k * n + p] = c * x - s * y;
+          a[(size_t)k * n + q] = s * x + c * y;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double x = a[(size_t)p * n + k], y = a[(size_t)q * n + k];
+          a[(size_t)p * n + k] = c * x - s * y;
+          a[(size_t)q * n + k] = s * x + c * y;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double x = v[(size_t)k * n + p], y = v[(size_t)k * n + q];
+          v[(size_t)k * n + p] = c * x - s * y;
+          v[(size_t)k * n + q] = s * x + c * y;
+        }
+      }
+  }
+  w.resize(n);
+  for (int i = 0; i < n; ++i) w[i] = a[(size_t)i * n + i];
+}
+
+std::vector<double> parse_list(const std::string& s) {
+  std::vector<double> out;
+  std::string tok;
+  std::stringstream ss(s);
+  while (std::getline(ss, tok, '/')) out.push_back(std::stod(tok));
+  return out;
+}
+
+}  // namespace
+
+std::vector<double> compute_gamma_cats(double alpha, int k) {
+  // Yang 1994, category means: cut points are quantiles of Gamma(alpha, rate alpha); the mean of
+  // a slice is K * [P(alpha+1, alpha*hi) - P(alpha+1, alpha*lo)].
+  std::vector<double> cuts(k + 1, 0.0), rates(k);
+  for (int i = 1; i < k; ++i) {
+    const double p = (double)i / k;
+    double lo = 0.0, hi = 1.0;
+    while (gamma_p(alpha, hi * alpha) < p) hi *= 2.0;
+    for (int it = 0; it < 300 && hi - lo > 1e-17 * hi; ++it) {
+      const double mid = 0.5 * (lo + hi);
+      (gamma_p(alpha, mid * alpha) < p ? lo : hi) = mid;
+    }
+    cuts[i] = 0.5 * (lo + hi);
+  }
+  double prev = 0.0;
+  for (int i = 0; i < k; ++i) {
+    const double cur = (i == k - 1) ? 1.0 : gamma_p(alpha + 1.0, cuts[i + 1] * alpha);
+    rates[i] = (cur - prev) * k;
+    prev = cur;
+  }
+  return rates;
+}
+
+Model::Model(int states, std::vector<double> subst, std::vector<double> freqs,
+             std::vector<double> rates, std::vector<double> weights)
+    : states_(states), subst_(std::move(subst)), freqs_(std::move(freqs)), rates_(std::move(rates)),
+      weights_(std::move(weights)) {
+  if ((int)subst_.size() != states * (states - 1) / 2 || (int)freqs_.size() != states)
+    throw std::runtime_error{"Model: wrong number of substitution rates / frequencies"};
+  if (weights_.empty()) weights_.assign(rates_.size(), 1.0 / rates_.size());
+  update_eigen();
+}
+
+Model::Model(const std::string& descriptor) {
+  // name up to the first of "+{["
+  size_t pos = descriptor.find_first_of("+{[");
+  std::string name = descriptor.substr(0, pos);
+  std::transform(name.begin(), name.end(), name.begin(), ::toupper);
+  if (name == "GTR" || name == "DNA") states_ = 4;
+  else if (name == "PROTGTR") states_ = 20;
+  else
+    throw std::runtime_error{"Invalid model name: " + name +
+                             " (this build knows GTR and PROTGTR with explicit parameters; named "
+                             "empirical AA matrices need the pll-modules model database)"};
+  const int nr = states_ * (states_ - 1) / 2;
+  // defaults of raxml::Model (Model.cpp:190-193,470,487-488): rates 0.5.. / 1.0, equal freqs
+  subst_.assign(nr, 0.5);
+  subst_.back() = 1.0;
+  freqs_.assign(states_, 1.0 / states_);
+  int cats = 1;
+  alpha_ = 1.0;
+  bool gamma = false;
+  std::string rest = pos == std::string::npos ? "" : descriptor.substr(pos);
+  size_t i = 0;
+  auto braces = [&](std::string& out) {
+    out.clear();
+    if (i < rest.size() && rest[i] == '{') {
+      size_t e = rest.find('}', i);
+      if (e == std::string::npos) throw std::runtime_error{"Model: unbalanced '{'"};
+      out = rest.substr(i + 1, e - i - 1);
+      i = e + 1;
+      return true;
+    }
+    return false;
+  };
+  std::string arg;
+  if (braces(arg)) {
+    subst_ = parse_list(arg);
+    if ((int)subst_.size() != nr) throw std::runtime_error{"Model: wrong number of rates"};
+  }
+  while (i < rest.size()) {
+    if (rest[i] != '+') throw std::runtime_error{"Model: cannot parse '" + rest.substr(i) + "'"};
+    ++i;
+    size_t b = i;
+    while (i < rest.size() && std::isalpha((unsigned char)rest[i])) ++i;
+    std::string opt = rest.substr(b, i - b);
+    std::transform(opt.begin(), opt.end(), opt.begin(), ::toupper);
+    if (opt == "FU" || opt == "F") {
+      if (braces(arg)) {
+        freqs_ = parse_list(arg);
+        if ((int)freqs_.size() != states_) throw std::runtime_error{"Model: wrong number of freqs"};
+        double sum = 0;
+        for (double f : freqs_) sum += f;
+        for (double& f : freqs_) f /= sum;
+      }
+    } else if (opt == "FE" || opt == "FO" || opt == "FC") {
+      // FE: equal; FO/FC need optimisation / counting, which EPA-ng never runs in the shipped
+      // flow -- treated as equal here like the starting value in Model.cpp:470
+    } else if (opt == "G") {
+      gamma = true;
+      cats = 4;
+      size_t nb = i;
+      while (i < rest.size() && std::isdigit((unsigned char)rest[i])) ++i;
+      if (i > nb) cats = std::stoi(rest.substr(nb, i - nb));
+      if (braces(arg)) alpha_ = std::stod(arg);
+    } else {
+      throw std::runtime_error{"Model: option +" + opt + " is not supported by this build"};
+    }
+  }
+  if (gamma) rates_ = compute_gamma_cats(alpha_, cats);
+  else rates_.assign(1, 1.0);
+  weights_.assign(rates_.size(), 1.0 / rates_.size());
+  update_eigen();
+}
+
+void Model::update_eigen() {
+  const int s = states_;
+  std::vector<double> q((size_t)s * s, 0.0);
+  int k = 0;
+  for (int i = 0; i < s; ++i)
+    for (int j = i + 1; j < s; ++j) {
+      q[(size_t)i * s + j] = subst_[k] * freqs_[j];
+      q[(size_t)j * s + i] = subst_[k] * freqs_[i];
+      ++k;
+    }
+  double mean = 0.0;
+  for (int i = 0; i < s; ++i) {
+    double d = 0.0;
+    for (int j = 0; j < s; ++j)
+      if (j != i) d += q[(size_t)i * s + j];
+    q[(size_t)i * s + i] = -d;
+    mean += freqs_[i] * d;
+  }
+  for (auto& v : q) v /= mean;
+  std::vector<double> a((size_t)s * s), sq(s), w, v;
+  for (int i = 0; i < s; ++i) sq[i] = std::sqrt(freqs_[i]);
+  for (int i = 0; i < s; ++i)
+    for (int j = 0; j < s; ++j) a[(size_t)i * s + j] = q[(size_t)i * s + j] * sq[i] / sq[j];
+  for (int i = 0; i < s; ++i)
+    for (int j = i + 1; j < s; ++j)
+      a[(size_t)i * s + j] = a[(size_t)j * s + i] = 0.5 * (a[(size_t)i * s + j] + a[(size_t)j * s + i]);
+  jacobi(s, a, w, v);
+  eigenvals_ = w;
+  u_.assign((size_t)s * s, 0.0);
+  uinv_.assign((size_t)s * s, 0.0);
+  for (int i = 0; i < s; ++i)
+    for (int j = 0; j < s; ++j) {
+      u_[(size_t)i * s + j] = v[(size_t)i * s + j] / sq[i];
+      uinv_[(size_t)i * s + j] = v[(size_t)j * s + i] * sq[j];
+    }
+}
+
+void Model::pmatrix(double t, int k, double* P) const {
+  const int s = states_;
+  std::vector<double> e(s);
+  for (int x = 0; x < s; ++x) e[x] = std::exp(eigenvals_[x] * rates_[k] * t);
+  for (int i = 0; i < s; ++i)
+    for (int j = 0; j < s; ++j) {
+      double acc = 0.0;
+      for (int x = 0; x < s; ++x) acc += u_[(size_t)i * s + x] * e[x] * uinv_[(size_t)x * s + j];
+      P[(size_t)i * s + j] = acc;
+    }
+}
+
+uint32_t Model::char_mask(char ch) const {
+  const int c = std::toupper((unsigned char)ch);
+  if (states_ == 4) {
+    switch (c) {
+      case 'A': return 1; case 'C': return 2; case 'G': return 4; case 'T': case 'U': return 8;
+      case 'R': return 5; case 'Y': return 10; case 'S': return 6; case 'W': return 9;
+      case 'K': return 12; case 'M': return 3; case 'B': return 14; case 'D': return 13;
+      case 'H': return 11; case 'V': return 7;
+      case 'N': case 'O': case 'X': case '-': case '?': case '.': return 15;
+      default: return 0;
+    }
+  }
+  if (c) {
+    const char* p = std::strchr(AA_STATE_ORDER, c);
+    if (p) return 1u << (p - AA_STATE_ORDER);
+  }
+  if (c == 'B') return (1u << 2) | (1u << 3);
+  if (c == 'Z') return (1u << 5) | (1u << 6);
+  if (c == 'X' || c == '-' || c == '?' || c == '*') return (1u << 20) - 1;
+  return 0;
+}
+
+std::string Model::to_string() const {
+  std::ostringstream s;
+  s.precision(6);
+  s << std::fixed << (states_ == 4 ? "GTR{" : "PROTGTR{");
+  for (size_t i = 0; i < subst_.size(); ++i) s << (i ? "/" : "") << subst_[i];
+  s << "}+FU{";
+  for (size_t i = 0; i < freqs_.size(); ++i) s << (i ? "/" : "") << freqs_[i];
+  s << "}";
+  if (rates_.size() > 1) s << "+G" << rates_.size() << "{" << alpha_ << "}";
+  return s.str();
+}
+
+}  // namespace epa

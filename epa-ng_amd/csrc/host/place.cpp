@@ -1,0 +1,254 @@
+// The chunk loop and its two hot loops, host side: the reference's place() / place_thorough() /
+// simple_mpi() (src/core/place.cpp) with the per-branch Tiny_Tree evaluator replaced by calls
+// into the C-ABI of libepa_dev.so.  Heuristics, LWR and filters are the reference's host-side
+// set operations (src/core/heuristics.hpp, src/set_manipulators.cpp) on flat arrays.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <fstream>
+#include <limits>
+#include <numeric>
+
+#include "epa_host.hpp"
+
+namespace epa {
+
+namespace {
+const double kDefaultBranchLength = -std::log(0.9);
+
+[[noreturn]] void throw_dev(epa_ctx* ctx, int rc) {
+  throw std::runtime_error{std::string(epa_dev_last_error(ctx)) + " (epa_dev status " +
+                           std::to_string(rc) + ")"};
+}
+}  // namespace
+
+Device_Evaluator::Device_Evaluator(const Tree& tree, const Options& options, int device) {
+  epa_ref_desc d;
+  std::vector<const double*> pc, dc;
+  std::vector<const uint32_t*> ps, ds;
+  std::vector<const uint8_t*> dt;
+  std::vector<double> bl;
+  tree.fill_desc(d, pc, ps, dc, dt, ds, bl);
+  d.flags = options.sliding_blo ? EPA_FLAG_SLIDING_BLO : 0x80000000u;  // non-sliding: rejected
+  d.aa_x_as_n = options.aa_x_as_n ? 1 : 0;
+  const int rc = epa_dev_create(&d, device, &ctx_);
+  if (rc != EPA_OK) throw_dev(nullptr, rc);
+}
+
+Device_Evaluator::~Device_Evaluator() { epa_dev_destroy(ctx_); }
+
+Encoded_Chunk encode_chunk(const MSA& chunk, const Tree& tree, const Options& options) {
+  Encoded_Chunk e;
+  const size_t Q = chunk.size(), W = tree.num_sites();
+  e.codes.resize(Q * W);
+  e.win_begin.resize(Q);
+  e.win_span.resize(Q);
+  std::vector<const char*> rows(Q);
+  for (size_t q = 0; q < Q; ++q) {
+    if (chunk[q].sequence().size() != W)  // Tiny_Tree.cpp:145-147
+      throw std::runtime_error{"Query sequence length not same as reference alignment!"};
+    rows[q] = chunk[q].sequence().c_str();
+  }
+  uint32_t bad = 0;
+  const int rc = epa_encode_queries((uint32_t)tree.model().num_states(), (uint32_t)W, (uint32_t)Q,
+                                    rows.data(), options.premasking, options.aa_x_as_n,
+                                    e.codes.data(), e.win_begin.data(), e.win_span.data(), &bad);
+  if (rc == EPA_ERR_QUERY_ALL_GAP)  // Tiny_Tree.cpp:153-156
+    throw std::runtime_error{std::string() + "Sequence with header '" + chunk[bad].header() +
+                             "' does not appear to have any non-gap sites!"};
+  if (rc == EPA_ERR_INVALID_CHAR)  // Lookup_Store.hpp:100-108
+    throw std::runtime_error{"char is invalid! (sequence '" + chunk[bad].header() + "')"};
+  return e;
+}
+
+void place(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, Device_Evaluator& dev,
+           std::vector<double>& lnl, const Options&) {
+  const size_t Q = chunk.size(), B = tree.num_branches();
+  lnl.resize(Q * B);
+  const int rc = epa_dev_preplace(dev.ctx(), enc.codes.data(), enc.win_begin.data(),
+                                  enc.win_span.data(), (uint32_t)Q, lnl.data());
+  if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
+}
+
+// ---- candidate selection ------------------------------------------------------------------
+static void row_lwr(const double* row, size_t B, std::vector<double>& lwr) {
+  // compute_and_set_lwr (src/set_manipulators.cpp:43-69)
+  const double mx = *std::max_element(row, row + B);
+  lwr.resize(B);
+  double total = 0.0;
+  for (size_t i = 0; i < B; ++i) { lwr[i] = std::exp(row[i] - mx); total += lwr[i]; }
+  for (size_t i = 0; i < B; ++i) lwr[i] /= total;
+}
+
+Work apply_heuristic(const std::vector<double>& lnl, size_t Q, size_t B, const Options& options) {
+  std::vector<std::vector<uint32_t>> keep(Q);
+#pragma omp parallel
+  {
+    std::vector<double> lwr;
+    std::vector<uint32_t> order(B);
+#pragma omp for schedule(dynamic)
+    for (long q = 0; q < (long)Q; ++q) {
+      const double* row = &lnl[(size_t)q * B];
+      std::iota(order.begin(), order.end(), 0u);
+      size_t n_keep = 0;
+      if (options.baseball) {
+        // baseball_heuristic (src/core/heuristics.hpp:70-117); quirk D7: clamp at B
+        const double strike_box = 3, best = *std::max_element(row, row + B);
+        const size_t max_strikes = 6, max_pitches = 40;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return row[a] > row[b]; });
+        size_t hits = 0;
+        while (hits < B && !(row[order[hits]] < best - strike_box)) ++hits;
+        const size_t to_add = hits >= max_pitches ? 0 : std::min(max_pitches - hits, max_strikes);
+        n_keep = std::min(B, hits + to_add);
+      } else {
+        row_lwr(row, B, lwr);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lwr[a] > lwr[b]; });
+        if (options.prescoring_by_percentage) {
+          // until_top_percent (src/set_manipulators.cpp:82-88)
+          n_keep = std::min(B, (size_t)std::ceil(options.prescoring_threshold * (double)B));
+        } else {
+          // until_accumulated_reached(pq, thresh, 1, inf) (:90-114)
+          double sum = 0.0;
+          while (n_keep < B && sum < options.prescoring_threshold) sum += lwr[order[n_keep++]];
+          if (n_keep < 1) n_keep = 1;
+        }
+      }
+      keep[q].assign(order.begin(), order.begin() + n_keep);
+    }
+  }
+  // Work is a map<branch, vector<seq>> in the reference: iteration order is branch-major
+  std::vector<size_t> per_branch(B + 1, 0);
+  for (const auto& k : keep)
+    for (uint32_t b : k) ++per_branch[b + 1];
+  for (size_t b = 0; b < B; ++b) per_branch[b + 1] += per_branch[b];
+  Work work(per_branch[B]);
+  std::vector<size_t> cur(per_branch.begin(), per_branch.end() - 1);
+  for (size_t q = 0; q < Q; ++q)
+    for (uint32_t b : keep[q]) work[cur[b]++] = Work_Pair{b, q};
+  return work;
+}
+
+void place_thorough(const Work& to_place, const MSA& chunk, const Encoded_Chunk& enc,
+                    const Tree& tree, Device_Evaluator& dev, Sample& sample, const Options&,
+                    size_t seq_id_offset) {
+  const size_t n = to_place.size(), Q = chunk.size();
+  std::vector<epa_pair> pairs(n);
+  for (size_t i = 0; i < n; ++i)
+    pairs[i] = epa_pair{(uint32_t)to_place[i].branch_id, (uint32_t)to_place[i].sequence_id};
+  std::vector<epa_result> res(n);
+  const int rc = epa_dev_thorough(dev.ctx(), pairs.data(), n, enc.codes.data(), enc.win_begin.data(),
+                                  enc.win_span.data(), (uint32_t)Q, res.data(), nullptr);
+  if (rc == EPA_ERR_NEG_INF)  // Tiny_Tree.cpp:209-212
+    throw std::runtime_error{epa_dev_last_error(dev.ctx())};
+  if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
+  // one PQuery per query, in query order (quirk D8: the reference's order is thread-dependent)
+  std::vector<long> slot(Q, -1);
+  sample.clear();
+  for (size_t i = 0; i < n; ++i) {
+    const size_t q = to_place[i].sequence_id;
+    if (slot[q] < 0) slot[q] = 0;
+  }
+  for (size_t q = 0; q < Q; ++q)
+    if (slot[q] == 0) {
+      slot[q] = (long)sample.size();
+      sample.emplace_back(seq_id_offset + q, chunk[q].header());
+    }
+  for (size_t i = 0; i < n; ++i) {
+    const size_t q = to_place[i].sequence_id;
+    sample[slot[q]].emplace_back(to_place[i].branch_id, res[i].lnl, res[i].pendant_length,
+                                 res[i].distal_length);
+  }
+  (void)tree;
+}
+
+void compute_and_set_lwr(Sample& sample) {
+#pragma omp parallel for schedule(dynamic)
+  for (long j = 0; j < (long)sample.size(); ++j) {
+    auto& pq = sample[j];
+    double mx = -std::numeric_limits<double>::infinity();
+    for (auto& p : pq) mx = std::max(mx, p.likelihood());
+    double total = 0.0;
+    std::vector<double> e(pq.size());
+    for (size_t i = 0; i < pq.size(); ++i) { e[i] = std::exp(pq[i].likelihood() - mx); total += e[i]; }
+    for (size_t i = 0; i < pq.size(); ++i) pq[i].lwr(e[i] / total);
+  }
+}
+
+static void sort_by_lwr(PQuery& pq) {
+  std::stable_sort(pq.begin(), pq.end(),
+                   [](const Placement& a, const Placement& b) { return a.lwr() > b.lwr(); });
+}
+
+void filter(Sample& sample, const Options& options) {
+  const double thresh = options.support_threshold;
+  if (thresh < 0.0 || thresh > 1.0)
+    throw std::range_error{"thresh is not a valid likelihood weight ratio (outside of [0,1])"};
+  if (options.filter_min < 1) throw std::range_error{"Filter min cannot be smaller than 1!"};
+  const size_t mn = options.filter_min, mx = options.filter_max;
+#pragma omp parallel for schedule(dynamic)
+  for (long i = 0; i < (long)sample.size(); ++i) {
+    auto& pq = sample[i];
+    sort_by_lwr(pq);
+    size_t n_keep = 0;
+    if (options.acc_threshold) {
+      // discard_by_accumulated_threshold (src/set_manipulators.cpp:165-190)
+      double sum = 0.0;
+      // (the reference tops up to min-1, not min: distance(pq_iter, begin + min - 1), :104-107)
+      while (n_keep < pq.size() && n_keep < mx && sum < thresh) sum += pq[n_keep++].lwr();
+      if (n_keep + 1 < mn) n_keep = std::min(pq.size(), mn - 1);
+    } else {
+      // discard_by_support_threshold (:131-163)
+      while (n_keep < pq.size() && pq[n_keep].lwr() > thresh) ++n_keep;
+      if (n_keep < mn) n_keep = std::min(pq.size(), mn);
+      if (mx && n_keep > mx) n_keep = mx;
+    }
+    pq.placements().resize(n_keep);
+  }
+}
+
+Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std::string& outdir,
+                     const Options& options, const std::string& invocation, int device) {
+  using clk = std::chrono::steady_clock;
+  Run_Stats st;
+  const size_t B = tree.num_branches();
+  Device_Evaluator dev(tree, options, device);
+  MSA all = read_fasta(query_file);
+  std::vector<Sample> results;
+  std::vector<double> lnl;
+  size_t done = 0;
+  while (done < all.size()) {
+    const size_t n = std::min<size_t>(options.chunk_size, all.size() - done);
+    MSA chunk(all.begin() + done, all.begin() + done + n);
+    const Encoded_Chunk enc = encode_chunk(chunk, tree, options);
+    Work blo_work;
+    auto t0 = clk::now();
+    if (options.prescoring) {
+      place(chunk, enc, tree, dev, lnl, options);
+      blo_work = apply_heuristic(lnl, n, B, options);
+    } else {  // --no-heur: all B x Q pairs (src/core/place.cpp:189,228)
+      blo_work.reserve(n * B);
+      for (size_t b = 0; b < B; ++b)
+        for (size_t q = 0; q < n; ++q) blo_work.push_back(Work_Pair{b, q});
+    }
+    auto t1 = clk::now();
+    Sample blo_sample;
+    place_thorough(blo_work, chunk, enc, tree, dev, blo_sample, options, done);
+    auto t2 = clk::now();
+    compute_and_set_lwr(blo_sample);
+    filter(blo_sample, options);
+    results.push_back(std::move(blo_sample));
+    st.pairs += blo_work.size();
+    st.seconds_place += std::chrono::duration<double>(t1 - t0).count();
+    st.seconds_thorough += std::chrono::duration<double>(t2 - t1).count();
+    done += n;
+  }
+  st.queries = done;
+  std::string dir = outdir;
+  if (!dir.empty() && dir.back() != '/') dir += "/";
+  std::ofstream os(dir + "epa_result.jplace");
+  if (!os) throw std::runtime_error{"cannot open " + dir + "epa_result.jplace"};
+  write_jplace(os, results, tree.numbered_newick(options.precision), invocation, options.precision);
+  return st;
+}
+
+}  // namespace epa

@@ -1,0 +1,365 @@
+// Reference tree: newick -> unrooted record structure, branch numbering, tip encoding and the
+// one-off precompute of every directional CLV (what Tree::Tree does through libpll,
+// src/tree/Tree.cpp:16-56; src/core/pll/epa_pll_util.cpp:10-107).  Runs once per run on the
+// host; its buffers are what epa_dev_create uploads to HBM.
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+#include <unordered_map>
+
+#include "epa_host.hpp"
+
+namespace epa {
+
+namespace {
+const double kDefaultBranchLength = -std::log(0.9);  // src/util/constants.hpp:12
+const double kScaleThreshold = std::ldexp(1.0, -256);
+const double kScaleFactor = std::ldexp(1.0, 256);
+
+void skip_ws(const char*& p) { while (*p && std::isspace((unsigned char)*p)) ++p; }
+
+void label_and_length(const char*& p, std::string* label, double& len) {
+  skip_ws(p);
+  const char* b = p;
+  while (*p && !std::strchr(":,();", *p) && !std::isspace((unsigned char)*p)) ++p;
+  if (label) label->assign(b, p);
+  skip_ws(p);
+  len = 0.0;
+  if (*p == ':') {
+    ++p;
+    char* e = nullptr;
+    len = std::strtod(p, &e);
+    p = e;
+  }
+  skip_ws(p);
+}
+}  // namespace
+
+int Tree::new_rec() {
+  recs_.emplace_back();
+  return (int)recs_.size() - 1;
+}
+
+// returns the record facing the parent
+int Tree::parse_subtree(const char*& p, double& len) {
+  skip_ws(p);
+  if (*p == '(') {
+    ++p;
+    double l1, l2;
+    const int k1 = parse_subtree(p, l1);
+    skip_ws(p);
+    if (*p != ',') throw std::invalid_argument{"Input Tree contains a unary node or is malformed!"};
+    ++p;
+    const int k2 = parse_subtree(p, l2);
+    skip_ws(p);
+    if (*p == ',') throw std::invalid_argument{"Input Tree contains multifurcations (polytomies)!"};
+    if (*p != ')') throw std::runtime_error{"Treeparsing failed! expected ')'"};
+    ++p;
+    const int a = new_rec(), b = new_rec(), c = new_rec();
+    recs_[a].next = b; recs_[b].next = c; recs_[c].next = a;
+    recs_[b].back = k1; recs_[k1].back = b; recs_[b].length = recs_[k1].length = l1;
+    recs_[c].back = k2; recs_[k2].back = c; recs_[c].length = recs_[k2].length = l2;
+    label_and_length(p, nullptr, len);
+    return a;
+  }
+  const int a = new_rec();
+  recs_[a].tip = (int)labels_.size();
+  std::string lab;
+  label_and_length(p, &lab, len);
+  if (lab.empty()) throw std::runtime_error{"Treeparsing failed! empty tip label"};
+  labels_.push_back(lab);
+  return a;
+}
+
+Tree::Tree(const std::string& newick, const MSA& ref_msa, const Model& model, const Options&)
+    : model_(model) {
+  const char* p = newick.c_str();
+  skip_ws(p);
+  if (*p != '(') throw std::runtime_error{"Treeparsing failed! expected '('"};
+  ++p;
+  int kids[3];
+  double kl[3];
+  int nk = 0;
+  for (;;) {
+    if (nk == 3) throw std::invalid_argument{"Input Tree contains multifurcations (polytomies)!"};
+    kids[nk] = parse_subtree(p, kl[nk]);
+    ++nk;
+    skip_ws(p);
+    if (*p == ',') { ++p; continue; }
+    if (*p == ')') { ++p; break; }
+    throw std::runtime_error{"Treeparsing failed! expected ',' or ')'"};
+  }
+  if (nk == 2)
+    throw std::runtime_error{"Rooted reference trees are not supported by this build yet "
+                             "(SURVEY.md section 8f-4): please unroot the tree"};
+  const int a = new_rec(), b = new_rec(), c = new_rec();
+  recs_[a].next = b; recs_[b].next = c; recs_[c].next = a;
+  const int ring[3] = {a, b, c};
+  for (int i = 0; i < 3; ++i) {
+    recs_[ring[i]].back = kids[i];
+    recs_[kids[i]].back = ring[i];
+    recs_[ring[i]].length = recs_[kids[i]].length = kl[i];
+  }
+  vroot_ = a;
+  if (labels_.size() < 3) throw std::runtime_error{"Number of tip nodes too small"};
+  // set_missing_branch_lengths (src/core/pll/pll_util.cpp:13-39): a zero length counts as missing
+  for (auto& r : recs_)
+    if (r.length == 0.0) r.length = kDefaultBranchLength;
+  const unsigned n = (unsigned)labels_.size();
+  nums_.tip_nodes = n;
+  nums_.inner_nodes = n - 2;
+  nums_.nodes = 2 * n - 2;
+  nums_.branches = 2 * n - 3;
+
+  // utree_query_branches (src/core/pll/pll_util.cpp:182-205): post-order from the three
+  // subtrees of the virtual root; the visited record is the distal end of its branch
+  branch_rec_.reserve(nums_.branches);
+  {
+    struct Frame { int rec; int state; };
+    for (int start : {recs_[vroot_].back, recs_[recs_[vroot_].next].back,
+                      recs_[recs_[recs_[vroot_].next].next].back}) {
+      std::vector<Frame> st{{start, 0}};
+      while (!st.empty()) {
+        Frame& f = st.back();
+        const Rec& r = recs_[f.rec];
+        if (r.next < 0 || f.state == 2) {
+          branch_rec_.push_back(f.rec);
+          st.pop_back();
+        } else if (f.state == 0) {
+          f.state = 1;
+          st.push_back({recs_[r.next].back, 0});
+        } else {
+          f.state = 2;
+          st.push_back({recs_[recs_[r.next].next].back, 0});
+        }
+      }
+    }
+  }
+  if (branch_rec_.size() != nums_.branches)
+    throw std::runtime_error{"Traversing the utree went wrong during pipeline startup!"};
+
+  // link_tree_msa (src/core/pll/epa_pll_util.cpp:10-60)
+  if (ref_msa.empty()) throw std::runtime_error{"empty reference MSA"};
+  sites_ = ref_msa[0].sequence().size();
+  std::unordered_map<std::string, size_t> by_label;
+  for (size_t i = 0; i < ref_msa.size(); ++i) by_label.emplace(ref_msa[i].header(), i);
+  const int s = model_.num_states();
+  std::unordered_map<uint32_t, uint8_t> code_of;
+  if (s == 4) {
+    tipmap_.resize(16);
+    for (uint32_t m = 0; m < 16; ++m) { tipmap_[m] = m; code_of[m] = (uint8_t)m; }
+  }
+  tipchars_.resize(n);
+  for (unsigned t = 0; t < n; ++t) {
+    auto it = by_label.find(labels_[t]);
+    if (it == by_label.end())
+      throw std::invalid_argument{"Bad tree/ref msa combination: failed to find " + labels_[t]};
+    const std::string& sq = ref_msa[it->second].sequence();
+    if (sq.size() != sites_) throw std::runtime_error{"reference MSA rows differ in length"};
+    tipchars_[t].resize(sites_);
+    for (size_t w = 0; w < sites_; ++w) {
+      const uint32_t m = model_.char_mask(sq[w]);
+      if (!m) throw std::invalid_argument{"Bad sequence: illegal character in " + labels_[t]};
+      auto c = code_of.find(m);
+      if (c == code_of.end()) {
+        if (tipmap_.size() >= 255) throw std::runtime_error{"too many distinct tip state sets"};
+        c = code_of.emplace(m, (uint8_t)tipmap_.size()).first;
+        tipmap_.push_back(m);
+      }
+      tipchars_[t][w] = c->second;
+    }
+  }
+  // precompute_clvs (src/core/pll/epa_pll_util.cpp:62-107): all three directions per inner node
+  clv_.resize(recs_.size());
+  scaler_.resize(recs_.size());
+  for (int r = 0; r < (int)recs_.size(); ++r) compute_clv(r);
+}
+
+void Tree::side(int rec, const double*& clv, const uint8_t*& tip, const uint32_t*& sc) const {
+  const Rec& r = recs_[rec];
+  if (r.tip >= 0) { clv = nullptr; tip = tipchars_[r.tip].data(); sc = nullptr; }
+  else { clv = clv_[rec].data(); tip = nullptr; sc = scaler_[rec].data(); }
+}
+
+void Tree::compute_clv(int root) {
+  if (recs_[root].tip >= 0 || !clv_[root].empty()) return;
+  // explicit post-order stack: caterpillar trees of thousands of tips would overflow recursion
+  std::vector<int> st{root};
+  const int s = model_.num_states(), c = model_.num_ratecats();
+  const size_t cs = (size_t)c * s;
+  while (!st.empty()) {
+    const int rec = st.back();
+    const int c1 = recs_[recs_[rec].next].back, c2 = recs_[recs_[recs_[rec].next].next].back;
+    const bool need1 = recs_[c1].tip < 0 && clv_[c1].empty();
+    const bool need2 = recs_[c2].tip < 0 && clv_[c2].empty();
+    if (need1 || need2) {
+      if (need1) st.push_back(c1);
+      if (need2) st.push_back(c2);
+      continue;
+    }
+    st.pop_back();
+    if (!clv_[rec].empty()) continue;
+    std::vector<double> P1(cs * s), P2(cs * s);
+    for (int k = 0; k < c; ++k) {
+      model_.pmatrix(recs_[c1].length, k, &P1[(size_t)k * s * s]);
+      model_.pmatrix(recs_[c2].length, k, &P2[(size_t)k * s * s]);
+    }
+    const double *v1, *v2;
+    const uint8_t *t1, *t2;
+    const uint32_t *s1, *s2;
+    side(c1, v1, t1, s1);
+    side(c2, v2, t2, s2);
+    std::vector<double> out(sites_ * cs);
+    std::vector<uint32_t> sc(sites_);
+#pragma omp parallel for schedule(static)
+    for (long w = 0; w < (long)sites_; ++w) {
+      bool all_small = true;
+      double* o = &out[(size_t)w * cs];
+      const uint32_t m1 = t1 ? tipmap_[t1[w]] : 0, m2 = t2 ? tipmap_[t2[w]] : 0;
+      for (int k = 0; k < c; ++k)
+        for (int i = 0; i < s; ++i) {
+          const double* r1 = &P1[((size_t)k * s + i) * s];
+          const double* r2 = &P2[((size_t)k * s + i) * s];
+          double a = 0.0, b = 0.0;
+          if (t1) { for (int j = 0; j < s; ++j) if ((m1 >> j) & 1u) a += r1[j]; }
+          else { const double* x = v1 + (size_t)w * cs + (size_t)k * s; for (int j = 0; j < s; ++j) a += r1[j] * x[j]; }
+          if (t2) { for (int j = 0; j < s; ++j) if ((m2 >> j) & 1u) b += r2[j]; }
+          else { const double* x = v2 + (size_t)w * cs + (size_t)k * s; for (int j = 0; j < s; ++j) b += r2[j] * x[j]; }
+          const double v = a * b;
+          o[(size_t)k * s + i] = v;
+          all_small = all_small && v < kScaleThreshold;
+        }
+      uint32_t cnt = (s1 ? s1[w] : 0) + (s2 ? s2[w] : 0);
+      if (all_small) {
+        for (size_t x = 0; x < cs; ++x) o[x] *= kScaleFactor;
+        ++cnt;
+      }
+      sc[w] = cnt;
+    }
+    clv_[rec] = std::move(out);
+    scaler_[rec] = std::move(sc);
+  }
+}
+
+Tree::Branch Tree::branch(size_t b) const {
+  int d = branch_rec_.at(b), p = recs_[d].back;
+  const double len = recs_[d].length;
+  // the reference tip is always DISTAL (src/tree/Tiny_Tree.cpp:64-74)
+  if (recs_[d].tip < 0 && recs_[p].tip >= 0) std::swap(d, p);
+  Branch br{};
+  const uint8_t* ptip;
+  side(p, br.prox_clv, ptip, br.prox_scaler);
+  side(d, br.dist_clv, br.dist_tipchars, br.dist_scaler);
+  br.length = len;
+  return br;
+}
+
+void Tree::fill_desc(epa_ref_desc& d, std::vector<const double*>& pc,
+                     std::vector<const uint32_t*>& ps, std::vector<const double*>& dc,
+                     std::vector<const uint8_t*>& dt, std::vector<const uint32_t*>& ds,
+                     std::vector<double>& bl) const {
+  std::memset(&d, 0, sizeof(d));
+  const size_t B = nums_.branches;
+  pc.resize(B); ps.resize(B); dc.resize(B); dt.resize(B); ds.resize(B); bl.resize(B);
+  for (size_t b = 0; b < B; ++b) {
+    const Branch br = branch(b);
+    pc[b] = br.prox_clv; ps[b] = br.prox_scaler;
+    dc[b] = br.dist_clv; dt[b] = br.dist_tipchars; ds[b] = br.dist_scaler;
+    bl[b] = br.length;
+  }
+  d.states = (uint32_t)model_.num_states();
+  d.rate_cats = (uint32_t)model_.num_ratecats();
+  d.sites = (uint32_t)sites_;
+  d.branches = (uint32_t)B;
+  d.eigenvals = model_.eigenvals().data();
+  d.eigenvecs_u = model_.eigenvecs_u().data();
+  d.eigenvecs_uinv = model_.eigenvecs_uinv().data();
+  d.freqs = model_.base_freqs().data();
+  d.rates = model_.ratecat_rates().data();
+  d.rate_weights = model_.ratecat_weights().data();
+  d.prop_invar = 0.0;
+  d.prox_clv = pc.data(); d.prox_scaler = ps.data();
+  d.dist_clv = dc.data(); d.dist_tipchars = dt.data(); d.dist_scaler = ds.data();
+  d.branch_length = bl.data();
+  d.tipmap = tipmap_.data();
+  d.tipmap_size = (uint32_t)tipmap_.size();
+}
+
+double Tree::ref_tree_logl(size_t b) const {
+  const int d = branch_rec_.at(b), p = recs_[d].back;
+  const int s = model_.num_states(), c = model_.num_ratecats();
+  const size_t cs = (size_t)c * s;
+  std::vector<double> P(cs * s);
+  for (int k = 0; k < c; ++k) model_.pmatrix(recs_[d].length, k, &P[(size_t)k * s * s]);
+  const double *vp, *vd;
+  const uint8_t *tp, *td;
+  const uint32_t *sp, *sd;
+  side(p, vp, tp, sp);
+  side(d, vd, td, sd);
+  const double log_thr = std::log(kScaleThreshold);
+  double logl = 0.0;
+  for (size_t w = 0; w < sites_; ++w) {
+    double site = 0.0;
+    for (int k = 0; k < c; ++k) {
+      double cat = 0.0;
+      for (int i = 0; i < s; ++i) {
+        const double pv = tp ? (((tipmap_[tp[w]] >> i) & 1u) ? 1.0 : 0.0) : vp[w * cs + (size_t)k * s + i];
+        if (pv == 0.0) continue;
+        double t = 0.0;
+        for (int j = 0; j < s; ++j) {
+          const double dv = td ? (((tipmap_[td[w]] >> j) & 1u) ? 1.0 : 0.0) : vd[w * cs + (size_t)k * s + j];
+          t += P[((size_t)k * s + i) * s + j] * dv;
+        }
+        cat += pv * model_.base_freqs()[i] * t;
+      }
+      site += cat * model_.ratecat_weights()[k];
+    }
+    const uint32_t cnt = (sp ? sp[w] : 0) + (sd ? sd[w] : 0);
+    logl += std::log(site) + cnt * log_thr;
+  }
+  return logl;
+}
+
+std::string Tree::numbered_newick(unsigned int precision) const {
+  // get_numbered_newick_string (src/core/pll/pll_util.cpp:207-259); literal expectations in the
+  // reference's test/src/pll_util.cpp:134-143.  Inner labels are not kept.
+  std::ostringstream ss;
+  ss.precision(precision);
+  ss.setf(std::ios::fixed, std::ios::floatfield);
+  unsigned idx = 0;
+  struct Frame { int rec; int state; };
+  auto emit = [&](int start) {
+    std::vector<Frame> st{{start, 0}};
+    while (!st.empty()) {
+      Frame& f = st.back();
+      const Rec& r = recs_[f.rec];
+      if (r.next < 0) {
+        ss << labels_[r.tip] << ":" << r.length << "{" << idx++ << "}";
+        st.pop_back();
+      } else if (f.state == 0) {
+        ss << "(";
+        f.state = 1;
+        st.push_back({recs_[r.next].back, 0});
+      } else if (f.state == 1) {
+        ss << ",";
+        f.state = 2;
+        st.push_back({recs_[recs_[r.next].next].back, 0});
+      } else {
+        ss << "):" << r.length << "{" << idx++ << "}";
+        st.pop_back();
+      }
+    }
+  };
+  ss << "(";
+  emit(recs_[vroot_].back);
+  ss << ",";
+  emit(recs_[recs_[vroot_].next].back);
+  ss << ",";
+  emit(recs_[recs_[recs_[vroot_].next].next].back);
+  ss << ");";
+  return ss.str();
+}
+
+}  // namespace epa

@@ -1,0 +1,125 @@
+"""CPU tests of the product's C++ host library (libepa_host.so): model, reference-tree
+precompute, heuristics and filters -- checked against the oracle, the golden vectors and the
+reference's own literal test vectors.  No GPU, no compute calls into libepa_dev."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import epa_ng_amd as epa
+from epa_ng_amd import hostlib
+from golden_util import CASES, load_case
+from oracle_lib import Oracle
+
+
+def refs(g):
+    labels = [a for a, _ in g["msa"]]
+    seqs = [b for _, b in g["msa"]]
+    o = Oracle(g["newick"], labels, seqs, g["states"], g["subst"], g["freqs"], g["gamma_rates"])
+    r = hostlib.Reference(g["newick"], labels, seqs, states=g["states"], subst=g["subst"],
+                          freqs=g["freqs"], rates=g["gamma_rates"])
+    return o, r
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "epa_dev.h")).read()
+    names = set(re.findall(r"\b(epa_(?:dev_)?[a-z_]+)\s*\(", hdr))
+    names -= {"epa_dev_h"}
+    assert len(names) >= 11
+    L = epa.dev_lib()
+    for n in names:
+        assert hasattr(L, n), n
+    assert epa.device_count() >= 0
+
+
+def test_no_device_is_loud_not_a_fallback():
+    if epa.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    g = load_case("dna8_gtr_g_default")
+    _, r = refs(g)
+    with pytest.raises(epa.EpaError) as e:
+        r.evaluator()
+    assert e.value.code == -3  # EPA_ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_reference_precompute_matches_oracle_and_golden(case):
+    g = load_case(case)
+    o, r = refs(g)
+    assert (r.B, r.W, r.s, r.c) == (o.B, o.W, o.s, o.c)
+    assert r.numbered_newick(2) == g["numbered_newick_p2"]
+    for b in range(r.B):
+        assert abs(r.tree_lnl(b) - g["tree_lnl"]) < 1e-8
+    tm = r.tipmap()
+    for b in range(r.B):
+        hb = r.branch(b)
+        cp, sp, cd, sd = o.branch_sides(b)
+        assert abs(hb["length"] - o.branch_info(b)[0]) == 0.0
+        assert np.allclose(hb["prox_clv"], cp, rtol=1e-12, atol=0)
+        assert np.array_equal(hb["prox_scaler"], sp)
+        if hb["dist_clv"] is not None:
+            assert np.allclose(hb["dist_clv"], cd, rtol=1e-12, atol=0)
+            assert np.array_equal(hb["dist_scaler"], sd)
+        else:
+            masks = tm[hb["dist_tip"]]
+            exp = ((masks[:, None] >> np.arange(r.s)[None, :]) & 1).astype(float)
+            assert np.array_equal(np.broadcast_to(exp[:, None, :], cd.shape), cd)
+
+
+def test_model_descriptor_parsing_and_gamma():
+    g = load_case("dna8_gtr_fu_g4")
+    labels = [a for a, _ in g["msa"]]
+    seqs = [b for _, b in g["msa"]]
+    # descriptor literal pinned by the reference's test/src/parse_model.cpp:10-11
+    desc = ("GTR{0.787874/1.821672/1.294006/0.698421/3.034135/1.000000}+FU{0.256465/0.222535/"
+            "0.308594/0.212406}+G4{0.478218}")
+    r = hostlib.Reference(g["newick"], labels, seqs, model=desc)
+    m = r.model()
+    assert np.allclose(m["rates"], g["gamma_rates"], rtol=1e-10)
+    assert abs(r.tree_lnl() - g["tree_lnl"]) < 1e-7
+    r2 = hostlib.Reference(g["newick"], labels, seqs, model="GTR+G")
+    g0 = load_case("dna8_gtr_g_default")
+    assert abs(r2.tree_lnl() - g0["tree_lnl"]) < 1e-7
+    # eigen system reproduces Q: U diag(lam) U^-1 rows sum to 0, detailed balance
+    q = m["u"] @ np.diag(m["eigenvals"]) @ m["uinv"]
+    assert np.allclose(q.sum(1), 0, atol=1e-12)
+    assert np.allclose(m["freqs"][:, None] * q, (m["freqs"][:, None] * q).T, atol=1e-12)
+    assert np.allclose(m["u"] @ m["uinv"], np.eye(4), atol=1e-12)
+    with pytest.raises(RuntimeError):
+        hostlib.Reference(g["newick"], labels, seqs, model="LG+G")
+
+
+def test_filters_reference_literals():
+    # literal vectors and expected counts of the reference's test/src/set_manipulators.cpp:372-443
+    wa = [0.001, 0.23, 0.05, 0.02, 0.4, 0.009, 0.2, 0.09]
+    wb = [0.01, 0.02, 0.005, 0.002, 0.94, 0.003, 0.02]
+    assert [len(hostlib.filter_lwr(w, 0.95, acc=True)) for w in (wa, wb, [1.0])] == [5, 2, 1]
+    assert [len(hostlib.filter_lwr(w, 0.01)) for w in (wa, wb, [1.0])] == [6, 3, 1]
+    # defaults of the CLI: min 1, max 7 (src/util/Options.hpp:17-20)
+    kept = hostlib.filter_lwr([0.12] * 8 + [0.04], 0.01, mn=1, mx=7)
+    assert len(kept) == 7
+    assert list(hostlib.filter_lwr([0.5, 0.3, 0.2], 0.6, mn=1)) == [0]  # none above -> keep min 1
+
+
+def test_heuristics_against_numpy():
+    rng = np.random.RandomState(3)
+    lnl = -1000 + 30 * rng.rand(50, 37)
+    lnl[:, 5] += 25
+    pb, ps = hostlib.heuristic(lnl, "dynamic", 0.99999)
+    exp = []
+    for q in range(lnl.shape[0]):
+        row = lnl[q]
+        lw = np.exp(row - row.max()); lw /= lw.sum()
+        s, k = 0.0, 0
+        for b in np.argsort(-lw, kind="stable"):
+            if not s < 0.99999:
+                break
+            s += lw[b]; exp.append((b, q))
+    assert sorted(zip(pb.tolist(), ps.tolist())) == sorted(exp)
+    assert np.all(np.diff(pb.astype(int)) >= 0)
+    pb, ps = hostlib.heuristic(lnl, "fixed", 0.1)
+    assert len(pb) == 50 * int(np.ceil(0.1 * 37))
+    pb, ps = hostlib.heuristic(lnl, "baseball")
+    assert np.all(np.bincount(ps) <= 40) and np.all(np.bincount(ps) >= 6)
