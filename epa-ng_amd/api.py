@@ -60,6 +60,15 @@ def dev_lib():
         if not os.path.exists(DEV_SO):
             raise ImportError("libepa_dev.so is missing: run `python __graft_entry__.py` "
                               "(build()) -- the HIP extension is the only compute path")
+        # When PyTorch shares the process (bench.py, tests: device buffers, torch.distributed) its
+        # bundled HIP runtime must be the first one loaded, otherwise torch later finds "No HIP
+        # GPUs": import it before dlopen()ing the extension.  torch is plumbing, never compute.
+        try:
+            import torch  # noqa: F401
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         L = C.CDLL(DEV_SO)
         L.epa_dev_device_count.restype = C.c_int
         L.epa_dev_create.argtypes = [C.POINTER(_RefDesc), C.c_int, C.POINTER(C.c_void_p)]
