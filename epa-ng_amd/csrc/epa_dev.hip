@@ -546,9 +546,9 @@ extern "C" int epa_dev_thorough(epa_ctx* ctx, const epa_pair* pairs, uint64_t n_
     return epa_fail(ctx, EPA_ERR_HIP, "thorough input upload failed");
   const bool out_dev = epa_is_device_ptr(out);
   epa_result* d_out = out_dev ? out : (epa_result*)epa_scratch(ctx, 5, sizeof(epa_result) * n_pairs);
-  unsigned long long* d_stats = (unsigned long long*)epa_scratch(ctx, 6, 64);
+  unsigned long long* d_stats = (unsigned long long*)epa_scratch(ctx, 6, 256);
   if (!d_out || !d_stats) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(thorough out)");
-  EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 64, ctx->stream));
+  EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, ctx->stream));
   rc = launch_thorough(ctx, d_pairs, n_pairs, d_codes, d_begin, d_span, max_span, d_out, d_stats);
   if (rc) return rc;
   unsigned long long hst[8];

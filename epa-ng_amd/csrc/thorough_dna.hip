@@ -213,17 +213,8 @@ __device__ __forceinline__ double newton(const ModelDNA& m, const SiteState<NCH>
 }
 
 template <int NCH>
-__global__ void __launch_bounds__(256) k_thorough_dna(const ThArgs a) {
+__device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid, const int lane) {
   const ModelDNA& m = a.m;
-  const int lane = threadIdx.x & 63;
-  // XCD-aware pair mapping: workgroup g runs on XCD g % 8; give each XCD a contiguous range of
-  // the branch-sorted pair list so one branch's CLV windows stay in one 4 MiB L2.
-  const uint32_t nwg = gridDim.x;
-  const uint32_t per = (nwg + 7) / 8;
-  const uint32_t wg = (blockIdx.x % 8) * per + blockIdx.x / 8;
-  const uint64_t pid = (uint64_t)wg * 4 + (threadIdx.x >> 6);
-  if (pid >= a.n_pairs) return;
-
   const epa_pair pr = a.pairs[pid];
   const uint32_t b = pr.branch_id, q = pr.seq_id;
   const uint32_t begin = a.win_begin[q], n = a.win_span[q];
@@ -357,6 +348,22 @@ __global__ void __launch_bounds__(256) k_thorough_dna(const ThArgs a) {
   }
 }
 
+// Persistent single-wave workgroups.  Workgroup g is observed to run on XCD g % 8 (used for
+// speed only): XCD x owns the x-th eighth of the branch-sorted pair list, so one branch's CLV
+// windows are served by one 4 MiB L2.  Inside its XCD slice a wave takes pairs round-robin
+// (wave, wave + stride, ...): neighbouring waves work on neighbouring pairs = the same branch,
+// and every wave gets a ~25-pair random sample of the 10x cost spread (1..32 NR rounds).
+template <int NCH>
+__global__ void __launch_bounds__(64) k_thorough_dna(const ThArgs a) {
+  const int lane = threadIdx.x;
+  const uint32_t x = blockIdx.x & 7;
+  const uint32_t w = blockIdx.x >> 3, stride = gridDim.x >> 3;
+  const uint64_t per = (a.n_pairs + 7) / 8;
+  const uint64_t lo = (uint64_t)x * per;
+  const uint64_t hi = lo + per < a.n_pairs ? lo + per : a.n_pairs;
+  for (uint64_t p = lo + w; p < hi; p += stride) process_pair<NCH>(a, p, lane);
+}
+
 }  // namespace
 
 int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
@@ -386,10 +393,11 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
   a.W = ctx->W;
   a.Wpad = 0;
   const uint32_t nch = (max_span + 63) / 64;
-  uint32_t nwg = (uint32_t)((n_pairs + 3) / 4);
-  nwg = (nwg + 7) / 8 * 8;  // the XCD remap wants a multiple of 8
+  // persistent grid: 8 single-wave workgroups per CU (2 per SIMD at this kernel's VGPR budget)
+  uint32_t nwg = 256 * 8;
+  if ((uint64_t)nwg > n_pairs) nwg = (uint32_t)((n_pairs + 7) / 8 * 8);
   epa_timer_start(ctx, ctx->t_thorough);
-#define LAUNCH(N) hipLaunchKernelGGL(k_thorough_dna<N>, dim3(nwg), dim3(256), 0, ctx->stream, a)
+#define LAUNCH(N) hipLaunchKernelGGL(k_thorough_dna<N>, dim3(nwg), dim3(64), 0, ctx->stream, a)
   if (nch <= 1) LAUNCH(1);
   else if (nch <= 2) LAUNCH(2);
   else if (nch <= 3) LAUNCH(3);
