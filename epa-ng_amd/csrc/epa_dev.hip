@@ -342,6 +342,24 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx) {
   for (int i = 0; i < s * s; ++i) { m.U[i] = d->eigenvecs_u[i]; m.Ui[i] = d->eigenvecs_uinv[i]; }
   for (int i = 0; i < s; ++i) { m.lam[i] = d->eigenvals[i]; m.pi[i] = d->freqs[i]; }
   for (int k = 0; k < c; ++k) { m.rate[k] = d->rates[k]; m.w[k] = d->rate_weights[k]; }
+  {
+    // Internal convention: eigenvalue 0 is the stationary (zero) one.  Swap the largest
+    // eigenvalue to index 0 (columns of U, rows of U^-1); when it is numerically zero it is
+    // set to exactly 0 so the kernels can drop its derivative terms.
+    int imax = 0;
+    double amax = 0.0;
+    for (int i = 0; i < s; ++i) {
+      if (m.lam[i] > m.lam[imax]) imax = i;
+      amax = std::max(amax, fabs(m.lam[i]));
+    }
+    if (imax != 0) {
+      std::swap(m.lam[0], m.lam[imax]);
+      for (int i = 0; i < s; ++i) std::swap(m.U[i * s], m.U[i * s + imax]);
+      for (int j = 0; j < s; ++j) std::swap(m.Ui[j], m.Ui[imax * s + j]);
+    }
+    ctx->dna_zero0 = fabs(m.lam[0]) <= 1e-9 * amax;
+    if (ctx->dna_zero0) m.lam[0] = 0.0;
+  }
   for (int col = 0; col < ctx->ncols; ++col) {
     m.colmask[col] = column_mask(s, col);
     for (int x = 0; x < s; ++x) {

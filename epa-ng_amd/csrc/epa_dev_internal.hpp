@@ -59,6 +59,7 @@ struct epa_ctx {
   ModelDev hmodel;          // host copy
   ModelDev* dmodel = nullptr;
   ModelDNA dna;             // valid when s == 4 && c == 4
+  bool dna_zero0 = false;   // eigenvalue 0 is the (exactly) zero one after the create-time reorder
   BloConsts blo;
   int aa_x_as_n = 0;
 

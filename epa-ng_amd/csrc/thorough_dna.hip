@@ -54,25 +54,66 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-  return readlane_d(v, 0);
+// v + (v moved by a DPP pattern); lanes without a source (or outside row_mask) add 0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return v + __hiloint2double(hi, lo);
 }
 
-// exp(lam_x * r_k * t) for the 16 (k,x) pairs: lane l < 16 computes pair l, all lanes receive all
-struct E16 { double v[16]; };
-__device__ __forceinline__ void exp_table(const ModelDNA& m, double lr_lane, double t, double scale_lane,
-                                          E16& e) {
-  const double mine = exp(lr_lane * t) * scale_lane;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) e.v[i] = readlane_d(mine, i);
+// wave64 sum without LDS: row_shr 1/2/4/8 inside the 16-lane rows, row_bcast 15 / 31 across
+// rows, total lands in lane 63 and is broadcast through an SGPR pair (wave-uniform result).
+__device__ __forceinline__ double wave_sum(double v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+  return readlane_d(v, 63);
+}
+
+// 1/x: v_rcp_f64 + two Newton steps (the quotient feeds Newton's f, f' only)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+}
+
+// Orders the NEXT chunk's loads after THIS chunk's arithmetic: returns 0 but the compiler must
+// assume it depends on `v`.  Without it the 32 loads of every chunk (and of every later phase)
+// are all issued up front and live ranges explode into scratch.
+__device__ __forceinline__ uint32_t zero_after(double v) {
+  uint32_t z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(__double2loint(v)));
+  return z;
+}
+
+// ---- wave-uniform tables through LDS: every lane computes ONE exp(), writes it to the
+// workgroup's (= wave's) 64-entry table, then all lanes read the entries they need with
+// uniform-address ds_read (broadcast, no bank conflicts).  Lane l holds pair kx = l & 15
+// (k = rate category, x = eigenvalue index) and "slot" l >> 4.
+struct LaneConst {
+  double lr;   // lambda_x * r_k
+  double cN;   // Newton table coefficient: w_k * lr^slot (slot 0,1,2), 0 for slot 3
+  double w;    // w_k
+  int slot;
+};
+
+__device__ __forceinline__ void table_publish(double* tab, int lane, double v) {
+  tab[lane] = v;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // one site: I_ki = (U (ea_k o A_k))_i * (U (eb_k o Bv_k))_i, per-site rescale, return U^-1 I
-// A, Bv: eigen-space vectors [k][x]; ea/eb uniform exp tables.  resc: 1 if rescaled.
-__device__ __forceinline__ void inner_site(const ModelDNA& m, const double (&A)[16], const E16& ea,
-                                           const double (&Bv)[16], const E16& eb, double (&It)[16],
+// A, Bv: eigen-space vectors [k][x]; ea/eb: exp tables.  resc: 1 if rescaled.
+__device__ __forceinline__ void inner_site(const ModelDNA& m, const double (&A)[16], const double* ea,
+                                           const double (&Bv)[16], const double* eb, double (&It)[16],
                                            uint32_t& resc) {
   double I[16];
   double mx = 0.0;
@@ -81,8 +122,8 @@ __device__ __forceinline__ void inner_site(const ModelDNA& m, const double (&A)[
     double av[4], bv[4];
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-      av[x] = A[k * 4 + x] * ea.v[k * 4 + x];
-      bv[x] = Bv[k * 4 + x] * eb.v[k * 4 + x];
+      av[x] = A[k * 4 + x] * ea[k * 4 + x];
+      bv[x] = Bv[k * 4 + x] * eb[k * 4 + x];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -120,32 +161,33 @@ struct SiteState {
   bool valid[NCH];
 };
 
-// sum over the wave's sites of  -l1/l0  and  (l1/l0)^2 - l2/l0   (pll_compute_likelihood_
-// derivatives).  ew = w_k * exp(lam_x r_k t).
-template <int NCH>
-__device__ __forceinline__ void derivatives(const ModelDNA& m, const SiteState<NCH>& st,
-                                            const E16& ew, double& f, double& df) {
+// Newton tables for proposal t: e = w exp(lr t), e1 = w lr exp(lr t), e2 = w lr^2 exp(lr t).
+// ZERO0: eigenvalue 0 is exactly 0 (stationary mode) -> its e1/e2 columns vanish.
+// Then  f = sum_sites -l1/l0,  f' = sum_sites (l1/l0)^2 - l2/l0   (pll_compute_likelihood_
+// derivatives): 40 (48) FMAs per site.
+template <int NCH, bool ZERO0>
+__device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* tab, int lane,
+                                            const LaneConst& lc, double t, double& f, double& df) {
+  table_publish(tab, lane, exp(lc.lr * t) * lc.cN);
+  double e[16], e1[16], e2[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    e[i] = tab[i];
+    if (!(ZERO0 && (i & 3) == 0)) { e1[i] = tab[16 + i]; e2[i] = tab[32 + i]; }
+  }
   double fl = 0.0, dfl = 0.0;
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     double l0 = 0.0, l1 = 0.0, l2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      double u0 = 0.0, u1 = 0.0, u2 = 0.0;
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        const double t = st.S[ch][k * 4 + x] * ew.v[k * 4 + x];
-        const double lx = m.lam[x];
-        u0 += t;
-        u1 = fma(t, lx, u1);
-        u2 = fma(t, lx * lx, u2);
+    for (int i = 0; i < 16; ++i) {
+      l0 = fma(st.S[ch][i], e[i], l0);
+      if (!(ZERO0 && (i & 3) == 0)) {
+        l1 = fma(st.S[ch][i], e1[i], l1);
+        l2 = fma(st.S[ch][i], e2[i], l2);
       }
-      const double r = m.rate[k];
-      l0 += u0;
-      l1 = fma(u1, r, l1);
-      l2 = fma(u2, r * r, l2);
     }
-    const double inv = 1.0 / l0;
+    const double inv = fast_rcp(l0);
     const double d1 = -l1 * inv;
     const double d2 = fma(d1, d1, -l2 * inv);
     if (st.valid[ch]) { fl += d1; dfl += d2; }
@@ -154,37 +196,41 @@ __device__ __forceinline__ void derivatives(const ModelDNA& m, const SiteState<N
   df = wave_sum(dfl);
 }
 
-// sum over the window of log L_site(t) + scalers * log(2^-256)  (pll_compute_edge_loglikelihood)
+// sum over the window of log L_site + scalers * log(2^-256)  (pll_compute_edge_loglikelihood);
+// ew = w_k exp(lam_x r_k t_pendant).  Per lane the NCH site likelihoods are split into mantissa
+// and exponent (v_frexp_*), mantissas multiplied, exponents and scaler counts added as integers:
+//   sum_ch log(L_ch) + sc_ch log 2^-256  =  log(prod mant) + ln2 * (sum exp - 256 sum sc)
+// -> ONE log() per lane instead of NCH.
 template <int NCH>
-__device__ __forceinline__ double window_lnl(const SiteState<NCH>& st, const E16& ew) {
-  double acc = 0.0;
+__device__ __forceinline__ double window_lnl(const SiteState<NCH>& st, const double (&ew)[16]) {
+  double mant = 1.0;
+  int ex = 0;
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     double l0 = 0.0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      double u0 = 0.0;
-#pragma unroll
-      for (int x = 0; x < 4; ++x) u0 = fma(st.S[ch][k * 4 + x], ew.v[k * 4 + x], u0);
-      l0 += u0;
+    for (int i = 0; i < 16; ++i) l0 = fma(st.S[ch][i], ew[i], l0);
+    if (!st.valid[ch]) l0 = 1.0;
+    const int sc = st.valid[ch] ? (int)(st.sc[ch] + st.resc[ch]) : 0;
+    mant *= __builtin_amdgcn_frexp_mant(l0);
+    ex += __builtin_amdgcn_frexp_exp(l0) - 256 * sc;
+    if ((ch & 7) == 7) {  // long windows: keep the running product normalised
+      ex += __builtin_amdgcn_frexp_exp(mant);
+      mant = __builtin_amdgcn_frexp_mant(mant);
     }
-    const double v = log(l0) + (double)(st.sc[ch] + st.resc[ch]) * LOG_THR;
-    if (st.valid[ch]) acc += v;
   }
-  return wave_sum(acc);
+  return wave_sum(log(mant) + (double)ex * 0.6931471805599453094);
 }
 
 // pllmod_opt_minimize_newton (pll-modules; rtsafe-style safeguarded Newton).  Wave-uniform.
-template <int NCH>
-__device__ __forceinline__ double newton(const ModelDNA& m, const SiteState<NCH>& st, double lr_lane,
-                                         double w_lane, double x1, double xguess, double x2,
+template <int NCH, bool ZERO0>
+__device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, int lane,
+                                         const LaneConst& lc, double x1, double xguess, double x2,
                                          double tol, int max_iters, uint32_t& evals) {
   double rts = xguess, f, df, xl, xh, dx;
   if (rts < x1) rts = x1;
   if (rts > x2) rts = x2;
-  E16 ew;
-  exp_table(m, lr_lane, rts, w_lane, ew);
-  derivatives<NCH>(m, st, ew, f, df);
+  derivatives<NCH, ZERO0>(st, tab, lane, lc, rts, f, df);
   ++evals;
   if (!isfinite(f) || !isfinite(df)) return NAN;
   if (df >= 0.0 && fabs(f) < tol) return rts;
@@ -202,8 +248,7 @@ __device__ __forceinline__ double newton(const ModelDNA& m, const SiteState<NCH>
     }
     if (fabs(dx) < tol || i == max_iters) return rts;
     if (rts < x1) rts = x1;
-    exp_table(m, lr_lane, rts, w_lane, ew);
-    derivatives<NCH>(m, st, ew, f, df);
+    derivatives<NCH, ZERO0>(st, tab, lane, lc, rts, f, df);
     ++evals;
     if (!isfinite(f) || !isfinite(df)) return NAN;
     if (df > 0.0 && fabs(f) < tol) return rts;
@@ -212,23 +257,24 @@ __device__ __forceinline__ double newton(const ModelDNA& m, const SiteState<NCH>
   return NAN;
 }
 
-template <int NCH>
-__device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid, const int lane) {
+template <int NCH, bool ZERO0>
+__device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid, const int lane,
+                                             double* tab, const double* qts, const LaneConst& lc) {
   const ModelDNA& m = a.m;
   const epa_pair pr = a.pairs[pid];
   const uint32_t b = pr.branch_id, q = pr.seq_id;
   const uint32_t begin = a.win_begin[q], n = a.win_span[q];
   const size_t cW = a.W;
-  const double* Xt = a.refT + (size_t)(2 * b) * 16 * cW + begin;
-  const double* Dt = a.refT + (size_t)(2 * b + 1) * 16 * cW + begin;
+  // one uniform base (SGPR pair) + 32-bit per-lane byte offsets: component c of the proximal
+  // CLV sits at c*W*8, of the distal CLV at (16+c)*W*8 (saddr + voffset addressing, no
+  // per-stream 64-bit pointers in VGPRs)
+  const char* ref = reinterpret_cast<const char*>(a.refT + (size_t)(2 * b) * 16 * cW + begin);
+  const uint32_t W8 = a.W * 8u;
+  auto ldX = [&](int c, uint32_t soff) { return *reinterpret_cast<const double*>(ref + (soff + (uint32_t)c * W8)); };
+  auto ldD = [&](int c, uint32_t soff) { return *reinterpret_cast<const double*>(ref + (soff + (uint32_t)(16 + c) * W8)); };
   const uint32_t* scp = a.scSum + (size_t)b * cW + begin;
   const uint8_t* qc = a.codes + (size_t)q * cW + begin;
   const double orig = a.blen[b];
-
-  // lane-private constants for the broadcast exp tables: pair (k,x) = lane & 15
-  const int lk = (lane >> 2) & 3, lx = lane & 3;
-  const double lr_lane = m.lam[lx] * m.rate[lk];
-  const double w_lane = m.w[lk];
 
   SiteState<NCH> st;
 #pragma unroll
@@ -243,20 +289,23 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 
   double tp = a.blo.pendant_default, td = orig * 0.5, tx = orig * 0.5;
   uint32_t evals = 0, rounds = 0, reverted = 0;
+  uint32_t chain = 0;  // zero_after() token: serialises load batches behind the preceding math
 
-  // inner CLV toward the query at the current (td, tx), folded with the query: S = (U^-1 I) o qt
-  auto score_sumtable = [&](double td_, double tx_) {
-    E16 ed, ex;
-    exp_table(m, lr_lane, td_, 1.0, ed);
-    exp_table(m, lr_lane, tx_, 1.0, ex);
+  // Inner CLV toward the query at (td, tx) folded with the query, S = (U^-1 I) o qt, and the
+  // window lnL at pendant length tp_.  One table pass: slot 0 -> exp(lr td), slot 1 ->
+  // exp(lr tx), slot 2 -> w exp(lr tp).
+  auto score = [&](double td_, double tx_, double tp_) -> double {
+    const double tl = lc.slot == 0 ? td_ : (lc.slot == 1 ? tx_ : tp_);
+    table_publish(tab, lane, exp(lc.lr * tl) * (lc.slot == 2 ? lc.w : 1.0));
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      const uint32_t s = st.valid[ch] ? ch * 64 + lane : 0;
+      // one chunk's 32 loads in flight at a time (VGPR budget)
+      const uint32_t s = (st.valid[ch] ? ch * 64 + lane : 0) * 8u + chain;
       double D[16], X[16], It[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) { D[c] = Dt[(size_t)c * cW + s]; X[c] = Xt[(size_t)c * cW + s]; }
-      inner_site(m, D, ed, X, ex, It, st.resc[ch]);
-      const double* qv = a.qt + st.code[ch] * 4;
+      for (int c = 0; c < 16; ++c) { D[c] = ldD(c, s); X[c] = ldX(c, s); }
+      inner_site(m, D, tab, X, tab + 16, It, st.resc[ch]);
+      const double* qv = qts + st.code[ch] * 4;
       const double q0 = qv[0], q1 = qv[1], q2 = qv[2], q3 = qv[3];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -265,40 +314,38 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
         st.S[ch][k * 4 + 2] = It[k * 4 + 2] * q2;
         st.S[ch][k * 4 + 3] = It[k * 4 + 3] * q3;
       }
+      chain = zero_after(st.S[ch][15]);
     }
+    double ew[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
+    return window_lnl<NCH>(st, ew);
   };
   // inner CLV toward distal: I' = (P_pend q) o (P_prox X); S = Dt o (U^-1 I')
   auto distal_sumtable = [&](double tp_, double tx_) {
-    E16 ep, ex;
-    exp_table(m, lr_lane, tp_, 1.0, ep);
-    exp_table(m, lr_lane, tx_, 1.0, ex);
+    table_publish(tab, lane, exp(lc.lr * (lc.slot == 0 ? tp_ : tx_)));
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      const uint32_t s = st.valid[ch] ? ch * 64 + lane : 0;
+      const uint32_t s = (st.valid[ch] ? ch * 64 + lane : 0) * 8u + chain;
       double Qv[16], X[16], It[16];
-      const double* qv = a.qt + st.code[ch] * 4;
+      const double* qv = qts + st.code[ch] * 4;
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
         const double v = qv[x];
         Qv[x] = v; Qv[4 + x] = v; Qv[8 + x] = v; Qv[12 + x] = v;
       }
 #pragma unroll
-      for (int c = 0; c < 16; ++c) X[c] = Xt[(size_t)c * cW + s];
+      for (int c = 0; c < 16; ++c) X[c] = ldX(c, s);
       uint32_t r;
-      inner_site(m, Qv, ep, X, ex, It, r);
+      inner_site(m, Qv, tab, X, tab + 16, It, r);
 #pragma unroll
-      for (int c = 0; c < 16; ++c) st.S[ch][c] = Dt[(size_t)c * cW + s] * It[c];
+      for (int c = 0; c < 16; ++c) st.S[ch][c] = ldD(c, s) * It[c];
+      chain = zero_after(st.S[ch][15]);
     }
-  };
-  auto lnl_at = [&](double tp_) {
-    E16 ew;
-    exp_table(m, lr_lane, tp_, w_lane, ew);
-    return window_lnl<NCH>(st, ew);
   };
 
   // traverse_update_partials + initial score (optimize.cpp:15-42,111-113)
-  score_sumtable(td, tx);
-  double loglikelihood = -lnl_at(tp);
+  double loglikelihood = -score(td, tx, tp);
 
   uint32_t smoothings = a.blo.max_rounds;
   while (smoothings) {
@@ -307,8 +354,9 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     double xmin = a.blo.min_branch, xmax = a.blo.max_branch, xtol = xmin / 10.0;
     double xguess = tp;
     if (xguess < xmin || xguess > xmax) xguess = a.blo.default_branch;
-    double xres = newton<NCH>(m, st, lr_lane, w_lane, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
+    double xres = newton<NCH, ZERO0>(st, tab, lane, lc, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
     if (xres > 0.0) tp = xres;
+    chain = zero_after(tp);
     // ---- NR for the distal length with the proximal P-matrix held fixed (:170-211)
     distal_sumtable(tp, tx);
     xguess = td;
@@ -316,11 +364,11 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     xtol = xmin / 10.0;
     xmax = orig - xtol;
     if (xguess < xmin || xguess > xmax) xguess = orig / 2.0;
-    xres = newton<NCH>(m, st, lr_lane, w_lane, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
+    xres = newton<NCH, ZERO0>(st, tab, lane, lc, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
     if (xres > 0.0) { td = xres; tx = orig - xres; }
+    chain = zero_after(td);
     // ---- score (:217-222)
-    score_sumtable(td, tx);
-    const double new_ll = -lnl_at(tp);
+    const double new_ll = -score(td, tx, tp);
     ++rounds;
     if (new_ll - loglikelihood > new_ll * 1e-14) {  // worse: restore lengths, keep the old lnL
       tp = old_tp; td = old_td; tx = orig - old_td;
@@ -353,15 +401,27 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 // windows are served by one 4 MiB L2.  Inside its XCD slice a wave takes pairs round-robin
 // (wave, wave + stride, ...): neighbouring waves work on neighbouring pairs = the same branch,
 // and every wave gets a ~25-pair random sample of the 10x cost spread (1..32 NR rounds).
-template <int NCH>
-__global__ void __launch_bounds__(64) k_thorough_dna(const ThArgs a) {
+template <int NCH, bool ZERO0>
+__global__ void __launch_bounds__(64, 2) k_thorough_dna(const ThArgs a) {
+  __shared__ double tab[64];   // broadcast table of the wave
+  __shared__ double qts[64];   // U^-1 image of the 16 query column codes
   const int lane = threadIdx.x;
+  qts[lane] = a.qt[lane];
+  LaneConst lc;
+  {
+    const int lk = (lane >> 2) & 3, lx = lane & 3;
+    lc.slot = lane >> 4;
+    lc.lr = a.m.lam[lx] * a.m.rate[lk];
+    lc.w = a.m.w[lk];
+    lc.cN = lc.slot == 0 ? lc.w : (lc.slot == 1 ? lc.w * lc.lr : (lc.slot == 2 ? lc.w * lc.lr * lc.lr : 0.0));
+  }
+  __syncthreads();
   const uint32_t x = blockIdx.x & 7;
   const uint32_t w = blockIdx.x >> 3, stride = gridDim.x >> 3;
   const uint64_t per = (a.n_pairs + 7) / 8;
   const uint64_t lo = (uint64_t)x * per;
   const uint64_t hi = lo + per < a.n_pairs ? lo + per : a.n_pairs;
-  for (uint64_t p = lo + w; p < hi; p += stride) process_pair<NCH>(a, p, lane);
+  for (uint64_t p = lo + w; p < hi; p += stride) process_pair<NCH, ZERO0>(a, p, lane, tab, qts, lc);
 }
 
 }  // namespace
@@ -397,7 +457,11 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
   uint32_t nwg = 256 * 8;
   if ((uint64_t)nwg > n_pairs) nwg = (uint32_t)((n_pairs + 7) / 8 * 8);
   epa_timer_start(ctx, ctx->t_thorough);
-#define LAUNCH(N) hipLaunchKernelGGL(k_thorough_dna<N>, dim3(nwg), dim3(64), 0, ctx->stream, a)
+#define LAUNCH(N)                                                                              \
+  do {                                                                                         \
+    if (ctx->dna_zero0) hipLaunchKernelGGL((k_thorough_dna<N, true>), dim3(nwg), dim3(64), 0, ctx->stream, a); \
+    else hipLaunchKernelGGL((k_thorough_dna<N, false>), dim3(nwg), dim3(64), 0, ctx->stream, a); \
+  } while (0)
   if (nch <= 1) LAUNCH(1);
   else if (nch <= 2) LAUNCH(2);
   else if (nch <= 3) LAUNCH(3);
