@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-DEV_SO = os.path.join(HERE, "libepa_dev.so")
+DEV_SO = os.environ.get("EPA_DEV_SO", os.path.join(HERE, "libepa_dev.so"))
 
 __all__ = ["EpaError", "dev_lib", "device_count", "encode_queries", "Evaluator", "PAIR_DTYPE",
            "RESULT_DTYPE", "DEV_SO"]

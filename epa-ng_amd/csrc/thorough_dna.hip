@@ -259,7 +259,8 @@ __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, 
 
 template <int NCH, bool ZERO0>
 __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid, const int lane,
-                                             double* tab, const double* qts, const LaneConst& lc) {
+                                             double* tab, const double* qts, const LaneConst& lc,
+                                             uint32_t (&wstat)[3]) {
   const ModelDNA& m = a.m;
   const epa_pair pr = a.pairs[pid];
   const uint32_t b = pr.branch_id, q = pr.seq_id;
@@ -304,6 +305,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
       double D[16], X[16], It[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) { D[c] = ldD(c, s); X[c] = ldX(c, s); }
+      asm volatile("" ::: "memory");  // all 32 loads are issued here, none is sunk to its use
       inner_site(m, D, tab, X, tab + 16, It, st.resc[ch]);
       const double* qv = qts + st.code[ch] * 4;
       const double q0 = qv[0], q1 = qv[1], q2 = qv[2], q3 = qv[3];
@@ -327,7 +329,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const uint32_t s = (st.valid[ch] ? ch * 64 + lane : 0) * 8u + chain;
-      double Qv[16], X[16], It[16];
+      double Qv[16], X[16], D[16], It[16];
       const double* qv = qts + st.code[ch] * 4;
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
@@ -335,11 +337,12 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
         Qv[x] = v; Qv[4 + x] = v; Qv[8 + x] = v; Qv[12 + x] = v;
       }
 #pragma unroll
-      for (int c = 0; c < 16; ++c) X[c] = ldX(c, s);
+      for (int c = 0; c < 16; ++c) { X[c] = ldX(c, s); D[c] = ldD(c, s); }
+      asm volatile("" ::: "memory");  // issue the whole batch up front (see score)
       uint32_t r;
       inner_site(m, Qv, tab, X, tab + 16, It, r);
 #pragma unroll
-      for (int c = 0; c < 16; ++c) st.S[ch][c] = ldD(c, s) * It[c];
+      for (int c = 0; c < 16; ++c) st.S[ch][c] = D[c] * It[c];
       chain = zero_after(st.S[ch][15]);
     }
   };
@@ -387,13 +390,15 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     r.pendant_length = tp;
     r.distal_length = (orig / (td + tx)) * td;  // Tiny_Tree.cpp:183-185
     a.out[pid] = r;
-    atomicAdd(&a.stats[0], (unsigned long long)rounds);
-    atomicAdd(&a.stats[1], (unsigned long long)evals);
-    atomicAdd(&a.stats[2], (unsigned long long)reverted);
     if (!isfinite(lnl)) {
       if (atomicAdd(&a.stats[3], 1ull) == 0) a.stats[4] = ((unsigned long long)b << 32) | q;
     }
   }
+  // counters stay in registers: one atomic per WAVE at kernel end, not three per pair (a single
+  // L2 word retires ~1 atomic / 12 ns: 3 x 50k pairs on shared words would cost ~2 ms)
+  wstat[0] += rounds;
+  wstat[1] += evals;
+  wstat[2] += reverted;
 }
 
 // Persistent single-wave workgroups.  Workgroup g is observed to run on XCD g % 8 (used for
@@ -421,7 +426,13 @@ __global__ void __launch_bounds__(64, 2) k_thorough_dna(const ThArgs a) {
   const uint64_t per = (a.n_pairs + 7) / 8;
   const uint64_t lo = (uint64_t)x * per;
   const uint64_t hi = lo + per < a.n_pairs ? lo + per : a.n_pairs;
-  for (uint64_t p = lo + w; p < hi; p += stride) process_pair<NCH, ZERO0>(a, p, lane, tab, qts, lc);
+  uint32_t wstat[3] = {0, 0, 0};
+  for (uint64_t p = lo + w; p < hi; p += stride) process_pair<NCH, ZERO0>(a, p, lane, tab, qts, lc, wstat);
+  if (lane == 0) {
+    atomicAdd(&a.stats[0], (unsigned long long)wstat[0]);
+    atomicAdd(&a.stats[1], (unsigned long long)wstat[1]);
+    atomicAdd(&a.stats[2], (unsigned long long)wstat[2]);
+  }
 }
 
 }  // namespace
