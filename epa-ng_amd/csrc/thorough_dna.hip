@@ -25,6 +25,9 @@
 //  * no P-matrix, no sumtable, no inner CLV ever touches memory.
 #include "epa_dev_internal.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace {
 
 constexpr double LOG_THR = -256.0 * 0.6931471805599453094;  // log(2^-256)
@@ -464,9 +467,15 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
   a.W = ctx->W;
   a.Wpad = 0;
   const uint32_t nch = (max_span + 63) / 64;
-  // persistent grid: 8 single-wave workgroups per CU (2 per SIMD at this kernel's VGPR budget)
-  uint32_t nwg = 256 * 8;
-  if ((uint64_t)nwg > n_pairs) nwg = (uint32_t)((n_pairs + 7) / 8 * 8);
+  // Grid: single-wave workgroups, 2048 of them are resident (8 per CU, 2 per SIMD at this
+  // kernel's VGPR budget).  Oversubscribing the resident set lets the hardware dispatcher do the
+  // load balancing (pairs differ 10x in cost): a finished wave's slot is refilled at once.
+  // EPA_TH_WAVES_PER_SLOT tunes it (default 8 -> ~3 pairs per wave at 50k pairs).
+  uint32_t per_slot = 8;
+  if (const char* e = getenv("EPA_TH_WAVES_PER_SLOT")) per_slot = (uint32_t)std::max(1, atoi(e));
+  uint64_t want = (uint64_t)256 * 8 * per_slot;
+  if (want > n_pairs) want = n_pairs;
+  uint32_t nwg = (uint32_t)((want + 7) / 8 * 8);
   epa_timer_start(ctx, ctx->t_thorough);
 #define LAUNCH(N)                                                                              \
   do {                                                                                         \
