@@ -85,7 +85,6 @@ def main():
         chunks.append((torch.from_numpy(codes).to(dev), torch.from_numpy(wb.view(np.int32)).to(dev),
                        torch.from_numpy(ws.view(np.int32)).to(dev), codes, wb, ws))
     cap = Q * 64   # pair capacity per step (dynamic heuristic selects a handful per read)
-    d_lnl = torch.empty((Q, B), dtype=torch.float64, device=dev)
     d_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
     d_res = torch.zeros((cap, 3), dtype=torch.float64, device=dev)
     gather_list = None
@@ -96,9 +95,9 @@ def main():
 
     def step(i, record):
         dc, dwb, dws = chunks[i][0], chunks[i][1], chunks[i][2]
-        ev.preplace(dc, dwb, dws, Q=Q, out=d_lnl)
-        n = ev.select(d_lnl, Q, 0.99999, max_pairs=cap, out=d_pairs)
-        ev.thorough(d_pairs, dc, dwb, dws, Q=Q, n_pairs=n, out=d_res)
+        # one fused call = the reference's chunk body: place() -> apply_heuristic() -> place_thorough()
+        n = ev.place_chunk(dc, dwb, dws, Q=Q, threshold=0.99999, max_span=a.read_len, max_pairs=cap,
+                           pairs_out=d_pairs, results_out=d_res)
         if world > 1:
             dist.gather(d_res, gather_list, dst=0)   # the path's only exchange: results -> rank 0
         if record:

@@ -86,6 +86,9 @@ def dev_lib():
                                        C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(_Stats)]
         L.epa_dev_select_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double,
                                                 C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.epa_dev_place_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                          C.c_uint32, C.c_double, C.c_void_p, C.c_void_p,
+                                          C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(_Stats)]
         L.epa_dev_last_kernel_ms.restype = C.c_double
         L.epa_dev_last_kernel_ms.argtypes = [C.c_void_p, C.c_char_p]
         _LIB = L
@@ -242,6 +245,29 @@ class Evaluator:
         self._check(self.L.epa_dev_select_candidates(self.h, _ptr(lnl), Q, threshold, _ptr(out),
                                                      max_pairs, C.byref(n)))
         return out[:n.value] if host_out else n.value
+
+    def place_chunk(self, codes, win_begin, win_span, Q=None, threshold=0.99999, max_span=0,
+                    max_pairs=None, pairs_out=None, results_out=None):
+        """preplace -> dynamic heuristic -> thorough, fused on device (epa_dev_place_chunk).
+        Returns (pairs, results) numpy arrays, or n_pairs when device buffers are supplied."""
+        Q = len(win_begin) if Q is None else Q
+        if max_pairs is None:
+            max_pairs = Q * 64
+        host = pairs_out is None
+        if host:
+            pairs_out = np.empty(max_pairs, PAIR_DTYPE)
+            results_out = np.empty(max_pairs, RESULT_DTYPE)
+        n = C.c_uint64(0)
+        st = _Stats()
+        self._check(self.L.epa_dev_place_chunk(self.h, _ptr(codes), _ptr(win_begin), _ptr(win_span),
+                                               Q, max_span, threshold, _ptr(pairs_out),
+                                               _ptr(results_out), max_pairs, C.byref(n),
+                                               C.byref(st)))
+        self.last_stats = {"pairs": st.pairs, "rounds": st.rounds,
+                           "newton_evals": st.newton_evals, "reverts": st.reverts}
+        if host:
+            return pairs_out[:n.value], results_out[:n.value]
+        return n.value
 
     def kernel_ms(self, which):
         return self.L.epa_dev_last_kernel_ms(self.h, which.encode())

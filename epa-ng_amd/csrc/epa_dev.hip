@@ -509,13 +509,6 @@ extern "C" int epa_dev_preplace(epa_ctx* ctx, const uint8_t* q_codes, const uint
   EPA_HIP(ctx, hipSetDevice(ctx->device));
   int rc = epa_dev_build_lookup(ctx);
   if (rc) return rc;
-  std::vector<uint32_t> hb_buf, hs_buf;
-  const uint32_t* hb = host_view(win_begin, Q, hb_buf, ctx->stream);
-  const uint32_t* hs = host_view(win_span, Q, hs_buf, ctx->stream);
-  if (!hb || !hs) return epa_fail(ctx, EPA_ERR_HIP, "cannot read window arrays");
-  uint32_t max_span = 0;
-  rc = check_windows(ctx, hb, hs, Q, &max_span);
-  if (rc) return rc;
   const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * ctx->W);
   const uint32_t* d_begin = (const uint32_t*)epa_to_device(ctx, 1, win_begin, sizeof(uint32_t) * Q);
   const uint32_t* d_span = (const uint32_t*)epa_to_device(ctx, 2, win_span, sizeof(uint32_t) * Q);
@@ -523,14 +516,13 @@ extern "C" int epa_dev_preplace(epa_ctx* ctx, const uint8_t* q_codes, const uint
   const bool out_dev = epa_is_device_ptr(lnl);
   double* d_lnl = out_dev ? lnl : (double*)epa_scratch(ctx, 3, sizeof(double) * (size_t)Q * ctx->B);
   if (!d_lnl) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(lnl)");
-  rc = launch_preplace(ctx, d_codes, hb, hs, d_begin, d_span, Q, d_lnl);
+  rc = launch_preplace(ctx, d_codes, d_begin, d_span, Q, d_lnl);
   if (rc) return rc;
-  if (!out_dev) {
+  if (!out_dev)
     EPA_HIP(ctx, hipMemcpyAsync(lnl, d_lnl, sizeof(double) * (size_t)Q * ctx->B,
                                 hipMemcpyDeviceToHost, ctx->stream));
-    EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  return EPA_OK;
+  EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return preplace_check_status(ctx);  // windows are validated on device (k_make_groups)
 }
 
 extern "C" int epa_dev_thorough(epa_ctx* ctx, const epa_pair* pairs, uint64_t n_pairs,
@@ -606,6 +598,74 @@ extern "C" int epa_dev_select_candidates(epa_ctx* ctx, const double* lnl, uint32
   if (!out_dev && *n_pairs) {
     EPA_HIP(ctx, hipMemcpy(pairs, d_pairs, sizeof(epa_pair) * (*n_pairs), hipMemcpyDeviceToHost));
   }
+  return EPA_OK;
+}
+
+// The body of the reference's chunk loop (src/core/place.cpp:219-235) for the default dynamic
+// heuristic, entirely on device: place() -> apply_heuristic() -> place_thorough().  The Q x B
+// table never leaves HBM; one host sync in the middle (the candidate count sizes the thorough
+// launch) and one at the end.
+extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_begin,
+                                   const uint32_t* win_span, uint32_t Q, uint32_t max_span,
+                                   double threshold, epa_pair* pairs, epa_result* results,
+                                   uint64_t max_pairs, uint64_t* n_pairs, epa_thorough_stats* stats) {
+  if (!ctx || !q_codes || !win_begin || !win_span || !pairs || !results || !n_pairs)
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "null argument");
+  *n_pairs = 0;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (Q == 0) return EPA_OK;
+  EPA_HIP(ctx, hipSetDevice(ctx->device));
+  if (!(ctx->s == 4 && ctx->c == 4) && !(ctx->s == 20))
+    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "thorough: DNA needs 4 rate categories");
+  int rc = epa_dev_build_lookup(ctx);
+  if (rc) return rc;
+  if (max_span == 0) {  // not supplied: look at the spans (host array, or one small D2H copy)
+    std::vector<uint32_t> buf;
+    const uint32_t* hs = host_view(win_span, Q, buf, ctx->stream);
+    if (!hs) return epa_fail(ctx, EPA_ERR_HIP, "cannot read window spans");
+    for (uint32_t q = 0; q < Q; ++q) max_span = std::max(max_span, hs[q]);
+  }
+  if (max_span > ctx->W) max_span = ctx->W;
+  const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * ctx->W);
+  const uint32_t* d_begin = (const uint32_t*)epa_to_device(ctx, 1, win_begin, sizeof(uint32_t) * Q);
+  const uint32_t* d_span = (const uint32_t*)epa_to_device(ctx, 2, win_span, sizeof(uint32_t) * Q);
+  if (!d_codes || !d_begin || !d_span) return epa_fail(ctx, EPA_ERR_HIP, "query upload failed");
+  double* d_lnl = (double*)epa_scratch(ctx, 3, sizeof(double) * (size_t)Q * ctx->B);
+  const bool pairs_dev = epa_is_device_ptr(pairs), res_dev = epa_is_device_ptr(results);
+  epa_pair* d_pairs = pairs_dev ? pairs : (epa_pair*)epa_scratch(ctx, 4, sizeof(epa_pair) * max_pairs);
+  epa_result* d_res = res_dev ? results : (epa_result*)epa_scratch(ctx, 5, sizeof(epa_result) * max_pairs);
+  if (!d_lnl || !d_pairs || !d_res) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(chunk buffers)");
+  rc = launch_preplace(ctx, d_codes, d_begin, d_span, Q, d_lnl);
+  if (rc) return rc;
+  uint64_t n = 0;
+  rc = launch_select(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, &n);  // syncs once
+  if (rc) return rc;
+  rc = preplace_check_status(ctx);
+  if (rc) return rc;
+  *n_pairs = n;
+  if (n == 0) return EPA_OK;
+  // thorough counters: second half of the 256-byte status block at the head of scratch 6
+  unsigned long long* d_stats =
+      reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->d_status) + 128);
+  EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, ctx->stream));
+  rc = launch_thorough(ctx, d_pairs, n, d_codes, d_begin, d_span, max_span, d_res, d_stats);
+  if (rc) return rc;
+  unsigned long long hst[8];
+  if (!pairs_dev)
+    EPA_HIP(ctx, hipMemcpyAsync(pairs, d_pairs, sizeof(epa_pair) * n, hipMemcpyDeviceToHost, ctx->stream));
+  if (!res_dev)
+    EPA_HIP(ctx, hipMemcpyAsync(results, d_res, sizeof(epa_result) * n, hipMemcpyDeviceToHost, ctx->stream));
+  EPA_HIP(ctx, hipMemcpyAsync(hst, d_stats, 64, hipMemcpyDeviceToHost, ctx->stream));
+  EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->last_stats.pairs = n;
+  ctx->last_stats.rounds = hst[0];
+  ctx->last_stats.newton_evals = hst[1];
+  ctx->last_stats.reverts = hst[2];
+  if (stats) *stats = ctx->last_stats;
+  if (hst[3])
+    return epa_fail(ctx, EPA_ERR_NEG_INF,
+                    "-INF logl at branch " + std::to_string((uint32_t)(hst[4] >> 32)) +
+                        " with sequence " + std::to_string((uint32_t)(hst[4] & 0xffffffffu)));
   return EPA_OK;
 }
 

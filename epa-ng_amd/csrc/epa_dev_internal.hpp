@@ -79,6 +79,9 @@ struct epa_ctx {
   void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t scratch_sz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
+  uint32_t* d_status = nullptr;   // window-validation words of the last preplace (in scratch 6)
+  uint32_t select_cap = 64;       // staging slots per query of the candidate selection
+
   EvTimer t_lookup, t_preplace, t_thorough, t_select;
   epa_thorough_stats last_stats{};
 };
@@ -103,9 +106,9 @@ void epa_timer_stop(epa_ctx* ctx, EvTimer& t);
 int launch_transform(epa_ctx* ctx, const double* d_clv_or_null, const uint8_t* d_tip_or_null,
                      const uint32_t* d_tipmap, uint32_t tipmap_size, double* dst);
 int launch_build_lookup(epa_ctx* ctx);
-int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* h_begin,
-                    const uint32_t* h_span, const uint32_t* d_begin, const uint32_t* d_span,
-                    uint32_t Q, double* d_lnl);
+int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin,
+                    const uint32_t* d_span, uint32_t Q, double* d_lnl);
+int preplace_check_status(epa_ctx* ctx);
 int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
                     const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
                     epa_result* d_out, unsigned long long* d_stats);

@@ -225,6 +225,11 @@ void place_thorough(const Work& to_place, const MSA& chunk, const Encoded_Chunk&
                     const Tree& tree, Device_Evaluator& dev, Sample& sample, const Options& options,
                     size_t seq_id_offset = 0);
 
+// place() + apply_heuristic(dynamic) + place_thorough() in one device-side pass
+// (epa_dev_place_chunk); fills `work` (branch-major) and `sample`.
+void place_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, Device_Evaluator& dev,
+                 Work& work, Sample& sample, const Options& options, size_t seq_id_offset = 0);
+
 void compute_and_set_lwr(Sample& sample);            // src/set_manipulators.cpp:43-69
 void filter(Sample& sample, const Options& options);  // :192-204
 

@@ -128,6 +128,25 @@ Work apply_heuristic(const std::vector<double>& lnl, size_t Q, size_t B, const O
   return work;
 }
 
+// one PQuery per query, in query order (quirk D8: the reference's order is thread-dependent)
+static void build_sample(const Work& to_place, const std::vector<epa_result>& res, const MSA& chunk,
+                         Sample& sample, size_t seq_id_offset) {
+  const size_t n = to_place.size(), Q = chunk.size();
+  std::vector<long> slot(Q, -1);
+  sample.clear();
+  for (size_t i = 0; i < n; ++i) slot[to_place[i].sequence_id] = 0;
+  for (size_t q = 0; q < Q; ++q)
+    if (slot[q] == 0) {
+      slot[q] = (long)sample.size();
+      sample.emplace_back(seq_id_offset + q, chunk[q].header());
+    }
+  for (size_t i = 0; i < n; ++i) {
+    const size_t q = to_place[i].sequence_id;
+    sample[slot[q]].emplace_back(to_place[i].branch_id, res[i].lnl, res[i].pendant_length,
+                                 res[i].distal_length);
+  }
+}
+
 void place_thorough(const Work& to_place, const MSA& chunk, const Encoded_Chunk& enc,
                     const Tree& tree, Device_Evaluator& dev, Sample& sample, const Options&,
                     size_t seq_id_offset) {
@@ -141,24 +160,37 @@ void place_thorough(const Work& to_place, const MSA& chunk, const Encoded_Chunk&
   if (rc == EPA_ERR_NEG_INF)  // Tiny_Tree.cpp:209-212
     throw std::runtime_error{epa_dev_last_error(dev.ctx())};
   if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
-  // one PQuery per query, in query order (quirk D8: the reference's order is thread-dependent)
-  std::vector<long> slot(Q, -1);
-  sample.clear();
-  for (size_t i = 0; i < n; ++i) {
-    const size_t q = to_place[i].sequence_id;
-    if (slot[q] < 0) slot[q] = 0;
-  }
-  for (size_t q = 0; q < Q; ++q)
-    if (slot[q] == 0) {
-      slot[q] = (long)sample.size();
-      sample.emplace_back(seq_id_offset + q, chunk[q].header());
-    }
-  for (size_t i = 0; i < n; ++i) {
-    const size_t q = to_place[i].sequence_id;
-    sample[slot[q]].emplace_back(to_place[i].branch_id, res[i].lnl, res[i].pendant_length,
-                                 res[i].distal_length);
-  }
+  build_sample(to_place, res, chunk, sample, seq_id_offset);
   (void)tree;
+}
+
+void place_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, Device_Evaluator& dev,
+                 Work& work, Sample& sample, const Options& options, size_t seq_id_offset) {
+  const size_t Q = chunk.size();
+  uint64_t cap = (uint64_t)Q * 64, n = 0;
+  std::vector<epa_pair> pairs;
+  std::vector<epa_result> res;
+  uint32_t max_span = 0;
+  for (uint32_t s : enc.win_span) max_span = std::max(max_span, s);
+  for (;;) {
+    pairs.resize(cap);
+    res.resize(cap);
+    const int rc = epa_dev_place_chunk(dev.ctx(), enc.codes.data(), enc.win_begin.data(),
+                                       enc.win_span.data(), (uint32_t)Q, max_span,
+                                       options.prescoring_threshold, pairs.data(), res.data(), cap, &n,
+                                       nullptr);
+    if (rc == EPA_ERR_INVALID_ARG && cap < (uint64_t)Q * tree.num_branches()) {
+      cap = std::min<uint64_t>(cap * 8, (uint64_t)Q * tree.num_branches());  // candidate overflow
+      continue;
+    }
+    if (rc == EPA_ERR_NEG_INF) throw std::runtime_error{epa_dev_last_error(dev.ctx())};
+    if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
+    break;
+  }
+  work.resize(n);
+  for (size_t i = 0; i < n; ++i) work[i] = Work_Pair{pairs[i].branch_id, pairs[i].seq_id};
+  res.resize(n);
+  build_sample(work, res, chunk, sample, seq_id_offset);
 }
 
 void compute_and_set_lwr(Sample& sample) {
@@ -221,18 +253,28 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
     MSA chunk(all.begin() + done, all.begin() + done + n);
     const Encoded_Chunk enc = encode_chunk(chunk, tree, options);
     Work blo_work;
-    auto t0 = clk::now();
-    if (options.prescoring) {
-      place(chunk, enc, tree, dev, lnl, options);
-      blo_work = apply_heuristic(lnl, n, B, options);
-    } else {  // --no-heur: all B x Q pairs (src/core/place.cpp:189,228)
-      blo_work.reserve(n * B);
-      for (size_t b = 0; b < B; ++b)
-        for (size_t q = 0; q < n; ++q) blo_work.push_back(Work_Pair{b, q});
-    }
-    auto t1 = clk::now();
     Sample blo_sample;
-    place_thorough(blo_work, chunk, enc, tree, dev, blo_sample, options, done);
+    auto t0 = clk::now();
+    auto t1 = t0;
+    const bool fused = options.prescoring && options.device_select && !options.baseball &&
+                       !options.prescoring_by_percentage && B <= 4096;
+    if (fused) {
+      // default configuration: the whole chunk body runs on the GPU (epa_dev_place_chunk), the
+      // Q x B table never crosses PCIe
+      place_chunk(chunk, enc, tree, dev, blo_work, blo_sample, options, done);
+      t1 = clk::now();
+    } else {
+      if (options.prescoring) {
+        place(chunk, enc, tree, dev, lnl, options);
+        blo_work = apply_heuristic(lnl, n, B, options);
+      } else {  // --no-heur: all B x Q pairs (src/core/place.cpp:189,228)
+        blo_work.reserve(n * B);
+        for (size_t b = 0; b < B; ++b)
+          for (size_t q = 0; q < n; ++q) blo_work.push_back(Work_Pair{b, q});
+      }
+      t1 = clk::now();
+      place_thorough(blo_work, chunk, enc, tree, dev, blo_sample, options, done);
+    }
     auto t2 = clk::now();
     compute_and_set_lwr(blo_sample);
     filter(blo_sample, options);

@@ -1,40 +1,90 @@
-// Hot loop 1 on device: preplacement gather-sum + candidate selection.
+// Hot loop 1 on device: preplacement gather-sum + candidate selection, no host in the loop.
 //
 // k_preplace replaces Lookup_Store::sum_precomputed_sitelk inside place()
 // (src/core/Lookup_Store.hpp:110-141, src/core/place.cpp:65-91):
 //     lnl[q][b] = sum_{site in window(q)} T[b][site][code(q, site)]
 // with the reference's association order ((a0+a1)+(a2+a3) per group of 4, then singles).
 //
-// Mapping (MI355X): queries are sorted by window start on the host and cut into groups of
-// <= 256 whose window starts lie within SPREAD sites.  A workgroup = one query group x one
-// tile of NB branches.  Per (branch, 160-site chunk) the 256 x ncols slice of T that the whole
-// group can touch is staged through LDS once (coalesced 16 B/lane loads), every thread then
-// gathers its own query's values with ds_read_b64.  Query codes live in registers (packed
-// byte offsets), partial sums in LDS, so the only HBM traffic is T-slices in (L2/MALL resident:
-// T is 196 MB at cfg2), codes in, and the Q x B table out.
+// Pipeline (all on the stream, nothing is read back):
+//   1. queries are radix-sorted by window start (rocprim), k_make_groups cuts the sorted list into
+//      groups of <= 256 queries whose starts fall into one SPREAD-site bucket;
+//   2. k_preplace: workgroup = one query group x one tile of NB branches.  Per (branch,
+//      160-site chunk) the 256-row x ncols slice of T the whole group can touch is staged through
+//      LDS once (coalesced 16 B/lane loads), then every thread gathers its own query's values
+//      with ds_read_b64.  Query codes sit in registers as packed byte offsets, partial sums in
+//      LDS, so HBM sees T-slices in (L2/MALL resident: T is 196 MB at cfg2), codes in and the
+//      Q x B table out.  For the 16-column DNA table the LDS columns are XOR-swizzled by the row
+//      ((row >> 1) & 15): DNA reads use 4 of 16 columns, which would pile a half-wave onto 8 of
+//      the 32 8-byte bank slots.
+//   3. k_select (dynamic heuristic) works on the table in HBM: one wave per query, the row lives
+//      in registers, candidates go to a per-query staging row; an exclusive scan of the counts
+//      gives every query its output offset (no atomics on a shared counter, deterministic
+//      order); the keys (branch << 32 | query) are radix-sorted into Work's branch-major order.
 #include "epa_dev_internal.hpp"
 
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
-#include <numeric>
 
 namespace {
 
 constexpr int GQ = 256;      // queries (threads) per group
 constexpr int CH = 160;      // sites per chunk (multiple of 4)
-constexpr int SPREAD = 96;   // max spread of window starts inside a group
+constexpr int SPREAD = 96;   // window starts of a group lie in one bucket of SPREAD sites
 constexpr int TROWS = CH + SPREAD;  // rows of T staged per (branch, chunk)
 constexpr int NB = 16;       // branches per workgroup
 constexpr int CW = CH / 4;   // packed code words per chunk
 
 struct Group {
-  uint32_t start;     // first index into perm[]
-  uint32_t count;
-  uint32_t min_begin;
-  uint32_t max_span;
+  uint32_t start;      // first index into the sorted order
+  uint32_t count;      // 0 = unused slot of the over-provisioned group table
+  uint32_t min_begin;  // bucket start
+  uint32_t pad;
 };
+
+__global__ void k_iota(uint32_t* v, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+
+// One workgroup.  sorted_begin ascending.  Bucket k = starts in [k*SPREAD, (k+1)*SPREAD); every
+// bucket is cut into groups of <= GQ queries.  Also validates the windows (error word).
+__global__ void __launch_bounds__(256) k_make_groups(const uint32_t* __restrict__ sorted_begin,
+                                                     const uint32_t* __restrict__ win_begin,
+                                                     const uint32_t* __restrict__ win_span, uint32_t Q,
+                                                     uint32_t W, uint32_t n_buckets,
+                                                     Group* __restrict__ groups, uint32_t max_groups,
+                                                     uint32_t* __restrict__ status) {
+  extern __shared__ uint32_t lo[];  // [n_buckets + 1] first sorted index of each bucket
+  for (uint32_t i = threadIdx.x; i < Q; i += blockDim.x) {
+    const uint32_t s = win_span[i];
+    if (s == 0) atomicMax(&status[0], 0x80000000u | i);                    // all-gap query
+    else if ((uint64_t)win_begin[i] + s > W) atomicMax(&status[1], 0x80000000u | i);  // width
+  }
+  for (uint32_t k = threadIdx.x; k <= n_buckets; k += blockDim.x) {
+    const uint32_t key = k * SPREAD;  // lower_bound(sorted_begin, key)
+    uint32_t a = 0, b = Q;
+    while (a < b) {
+      const uint32_t m = (a + b) >> 1;
+      if (sorted_begin[m] < key) a = m + 1; else b = m;
+    }
+    lo[k] = a;
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < max_groups; i += blockDim.x) groups[i] = Group{0, 0, 0, 0};
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t g = 0;
+    for (uint32_t k = 0; k < n_buckets; ++k) {
+      for (uint32_t s = lo[k]; s < lo[k + 1]; s += GQ) {
+        if (g < max_groups) groups[g] = Group{s, min((uint32_t)GQ, lo[k + 1] - s), k * SPREAD, 0};
+        ++g;
+      }
+    }
+  }
+}
 
 template <int NCOLS>
 __global__ void __launch_bounds__(GQ) k_preplace(const double* __restrict__ lookup,
@@ -45,10 +95,13 @@ __global__ void __launch_bounds__(GQ) k_preplace(const double* __restrict__ look
                                                  const Group* __restrict__ groups, uint32_t W,
                                                  uint32_t B, size_t codes_bytes,
                                                  double* __restrict__ lnl) {
+  constexpr bool SWZ = NCOLS == 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* tile = reinterpret_cast<double*>(smem);                  // [TROWS][NCOLS]
   double* accs = tile + (size_t)TROWS * NCOLS;                     // [NB][GQ]
+  __shared__ uint32_t s_maxspan;
   const Group g = groups[blockIdx.x];
+  if (g.count == 0) return;
   const uint32_t b0 = blockIdx.y * NB;
   const uint32_t nb = min((uint32_t)NB, B - b0);
   const int t = threadIdx.x;
@@ -58,10 +111,15 @@ __global__ void __launch_bounds__(GQ) k_preplace(const double* __restrict__ look
     qi = perm[g.start + t];
     begin = win_begin[qi];
     span = win_span[qi];
+    if ((uint64_t)begin + span > W) span = 0;  // invalid window: flagged by k_make_groups
   }
-  const uint32_t rel = begin - g.min_begin;  // < SPREAD for active threads
-  const uint32_t nchunks = (g.max_span + CH - 1) / CH;
+  if (t == 0) s_maxspan = 0;
+  __syncthreads();
+  atomicMax(&s_maxspan, span);
   for (uint32_t j = 0; j < nb; ++j) accs[j * GQ + t] = 0.0;
+  __syncthreads();
+  const uint32_t rel = begin - g.min_begin;  // < SPREAD for active threads
+  const uint32_t nchunks = (s_maxspan + CH - 1) / CH;
 
   for (uint32_t c = 0; c < nchunks; ++c) {
     const uint32_t cbase = c * CH;           // chunk offset inside every thread's own window
@@ -96,21 +154,35 @@ __global__ void __launch_bounds__(GQ) k_preplace(const double* __restrict__ look
             lookup + ((size_t)(b0 + j) * W + row0) * NCOLS);
         double2* dst = reinterpret_cast<double2*>(tile);
         const uint32_t n2 = rows * NCOLS / 2;
-        for (uint32_t i = t; i < n2; i += GQ) dst[i] = src[i];
+        for (uint32_t i = t; i < n2; i += GQ) {
+          double2 v = src[i];
+          uint32_t o = i;
+          if (SWZ) {  // column pair (2p, 2p+1) of row r goes to columns (2p ^ f, (2p+1) ^ f)
+            const uint32_t r = i >> 3, f = (r >> 1) & 15;
+            o = (r << 3) | (((i & 7) ^ (f >> 1)));
+            if (f & 1) { const double x = v.x; v.x = v.y; v.y = x; }
+          }
+          dst[o] = v;
+        }
       }
       __syncthreads();
       if (mine) {
         double sum = accs[j * GQ + t];
-        const char* base = reinterpret_cast<const char*>(tile) + (size_t)rel * NCOLS * 8;
+        const char* base = reinterpret_cast<const char*>(tile);
+        auto at = [&](uint32_t s, uint32_t boff) -> double {
+          const uint32_t row = rel + s;
+          const uint32_t off = SWZ ? (boff ^ (((row >> 1) & 15) << 3)) : boff;
+          return *reinterpret_cast<const double*>(base + row * (NCOLS * 8) + off);
+        };
 #pragma unroll
         for (int i = 0; i < CW; ++i) {
           const uint32_t s0 = 4 * i;
           if (s0 + 3 < rem) {
             const uint32_t w = cw[i];
-            const double v0 = *reinterpret_cast<const double*>(base + (s0 + 0) * NCOLS * 8 + (w & 0xff));
-            const double v1 = *reinterpret_cast<const double*>(base + (s0 + 1) * NCOLS * 8 + ((w >> 8) & 0xff));
-            const double v2 = *reinterpret_cast<const double*>(base + (s0 + 2) * NCOLS * 8 + ((w >> 16) & 0xff));
-            const double v3 = *reinterpret_cast<const double*>(base + (s0 + 3) * NCOLS * 8 + (w >> 24));
+            const double v0 = at(s0 + 0, w & 0xff);
+            const double v1 = at(s0 + 1, (w >> 8) & 0xff);
+            const double v2 = at(s0 + 2, (w >> 16) & 0xff);
+            const double v3 = at(s0 + 3, w >> 24);
             double s1 = v0 + v1;
             const double s2 = v2 + v3;
             s1 += s2;
@@ -119,8 +191,7 @@ __global__ void __launch_bounds__(GQ) k_preplace(const double* __restrict__ look
             const uint32_t w = cw[i];
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-              if (s0 + k < rem)
-                sum += *reinterpret_cast<const double*>(base + (s0 + k) * NCOLS * 8 + ((w >> (8 * k)) & 0xff));
+              if (s0 + k < rem) sum += at(s0 + k, (w >> (8 * k)) & 0xff);
           }
         }
         accs[j * GQ + t] = sum;
@@ -136,41 +207,55 @@ __global__ void __launch_bounds__(GQ) k_preplace(const double* __restrict__ look
 // ---------------------------------------------------------------------------------------------
 // k_select: dynamic heuristic on device (apply_heuristic -> dynamic_heuristic,
 // src/core/heuristics.hpp:40-68; compute_and_set_lwr src/set_manipulators.cpp:43-69;
-// until_accumulated_reached :90-114).  One wave per query; the row of B log-likelihoods is
-// cached in LDS, then the largest remaining LWR is extracted until the running sum reaches
-// `threshold` (the crossing element is included, min 1).  Ties: lowest branch id first
-// (the reference's std::sort is unstable).
+// until_accumulated_reached :90-114).  One wave per query, the row of B log-likelihoods in
+// registers (NR values per lane); the largest remaining LWR is extracted until the running sum
+// reaches `threshold` (the crossing element is included, min 1).  Ties: lowest branch id first
+// (the reference's std::sort is unstable).  Selections go to stage[q][0..cap).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_select(const double* __restrict__ lnl, uint32_t B,
-                                               double threshold,
-                                               unsigned long long* __restrict__ keys,
-                                               unsigned long long max_pairs,
-                                               unsigned long long* __restrict__ counter) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  double* row = reinterpret_cast<double*>(smem);
-  const uint32_t q = blockIdx.x;
-  const int lane = threadIdx.x;
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ double wave_add(double v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int NR>
+__global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, uint32_t Q, uint32_t B,
+                                                double threshold, uint32_t cap,
+                                                unsigned long long* __restrict__ stage,
+                                                uint32_t* __restrict__ counts,
+                                                uint32_t* __restrict__ status) {
+  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= Q) return;
   const double* src = lnl + (size_t)q * B;
+  double v[NR];
   double mx = -INFINITY;
-  for (uint32_t i = lane; i < B; i += 64) {
-    const double v = src[i];
-    row[i] = v;
-    mx = fmax(mx, v);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const uint32_t i = r * 64 + lane;
+    v[r] = i < B ? src[i] : -INFINITY;
+    mx = fmax(mx, v[r]);
   }
-  for (int o = 32; o; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+  mx = wave_max(mx);
   double tot = 0.0;
-  for (uint32_t i = lane; i < B; i += 64) tot += exp(row[i] - mx);
-  for (int o = 32; o; o >>= 1) tot += __shfl_xor(tot, o);
-  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < NR; ++r) tot += exp(v[r] - mx);  // exp(-inf) == 0 for the padding
+  tot = wave_add(tot);
   double sum = 0.0;
   uint32_t taken = 0;
+  unsigned long long* out = stage + (size_t)q * cap;
   while (taken < B && sum < threshold) {
     double best = -INFINITY;
     uint32_t bi = 0xffffffffu;
-    for (uint32_t i = lane; i < B; i += 64) {
-      const double v = row[i];
-      if (v > best) { best = v; bi = i; }  // first (lowest index) maximum per lane
-    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+      if (v[r] > best) { best = v[r]; bi = r * 64 + lane; }
+#pragma unroll
     for (int o = 32; o; o >>= 1) {
       const double ob = __shfl_xor(best, o);
       const uint32_t oi = __shfl_xor(bi, o);
@@ -178,14 +263,27 @@ __global__ void __launch_bounds__(64) k_select(const double* __restrict__ lnl, u
     }
     if (bi == 0xffffffffu) break;
     sum += exp(best - mx) / tot;
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+      if ((uint32_t)(r * 64 + lane) == bi) v[r] = -INFINITY;
     if (lane == 0) {
-      row[bi] = -INFINITY;
-      const unsigned long long slot = atomicAdd(counter, 1ull);
-      if (slot < max_pairs) keys[slot] = ((unsigned long long)bi << 32) | q;
+      if (taken < cap) out[taken] = ((unsigned long long)bi << 32) | q;
+      else atomicMax(&status[2], taken + 1);  // staging row too short: caller retries wider
     }
     ++taken;
-    __builtin_amdgcn_wave_barrier();
   }
+  if (lane == 0) counts[q] = min(taken, cap);
+}
+
+__global__ void __launch_bounds__(256) k_compact(const unsigned long long* __restrict__ stage,
+                                                 const uint32_t* __restrict__ counts,
+                                                 const uint32_t* __restrict__ offsets, uint32_t Q,
+                                                 uint32_t cap, unsigned long long* __restrict__ keys) {
+  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= Q) return;
+  const uint32_t n = counts[q], o = offsets[q];
+  for (uint32_t i = lane; i < n; i += 64) keys[o + i] = stage[(size_t)q * cap + i];
 }
 
 __global__ void k_keys_to_pairs(const unsigned long long* __restrict__ keys, uint64_t n,
@@ -197,81 +295,128 @@ __global__ void k_keys_to_pairs(const unsigned long long* __restrict__ keys, uin
   }
 }
 
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 }  // namespace
 
-int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* hb, const uint32_t* hs,
-                    const uint32_t* d_begin, const uint32_t* d_span, uint32_t Q, double* d_lnl) {
-  // sort by window start, cut into groups (host: Q is a few thousand..1e5 keys)
-  std::vector<uint32_t> perm(Q);
-  std::iota(perm.begin(), perm.end(), 0u);
-  std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return hb[a] < hb[b]; });
-  std::vector<Group> groups;
-  uint32_t i = 0;
-  while (i < Q) {
-    Group g{i, 0, hb[perm[i]], 0};
-    while (i < Q && g.count < (uint32_t)GQ && hb[perm[i]] - g.min_begin < (uint32_t)SPREAD) {
-      g.max_span = std::max(g.max_span, hs[perm[i]]);
-      ++g.count;
-      ++i;
-    }
-    groups.push_back(g);
-  }
-  uint32_t* d_perm = (uint32_t*)epa_scratch(ctx, 6, sizeof(uint32_t) * Q + sizeof(Group) * groups.size() + 64);
-  if (!d_perm) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(perm)");
-  Group* d_groups = reinterpret_cast<Group*>(d_perm + ((Q + 3) & ~3u));
-  EPA_HIP(ctx, hipMemcpyAsync(d_perm, perm.data(), sizeof(uint32_t) * Q, hipMemcpyHostToDevice, ctx->stream));
-  EPA_HIP(ctx, hipMemcpyAsync(d_groups, groups.data(), sizeof(Group) * groups.size(),
-                              hipMemcpyHostToDevice, ctx->stream));
-  EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // perm/groups are stack-owned host buffers
-  dim3 grid((uint32_t)groups.size(), (ctx->B + NB - 1) / NB);
+int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin,
+                    const uint32_t* d_span, uint32_t Q, double* d_lnl) {
+  const uint32_t n_buckets = (ctx->W + SPREAD - 1) / SPREAD;
+  const uint32_t max_groups = (Q + GQ - 1) / GQ + n_buckets;
+  // scratch 6: [status 256 B | iota Q | sorted_begin Q | perm Q | groups | rocprim temp]
+  size_t temp_bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, temp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  (uint32_t*)nullptr, (uint32_t*)nullptr, Q, 0, 32, ctx->stream);
+  const size_t qb = align256(sizeof(uint32_t) * Q);
+  const size_t need = 256 + 3 * qb + align256(sizeof(Group) * max_groups) + temp_bytes;
+  char* base = (char*)epa_scratch(ctx, 6, need);
+  if (!base) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(preplace scratch)");
+  uint32_t* status = reinterpret_cast<uint32_t*>(base);
+  uint32_t* iota = reinterpret_cast<uint32_t*>(base + 256);
+  uint32_t* sorted_begin = reinterpret_cast<uint32_t*>(base + 256 + qb);
+  uint32_t* perm = reinterpret_cast<uint32_t*>(base + 256 + 2 * qb);
+  Group* groups = reinterpret_cast<Group*>(base + 256 + 3 * qb);
+  void* temp = base + 256 + 3 * qb + align256(sizeof(Group) * max_groups);
+  ctx->d_status = status;
+  EPA_HIP(ctx, hipMemsetAsync(status, 0, 256, ctx->stream));
+  hipLaunchKernelGGL(k_iota, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, iota, Q);
+  EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, d_begin, sorted_begin, iota, perm, Q, 0, 32,
+                                         ctx->stream));
+  hipLaunchKernelGGL(k_make_groups, dim3(1), dim3(256), sizeof(uint32_t) * (n_buckets + 1), ctx->stream,
+                     sorted_begin, d_begin, d_span, Q, ctx->W, n_buckets, groups, max_groups, status);
+  dim3 grid(max_groups, (ctx->B + NB - 1) / NB);
   const size_t lds = sizeof(double) * ((size_t)TROWS * ctx->ncols + (size_t)NB * GQ);
   const size_t codes_bytes = (size_t)Q * ctx->W;
   epa_timer_start(ctx, ctx->t_preplace);
   if (ctx->ncols == 16) {
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_preplace<16>, grid, dim3(GQ), lds, ctx->stream, ctx->lookup, d_codes, d_begin,
-                       d_span, d_perm, d_groups, ctx->W, ctx->B, codes_bytes, d_lnl);
+                       d_span, perm, groups, ctx->W, ctx->B, codes_bytes, d_lnl);
   } else {
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_preplace<24>, grid, dim3(GQ), lds, ctx->stream, ctx->lookup, d_codes, d_begin,
-                       d_span, d_perm, d_groups, ctx->W, ctx->B, codes_bytes, d_lnl);
+                       d_span, perm, groups, ctx->W, ctx->B, codes_bytes, d_lnl);
   }
   epa_timer_stop(ctx, ctx->t_preplace);
   EPA_HIP(ctx, hipGetLastError());
   return EPA_OK;
 }
 
+// reads the window-validation words written by k_make_groups (call after a stream sync)
+int preplace_check_status(epa_ctx* ctx) {
+  if (!ctx->d_status) return EPA_OK;
+  uint32_t st[4];
+  EPA_HIP(ctx, hipMemcpy(st, ctx->d_status, sizeof(st), hipMemcpyDeviceToHost));
+  if (st[0])
+    return epa_fail(ctx, EPA_ERR_QUERY_ALL_GAP, "Sequence " + std::to_string(st[0] & 0x7fffffffu) +
+                                                    " does not appear to have any non-gap sites!");
+  if (st[1])
+    return epa_fail(ctx, EPA_ERR_QUERY_WIDTH, "Query sequence length not same as reference alignment!");
+  return EPA_OK;
+}
+
 int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshold,
                   epa_pair* d_pairs, uint64_t max_pairs, uint64_t* n_pairs) {
-  // scratch 7: [counter | keys_in[max] | keys_out[max] | rocprim temp]
-  size_t temp_bytes = 0;
-  (void)rocprim::radix_sort_keys(nullptr, temp_bytes, (unsigned long long*)nullptr,
-                                 (unsigned long long*)nullptr, max_pairs, 0, 64, ctx->stream);
-  const size_t need = 256 + 2 * sizeof(unsigned long long) * max_pairs + temp_bytes;
-  char* base = (char*)epa_scratch(ctx, 7, need);
-  if (!base) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(select scratch)");
-  unsigned long long* counter = reinterpret_cast<unsigned long long*>(base);
-  unsigned long long* keys_in = reinterpret_cast<unsigned long long*>(base + 256);
-  unsigned long long* keys_out = keys_in + max_pairs;
-  void* temp = keys_out + max_pairs;
-  EPA_HIP(ctx, hipMemsetAsync(counter, 0, 8, ctx->stream));
-  epa_timer_start(ctx, ctx->t_select);
-  hipLaunchKernelGGL(k_select, dim3(Q), dim3(64), sizeof(double) * ctx->B, ctx->stream, d_lnl, ctx->B,
-                     threshold, keys_in, (unsigned long long)max_pairs, counter);
-  unsigned long long n = 0;
-  EPA_HIP(ctx, hipMemcpyAsync(&n, counter, 8, hipMemcpyDeviceToHost, ctx->stream));
-  EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (n > max_pairs)
-    return epa_fail(ctx, EPA_ERR_INVALID_ARG,
-                    "select_candidates: " + std::to_string(n) + " candidates exceed max_pairs");
-  if (n) {
-    // branch-major order == Work iteration order (std::map<branch, vector<seq>>)
-    EPA_HIP(ctx, rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, (size_t)n, 0, 64, ctx->stream));
-    hipLaunchKernelGGL(k_keys_to_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       keys_out, (uint64_t)n, d_pairs);
+  const uint32_t B = ctx->B;
+  if (B > 64 * 64)
+    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "select_candidates: more than 4096 branches");
+  for (;;) {
+    const uint32_t cap = ctx->select_cap;
+    size_t scan_bytes = 0, sort_bytes = 0;
+    (void)rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, Q,
+                                  rocprim::plus<uint32_t>(), ctx->stream);
+    const size_t worst = std::min<uint64_t>(max_pairs, (uint64_t)Q * cap);
+    (void)rocprim::radix_sort_keys(nullptr, sort_bytes, (unsigned long long*)nullptr,
+                                   (unsigned long long*)nullptr, worst, 0, 64, ctx->stream);
+    // scratch 7: [status | counts Q+1 | offsets Q+1 | stage Q*cap | keys_a worst | keys_b worst | temp]
+    const size_t qb = align256(sizeof(uint32_t) * (Q + 1));
+    const size_t sb = align256(sizeof(unsigned long long) * (size_t)Q * cap);
+    const size_t kb = align256(sizeof(unsigned long long) * worst);
+    const size_t tb = std::max(scan_bytes, sort_bytes);
+    char* base = (char*)epa_scratch(ctx, 7, 256 + 2 * qb + sb + 2 * kb + tb);
+    if (!base) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(select scratch)");
+    uint32_t* status = reinterpret_cast<uint32_t*>(base);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(base + 256);
+    uint32_t* offsets = reinterpret_cast<uint32_t*>(base + 256 + qb);
+    unsigned long long* stage = reinterpret_cast<unsigned long long*>(base + 256 + 2 * qb);
+    unsigned long long* keys_a = reinterpret_cast<unsigned long long*>(base + 256 + 2 * qb + sb);
+    unsigned long long* keys_b = reinterpret_cast<unsigned long long*>(base + 256 + 2 * qb + sb + kb);
+    void* temp = base + 256 + 2 * qb + sb + 2 * kb;
+    EPA_HIP(ctx, hipMemsetAsync(status, 0, 256, ctx->stream));
+    EPA_HIP(ctx, hipMemsetAsync(counts + Q, 0, sizeof(uint32_t), ctx->stream));
+    epa_timer_start(ctx, ctx->t_select);
+    const dim3 grid((Q + 3) / 4);
+    const int nr = (int)((B + 63) / 64);
+#define SEL(N) hipLaunchKernelGGL(k_select<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, cap, stage, counts, status)
+    if (nr <= 2) SEL(2); else if (nr <= 4) SEL(4); else if (nr <= 8) SEL(8); else if (nr <= 16) SEL(16);
+    else if (nr <= 32) SEL(32); else SEL(64);
+#undef SEL
+    EPA_HIP(ctx, rocprim::exclusive_scan(temp, scan_bytes, counts, offsets, 0u, Q + 1,
+                                         rocprim::plus<uint32_t>(), ctx->stream));
+    uint32_t hst[4] = {0, 0, 0, 0}, total = 0;
+    EPA_HIP(ctx, hipMemcpyAsync(&total, offsets + Q, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    EPA_HIP(ctx, hipMemcpyAsync(hst, status, sizeof(hst), hipMemcpyDeviceToHost, ctx->stream));
+    EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (hst[2]) {  // some query selected more candidates than the staging row holds: widen, redo
+      ctx->select_cap = std::min<uint32_t>(B, std::max(cap * 4, hst[2]));
+      if (cap >= B) return epa_fail(ctx, EPA_ERR_HIP, "select_candidates: staging overflow");
+      continue;
+    }
+    if (total > max_pairs)
+      return epa_fail(ctx, EPA_ERR_INVALID_ARG,
+                      "select_candidates: " + std::to_string(total) + " candidates exceed max_pairs");
+    if (total) {
+      hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, ctx->stream, stage, counts, offsets, Q, cap, keys_a);
+      // branch-major order == Work iteration order (std::map<branch, vector<seq>>)
+      int bits = 33;
+      while ((1ull << (bits - 32)) <= B && bits < 64) ++bits;
+      EPA_HIP(ctx, rocprim::radix_sort_keys(temp, sort_bytes, keys_a, keys_b, (size_t)total, 0, bits, ctx->stream));
+      hipLaunchKernelGGL(k_keys_to_pairs, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, keys_b,
+                         (uint64_t)total, d_pairs);
+    }
+    epa_timer_stop(ctx, ctx->t_select);
+    EPA_HIP(ctx, hipGetLastError());
+    *n_pairs = total;
+    return EPA_OK;
   }
-  epa_timer_stop(ctx, ctx->t_select);
-  EPA_HIP(ctx, hipGetLastError());
-  *n_pairs = n;
-  return EPA_OK;
 }

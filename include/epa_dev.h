@@ -188,6 +188,19 @@ int epa_dev_thorough(epa_ctx* ctx, const epa_pair* pairs, uint64_t n_pairs,
 int epa_dev_select_candidates(epa_ctx* ctx, const double* lnl, uint32_t Q, double threshold,
                               epa_pair* pairs, uint64_t max_pairs, uint64_t* n_pairs);
 
+/*
+ * The body of the reference's chunk loop for the default configuration (src/core/place.cpp:
+ * 219-235): place() -> apply_heuristic() [dynamic, `threshold`] -> place_thorough(), fused so
+ * that the Q x B preplacement table never leaves HBM and the host is only consulted once (the
+ * candidate count sizes the thorough launch).  pairs / results: caller buffers of max_pairs
+ * entries (host or device), filled branch-major; *n_pairs = number of candidate placements.
+ * max_span: an upper bound of win_span[] if the caller knows it, 0 to let the library find it.
+ */
+int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_begin,
+                        const uint32_t* win_span, uint32_t Q, uint32_t max_span, double threshold,
+                        epa_pair* pairs, epa_result* results, uint64_t max_pairs,
+                        uint64_t* n_pairs, epa_thorough_stats* stats);
+
 /* duration in milliseconds of the last launch of the named kernel family on ctx's stream,
  * measured with HIP events ("preplace", "thorough", "lookup", "select"); < 0 if never run. */
 double epa_dev_last_kernel_ms(const epa_ctx* ctx, const char* which);

@@ -94,3 +94,26 @@ def test_chunk_loop_to_jplace(tmp_path):
             assert abs(distal - gold["distal"]) < 1e-6 and abs(pendant - gold["pendant"]) < 1e-5 * max(1, gold["pendant"])
         # best edge: Rat -> 4, Carp -> 3
     assert jp["placements"][0]["p"][0][0] == 4 and jp["placements"][1]["p"][0][0] == 3
+
+
+def test_fused_place_chunk_equals_three_calls():
+    w = synth.dna_workload(96, 700, 900, 150, (61, 62, 63))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    codes, wb, ws = epa.encode_queries(4, w["reads"])
+    lnl = ev.preplace(codes, wb, ws)
+    pairs = ev.select(lnl, len(w["reads"]), 0.99999)
+    res = ev.thorough(pairs, codes, wb, ws)
+    p2, r2 = ev.place_chunk(codes, wb, ws)
+    assert np.array_equal(p2, pairs)
+    assert np.array_equal(r2["lnl"], res["lnl"]) and np.array_equal(r2["distal_length"], res["distal_length"])
+    # mixed window lengths incl. long ones, max_span left to the library
+    base = w["seqs"][5]
+    W = len(base)
+    qs = [base, "-" * 10 + base[10:400] + "-" * (W - 400), "-" * 300 + base[300:301] + "-" * (W - 301)] + w["reads"][:50]
+    c2, b2, s2 = epa.encode_queries(4, qs)
+    p3, r3 = ev.place_chunk(c2, b2, s2)
+    o = Oracle(w["newick"], w["labels"], w["seqs"], 4, w["subst"], w["freqs"], w["rates"])
+    tl, tp, td = o.thorough(p3["branch_id"], p3["seq_id"], qs)
+    assert np.max(np.abs(r3["lnl"] - tl)) < 1e-6
