@@ -118,7 +118,11 @@ __global__ void __launch_bounds__(GQ) k_preplace(const double* __restrict__ look
   atomicMax(&s_maxspan, span);
   for (uint32_t j = 0; j < nb; ++j) accs[j * GQ + t] = 0.0;
   __syncthreads();
-  const uint32_t rel = begin - g.min_begin;  // < SPREAD for active threads
+  // the group is a run of the begin-sorted order: its first / last member bound the rows of T
+  // any member can touch in a chunk -> stage only those (spread + CH <= TROWS rows)
+  const uint32_t gmin = win_begin[perm[g.start]];
+  const uint32_t gspread = win_begin[perm[g.start + g.count - 1]] - gmin;  // < SPREAD
+  const uint32_t rel = begin - gmin;
   const uint32_t nchunks = (s_maxspan + CH - 1) / CH;
 
   for (uint32_t c = 0; c < nchunks; ++c) {
@@ -138,18 +142,25 @@ __global__ void __launch_bounds__(GQ) k_preplace(const double* __restrict__ look
       for (int i = 0; i < CW; ++i) {
         const uint32_t nxt = p[min(a0 + 4 * (i + 1), last) >> 2];
         const uint32_t v = __funnelshift_r(prev, nxt, sh);
-        cw[i] = v << 3;  // each byte < 32 -> *8 stays inside the byte
+        uint32_t o = v << 3;  // each byte < 32 -> *8 stays inside the byte
+        if (SWZ) {  // fold the row swizzle into the offsets once per chunk, not once per gather
+          const uint32_t r = rel + 4 * i;  // tile row of the word's first site
+          o ^= (((r >> 1) & 15) << 3) | ((((r + 1) >> 1) & 15) << 11) | ((((r + 2) >> 1) & 15) << 19) |
+               ((((r + 3) >> 1) & 15) << 27);
+        }
+        cw[i] = o;
         prev = nxt;
       }
     } else {
 #pragma unroll
       for (int i = 0; i < CW; ++i) cw[i] = 0;
     }
-    const uint32_t row0 = g.min_begin + cbase;  // first alignment site of the staged slice
+    const uint32_t row0 = gmin + cbase;  // first alignment site of the staged slice
+    const uint32_t need = min((uint32_t)TROWS, gspread + min((uint32_t)CH, s_maxspan - cbase));
     for (uint32_t j = 0; j < nb; ++j) {
       __syncthreads();  // previous consumers of `tile` are done
       {
-        const uint32_t rows = (row0 < W) ? min((uint32_t)TROWS, W - row0) : 0;
+        const uint32_t rows = (row0 < W) ? min(need, W - row0) : 0;
         const double2* src = reinterpret_cast<const double2*>(
             lookup + ((size_t)(b0 + j) * W + row0) * NCOLS);
         double2* dst = reinterpret_cast<double2*>(tile);
@@ -169,10 +180,9 @@ __global__ void __launch_bounds__(GQ) k_preplace(const double* __restrict__ look
       if (mine) {
         double sum = accs[j * GQ + t];
         const char* base = reinterpret_cast<const char*>(tile);
+        const char* mybase = base + (size_t)rel * (NCOLS * 8);
         auto at = [&](uint32_t s, uint32_t boff) -> double {
-          const uint32_t row = rel + s;
-          const uint32_t off = SWZ ? (boff ^ (((row >> 1) & 15) << 3)) : boff;
-          return *reinterpret_cast<const double*>(base + row * (NCOLS * 8) + off);
+          return *reinterpret_cast<const double*>(mybase + s * (NCOLS * 8) + boff);
         };
 #pragma unroll
         for (int i = 0; i < CW; ++i) {
