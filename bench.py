@@ -87,9 +87,7 @@ def main():
     cap = Q * 64   # pair capacity per step (dynamic heuristic selects a handful per read)
     d_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
     d_res = torch.zeros((cap, 3), dtype=torch.float64, device=dev)
-    gather_list = None
-    if world > 1 and rank == 0:
-        gather_list = [torch.empty_like(d_res) for _ in range(world)]
+    nmax_t = torch.zeros(1, dtype=torch.int64, device=dev)
 
     th_ms, th_pairs, th_rounds, th_evals, pre_ms, sel_ms = [], [], [], [], [], []
 
@@ -99,7 +97,15 @@ def main():
         n = ev.place_chunk(dc, dwb, dws, Q=Q, threshold=0.99999, max_span=a.read_len, max_pairs=cap,
                            pairs_out=d_pairs, results_out=d_res)
         if world > 1:
-            dist.gather(d_res, gather_list, dst=0)   # the path's only exchange: results -> rank 0
+            # the path's only exchange: every rank's candidate placements -> rank 0 (RCCL over
+            # xGMI; the reference gathers jplace byte ranges, src/io/jplace_writer.hpp:117-129)
+            nmax_t[0] = n
+            dist.all_reduce(nmax_t, op=dist.ReduceOp.MAX)
+            m = int(nmax_t.item())
+            gp = [torch.empty((m, 2), dtype=torch.int32, device=dev) for _ in range(world)] if rank == 0 else None
+            gr = [torch.empty((m, 3), dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
+            dist.gather(d_pairs[:m], gp, dst=0)
+            dist.gather(d_res[:m], gr, dst=0)
         if record:
             th_ms.append(ev.kernel_ms("thorough")); pre_ms.append(ev.kernel_ms("preplace"))
             sel_ms.append(ev.kernel_ms("select"))

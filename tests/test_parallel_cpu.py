@@ -1,0 +1,73 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard the queries like the reference's
+local_seq_package and gather per-pair results to rank 0 (the GPU run uses RCCL for the same
+calls).  No GPU compute: results are synthetic functions of (branch, global seq id)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["EPA_ROOT"])
+import torch.distributed as dist
+import epa_ng_amd as epa
+from epa_ng_amd import parallel
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+N = 1001
+off, cnt = parallel.local_seq_package(N, rank, world)
+rng = np.random.RandomState(5)
+nb = rng.randint(1, 4, N)                      # candidates per (global) query
+pairs, res = [], []
+for q in range(off, off + cnt):
+    for j in range(nb[q]):
+        pairs.append((7 * q % 13 + j, q - off))
+pairs = np.array(pairs, dtype=epa.PAIR_DTYPE)
+res = np.zeros(len(pairs), epa.RESULT_DTYPE)
+res["lnl"] = -(pairs["branch_id"] * 1000.0 + pairs["seq_id"] + off)
+out = parallel.gather_results(pairs, res, off, dist)
+if rank == 0:
+    assert out.shape == (nb.sum(), 5), out.shape
+    assert np.array_equal(np.unique(out[:, 1]), np.arange(N))
+    assert np.allclose(out[:, 2], -(out[:, 0] * 1000.0 + out[:, 1]))
+    print("GATHER_OK", out.shape[0])
+else:
+    assert out is None
+dist.destroy_process_group()
+'''
+
+
+def test_local_seq_package_matches_reference_formula():
+    from epa_ng_amd import parallel
+    for n in (0, 1, 7, 8, 9, 1000, 1001):
+        for world in (1, 2, 3, 8):
+            slices = [parallel.local_seq_package(n, r, world) for r in range(world)]
+            assert sum(c for _, c in slices) == n
+            pos = 0
+            for off, cnt in slices:
+                assert off == min(pos, n)
+                pos += cnt
+            part = -(-n // world) if n else 0
+            assert all(c <= part for _, c in slices)
+
+
+def test_two_rank_gloo_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, EPA_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GATHER_OK" in outs[0]
