@@ -1,7 +1,340 @@
-// 20-state thorough placement (MFMA path) -- placeholder until the kernel lands.
+// Hot loop 2 on device, 20-state models with 4 rate categories.
+//
+// Same algorithm and control flow as k_thorough_dna (see thorough_dna.hip for the mapping to
+// the reference: Tiny_Tree::place -> optimize_branch_triplet -> opt_branch_lengths_pplacer,
+// src/core/pll/optimize.cpp:60-286, and the eigenbasis reformulation), different geometry:
+//
+//   workgroup = one (branch, query) pair, 4 wavefronts = the 4 rate categories,
+//   lane      = alignment site of the query's window (64 sites per pass),
+//   U, U^-1   = wave-uniform operands fetched through the scalar cache (s_load -> SGPR operands
+//               of v_fma_f64); the 20x20 contraction is 400 FMAs per (site, category),
+//   sumtable  = 20 doubles per (site, category): too large for registers at AA window lengths,
+//               it lives in a per-workgroup slab of HBM scratch (component-major, L2 resident:
+//               80 x n x 8 B = 64 KB at n = 100) and is streamed once per Newton evaluation,
+//   cross-category sums (site likelihood and derivatives, the "all 80 entries < 2^-256"
+//   rescale test) go through LDS with one workgroup barrier.
+//
+// Why not v_mfma_f64_16x16x4_f64 for the 20x20 contraction: on MI355X the fp64 matrix peak equals
+// the fp64 vector peak (78.6 TFLOP/s), and M = 20 has to be padded to 32 (two 16-row tiles), so
+// the MFMA formulation needs 1.6x the cycles of the VALU one (30 MFMA x 64 cycles vs 1200 FMA x
+// 4 cycles per 16 sites and category).  DESIGN.md section 4.2 keeps the arithmetic.
 #include "epa_dev_internal.hpp"
 
-int launch_thorough_aa(epa_ctx* ctx, const epa_pair*, uint64_t, const uint8_t*, const uint32_t*,
-                       const uint32_t*, uint32_t, epa_result*, unsigned long long*) {
-  return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "thorough placement for 20-state models is not implemented yet");
+#include <algorithm>
+
+namespace {
+
+constexpr int S = 20;
+constexpr int C = 4;
+constexpr double LOG_2 = 0.6931471805599453094;
+
+struct ThArgsAA {
+  const ModelDev* m;
+  BloConsts blo;
+  const double* refT;      // [2B][80][W]
+  const uint32_t* scSum;   // [B][W]
+  const double* blen;      // [B]
+  const epa_pair* pairs;
+  const uint8_t* codes;    // [Q][W]
+  const uint32_t* win_begin;
+  const uint32_t* win_span;
+  epa_result* out;
+  unsigned long long* stats;
+  double* sscratch;        // [gridDim.x][80][Wpad]
+  uint64_t n_pairs;
+  uint32_t W;
+  uint32_t Wpad;
+};
+
+__device__ __forceinline__ double wave_sum_aa(double v) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+struct Shared {
+  double tab[3][80];      // wave-uniform exp tables, [slot][k*20 + x]
+  double red[3][C][64];   // per-site per-category partial sums of the current pass
+  double bc[4];           // broadcast scalars (f, f', lnL partial)
+  double lnl_acc;
+};
+
+// y[i] = sum_x M[i*20 + x] * v[x]  with M wave-uniform (scalar loads)
+__device__ __forceinline__ void matvec20(const double* __restrict__ M, const double (&v)[S], double (&y)[S]) {
+#pragma unroll
+  for (int i = 0; i < S; ++i) {
+    double acc = M[i * S] * v[0];
+#pragma unroll
+    for (int x = 1; x < S; ++x) acc = fma(M[i * S + x], v[x], acc);
+    y[i] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
+  __shared__ Shared sh;
+  const ModelDev* __restrict__ m = a.m;
+  const int tid = threadIdx.x, lane = tid & 63, k = tid >> 6;  // k = rate category of this wave
+  double* Sg = a.sscratch + (size_t)blockIdx.x * 80 * a.Wpad + (size_t)k * S * a.Wpad;  // [x][site]
+  // per-thread table constants: thread t < 240 owns (slot = t / 80, kx = t % 80)
+  const int tslot = tid / 80, tkx = tid % 80;
+  double t_lr = 0.0, t_w = 0.0;
+  if (tid < 240) {
+    t_lr = m->lam[tkx % S] * m->rate[tkx / S];
+    t_w = m->w[tkx / S];
+  }
+  const double cN = tslot == 0 ? t_w : (tslot == 1 ? t_w * t_lr : t_w * t_lr * t_lr);
+
+  uint32_t wrounds = 0, wevals = 0, wreverts = 0;
+  for (uint64_t pid = blockIdx.x; pid < a.n_pairs; pid += gridDim.x) {
+    const epa_pair pr = a.pairs[pid];
+    const uint32_t b = pr.branch_id, q = pr.seq_id;
+    const uint32_t begin = a.win_begin[q], n = a.win_span[q];
+    const size_t cW = a.W;
+    const double* Xt = a.refT + ((size_t)(2 * b) * 80 + (size_t)k * S) * cW + begin;
+    const double* Dt = a.refT + ((size_t)(2 * b + 1) * 80 + (size_t)k * S) * cW + begin;
+    const uint32_t* scp = a.scSum + (size_t)b * cW + begin;
+    const uint8_t* qc = a.codes + (size_t)q * cW + begin;
+    const double orig = a.blen[b];
+    const uint32_t npass = (n + 63) / 64;
+
+    // ---- table publication: every thread < 240 computes one exp()
+    auto publish = [&](double t0, double t1, double t2, bool newton) {
+      __syncthreads();  // previous readers of sh.tab are done
+      if (tid < 240) {
+        const double t = tslot == 0 ? t0 : (tslot == 1 ? t1 : t2);
+        const double e = exp(t_lr * t);
+        sh.tab[tslot][tkx] = newton ? e * cN : (tslot == 2 ? e * t_w : e);
+      }
+      __syncthreads();
+    };
+
+    // Inner CLV toward the query (mode 0: A = distal, lnL computed) or toward distal (mode 1:
+    // A = query tip, sumtable folded with D).  Writes this category's sumtable slab.
+    auto phase = [&](int mode, double& lnl_out) {
+      double mant = 1.0;
+      int ex = 0;
+      for (uint32_t p = 0; p < npass; ++p) {
+        const uint32_t site = p * 64 + lane;
+        const bool valid = site < n;
+        const uint32_t s = valid ? site : 0;
+        double A[S], Xv[S], I[S];
+        const uint32_t code = qc[s];
+        if (mode == 0) {
+#pragma unroll
+          for (int x = 0; x < S; ++x) A[x] = Dt[(size_t)x * cW + s] * sh.tab[0][k * S + x];
+        } else {
+#pragma unroll
+          for (int x = 0; x < S; ++x) A[x] = m->qt[code * S + x] * sh.tab[0][k * S + x];
+        }
+#pragma unroll
+        for (int x = 0; x < S; ++x) Xv[x] = Xt[(size_t)x * cW + s] * sh.tab[1][k * S + x];
+        double av[S], bv[S];
+        matvec20(m->U, A, av);
+        matvec20(m->U, Xv, bv);
+        double mx = 0.0;
+#pragma unroll
+        for (int i = 0; i < S; ++i) { I[i] = av[i] * bv[i]; mx = fmax(mx, I[i]); }
+        // per-site rescale: ALL 80 entries (4 categories = 4 waves) below 2^-256
+        sh.red[0][k][lane] = mx;
+        __syncthreads();
+        const double mall = fmax(fmax(sh.red[0][0][lane], sh.red[0][1][lane]),
+                                 fmax(sh.red[0][2][lane], sh.red[0][3][lane]));
+        const bool resc = mall < 0x1p-256;
+        const double mult = resc ? 0x1p+256 : 1.0;
+        double It[S];
+        matvec20(m->Ui, I, It);
+        double l0 = 0.0;
+        if (mode == 0) {
+#pragma unroll
+          for (int x = 0; x < S; ++x) {
+            const double sv = It[x] * mult * m->qt[code * S + x];
+            Sg[(size_t)x * a.Wpad + site] = sv;
+            l0 = fma(sv, sh.tab[2][k * S + x], l0);
+          }
+        } else {
+#pragma unroll
+          for (int x = 0; x < S; ++x) Sg[(size_t)x * a.Wpad + site] = Dt[(size_t)x * cW + s] * It[x] * mult;
+        }
+        __syncthreads();  // sh.red[0] consumed
+        if (mode == 0) {
+          sh.red[1][k][lane] = l0;
+          __syncthreads();
+          if (k == 0) {
+            double ls = (sh.red[1][0][lane] + sh.red[1][1][lane]) + (sh.red[1][2][lane] + sh.red[1][3][lane]);
+            if (!valid) ls = 1.0;
+            const int sc = valid ? (int)(scp[s] + (resc ? 1u : 0u)) : 0;
+            mant *= __builtin_amdgcn_frexp_mant(ls);
+            ex += __builtin_amdgcn_frexp_exp(ls) - 256 * sc;
+            ex += __builtin_amdgcn_frexp_exp(mant);
+            mant = __builtin_amdgcn_frexp_mant(mant);
+          }
+          __syncthreads();
+        }
+      }
+      if (mode == 0) {
+        if (k == 0) {
+          const double tot = wave_sum_aa(log(mant) + (double)ex * LOG_2);
+          if (lane == 0) sh.bc[2] = tot;
+        }
+        __syncthreads();
+        lnl_out = sh.bc[2];
+      }
+    };
+
+    // f, f' at proposal t from this pair's sumtable slab
+    auto derivatives = [&](double t, double& f, double& df) {
+      publish(t, t, t, true);
+      double fl = 0.0, dfl = 0.0;
+      for (uint32_t p = 0; p < npass; ++p) {
+        const uint32_t site = p * 64 + lane;
+        double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+#pragma unroll
+        for (int x = 0; x < S; ++x) {
+          const double sv = Sg[(size_t)x * a.Wpad + site];
+          l0 = fma(sv, sh.tab[0][k * S + x], l0);
+          l1 = fma(sv, sh.tab[1][k * S + x], l1);
+          l2 = fma(sv, sh.tab[2][k * S + x], l2);
+        }
+        sh.red[0][k][lane] = l0; sh.red[1][k][lane] = l1; sh.red[2][k][lane] = l2;
+        __syncthreads();
+        if (k == 0 && site < n) {
+          const double s0 = (sh.red[0][0][lane] + sh.red[0][1][lane]) + (sh.red[0][2][lane] + sh.red[0][3][lane]);
+          const double s1 = (sh.red[1][0][lane] + sh.red[1][1][lane]) + (sh.red[1][2][lane] + sh.red[1][3][lane]);
+          const double s2 = (sh.red[2][0][lane] + sh.red[2][1][lane]) + (sh.red[2][2][lane] + sh.red[2][3][lane]);
+          const double inv = 1.0 / s0;
+          const double d1 = -s1 * inv;
+          fl += d1;
+          dfl += fma(d1, d1, -s2 * inv);
+        }
+        __syncthreads();
+      }
+      if (k == 0) {
+        const double ft = wave_sum_aa(fl), dft = wave_sum_aa(dfl);
+        if (lane == 0) { sh.bc[0] = ft; sh.bc[1] = dft; }
+      }
+      __syncthreads();
+      f = sh.bc[0];
+      df = sh.bc[1];
+    };
+
+    // pllmod_opt_minimize_newton (rtsafe-style), uniform across the workgroup
+    uint32_t evals = 0;
+    auto newton = [&](double x1, double xguess, double x2, double tol, int max_iters) -> double {
+      double rts = xguess, f, df, xl, xh, dx;
+      if (rts < x1) rts = x1;
+      if (rts > x2) rts = x2;
+      derivatives(rts, f, df);
+      ++evals;
+      if (!isfinite(f) || !isfinite(df)) return NAN;
+      if (df >= 0.0 && fabs(f) < tol) return rts;
+      if (f < 0.0) { xl = rts; xh = x2; } else { xh = rts; xl = x1; }
+      for (int i = 1; i <= max_iters; ++i) {
+        if (df <= 0.0 || (((rts - xh) * df - f) * ((rts - xl) * df - f) >= 0.0)) {
+          dx = 0.5 * (xh - xl);
+          rts = xl + dx;
+          if (xl == rts) return rts;
+        } else {
+          dx = f / df;
+          const double temp = rts;
+          rts -= dx;
+          if (temp == rts) return rts;
+        }
+        if (fabs(dx) < tol || i == max_iters) return rts;
+        if (rts < x1) rts = x1;
+        derivatives(rts, f, df);
+        ++evals;
+        if (!isfinite(f) || !isfinite(df)) return NAN;
+        if (df > 0.0 && fabs(f) < tol) return rts;
+        if (f < 0.0) xl = rts; else xh = rts;
+      }
+      return NAN;
+    };
+
+    double tp = a.blo.pendant_default, td = orig * 0.5, tx = orig * 0.5;
+    uint32_t rounds = 0, reverted = 0;
+    double lnl_now = 0.0;
+    publish(td, tx, tp, false);
+    phase(0, lnl_now);
+    double loglikelihood = -lnl_now;
+    uint32_t smoothings = a.blo.max_rounds;
+    while (smoothings) {
+      const double old_td = td, old_tp = tp;
+      double xmin = a.blo.min_branch, xmax = a.blo.max_branch, xtol = xmin / 10.0;
+      double xguess = tp;
+      if (xguess < xmin || xguess > xmax) xguess = a.blo.default_branch;
+      double xres = newton(xmin, xguess, xmax, xtol, (int)a.blo.max_newton);
+      if (xres > 0.0) tp = xres;
+      publish(tp, tx, tp, false);
+      double dummy;
+      phase(1, dummy);
+      xguess = td;
+      xmin = fmin(a.blo.min_branch / 2.0, orig / 2.0);
+      xtol = xmin / 10.0;
+      xmax = orig - xtol;
+      if (xguess < xmin || xguess > xmax) xguess = orig / 2.0;
+      xres = newton(xmin, xguess, xmax, xtol, (int)a.blo.max_newton);
+      if (xres > 0.0) { td = xres; tx = orig - xres; }
+      publish(td, tx, tp, false);
+      phase(0, lnl_now);
+      const double new_ll = -lnl_now;
+      ++rounds;
+      if (new_ll - loglikelihood > new_ll * 1e-14) {
+        tp = old_tp; td = old_td; tx = orig - old_td;
+        reverted = 1;
+        break;
+      }
+      --smoothings;
+      if (fabs(new_ll - loglikelihood) < a.blo.epsilon) smoothings = 0;
+      loglikelihood = new_ll;
+    }
+    if (tid == 0) {
+      const double lnl = -loglikelihood;
+      epa_result r;
+      r.lnl = lnl;
+      r.pendant_length = tp;
+      r.distal_length = (orig / (td + tx)) * td;
+      a.out[pid] = r;
+      if (!isfinite(lnl)) {
+        if (atomicAdd(&a.stats[3], 1ull) == 0) a.stats[4] = ((unsigned long long)b << 32) | q;
+      }
+    }
+    wrounds += rounds; wevals += evals; wreverts += reverted;
+  }
+  if (tid == 0) {
+    atomicAdd(&a.stats[0], (unsigned long long)wrounds);
+    atomicAdd(&a.stats[1], (unsigned long long)wevals);
+    atomicAdd(&a.stats[2], (unsigned long long)wreverts);
+  }
+}
+
+}  // namespace
+
+int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
+                       const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
+                       epa_result* d_out, unsigned long long* d_stats) {
+  if (ctx->c != 4)
+    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "thorough (20 states): needs 4 rate categories");
+  ThArgsAA a;
+  a.m = ctx->dmodel;
+  a.blo = ctx->blo;
+  a.refT = ctx->refT;
+  a.scSum = ctx->scSum;
+  a.blen = ctx->blen;
+  a.pairs = d_pairs;
+  a.codes = d_codes;
+  a.win_begin = d_begin;
+  a.win_span = d_span;
+  a.out = d_out;
+  a.stats = d_stats;
+  a.n_pairs = n_pairs;
+  a.W = ctx->W;
+  a.Wpad = (max_span + 63) / 64 * 64;
+  uint32_t nwg = (uint32_t)std::min<uint64_t>(n_pairs, 512);  // 2 resident workgroups per CU
+  a.sscratch = (double*)epa_scratch(ctx, 7, sizeof(double) * (size_t)nwg * 80 * a.Wpad);
+  if (!a.sscratch) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(AA sumtable scratch)");
+  epa_timer_start(ctx, ctx->t_thorough);
+  hipLaunchKernelGGL(k_thorough_aa, dim3(nwg), dim3(256), 0, ctx->stream, a);
+  epa_timer_stop(ctx, ctx->t_thorough);
+  EPA_HIP(ctx, hipGetLastError());
+  return EPA_OK;
 }

@@ -155,3 +155,24 @@ def dna_workload(n_tips=512, W=1500, n_reads=100000, read_len=150, seeds=(1, 2, 
     return {"newick": newick(root), "labels": labels, "seqs": seqs, "reads": reads,
             "states": 4, "subst": CFG2_SUBST, "freqs": CFG2_FREQS, "rates": rates,
             "weights": np.full(4, 0.25)}
+
+
+def aa_model(seed=7):
+    """deterministic pseudo-random PROTGTR exchangeabilities + frequencies (cfg3 stand-in: the
+    named LG matrix lives in the pll-modules model database, which is not available)"""
+    rng = np.random.RandomState(seed)
+    subst = np.round(rng.gamma(1.0, 2.0, 190) + 0.01, 6)
+    freqs = rng.dirichlet(np.full(20, 8.0))
+    freqs = freqs / freqs.sum()
+    return subst.tolist(), freqs.tolist()
+
+
+def aa_workload(n_tips=2000, W=500, n_reads=50000, read_len=100, seeds=(11, 12, 13), alpha=0.563473):
+    """cfg3 of BASELINE.json."""
+    subst, freqs = aa_model()
+    root = random_tree(n_tips, seeds[0])
+    rates = gamma_rates(alpha)
+    labels, seqs = simulate_msa(root, W, subst, freqs, rates, seeds[1])
+    reads, _ = make_reads(seqs, n_reads, read_len, 0.03, seeds[2], states=20)
+    return {"newick": newick(root), "labels": labels, "seqs": seqs, "reads": reads, "states": 20,
+            "subst": subst, "freqs": freqs, "rates": rates, "weights": np.full(4, 0.25)}

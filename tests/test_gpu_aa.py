@@ -1,0 +1,53 @@
+"""20-state (amino-acid) GPU parity: BASELINE configs[2] shape at test size + the golden AA case."""
+import numpy as np
+import pytest
+
+import epa_ng_amd as epa
+from epa_ng_amd import hostlib, synth
+from golden_util import load_case
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_golden_aa_preplace_and_thorough():
+    g = load_case("aa8_protgtr_g4")
+    labels = [a for a, _ in g["msa"]]
+    seqs = [b for _, b in g["msa"]]
+    ref = hostlib.Reference(g["newick"], labels, seqs, states=20, subst=g["subst"], freqs=g["freqs"],
+                            rates=g["gamma_rates"])
+    ev = ref.evaluator()
+    qs = [q["seq"] for q in g["queries"]]
+    codes, wb, ws = epa.encode_queries(20, qs)
+    lnl = ev.preplace(codes, wb, ws)
+    assert np.max(np.abs(lnl - np.array(g["preplace"]))) < 1e-6
+    pairs = np.zeros(ref.B * len(qs), epa.PAIR_DTYPE)
+    pairs["branch_id"] = np.repeat(np.arange(ref.B), len(qs))
+    pairs["seq_id"] = np.tile(np.arange(len(qs)), ref.B)
+    res = ev.thorough(pairs, codes, wb, ws)
+    nrev = 0
+    for i, p in enumerate(pairs):
+        gold = g["thorough"][p["seq_id"]][p["branch_id"]]
+        assert abs(res["lnl"][i] - gold["lnl"]) < 1e-6, (p, res[i], gold)
+        assert abs(res["distal_length"][i] - gold["distal"]) < 1e-6
+        assert abs(res["pendant_length"][i] - gold["pendant"]) < 1e-6 * max(1.0, gold["pendant"])
+        nrev += gold["reverted"]
+    assert ev.last_stats["reverts"] == nrev
+
+
+def test_synthetic_aa_vs_oracle():
+    w = synth.aa_workload(48, 300, 250, 100, (71, 72, 73))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=20, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    o = Oracle(w["newick"], w["labels"], w["seqs"], 20, w["subst"], w["freqs"], w["rates"])
+    codes, wb, ws = epa.encode_queries(20, w["reads"])
+    pairs, res = ev.place_chunk(codes, wb, ws)
+    lnl = ev.preplace(codes, wb, ws)
+    assert np.max(np.abs(lnl - o.preplace(w["reads"]))) < 1e-6
+    hb, hs = hostlib.heuristic(lnl, "dynamic", 0.99999)
+    assert sorted(zip(hb.tolist(), hs.tolist())) == sorted(zip(pairs["branch_id"].tolist(), pairs["seq_id"].tolist()))
+    tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], w["reads"])
+    assert np.max(np.abs(res["lnl"] - tl)) < 1e-6
+    assert np.max(np.abs(res["distal_length"] - td)) < 1e-6
+    assert ev.last_stats["rounds"] == o.last_stats["rounds"]
