@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) k_make_groups(const uint32_t* __restrict_
 }
 
 template <int NCOLS>
-__global__ void __launch_bounds__(GQ) k_preplace(const double* __restrict__ lookup,
+__global__ void __launch_bounds__(GQ, 2) k_preplace(const double* __restrict__ lookup,
                                                  const uint8_t* __restrict__ codes,
                                                  const uint32_t* __restrict__ win_begin,
                                                  const uint32_t* __restrict__ win_span,
@@ -165,15 +165,26 @@ __global__ void __launch_bounds__(GQ) k_preplace(const double* __restrict__ look
             lookup + ((size_t)(b0 + j) * W + row0) * NCOLS);
         double2* dst = reinterpret_cast<double2*>(tile);
         const uint32_t n2 = rows * NCOLS / 2;
-        for (uint32_t i = t; i < n2; i += GQ) {
-          double2 v = src[i];
-          uint32_t o = i;
-          if (SWZ) {  // column pair (2p, 2p+1) of row r goes to columns (2p ^ f, (2p+1) ^ f)
-            const uint32_t r = i >> 3, f = (r >> 1) & 15;
-            o = (r << 3) | (((i & 7) ^ (f >> 1)));
-            if (f & 1) { const double x = v.x; v.x = v.y; v.y = x; }
+        constexpr int PF = (TROWS * NCOLS / 2 + GQ - 1) / GQ;
+        double2 pf[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {  // all loads of the slice in flight at once
+          const uint32_t i = u * GQ + t;
+          if (i < n2) pf[u] = src[i];
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          const uint32_t i = u * GQ + t;
+          if (i < n2) {
+            double2 v = pf[u];
+            uint32_t o = i;
+            if (SWZ) {  // column pair (2p, 2p+1) of row r goes to columns (2p ^ f, (2p+1) ^ f)
+              const uint32_t r = i >> 3, f = (r >> 1) & 15;
+              o = (r << 3) | ((i & 7) ^ (f >> 1));
+              if (f & 1) { const double x = v.x; v.x = v.y; v.y = x; }
+            }
+            dst[o] = v;
           }
-          dst[o] = v;
         }
       }
       __syncthreads();
@@ -184,25 +195,52 @@ __global__ void __launch_bounds__(GQ) k_preplace(const double* __restrict__ look
         auto at = [&](uint32_t s, uint32_t boff) -> double {
           return *reinterpret_cast<const double*>(mybase + s * (NCOLS * 8) + boff);
         };
+        // Branch-free main loop: every group of 4 is read and summed in the reference's
+        // association order, groups past the window contribute an exact +0.0.  (A branch per
+        // group would end the basic block after 4 reads and expose the full LDS latency 40
+        // times per slice; this way up to 15 reads stay in flight.)
+        const uint32_t cur = min(rem, (uint32_t)CH);
+        const uint32_t nfull = cur >> 2, ntail = cur & 3;
+        // Software pipeline: batch k+1 (2 groups = 8 ds_read_b64) is issued before batch k is
+        // summed; sched_barriers pin that order (left alone, hipcc sinks every read next to its
+        // use and each group of 4 waits out a full LDS round trip: measured 183 cycles/group).
+        constexpr int GPB = 2, NBATCH = CW / GPB;
+        double rb[2][GPB * 4];
+        auto issue = [&](int bt) {
 #pragma unroll
-        for (int i = 0; i < CW; ++i) {
-          const uint32_t s0 = 4 * i;
-          if (s0 + 3 < rem) {
-            const uint32_t w = cw[i];
-            const double v0 = at(s0 + 0, w & 0xff);
-            const double v1 = at(s0 + 1, (w >> 8) & 0xff);
-            const double v2 = at(s0 + 2, (w >> 16) & 0xff);
-            const double v3 = at(s0 + 3, w >> 24);
-            double s1 = v0 + v1;
-            const double s2 = v2 + v3;
-            s1 += s2;
-            sum += s1;
-          } else if (s0 < rem) {  // tail of the window: singles, in order
-            const uint32_t w = cw[i];
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-              if (s0 + k < rem) sum += at(s0 + k, (w >> (8 * k)) & 0xff);
+          for (int g = 0; g < GPB; ++g) {
+            const int i = bt * GPB + g;
+            const uint32_t w = cw[i], s0 = 4 * i;
+            rb[bt & 1][g * 4 + 0] = at(s0 + 0, w & 0xff);
+            rb[bt & 1][g * 4 + 1] = at(s0 + 1, (w >> 8) & 0xff);
+            rb[bt & 1][g * 4 + 2] = at(s0 + 2, (w >> 16) & 0xff);
+            rb[bt & 1][g * 4 + 3] = at(s0 + 3, w >> 24);
           }
+        };
+        issue(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int bt = 0; bt < NBATCH; ++bt) {
+          if (bt + 1 < NBATCH) issue(bt + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int g = 0; g < GPB; ++g) {
+            const double* v = &rb[bt & 1][g * 4];
+            double s1 = v[0] + v[1];
+            const double s2 = v[2] + v[3];
+            s1 += s2;
+            sum += ((uint32_t)(bt * GPB + g) < nfull) ? s1 : 0.0;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ntail) {  // tail of the window: singles, in order
+          uint32_t w = 0;
+#pragma unroll
+          for (int i = 0; i < CW; ++i) w = ((uint32_t)i == nfull) ? cw[i] : w;
+          const uint32_t s0 = 4 * nfull;
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if ((uint32_t)k < ntail) sum += at(s0 + k, (w >> (8 * k)) & 0xff);
         }
         accs[j * GQ + t] = sum;
       }
