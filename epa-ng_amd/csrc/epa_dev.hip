@@ -516,7 +516,7 @@ extern "C" int epa_dev_preplace(epa_ctx* ctx, const uint8_t* q_codes, const uint
   const bool out_dev = epa_is_device_ptr(lnl);
   double* d_lnl = out_dev ? lnl : (double*)epa_scratch(ctx, 3, sizeof(double) * (size_t)Q * ctx->B);
   if (!d_lnl) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(lnl)");
-  rc = launch_preplace(ctx, d_codes, d_begin, d_span, Q, d_lnl);
+  rc = launch_preplace(ctx, d_codes, d_begin, d_span, Q, d_lnl, 0);
   if (rc) return rc;
   if (!out_dev)
     EPA_HIP(ctx, hipMemcpyAsync(lnl, d_lnl, sizeof(double) * (size_t)Q * ctx->B,
@@ -635,7 +635,7 @@ extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const u
   epa_pair* d_pairs = pairs_dev ? pairs : (epa_pair*)epa_scratch(ctx, 4, sizeof(epa_pair) * max_pairs);
   epa_result* d_res = res_dev ? results : (epa_result*)epa_scratch(ctx, 5, sizeof(epa_result) * max_pairs);
   if (!d_lnl || !d_pairs || !d_res) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(chunk buffers)");
-  rc = launch_preplace(ctx, d_codes, d_begin, d_span, Q, d_lnl);
+  rc = launch_preplace(ctx, d_codes, d_begin, d_span, Q, d_lnl, max_span);
   if (rc) return rc;
   uint64_t n = 0;
   rc = launch_select(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, &n);  // syncs once

@@ -107,7 +107,7 @@ int launch_transform(epa_ctx* ctx, const double* d_clv_or_null, const uint8_t* d
                      const uint32_t* d_tipmap, uint32_t tipmap_size, double* dst);
 int launch_build_lookup(epa_ctx* ctx);
 int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin,
-                    const uint32_t* d_span, uint32_t Q, double* d_lnl);
+                    const uint32_t* d_span, uint32_t Q, double* d_lnl, uint32_t max_span);
 int preplace_check_status(epa_ctx* ctx);
 int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
                     const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,

@@ -86,8 +86,11 @@ __global__ void __launch_bounds__(256) k_make_groups(const uint32_t* __restrict_
   }
 }
 
-template <int NCOLS>
-__global__ void __launch_bounds__(GQ, 2) k_preplace(const double* __restrict__ lookup,
+// ACC: partial sums carried across 160-site chunks in LDS (windows longer than CH); the
+// short-window instantiation keeps no accumulators and stages only the slice (32 KB of LDS,
+// 4 workgroups per CU).
+template <int NCOLS, bool ACC>
+__global__ void __launch_bounds__(GQ, ACC ? 2 : 4) k_preplace(const double* __restrict__ lookup,
                                                  const uint8_t* __restrict__ codes,
                                                  const uint32_t* __restrict__ win_begin,
                                                  const uint32_t* __restrict__ win_span,
@@ -98,7 +101,7 @@ __global__ void __launch_bounds__(GQ, 2) k_preplace(const double* __restrict__ l
   constexpr bool SWZ = NCOLS == 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* tile = reinterpret_cast<double*>(smem);                  // [TROWS][NCOLS]
-  double* accs = tile + (size_t)TROWS * NCOLS;                     // [NB][GQ]
+  double* accs = tile + (size_t)TROWS * NCOLS;                     // [NB][GQ] (ACC only)
   __shared__ uint32_t s_maxspan;
   const Group g = groups[blockIdx.x];
   if (g.count == 0) return;
@@ -116,14 +119,14 @@ __global__ void __launch_bounds__(GQ, 2) k_preplace(const double* __restrict__ l
   if (t == 0) s_maxspan = 0;
   __syncthreads();
   atomicMax(&s_maxspan, span);
-  for (uint32_t j = 0; j < nb; ++j) accs[j * GQ + t] = 0.0;
+  if (ACC) for (uint32_t j = 0; j < nb; ++j) accs[j * GQ + t] = 0.0;
   __syncthreads();
   // the group is a run of the begin-sorted order: its first / last member bound the rows of T
   // any member can touch in a chunk -> stage only those (spread + CH <= TROWS rows)
   const uint32_t gmin = win_begin[perm[g.start]];
   const uint32_t gspread = win_begin[perm[g.start + g.count - 1]] - gmin;  // < SPREAD
   const uint32_t rel = begin - gmin;
-  const uint32_t nchunks = (s_maxspan + CH - 1) / CH;
+  const uint32_t nchunks = ACC ? (s_maxspan + CH - 1) / CH : 1;
 
   for (uint32_t c = 0; c < nchunks; ++c) {
     const uint32_t cbase = c * CH;           // chunk offset inside every thread's own window
@@ -189,9 +192,14 @@ __global__ void __launch_bounds__(GQ, 2) k_preplace(const double* __restrict__ l
       }
       __syncthreads();
       if (mine) {
-        double sum = accs[j * GQ + t];
+        double sum = ACC ? accs[j * GQ + t] : 0.0;
+        // the gather addresses (row base + per-site byte offset) are loop-invariant over the
+        // branches: left alone hipcc hoists all 160 of them into VGPRs; the zero token ties
+        // them to j so they are rebuilt (2 VALU per gather) and the kernel fits 4 workgroups/CU
+        uint32_t zj;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zj) : "v"(j));
         const char* base = reinterpret_cast<const char*>(tile);
-        const char* mybase = base + (size_t)rel * (NCOLS * 8);
+        const char* mybase = base + (size_t)(rel * (NCOLS * 8) + zj);
         auto at = [&](uint32_t s, uint32_t boff) -> double {
           return *reinterpret_cast<const double*>(mybase + s * (NCOLS * 8) + boff);
         };
@@ -242,11 +250,12 @@ __global__ void __launch_bounds__(GQ, 2) k_preplace(const double* __restrict__ l
           for (int k = 0; k < 3; ++k)
             if ((uint32_t)k < ntail) sum += at(s0 + k, (w >> (8 * k)) & 0xff);
         }
-        accs[j * GQ + t] = sum;
+        if (ACC) accs[j * GQ + t] = sum;
+        else lnl[(size_t)qi * B + b0 + j] = sum;
       }
     }
   }
-  if (active) {
+  if (ACC && active) {
     double* out = lnl + (size_t)qi * B + b0;
     for (uint32_t j = 0; j < nb; ++j) out[j] = accs[j * GQ + t];
   }
@@ -348,7 +357,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace
 
 int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin,
-                    const uint32_t* d_span, uint32_t Q, double* d_lnl) {
+                    const uint32_t* d_span, uint32_t Q, double* d_lnl, uint32_t max_span) {
   const uint32_t n_buckets = (ctx->W + SPREAD - 1) / SPREAD;
   const uint32_t max_groups = (Q + GQ - 1) / GQ + n_buckets;
   // scratch 6: [status 256 B | iota Q | sorted_begin Q | perm Q | groups | rocprim temp]
@@ -373,18 +382,21 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   hipLaunchKernelGGL(k_make_groups, dim3(1), dim3(256), sizeof(uint32_t) * (n_buckets + 1), ctx->stream,
                      sorted_begin, d_begin, d_span, Q, ctx->W, n_buckets, groups, max_groups, status);
   dim3 grid(max_groups, (ctx->B + NB - 1) / NB);
-  const size_t lds = sizeof(double) * ((size_t)TROWS * ctx->ncols + (size_t)NB * GQ);
+  // max_span: upper bound of the window spans when the caller knows it (0 = unknown)
+  const bool acc = max_span == 0 || max_span > (uint32_t)CH;
+  const size_t lds = sizeof(double) * ((size_t)TROWS * ctx->ncols + (acc ? (size_t)NB * GQ : 0));
   const size_t codes_bytes = (size_t)Q * ctx->W;
   epa_timer_start(ctx, ctx->t_preplace);
-  if (ctx->ncols == 16) {
-    EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_preplace<16>, grid, dim3(GQ), lds, ctx->stream, ctx->lookup, d_codes, d_begin,
-                       d_span, perm, groups, ctx->W, ctx->B, codes_bytes, d_lnl);
-  } else {
-    EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace<24>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_preplace<24>, grid, dim3(GQ), lds, ctx->stream, ctx->lookup, d_codes, d_begin,
-                       d_span, perm, groups, ctx->W, ctx->B, codes_bytes, d_lnl);
-  }
+#define PRE(NC, A)                                                                                  \
+  do {                                                                                              \
+    EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace<NC, A>,                                \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+    hipLaunchKernelGGL((k_preplace<NC, A>), grid, dim3(GQ), lds, ctx->stream, ctx->lookup, d_codes, \
+                       d_begin, d_span, perm, groups, ctx->W, ctx->B, codes_bytes, d_lnl);          \
+  } while (0)
+  if (ctx->ncols == 16) { if (acc) PRE(16, true); else PRE(16, false); }
+  else { if (acc) PRE(24, true); else PRE(24, false); }
+#undef PRE
   epa_timer_stop(ctx, ctx->t_preplace);
   EPA_HIP(ctx, hipGetLastError());
   return EPA_OK;
