@@ -6,7 +6,8 @@ Workload = cfg2 of SURVEY.md section 8d: 512-tip random-join tree (seed 1), 1500
 simulated on that tree (seed 2), 150 bp reads with 3 % substitutions (seed 3 + 1000*rank),
 dynamic heuristic 0.99999.  A "step" is one chunk of --chunk reads through
     preplace (Q x B lookup sums) -> candidate selection -> thorough NR placement
-with the encoded reads already resident in HBM; every rank works on its own reads (weak
+with the encoded reads already resident in HBM (default 50 000 reads per step: the GPU wants
+larger chunks than the reference's CPU default of 5000, it is the same --chunk-size knob); every rank works on its own reads (weak
 scaling, no data-path collective) and rank 0 gathers the per-pair results over RCCL.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
@@ -31,13 +32,13 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--steps", type=int, default=4)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--chunk", type=int, default=20000, help="reads per step (EPA-ng --chunk-size)")
+    p.add_argument("--chunk", type=int, default=50000, help="reads per step (EPA-ng --chunk-size)")
     p.add_argument("--tips", type=int, default=512)
     p.add_argument("--width", type=int, default=1500)
     p.add_argument("--read-len", type=int, default=150)
-    p.add_argument("--cpu-sample", type=int, default=1500, help="reads timed on the CPU baseline")
+    p.add_argument("--cpu-sample", type=int, default=20000, help="reads timed on the CPU baseline")
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
 
