@@ -117,3 +117,69 @@ def test_fused_place_chunk_equals_three_calls():
     o = Oracle(w["newick"], w["labels"], w["seqs"], 4, w["subst"], w["freqs"], w["rates"])
     tl, tp, td = o.thorough(p3["branch_id"], p3["seq_id"], qs)
     assert np.max(np.abs(r3["lnl"] - tl)) < 1e-6
+
+
+def test_cli_binary_matches_golden(tmp_path):
+    # the epa-ng-amd executable with the reference's flag names (src/main.cpp:96-270)
+    import subprocess
+    g = load_case("dna8_gtr_fu_g4")
+    data = os.path.join(GOLDEN, "data")
+    qf = tmp_path / "q.fasta"
+    with open(qf, "w") as f:
+        for q in g["queries"]:
+            f.write(">%s\n%s\n" % (q["name"], q["seq"]))
+    exe = os.path.join(os.path.dirname(hostlib.HOST_SO), "epa-ng-amd")
+    model = ("GTR{0.787874/1.821672/1.294006/0.698421/3.034135/1.0}+FU{0.256465/0.222535/0.308594/"
+             "0.212406}+G4{0.478218}")
+    r = subprocess.run([exe, "-t", os.path.join(data, "ref.tre"), "-s", os.path.join(data, "aln.fasta"),
+                        "-q", str(qf), "-m", model, "-w", str(tmp_path), "--filter-max", "13",
+                        "--filter-min-lwr", "0.0000001"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    jp = json.load(open(tmp_path / "epa_result.jplace"))
+    assert len(jp["placements"]) == len(g["queries"])
+    checked = 0
+    for qi, p in enumerate(jp["placements"]):
+        assert abs(sum(x[2] for x in p["p"]) - 1.0) < 1e-3 or len(p["p"]) < 13
+        for edge, lnl, lwr, distal, pendant in p["p"]:
+            gold = g["thorough"][qi][edge]
+            assert abs(lnl - gold["lnl"]) < 1e-6
+            checked += 1
+    assert checked >= len(g["queries"])
+    # --no-heur: every branch gets a thorough placement
+    r = subprocess.run([exe, "-t", os.path.join(data, "ref.tre"), "-s", os.path.join(data, "aln.fasta"),
+                        "-q", str(qf), "-m", model, "-w", str(tmp_path), "--no-heur", "--filter-max", "13",
+                        "--filter-min-lwr", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    jp = json.load(open(tmp_path / "epa_result.jplace"))
+    for qi, p in enumerate(jp["placements"]):
+        assert len(p["p"]) <= 13
+        for edge, lnl, lwr, distal, pendant in p["p"]:
+            assert abs(lnl - g["thorough"][qi][edge]["lnl"]) < 1e-6
+
+
+def test_edge_cases_single_query_unsorted_pairs_many_branches():
+    # B > 1024 exercises the 32-values-per-lane selection kernel; Q = 1; pairs in arbitrary order
+    w = synth.dna_workload(600, 200, 3, 120, (81, 82, 83))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    assert ref.B == 1197
+    ev = ref.evaluator()
+    o = Oracle(w["newick"], w["labels"], w["seqs"], 4, w["subst"], w["freqs"], w["rates"])
+    codes, wb, ws = epa.encode_queries(4, w["reads"][:1])
+    lnl = ev.preplace(codes, wb, ws)
+    assert lnl.shape == (1, ref.B)
+    assert np.max(np.abs(lnl - o.preplace(w["reads"][:1]))) < 1e-6
+    pairs, res = ev.place_chunk(codes, wb, ws)
+    hb, hs = hostlib.heuristic(lnl, "dynamic", 0.99999)
+    assert sorted(pairs["branch_id"].tolist()) == sorted(hb.tolist())
+    rng = np.random.RandomState(1)
+    codes3, wb3, ws3 = epa.encode_queries(4, w["reads"])
+    pr = np.zeros(40, epa.PAIR_DTYPE)
+    pr["branch_id"] = rng.randint(0, ref.B, 40)
+    pr["seq_id"] = rng.randint(0, 3, 40)
+    r2 = ev.thorough(pr, codes3, wb3, ws3)
+    tl, tp, td = o.thorough(pr["branch_id"], pr["seq_id"], w["reads"])
+    assert np.max(np.abs(r2["lnl"] - tl)) < 1e-6
+    # threshold 1.0 selects every branch with non-zero LWR mass until the sum reaches 1
+    p_all = ev.select(lnl, 1, 2.0)
+    assert len(p_all) == ref.B and len(set(p_all["branch_id"].tolist())) == ref.B
