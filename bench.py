@@ -40,6 +40,9 @@ def parse():
     p.add_argument("--read-len", type=int, default=150)
     p.add_argument("--cpu-sample", type=int, default=20000, help="reads timed on the CPU baseline")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--workload", choices=["dna", "aa"], default="dna",
+                   help="dna = cfg2 (the metric's config); aa = cfg3 shape (use --tips 2000 --width 500 "
+                        "--read-len 100), a parity/measurement case, not the headline")
     return p.parse_args()
 
 
@@ -66,13 +69,19 @@ def main():
 
     # ---------------- workload (identical reference on every rank, rank-private reads)
     n_chunks = a.steps + a.warmup
-    root = synth.random_tree(a.tips, 1)
-    rates = synth.gamma_rates(synth.CFG2_ALPHA)
-    labels, seqs = synth.simulate_msa(root, a.width, synth.CFG2_SUBST, synth.CFG2_FREQS, rates, 2)
+    states = 4 if a.workload == "dna" else 20
+    if a.workload == "dna":
+        subst, freqs, alpha, seeds = synth.CFG2_SUBST, synth.CFG2_FREQS, synth.CFG2_ALPHA, (1, 2, 3)
+    else:
+        subst, freqs = synth.aa_model()
+        alpha, seeds = 0.563473, (11, 12, 13)
+    root = synth.random_tree(a.tips, seeds[0])
+    rates = synth.gamma_rates(alpha)
+    labels, seqs = synth.simulate_msa(root, a.width, subst, freqs, rates, seeds[1])
     newick = synth.newick(root)
-    reads, _ = synth.make_reads(seqs, n_chunks * a.chunk, a.read_len, 0.03, 3 + 1000 * rank)
-    ref = hostlib.Reference(newick, labels, seqs, states=4, subst=synth.CFG2_SUBST,
-                            freqs=synth.CFG2_FREQS, rates=rates)
+    reads, _ = synth.make_reads(seqs, n_chunks * a.chunk, a.read_len, 0.03, seeds[2] + 1000 * rank,
+                                states=states)
+    ref = hostlib.Reference(newick, labels, seqs, states=states, subst=subst, freqs=freqs, rates=rates)
     ev = ref.evaluator(device=local)
     t0 = time.time()
     ev.build_lookup()
@@ -82,7 +91,7 @@ def main():
 
     chunks = []
     for c in range(n_chunks):
-        codes, wb, ws = epa.encode_queries(4, reads[c * Q:(c + 1) * Q])
+        codes, wb, ws = epa.encode_queries(states, reads[c * Q:(c + 1) * Q])
         chunks.append((torch.from_numpy(codes).to(dev), torch.from_numpy(wb.view(np.int32)).to(dev),
                        torch.from_numpy(ws.view(np.int32)).to(dev), codes, wb, ws))
     cap = Q * 64   # pair capacity per step (dynamic heuristic selects a handful per read)
@@ -143,11 +152,16 @@ def main():
     R = float(np.sum(th_rounds)) / float(np.sum(th_pairs))
     kbar = float(np.sum(th_evals)) / max(1.0, 2.0 * float(np.sum(th_rounds)))
     nq = a.read_len
-    flops_pair = nq * (884.0 + R * (1258.0 + 240.0 * kbar))
-    bytes_pair = 2 * nq * 16 * 8 + 2 * nq * 4 + nq + 24
+    if states == 4:
+        flops_pair = nq * (884.0 + R * (1258.0 + 240.0 * kbar))
+    else:  # same accounting with s = 20: P = c(4s^2+s), E = c(2s^2+2s), D = 6cs
+        P_, E_, D_ = 4 * (4 * 400 + 20), 4 * (2 * 400 + 40), 6 * 4 * 20
+        flops_pair = nq * ((2 * P_ + E_) + R * (4 * P_ + E_ + 2 * kbar * D_))
+    cs = 4 * states
+    bytes_pair = 2 * nq * cs * 8 + 2 * nq * 4 + nq + 24
     t_th = float(np.mean(th_ms)) * 1e-3
     ach_tflops = pairs * flops_pair / t_th / 1e12
-    roof = {"bound": "mfma", "kernel": "k_thorough_dna", "achieved": round(ach_tflops, 3),
+    roof = {"bound": "mfma", "kernel": "k_thorough_dna" if states == 4 else "k_thorough_aa", "achieved": round(ach_tflops, 3),
             "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tflops / FP64_PEAK_TFLOPS, 4),
             "traffic": None,
             "note": "fp64 VALU kernel priced against the fp64 vector=matrix peak (78.6 TF spec)",
@@ -163,9 +177,9 @@ def main():
         from oracle_lib import Oracle, lib as orc_lib
         ns = min(a.cpu_sample, Q)
         sample = reads[a.warmup * Q: a.warmup * Q + ns]
-        o = Oracle(newick, labels, seqs, 4, synth.CFG2_SUBST, synth.CFG2_FREQS, rates)
+        o = Oracle(newick, labels, seqs, states, subst, freqs, rates)
         o.preplace(sample[:8])                      # builds the per-branch lookups (one-off)
-        codes, wb, ws = epa.encode_queries(4, sample)
+        codes, wb, ws = epa.encode_queries(states, sample)
         lnl_gpu = ev.preplace(codes, wb, ws)
         prs = ev.select(lnl_gpu, ns, 0.99999)
         res_gpu = ev.thorough(prs, codes, wb, ws)
@@ -186,8 +200,10 @@ def main():
            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
-           "config": {"workload": "cfg2: %d-tip DNA GTR+G4 ref, W=%d, %d bp reads, dyn-heur 0.99999, "
-                                  "preplace+thorough" % (a.tips, a.width, a.read_len),
+           "config": {"workload": ("cfg2: %d-tip DNA GTR+G4 ref, W=%d, %d bp reads, dyn-heur 0.99999, "
+                                   "preplace+thorough" if states == 4 else
+                                   "cfg3-shape: %d-tip AA PROTGTR+G4 ref, W=%d, %d aa queries, dyn-heur "
+                                   "0.99999, preplace+thorough") % (a.tips, a.width, a.read_len),
                       "reads_per_step_per_gpu": Q, "branches": B, "parallelism": "query-shard x%d" % world,
                       "lookup_build_ms_once": round(lookup_ms, 3),
                       "kernel_ms_per_step": {"preplace": round(float(np.mean(pre_ms)), 3),
