@@ -60,7 +60,17 @@ struct Shared {
 };
 
 // y[i] = sum_x M[i*20 + x] * v[x]  with M wave-uniform (scalar loads)
-__device__ __forceinline__ void matvec20(const double* __restrict__ M, const double (&v)[S], double (&y)[S]) {
+typedef const __attribute__((address_space(4))) double* ConstD;
+
+// 0 in an SGPR that the optimiser cannot see through: added to a constant-space pointer it pins
+// the scalar loads behind it to this point of the program (they are invariant, and LICM would
+// otherwise hoist all 800 matrix words of U / U^-1 to kernel entry and spill them).
+__device__ __forceinline__ uint32_t szero(uint32_t dep) {
+  uint32_t z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z) : "s"(dep));
+  return z;
+}
+__device__ __forceinline__ void matvec20(ConstD M, const double (&v)[S], double (&y)[S]) {
 #pragma unroll
   for (int i = 0; i < S; ++i) {
     double acc = M[i * S] * v[0];
@@ -70,9 +80,14 @@ __device__ __forceinline__ void matvec20(const double* __restrict__ M, const dou
   }
 }
 
+// The model block is never written by any kernel: reading it through the constant address space
+// lets hipcc use scalar loads (s_load -> SGPR operands) for the wave-uniform U / U^-1 rows
+// instead of 64-lane vector loads of one address.
+typedef const __attribute__((address_space(4))) ModelDev* ConstModel;
+
 __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
   __shared__ Shared sh;
-  const ModelDev* __restrict__ m = a.m;
+  ConstModel m = (ConstModel)(a.m);
   const int tid = threadIdx.x, lane = tid & 63, k = tid >> 6;  // k = rate category of this wave
   double* Sg = a.sscratch + (size_t)blockIdx.x * 80 * a.Wpad + (size_t)k * S * a.Wpad;  // [x][site]
   // per-thread table constants: thread t < 240 owns (slot = t / 80, kx = t % 80)
@@ -128,12 +143,35 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
         }
 #pragma unroll
         for (int x = 0; x < S; ++x) Xv[x] = Xt[(size_t)x * cW + s] * sh.tab[1][k * S + x];
-        double av[S], bv[S];
-        matvec20(m->U, A, av);
-        matvec20(m->U, Xv, bv);
+        // I_i = (U A)_i (U X)_i : one pass over the rows of U feeds both products (each row is
+        // fetched once through the scalar cache and used for 40 FMAs)
+        // Row i+1 of U is fetched (s_load_dwordx16 x2.5 -> 40 SGPRs) while row i is being used;
+        // the sched_barrier keeps hipcc from hoisting all 20 rows (800 SGPRs -> spills to VGPR
+        // lanes).
         double mx = 0.0;
+        double ur[2][S];
+        {
+          ConstD row = m->U + szero(p);
 #pragma unroll
-        for (int i = 0; i < S; ++i) { I[i] = av[i] * bv[i]; mx = fmax(mx, I[i]); }
+          for (int x = 0; x < S; ++x) ur[0][x] = row[x];
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          if (i + 1 < S) {
+            ConstD row = m->U + (i + 1) * S + szero(p + i);
+#pragma unroll
+            for (int x = 0; x < S; ++x) ur[(i + 1) & 1][x] = row[x];
+          }
+          double pa = ur[i & 1][0] * A[0], pb = ur[i & 1][0] * Xv[0];
+#pragma unroll
+          for (int x = 1; x < S; ++x) {
+            pa = fma(ur[i & 1][x], A[x], pa);
+            pb = fma(ur[i & 1][x], Xv[x], pb);
+          }
+          I[i] = pa * pb;
+          mx = fmax(mx, I[i]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         // per-site rescale: ALL 80 entries (4 categories = 4 waves) below 2^-256
         sh.red[0][k][lane] = mx;
         __syncthreads();
@@ -142,7 +180,24 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
         const bool resc = mall < 0x1p-256;
         const double mult = resc ? 0x1p+256 : 1.0;
         double It[S];
-        matvec20(m->Ui, I, It);
+        {
+          ConstD row = m->Ui + szero(p);
+#pragma unroll
+          for (int x = 0; x < S; ++x) ur[0][x] = row[x];
+        }
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+          if (i + 1 < S) {
+            ConstD row = m->Ui + (i + 1) * S + szero(p + i);
+#pragma unroll
+            for (int x = 0; x < S; ++x) ur[(i + 1) & 1][x] = row[x];
+          }
+          double acc = ur[i & 1][0] * I[0];
+#pragma unroll
+          for (int x = 1; x < S; ++x) acc = fma(ur[i & 1][x], I[x], acc);
+          It[i] = acc;
+          __builtin_amdgcn_sched_barrier(0);
+        }
         double l0 = 0.0;
         if (mode == 0) {
 #pragma unroll
