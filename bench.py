@@ -161,9 +161,16 @@ def main():
     bytes_pair = 2 * nq * cs * 8 + 2 * nq * 4 + nq + 24
     t_th = float(np.mean(th_ms)) * 1e-3
     ach_tflops = pairs * flops_pair / t_th / 1e12
+    traffic = None   # HBM bytes per launch from the committed PMC passes, same workload only
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))["k_thorough_dna"]
+        if states == 4 and tj["reads_per_step"] == Q and abs(tj["pairs_per_launch"] - pairs) < 0.02 * pairs:
+            traffic = (tj["fetch_kb"] + tj["write_kb"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        pass
     roof = {"bound": "mfma", "kernel": "k_thorough_dna" if states == 4 else "k_thorough_aa", "achieved": round(ach_tflops, 3),
             "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tflops / FP64_PEAK_TFLOPS, 4),
-            "traffic": None,
+            "traffic": traffic,
             "note": "fp64 VALU kernel priced against the fp64 vector=matrix peak (78.6 TF spec)",
             "pairs_per_launch": pairs, "rounds_per_pair": round(R, 3), "newton_iters_per_solve": round(kbar, 3),
             "flops_per_pair": round(flops_pair), "ms_per_launch": round(t_th * 1e3, 4),
