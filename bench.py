@@ -64,8 +64,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("EPA_BENCH_BACKEND", "nccl")   # "gloo" only for 1-GPU plumbing tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local)
+    cdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")  # collective buffers
 
     # ---------------- workload (identical reference on every rank, rank-private reads)
     n_chunks = a.steps + a.warmup
@@ -97,7 +102,7 @@ def main():
     cap = Q * 64   # pair capacity per step (dynamic heuristic selects a handful per read)
     d_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
     d_res = torch.zeros((cap, 3), dtype=torch.float64, device=dev)
-    nmax_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    nmax_t = torch.zeros(1, dtype=torch.int64, device=cdev)
 
     th_ms, th_pairs, th_rounds, th_evals, pre_ms, sel_ms = [], [], [], [], [], []
 
@@ -112,10 +117,10 @@ def main():
             nmax_t[0] = n
             dist.all_reduce(nmax_t, op=dist.ReduceOp.MAX)
             m = int(nmax_t.item())
-            gp = [torch.empty((m, 2), dtype=torch.int32, device=dev) for _ in range(world)] if rank == 0 else None
-            gr = [torch.empty((m, 3), dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
-            dist.gather(d_pairs[:m], gp, dst=0)
-            dist.gather(d_res[:m], gr, dst=0)
+            gp = [torch.empty((m, 2), dtype=torch.int32, device=cdev) for _ in range(world)] if rank == 0 else None
+            gr = [torch.empty((m, 3), dtype=torch.float64, device=cdev) for _ in range(world)] if rank == 0 else None
+            dist.gather(d_pairs[:m].to(cdev), gp, dst=0)
+            dist.gather(d_res[:m].to(cdev), gr, dst=0)
         if record:
             th_ms.append(ev.kernel_ms("thorough")); pre_ms.append(ev.kernel_ms("preplace"))
             sel_ms.append(ev.kernel_ms("select"))
@@ -136,7 +141,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

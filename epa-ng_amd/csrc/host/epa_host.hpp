@@ -34,7 +34,7 @@ struct Options {  // defaults: src/util/Options.hpp:13-34
   unsigned int filter_max = 7;
   bool prescoring_by_percentage = false;
   double prescoring_threshold = 0.99999;
-  unsigned int chunk_size = 5000;
+  unsigned int chunk_size = 50000;  // the reference's CPU default is 5000 (Options.hpp:26); a GPU wants larger chunks
   unsigned int num_threads = 0;
   bool premasking = true;
   bool baseball = false;

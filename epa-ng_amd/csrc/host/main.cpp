@@ -26,7 +26,7 @@ static void usage() {
       "  --no-heur             thorough placement on every branch\n"
       "  --filter-acc-lwr X | --filter-min-lwr X | --filter-min N | --filter-max N\n"
       "  --precision N         output digits (default 10)\n"
-      "  --chunk-size N        queries per chunk (default 5000)\n"
+      "  --chunk-size N        queries per chunk (default 50000; EPA-ng's CPU default is 5000)\n"
       "  --no-pre-mask         evaluate all sites of every query\n"
       "  --device N            GPU ordinal (default 0)\n";
 }

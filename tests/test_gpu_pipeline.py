@@ -183,3 +183,36 @@ def test_edge_cases_single_query_unsorted_pairs_many_branches():
     # threshold 1.0 selects every branch with non-zero LWR mass until the sum reaches 1
     p_all = ev.select(lnl, 1, 2.0)
     assert len(p_all) == ref.B and len(set(p_all["branch_id"].tolist())) == ref.B
+
+
+def test_full_size_cfg2_properties():
+    """BASELINE configs[1] at full size (512 tips, W=1500, 100k reads): too big for the oracle, so
+    size-independent properties are checked: thorough lnL never below the preplacement lnL of
+    the same pair (the optimiser starts from the preplacement lengths and only accepts
+    improvements or reverts), sanity ranges, candidates == host heuristic on a sample, LWR
+    normalisation, bit-identical repeat."""
+    w = synth.dna_workload(512, 1500, 100000, 150, (1, 2, 3))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    codes, wb, ws = epa.encode_queries(4, w["reads"])
+    Q = len(w["reads"])
+    pairs, res = ev.place_chunk(codes, wb, ws, max_span=150)
+    assert len(pairs) >= Q and set(np.unique(pairs["seq_id"])) == set(range(Q))
+    assert np.all(np.isfinite(res["lnl"]))
+    assert np.all(np.diff(pairs["branch_id"].astype(np.int64)) >= 0)
+    bl = np.array([ref.branch(int(b))["length"] for b in range(ref.B)])
+    assert np.all(res["pendant_length"] >= 1e-4 - 1e-12) and np.all(res["pendant_length"] <= 100.0)
+    assert np.all(res["distal_length"] > 0) and np.all(res["distal_length"] < bl[pairs["branch_id"]])
+    sub = slice(0, 4000)
+    lnl = ev.preplace(codes[sub], wb[sub], ws[sub])
+    m = pairs["seq_id"] < 4000
+    pre = lnl[pairs["seq_id"][m], pairs["branch_id"][m]]
+    assert np.all(res["lnl"][m] >= pre - 1e-7)
+    hb, hs = hostlib.heuristic(lnl, "dynamic", 0.99999)
+    assert sorted(zip(hb.tolist(), hs.tolist())) == sorted(zip(pairs["branch_id"][m].tolist(), pairs["seq_id"][m].tolist()))
+    lw = np.exp(lnl - lnl.max(1, keepdims=True))
+    lw /= lw.sum(1, keepdims=True)
+    assert np.allclose(lw.sum(1), 1.0)
+    p2, r2 = ev.place_chunk(codes, wb, ws, max_span=150)
+    assert np.array_equal(p2, pairs) and np.array_equal(r2["lnl"], res["lnl"])
