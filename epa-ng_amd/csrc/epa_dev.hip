@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) k_transform(const ModelDev* __restrict__ 
                                                    const double* __restrict__ clv,
                                                    const uint8_t* __restrict__ tip,
                                                    const uint32_t* __restrict__ tipmap,
-                                                   uint32_t W, double* __restrict__ dst) {
+                                                   uint32_t W, int c_in, double* __restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* Ui = reinterpret_cast<double*>(smem);
   const int s = m->s, c = m->c;
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) k_transform(const ModelDev* __restrict__ 
         for (int i = 0; i < s; ++i)
           if ((mask >> i) & 1u) acc += Ui[x * s + i];
       } else {
-        const double* v = clv + ((size_t)site * c + k) * s;
+        const double* v = clv + ((size_t)site * c_in + (k % c_in)) * s;  // c_in < c: replicated categories
         for (int i = 0; i < s; ++i) acc = fma(Ui[x * s + i], v[i], acc);
       }
       dst[(size_t)(k * s + x) * W + site] = acc;
@@ -96,7 +96,7 @@ int launch_transform(epa_ctx* ctx, const double* d_clv, const uint8_t* d_tip,
   dim3 grid((ctx->W + 255) / 256);
   size_t lds = sizeof(double) * ctx->s * ctx->s;
   hipLaunchKernelGGL(k_transform, grid, dim3(256), lds, ctx->stream, ctx->dmodel, d_clv, d_tip,
-                     d_tipmap, ctx->W, dst);
+                     d_tipmap, ctx->W, ctx->c_in, dst);
   EPA_HIP(ctx, hipGetLastError());
   return EPA_OK;
 }
@@ -319,9 +319,13 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
 }
 
 static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx) {
-  const int s = (int)d->states, c = (int)d->rate_cats;
+  const int s = (int)d->states, c_in = (int)d->rate_cats;
   if (!(s == 4 || s == 20)) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "states must be 4 or 20");
-  if (c < 1 || c > EPA_MAX_CATS) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "rate_cats out of range");
+  if (c_in < 1 || c_in > EPA_MAX_CATS) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "rate_cats out of range");
+  // The thorough kernels are built for 4 rate categories.  1 or 2 categories (no +G, +G2) are
+  // replicated to 4 with the weights divided accordingly: sum_k w_k L_k is unchanged.
+  const int c = (c_in == 1 || c_in == 2) ? 4 : c_in;
+  ctx->c_in = c_in;
   if (!d->sites || !d->branches) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "empty reference");
   if (d->prop_invar != 0.0)
     return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "prop_invar > 0 (+I) is not implemented yet");
@@ -341,7 +345,10 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx) {
   m.s = s; m.c = c; m.ncols = ctx->ncols;
   for (int i = 0; i < s * s; ++i) { m.U[i] = d->eigenvecs_u[i]; m.Ui[i] = d->eigenvecs_uinv[i]; }
   for (int i = 0; i < s; ++i) { m.lam[i] = d->eigenvals[i]; m.pi[i] = d->freqs[i]; }
-  for (int k = 0; k < c; ++k) { m.rate[k] = d->rates[k]; m.w[k] = d->rate_weights[k]; }
+  for (int k = 0; k < c; ++k) {
+    m.rate[k] = d->rates[k % c_in];
+    m.w[k] = d->rate_weights[k % c_in] * (double)c_in / (double)c;
+  }
   {
     // Internal convention: eigenvalue 0 is the stationary (zero) one.  Swap the largest
     // eigenvalue to index 0 (columns of U, rows of U^-1); when it is numerically zero it is
@@ -422,7 +429,7 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx) {
       double* dst = ctx->refT + (2 * b + side) * cs * W;
       const int slot = side;  // staging slots 0/1
       if (clv) {
-        const double* dclv = (const double*)epa_to_device(ctx, slot, clv, sizeof(double) * W * cs);
+        const double* dclv = (const double*)epa_to_device(ctx, slot, clv, sizeof(double) * W * (size_t)c_in * s);
         if (!dclv) return epa_fail(ctx, EPA_ERR_HIP, "staging copy of CLV failed");
         int rc = launch_transform(ctx, dclv, nullptr, nullptr, 0, dst);
         if (rc) return rc;

@@ -55,6 +55,7 @@ struct epa_ctx {
   std::string err;
 
   int s = 0, c = 0, ncols = 0;
+  int c_in = 0;  // rate categories of the caller's CLVs (1 or 2 are replicated to c = 4)
   uint32_t W = 0, B = 0;
   ModelDev hmodel;          // host copy
   ModelDev* dmodel = nullptr;

@@ -168,3 +168,25 @@ def test_scaling_deep_tree():
     res = e.thorough(pairs, codes, wb, ws)
     tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
     assert np.max(np.abs(res["lnl"] - tl)) < LNL_TOL
+
+
+def test_single_rate_category_model():
+    # GTR without +G: one category, replicated to 4 on the device (same likelihood)
+    from epa_ng_amd import synth
+    root = synth.random_tree(20, 91)
+    labels, seqs = synth.simulate_msa(root, 260, synth.CFG2_SUBST, synth.CFG2_FREQS, [1.0], 92)
+    reads, _ = synth.make_reads(seqs, 30, 100, 0.04, 93)
+    o = Oracle(synth.newick(root), labels, seqs, 4, synth.CFG2_SUBST, synth.CFG2_FREQS, [1.0])
+    ev, u, ui = o.eigen()
+    pc, ps, dc, ds, bl = [], [], [], [], []
+    for b in range(o.B):
+        cp, sp, cd, sd = o.branch_sides(b)
+        pc.append(cp); ps.append(sp); dc.append(cd); ds.append(sd); bl.append(o.branch_info(b)[0])
+    e = epa.Evaluator(4, [1.0], [1.0], ev, u, ui, synth.CFG2_FREQS, bl, pc, dc, ps, ds)
+    codes, wb, ws = epa.encode_queries(4, reads)
+    lnl = e.preplace(codes, wb, ws)
+    assert np.max(np.abs(lnl - o.preplace(reads))) < LNL_TOL
+    pairs, res = e.place_chunk(codes, wb, ws)
+    tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
+    assert np.max(np.abs(res["lnl"] - tl)) < LNL_TOL
+    assert np.max(np.abs(res["distal_length"] - td)) < 1e-6
