@@ -21,6 +21,7 @@
 #include "epa_dev_internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -70,6 +71,11 @@ __device__ __forceinline__ uint32_t szero(uint32_t dep) {
   asm volatile("s_mov_b32 %0, 0" : "=s"(z) : "s"(dep));
   return z;
 }
+// same, data-dependent on a vector value: a scalar load addressed through it cannot be issued
+// before `dep` has been computed (one v_readfirstlane per use)
+__device__ __forceinline__ uint32_t szero_after(double dep) {
+  return szero((uint32_t)__builtin_amdgcn_readfirstlane(__double2loint(dep)));
+}
 __device__ __forceinline__ void matvec20(ConstD M, const double (&v)[S], double (&y)[S]) {
 #pragma unroll
   for (int i = 0; i < S; ++i) {
@@ -85,11 +91,32 @@ __device__ __forceinline__ void matvec20(ConstD M, const double (&v)[S], double 
 // instead of 64-lane vector loads of one address.
 typedef const __attribute__((address_space(4))) ModelDev* ConstModel;
 
+// LDS_SLAB: the pair's sumtable slab lives in dynamic LDS (80 x Wpad doubles, Wpad = window
+// length rounded up to 2, + 2; two workgroups per CU fit up to Wpad = 112); otherwise in HBM
+// scratch.
+template <bool LDS_SLAB>
 __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
   __shared__ Shared sh;
+  extern __shared__ double dyn_slab[];
   ConstModel m = (ConstModel)(a.m);
+  // U / U^-1 base pointers as stand-alone SGPR pairs: taken straight from the kernel-argument
+  // block they stay part of an 8-register tuple that is spilled and reloaded whole (16
+  // v_readlane per matrix row).
+  ConstD Ub, Uib;
+  {
+    uint64_t u0 = (uint64_t)(uintptr_t)m->U, u1 = (uint64_t)(uintptr_t)m->Ui, r0, r1;
+    asm volatile("s_mov_b64 %0, %2\n\ts_mov_b64 %1, %3" : "=s"(r0), "=s"(r1) : "s"(u0), "s"(u1));
+    Ub = (ConstD)r0;
+    Uib = (ConstD)r1;
+  }
   const int tid = threadIdx.x, lane = tid & 63, k = tid >> 6;  // k = rate category of this wave
-  double* Sg = a.sscratch + (size_t)blockIdx.x * 80 * a.Wpad + (size_t)k * S * a.Wpad;  // [x][site]
+  // this wave's category plane of the slab, [x][site]
+  double* Sglob = LDS_SLAB ? nullptr : a.sscratch + (size_t)blockIdx.x * 80 * a.Wpad + (size_t)k * S * a.Wpad;
+  const uint32_t slab_k = k * S * a.Wpad;
+  auto slab = [&](uint32_t idx) -> double& {
+    if constexpr (LDS_SLAB) return dyn_slab[slab_k + idx];
+    else return Sglob[idx];
+  };
   // per-thread table constants: thread t < 240 owns (slot = t / 80, kx = t % 80)
   const int tslot = tid / 80, tkx = tid % 80;
   double t_lr = 0.0, t_w = 0.0;
@@ -132,17 +159,27 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
         const uint32_t site = p * 64 + lane;
         const bool valid = site < n;
         const uint32_t s = valid ? site : 0;
-        double A[S], Xv[S], I[S];
+        // All 60 operand loads of the pass (proximal and distal reference vectors, the query
+        // column's tip vector) are requested before the first use: one memory round trip per
+        // pass.  Without the barrier hipcc interleaves load / wait / multiply one at a time.
+        double A[S], Xv[S], E[S], I[S];
         const uint32_t code = qc[s];
-        if (mode == 0) {
 #pragma unroll
-          for (int x = 0; x < S; ++x) A[x] = Dt[(size_t)x * cW + s] * sh.tab[0][k * S + x];
-        } else {
+        for (int x = 0; x < S; ++x) Xv[x] = Xt[(size_t)x * cW + s];
 #pragma unroll
-          for (int x = 0; x < S; ++x) A[x] = m->qt[code * S + x] * sh.tab[0][k * S + x];
+        for (int x = 0; x < S; ++x) A[x] = Dt[(size_t)x * cW + s];
+#pragma unroll
+        for (int x = 0; x < S; ++x) E[x] = m->qt[code * S + x];
+        asm volatile("" ::: "memory");
+        if (mode == 1) {
+          // A = query tip, the distal vector is folded in at the end
+#pragma unroll
+          for (int x = 0; x < S; ++x) { const double t = A[x]; A[x] = E[x]; E[x] = t; }
         }
 #pragma unroll
-        for (int x = 0; x < S; ++x) Xv[x] = Xt[(size_t)x * cW + s] * sh.tab[1][k * S + x];
+        for (int x = 0; x < S; ++x) A[x] *= sh.tab[0][k * S + x];
+#pragma unroll
+        for (int x = 0; x < S; ++x) Xv[x] *= sh.tab[1][k * S + x];
         // I_i = (U A)_i (U X)_i : one pass over the rows of U feeds both products (each row is
         // fetched once through the scalar cache and used for 40 FMAs)
         // Row i+1 of U is fetched (s_load_dwordx16 x2.5 -> 40 SGPRs) while row i is being used;
@@ -151,18 +188,23 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
         double mx = 0.0;
         double ur[2][S];
         {
-          ConstD row = m->U + szero(p);
+          ConstD row = Ub + szero(p);
 #pragma unroll
           for (int x = 0; x < S; ++x) ur[0][x] = row[x];
         }
 #pragma unroll
         for (int i = 0; i < S; ++i) {
+          // scalar loads complete out of order, so the only wait is lgkmcnt(0): the first use of
+          // row i (which waits) has to come BEFORE row i+1 is requested, or every row would wait
+          // for the request issued right in front of it.
+          double pa = ur[i & 1][0] * A[0], pb = ur[i & 1][0] * Xv[0];
+          __builtin_amdgcn_sched_barrier(0);
           if (i + 1 < S) {
-            ConstD row = m->U + (i + 1) * S + szero(p + i);
+            ConstD row = Ub + (i + 1) * S + szero_after(pa);
 #pragma unroll
             for (int x = 0; x < S; ++x) ur[(i + 1) & 1][x] = row[x];
           }
-          double pa = ur[i & 1][0] * A[0], pb = ur[i & 1][0] * Xv[0];
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int x = 1; x < S; ++x) {
             pa = fma(ur[i & 1][x], A[x], pa);
@@ -181,34 +223,35 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
         const double mult = resc ? 0x1p+256 : 1.0;
         double It[S];
         {
-          ConstD row = m->Ui + szero(p);
+          ConstD row = Uib + szero(p);
 #pragma unroll
           for (int x = 0; x < S; ++x) ur[0][x] = row[x];
         }
 #pragma unroll
         for (int i = 0; i < S; ++i) {
+          double acc = ur[i & 1][0] * I[0];
+          __builtin_amdgcn_sched_barrier(0);
           if (i + 1 < S) {
-            ConstD row = m->Ui + (i + 1) * S + szero(p + i);
+            ConstD row = Uib + (i + 1) * S + szero_after(acc);
 #pragma unroll
             for (int x = 0; x < S; ++x) ur[(i + 1) & 1][x] = row[x];
           }
-          double acc = ur[i & 1][0] * I[0];
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int x = 1; x < S; ++x) acc = fma(ur[i & 1][x], I[x], acc);
           It[i] = acc;
           __builtin_amdgcn_sched_barrier(0);
         }
         double l0 = 0.0;
-        if (mode == 0) {
+        // LDS slab: lanes past the window write to the spare last column (an `if (valid)` around
+        // the stores would let LLVM sink the whole U^-1 product into the branch and wreck the
+        // scalar-load pipeline above)
+        const uint32_t wsite = (LDS_SLAB && !valid) ? a.Wpad - 1 : site;
 #pragma unroll
-          for (int x = 0; x < S; ++x) {
-            const double sv = It[x] * mult * m->qt[code * S + x];
-            Sg[(size_t)x * a.Wpad + site] = sv;
-            l0 = fma(sv, sh.tab[2][k * S + x], l0);
-          }
-        } else {
-#pragma unroll
-          for (int x = 0; x < S; ++x) Sg[(size_t)x * a.Wpad + site] = Dt[(size_t)x * cW + s] * It[x] * mult;
+        for (int x = 0; x < S; ++x) {
+          const double sv = It[x] * mult * E[x];
+          slab(x * a.Wpad + wsite) = sv;
+          if (mode == 0) l0 = fma(sv, sh.tab[2][k * S + x], l0);
         }
         __syncthreads();  // sh.red[0] consumed
         if (mode == 0) {
@@ -243,12 +286,17 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
       for (uint32_t p = 0; p < npass; ++p) {
         const uint32_t site = p * 64 + lane;
         double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+        // all 20 slab loads are issued before the first FMA (one L2 round trip per pass; left to
+        // itself hipcc interleaves them with the FMAs two at a time -> ten serialized round trips)
+        double sv[S];
+#pragma unroll
+        for (int x = 0; x < S; ++x) sv[x] = slab(x * a.Wpad + (LDS_SLAB ? (site < n ? site : 0) : site));
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int x = 0; x < S; ++x) {
-          const double sv = Sg[(size_t)x * a.Wpad + site];
-          l0 = fma(sv, sh.tab[0][k * S + x], l0);
-          l1 = fma(sv, sh.tab[1][k * S + x], l1);
-          l2 = fma(sv, sh.tab[2][k * S + x], l2);
+          l0 = fma(sv[x], sh.tab[0][k * S + x], l0);
+          l1 = fma(sv[x], sh.tab[1][k * S + x], l1);
+          l2 = fma(sv[x], sh.tab[2][k * S + x], l2);
         }
         sh.red[0][k][lane] = l0; sh.red[1][k][lane] = l1; sh.red[2][k][lane] = l2;
         __syncthreads();
@@ -383,12 +431,26 @@ int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, 
   a.stats = d_stats;
   a.n_pairs = n_pairs;
   a.W = ctx->W;
-  a.Wpad = (max_span + 63) / 64 * 64;
   uint32_t nwg = (uint32_t)std::min<uint64_t>(n_pairs, 512);  // 2 resident workgroups per CU
-  a.sscratch = (double*)epa_scratch(ctx, 7, sizeof(double) * (size_t)nwg * 80 * a.Wpad);
-  if (!a.sscratch) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(AA sumtable scratch)");
+  const uint32_t wpad_lds = (max_span + 1) / 2 * 2 + 2;  // + spare column for lanes past the window
+  const bool lds_slab = wpad_lds <= 112 && !getenv("EPA_AA_HBM_SLAB");
+  if (lds_slab) {
+    a.Wpad = wpad_lds;
+    a.sscratch = nullptr;
+  } else {
+    a.Wpad = (max_span + 63) / 64 * 64;
+    a.sscratch = (double*)epa_scratch(ctx, 7, sizeof(double) * (size_t)nwg * 80 * a.Wpad);
+    if (!a.sscratch) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(AA sumtable scratch)");
+  }
+  if (lds_slab) {
+    const int dyn = (int)(sizeof(double) * 80 * a.Wpad);
+    EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_thorough_aa<true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+  }
   epa_timer_start(ctx, ctx->t_thorough);
-  hipLaunchKernelGGL(k_thorough_aa, dim3(nwg), dim3(256), 0, ctx->stream, a);
+  if (lds_slab)
+    hipLaunchKernelGGL(k_thorough_aa<true>, dim3(nwg), dim3(256), sizeof(double) * 80 * a.Wpad, ctx->stream, a);
+  else
+    hipLaunchKernelGGL(k_thorough_aa<false>, dim3(nwg), dim3(256), 0, ctx->stream, a);
   epa_timer_stop(ctx, ctx->t_thorough);
   EPA_HIP(ctx, hipGetLastError());
   return EPA_OK;
