@@ -19,11 +19,14 @@
 // the MFMA formulation needs 1.6x the cycles of the VALU one (30 MFMA x 64 cycles vs 1200 FMA x
 // 4 cycles per 16 sites and category).  DESIGN.md section 4.2 keeps the arithmetic.
 #include "epa_dev_internal.hpp"
+#include "wave_util.hpp"
 
 #include <algorithm>
 #include <cstdlib>
 
 namespace {
+
+using namespace epa_wave;
 
 constexpr int S = 20;
 constexpr int C = 4;
@@ -47,16 +50,11 @@ struct ThArgsAA {
   uint32_t Wpad;
 };
 
-__device__ __forceinline__ double wave_sum_aa(double v) {
-#pragma unroll
-  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
 
 struct Shared {
   double tab[3][80];      // wave-uniform exp tables, [slot][k*20 + x]
-  double red[3][C][64];   // per-site per-category partial sums of the current pass
-  double bc[4];           // broadcast scalars (f, f', lnL partial)
+  double red[2][3][C][64];  // per-site per-category partial sums of (up to) two passes
+  double bc[4];             // broadcast scalars (lnL; f, f' partials of the two ratio waves)
   double lnl_acc;
 };
 
@@ -92,7 +90,7 @@ __device__ __forceinline__ void matvec20(ConstD M, const double (&v)[S], double 
 typedef const __attribute__((address_space(4))) ModelDev* ConstModel;
 
 // LDS_SLAB: the pair's sumtable slab lives in dynamic LDS (80 x Wpad doubles, Wpad = window
-// length rounded up to 2, + 2; two workgroups per CU fit up to Wpad = 112); otherwise in HBM
+// length rounded up to 2, + 2; two workgroups per CU fit up to Wpad = 104); otherwise in HBM
 // scratch.
 template <bool LDS_SLAB>
 __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
@@ -104,8 +102,13 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
   // v_readlane per matrix row).
   ConstD Ub, Uib;
   {
-    uint64_t u0 = (uint64_t)(uintptr_t)m->U, u1 = (uint64_t)(uintptr_t)m->Ui, r0, r1;
-    asm volatile("s_mov_b64 %0, %2\n\ts_mov_b64 %1, %3" : "=s"(r0), "=s"(r1) : "s"(u0), "s"(u1));
+    auto uniform64 = [](uint64_t v) {
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+      return ((uint64_t)hi << 32) | lo;
+    };
+    uint64_t r0 = uniform64((uint64_t)(uintptr_t)m->U), r1 = uniform64((uint64_t)(uintptr_t)m->Ui);
+    asm volatile("" : "+s"(r0), "+s"(r1));
     Ub = (ConstD)r0;
     Uib = (ConstD)r1;
   }
@@ -124,7 +127,13 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
     t_lr = m->lam[tkx % S] * m->rate[tkx / S];
     t_w = m->w[tkx / S];
   }
-  const double cN = tslot == 0 ? t_w : (tslot == 1 ? t_w * t_lr : t_w * t_lr * t_lr);
+  // Newton tables of this wave's own category: lane = slot * 20 + x (lanes 60..63 idle)
+  double tl_lr = 0.0, tl_c = 0.0;
+  if (lane < 60) {
+    const int x = lane % S, slot = lane / S;
+    tl_lr = m->lam[x] * m->rate[k];
+    tl_c = slot == 0 ? m->w[k] : (slot == 1 ? m->w[k] * tl_lr : m->w[k] * tl_lr * tl_lr);
+  }
 
   uint32_t wrounds = 0, wevals = 0, wreverts = 0;
   for (uint64_t pid = blockIdx.x; pid < a.n_pairs; pid += gridDim.x) {
@@ -140,12 +149,12 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
     const uint32_t npass = (n + 63) / 64;
 
     // ---- table publication: every thread < 240 computes one exp()
-    auto publish = [&](double t0, double t1, double t2, bool newton) {
+    auto publish = [&](double t0, double t1, double t2) {
       __syncthreads();  // previous readers of sh.tab are done
       if (tid < 240) {
         const double t = tslot == 0 ? t0 : (tslot == 1 ? t1 : t2);
         const double e = exp(t_lr * t);
-        sh.tab[tslot][tkx] = newton ? e * cN : (tslot == 2 ? e * t_w : e);
+        sh.tab[tslot][tkx] = tslot == 2 ? e * t_w : e;
       }
       __syncthreads();
     };
@@ -155,31 +164,39 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
     auto phase = [&](int mode, double& lnl_out) {
       double mant = 1.0;
       int ex = 0;
+      // Reference operands of a pass (X = proximal, Dv = distal, 20 + 20 doubles per lane) are
+      // requested as one batch: left alone hipcc interleaves load / wait / multiply one value at
+      // a time.  (Requesting the next pass's batch under the U^-1 loop was tried: the extra 80
+      // live registers spill and the kernel gets 25% slower.)
+      double Xv[S], Dv[S];
+      auto request = [&](uint32_t pp, bool with_d) {
+        const uint32_t st = pp * 64 + lane;
+        const uint32_t sx = st < n ? st : 0;
+#pragma unroll
+        for (int x = 0; x < S; ++x) Xv[x] = Xt[(size_t)x * cW + sx];
+        if (with_d) {
+#pragma unroll
+          for (int x = 0; x < S; ++x) Dv[x] = Dt[(size_t)x * cW + sx];
+        }
+        asm volatile("" ::: "memory");
+      };
       for (uint32_t p = 0; p < npass; ++p) {
         const uint32_t site = p * 64 + lane;
         const bool valid = site < n;
         const uint32_t s = valid ? site : 0;
-        // All 60 operand loads of the pass (proximal and distal reference vectors, the query
-        // column's tip vector) are requested before the first use: one memory round trip per
-        // pass.  Without the barrier hipcc interleaves load / wait / multiply one at a time.
-        double A[S], Xv[S], E[S], I[S];
-        const uint32_t code = qc[s];
+        double A[S], E[S], Q[S], I[S];
+        const uint32_t code = qc[s];  // its latency hides under the 40 requests below
+        request(p, true);
 #pragma unroll
-        for (int x = 0; x < S; ++x) Xv[x] = Xt[(size_t)x * cW + s];
-#pragma unroll
-        for (int x = 0; x < S; ++x) A[x] = Dt[(size_t)x * cW + s];
-#pragma unroll
-        for (int x = 0; x < S; ++x) E[x] = m->qt[code * S + x];
+        for (int x = 0; x < S; ++x) Q[x] = m->qt[code * S + x];
         asm volatile("" ::: "memory");
-        if (mode == 1) {
-          // A = query tip, the distal vector is folded in at the end
+        // mode 0: A = distal, the query tip is folded in at the end; mode 1: the other way round
 #pragma unroll
-          for (int x = 0; x < S; ++x) { const double t = A[x]; A[x] = E[x]; E[x] = t; }
+        for (int x = 0; x < S; ++x) {
+          A[x] = (mode == 0 ? Dv[x] : Q[x]) * sh.tab[0][k * S + x];
+          E[x] = mode == 0 ? Q[x] : Dv[x];
+          Xv[x] *= sh.tab[1][k * S + x];
         }
-#pragma unroll
-        for (int x = 0; x < S; ++x) A[x] *= sh.tab[0][k * S + x];
-#pragma unroll
-        for (int x = 0; x < S; ++x) Xv[x] *= sh.tab[1][k * S + x];
         // I_i = (U A)_i (U X)_i : one pass over the rows of U feeds both products (each row is
         // fetched once through the scalar cache and used for 40 FMAs)
         // Row i+1 of U is fetched (s_load_dwordx16 x2.5 -> 40 SGPRs) while row i is being used;
@@ -212,13 +229,15 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
           }
           I[i] = pa * pb;
           mx = fmax(mx, I[i]);
+          asm volatile("" ::"v"(I[i]));  // pins row i's FMAs here (LLVM would sink them to their use)
           __builtin_amdgcn_sched_barrier(0);
         }
-        // per-site rescale: ALL 80 entries (4 categories = 4 waves) below 2^-256
-        sh.red[0][k][lane] = mx;
+        // per-site rescale: ALL 80 entries (4 categories = 4 waves) below 2^-256.  sh.red is
+        // double-buffered by pass parity, so one barrier per exchange is enough.
+        sh.red[p & 1][0][k][lane] = mx;
         __syncthreads();
-        const double mall = fmax(fmax(sh.red[0][0][lane], sh.red[0][1][lane]),
-                                 fmax(sh.red[0][2][lane], sh.red[0][3][lane]));
+        const double mall = fmax(fmax(sh.red[p & 1][0][0][lane], sh.red[p & 1][0][1][lane]),
+                                 fmax(sh.red[p & 1][0][2][lane], sh.red[p & 1][0][3][lane]));
         const bool resc = mall < 0x1p-256;
         const double mult = resc ? 0x1p+256 : 1.0;
         double It[S];
@@ -240,6 +259,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
 #pragma unroll
           for (int x = 1; x < S; ++x) acc = fma(ur[i & 1][x], I[x], acc);
           It[i] = acc;
+          asm volatile("" ::"v"(It[i]));
           __builtin_amdgcn_sched_barrier(0);
         }
         double l0 = 0.0;
@@ -253,12 +273,12 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
           slab(x * a.Wpad + wsite) = sv;
           if (mode == 0) l0 = fma(sv, sh.tab[2][k * S + x], l0);
         }
-        __syncthreads();  // sh.red[0] consumed
         if (mode == 0) {
-          sh.red[1][k][lane] = l0;
+          sh.red[p & 1][1][k][lane] = l0;
           __syncthreads();
           if (k == 0) {
-            double ls = (sh.red[1][0][lane] + sh.red[1][1][lane]) + (sh.red[1][2][lane] + sh.red[1][3][lane]);
+            double ls = (sh.red[p & 1][1][0][lane] + sh.red[p & 1][1][1][lane]) +
+                        (sh.red[p & 1][1][2][lane] + sh.red[p & 1][1][3][lane]);
             if (!valid) ls = 1.0;
             const int sc = valid ? (int)(scp[s] + (resc ? 1u : 0u)) : 0;
             mant *= __builtin_amdgcn_frexp_mant(ls);
@@ -266,58 +286,78 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
             ex += __builtin_amdgcn_frexp_exp(mant);
             mant = __builtin_amdgcn_frexp_mant(mant);
           }
-          __syncthreads();
         }
       }
       if (mode == 0) {
         if (k == 0) {
-          const double tot = wave_sum_aa(log(mant) + (double)ex * LOG_2);
+          const double tot = wave_sum(log(mant) + (double)ex * LOG_2);
           if (lane == 0) sh.bc[2] = tot;
         }
         __syncthreads();
         lnl_out = sh.bc[2];
       }
+      __syncthreads();  // sh.red / sh.bc / the slab are consistent for whoever comes next
     };
 
-    // f, f' at proposal t from this pair's sumtable slab
+    // f, f' at proposal t from this pair's sumtable slab.  Each wave builds the 60 table entries
+    // of its own category in one VGPR pair (lane = slot * 20 + x, one exp per lane) and feeds them
+    // to the FMAs as SGPR operands through v_readlane: no LDS traffic for the tables and no
+    // workgroup barrier to publish them.  Two 64-site passes are handled per barrier; the
+    // per-site ratio of pass j is done by wave j.
     auto derivatives = [&](double t, double& f, double& df) {
-      publish(t, t, t, true);
+      const double ev = exp(tl_lr * t) * tl_c;
       double fl = 0.0, dfl = 0.0;
-      for (uint32_t p = 0; p < npass; ++p) {
-        const uint32_t site = p * 64 + lane;
-        double l0 = 0.0, l1 = 0.0, l2 = 0.0;
-        // all 20 slab loads are issued before the first FMA (one L2 round trip per pass; left to
-        // itself hipcc interleaves them with the FMAs two at a time -> ten serialized round trips)
-        double sv[S];
+      constexpr uint32_t PG = LDS_SLAB ? 2 : 1;  // passes per barrier (HBM slab: register budget)
+      for (uint32_t p0 = 0; p0 < npass; p0 += PG) {
+        const bool two = PG == 2 && p0 + 1 < npass;
+        const uint32_t site0 = p0 * 64 + lane, site1 = site0 + 64;
+        const uint32_t i0 = site0 < n ? site0 : 0, i1 = site1 < n ? site1 : 0;
+        double sv0[S], sv1[S];
 #pragma unroll
-        for (int x = 0; x < S; ++x) sv[x] = slab(x * a.Wpad + (LDS_SLAB ? (site < n ? site : 0) : site));
+        for (int x = 0; x < S; ++x) sv0[x] = slab(x * a.Wpad + i0);
+        if (two) {
+#pragma unroll
+          for (int x = 0; x < S; ++x) sv1[x] = slab(x * a.Wpad + i1);
+        } else {
+#pragma unroll
+          for (int x = 0; x < S; ++x) sv1[x] = 0.0;
+        }
         asm volatile("" ::: "memory");
+        double l00 = 0.0, l01 = 0.0, l02 = 0.0, l10 = 0.0, l11 = 0.0, l12 = 0.0;
 #pragma unroll
         for (int x = 0; x < S; ++x) {
-          l0 = fma(sv[x], sh.tab[0][k * S + x], l0);
-          l1 = fma(sv[x], sh.tab[1][k * S + x], l1);
-          l2 = fma(sv[x], sh.tab[2][k * S + x], l2);
+          const double e0 = readlane_d(ev, x), e1 = readlane_d(ev, S + x), e2 = readlane_d(ev, 2 * S + x);
+          l00 = fma(sv0[x], e0, l00);
+          l01 = fma(sv0[x], e1, l01);
+          l02 = fma(sv0[x], e2, l02);
+          if (PG == 2) {
+            l10 = fma(sv1[x], e0, l10);
+            l11 = fma(sv1[x], e1, l11);
+            l12 = fma(sv1[x], e2, l12);
+          }
         }
-        sh.red[0][k][lane] = l0; sh.red[1][k][lane] = l1; sh.red[2][k][lane] = l2;
+        sh.red[0][0][k][lane] = l00; sh.red[0][1][k][lane] = l01; sh.red[0][2][k][lane] = l02;
+        if (PG == 2) { sh.red[1][0][k][lane] = l10; sh.red[1][1][k][lane] = l11; sh.red[1][2][k][lane] = l12; }
         __syncthreads();
-        if (k == 0 && site < n) {
-          const double s0 = (sh.red[0][0][lane] + sh.red[0][1][lane]) + (sh.red[0][2][lane] + sh.red[0][3][lane]);
-          const double s1 = (sh.red[1][0][lane] + sh.red[1][1][lane]) + (sh.red[1][2][lane] + sh.red[1][3][lane]);
-          const double s2 = (sh.red[2][0][lane] + sh.red[2][1][lane]) + (sh.red[2][2][lane] + sh.red[2][3][lane]);
-          const double inv = 1.0 / s0;
+        if (k < (int)PG && (k == 0 ? site0 : site1) < n) {
+          const double s0 = (sh.red[k][0][0][lane] + sh.red[k][0][1][lane]) + (sh.red[k][0][2][lane] + sh.red[k][0][3][lane]);
+          const double s1 = (sh.red[k][1][0][lane] + sh.red[k][1][1][lane]) + (sh.red[k][1][2][lane] + sh.red[k][1][3][lane]);
+          const double s2 = (sh.red[k][2][0][lane] + sh.red[k][2][1][lane]) + (sh.red[k][2][2][lane] + sh.red[k][2][3][lane]);
+          const double inv = fast_rcp(s0);
           const double d1 = -s1 * inv;
           fl += d1;
           dfl += fma(d1, d1, -s2 * inv);
         }
-        __syncthreads();
+        if (p0 + PG < npass) __syncthreads();  // sh.red is rewritten by the next group of passes
       }
-      if (k == 0) {
-        const double ft = wave_sum_aa(fl), dft = wave_sum_aa(dfl);
-        if (lane == 0) { sh.bc[0] = ft; sh.bc[1] = dft; }
+      if (k < 2) {  // wave 1 holds zeros when PG == 1
+        const double ft = wave_sum(fl), dft = wave_sum(dfl);
+        if (lane == 0) { sh.bc[k] = ft; sh.bc[2 + k] = dft; }
       }
       __syncthreads();
-      f = sh.bc[0];
-      df = sh.bc[1];
+      f = sh.bc[0] + sh.bc[1];
+      df = sh.bc[2] + sh.bc[3];
+      __syncthreads();  // sh.bc / sh.red are free again
     };
 
     // pllmod_opt_minimize_newton (rtsafe-style), uniform across the workgroup
@@ -356,7 +396,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
     double tp = a.blo.pendant_default, td = orig * 0.5, tx = orig * 0.5;
     uint32_t rounds = 0, reverted = 0;
     double lnl_now = 0.0;
-    publish(td, tx, tp, false);
+    publish(td, tx, tp);
     phase(0, lnl_now);
     double loglikelihood = -lnl_now;
     uint32_t smoothings = a.blo.max_rounds;
@@ -367,7 +407,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
       if (xguess < xmin || xguess > xmax) xguess = a.blo.default_branch;
       double xres = newton(xmin, xguess, xmax, xtol, (int)a.blo.max_newton);
       if (xres > 0.0) tp = xres;
-      publish(tp, tx, tp, false);
+      publish(tp, tx, tp);
       double dummy;
       phase(1, dummy);
       xguess = td;
@@ -377,7 +417,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
       if (xguess < xmin || xguess > xmax) xguess = orig / 2.0;
       xres = newton(xmin, xguess, xmax, xtol, (int)a.blo.max_newton);
       if (xres > 0.0) { td = xres; tx = orig - xres; }
-      publish(td, tx, tp, false);
+      publish(td, tx, tp);
       phase(0, lnl_now);
       const double new_ll = -lnl_now;
       ++rounds;
@@ -433,7 +473,8 @@ int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, 
   a.W = ctx->W;
   uint32_t nwg = (uint32_t)std::min<uint64_t>(n_pairs, 512);  // 2 resident workgroups per CU
   const uint32_t wpad_lds = (max_span + 1) / 2 * 2 + 2;  // + spare column for lanes past the window
-  const bool lds_slab = wpad_lds <= 112 && !getenv("EPA_AA_HBM_SLAB");
+  // two workgroups per CU: static + dynamic LDS <= 80 KB each
+  const bool lds_slab = sizeof(Shared) + sizeof(double) * 80 * wpad_lds <= 80 * 1024 && !getenv("EPA_AA_HBM_SLAB");
   if (lds_slab) {
     a.Wpad = wpad_lds;
     a.sscratch = nullptr;

@@ -51,3 +51,22 @@ def test_synthetic_aa_vs_oracle():
     assert np.max(np.abs(res["lnl"] - tl)) < 1e-6
     assert np.max(np.abs(res["distal_length"] - td)) < 1e-6
     assert ev.last_stats["rounds"] == o.last_stats["rounds"]
+
+
+@pytest.mark.parametrize("read_len,seeds", [(170, (81, 82, 83)), (37, (84, 85, 86))])
+def test_synthetic_aa_window_lengths(read_len, seeds):
+    """170-column windows: sumtable slab in HBM scratch, three 64-site passes (the LDS-resident
+    slab covers windows up to 102 columns); 37-column windows: a single partly filled pass."""
+    w = synth.aa_workload(24, 260, 60, read_len, seeds)
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=20, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    o = Oracle(w["newick"], w["labels"], w["seqs"], 20, w["subst"], w["freqs"], w["rates"])
+    codes, wb, ws = epa.encode_queries(20, w["reads"])
+    pairs, res = ev.place_chunk(codes, wb, ws)
+    tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], w["reads"])
+    assert np.max(np.abs(res["lnl"] - tl)) < 1e-6
+    assert np.max(np.abs(res["distal_length"] - td)) < 1e-6
+    assert np.max(np.abs(res["pendant_length"] - tp) / np.maximum(1.0, tp)) < 1e-6
+    assert ev.last_stats["rounds"] == o.last_stats["rounds"]
+    assert ev.last_stats["reverts"] == o.last_stats["reverts"]
