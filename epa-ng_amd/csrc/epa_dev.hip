@@ -206,8 +206,12 @@ int launch_build_lookup(epa_ctx* ctx) {
   else
     hipLaunchKernelGGL(k_build_lookup<20>, grid, dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT,
                        ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup);
-  epa_timer_stop(ctx, ctx->t_lookup);
   EPA_HIP(ctx, hipGetLastError());
+  if (ctx->s == 4) {
+    int rc = launch_build_lookup2(ctx);
+    if (rc != EPA_OK) return rc;
+  }
+  epa_timer_stop(ctx, ctx->t_lookup);
   return EPA_OK;
 }
 
@@ -312,6 +316,7 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
   if (ctx->scSum) (void)hipFree(ctx->scSum);
   if (ctx->blen) (void)hipFree(ctx->blen);
   if (ctx->lookup) (void)hipFree(ctx->lookup);
+  if (ctx->lookup2) (void)hipFree(ctx->lookup2);
   if (ctx->dmodel) (void)hipFree(ctx->dmodel);
   EvTimer* ts[4] = {&ctx->t_lookup, &ctx->t_preplace, &ctx->t_thorough, &ctx->t_select};
   for (auto* t : ts) { if (t->a) (void)hipEventDestroy(t->a); if (t->b) (void)hipEventDestroy(t->b); }

@@ -69,10 +69,12 @@ struct epa_ctx {
   //   scSum  [B][W]        prox + dist per-site scaler counts
   //   blen   [B]
   //   lookup [B][W][ncols]
+  //   lookup2 [B][W][36]   DNA: lookup[s][c0] + lookup[s+1][c1] over {A,C,G,T,N,none}^2
   double* refT = nullptr;
   uint32_t* scSum = nullptr;
   double* blen = nullptr;
   double* lookup = nullptr;
+  double* lookup2 = nullptr;  // DNA only: [B][W][36] site-pair sums (preplace.hip, k_preplace_pairs)
   bool lookup_built = false;
   std::vector<double> h_blen;
 
@@ -107,6 +109,7 @@ void epa_timer_stop(epa_ctx* ctx, EvTimer& t);
 int launch_transform(epa_ctx* ctx, const double* d_clv_or_null, const uint8_t* d_tip_or_null,
                      const uint32_t* d_tipmap, uint32_t tipmap_size, double* dst);
 int launch_build_lookup(epa_ctx* ctx);
+int launch_build_lookup2(epa_ctx* ctx);  // DNA site-pair table from `lookup` (preplace.hip)
 int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin,
                     const uint32_t* d_span, uint32_t Q, double* d_lnl, uint32_t max_span);
 int preplace_check_status(epa_ctx* ctx);

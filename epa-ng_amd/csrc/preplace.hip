@@ -16,12 +16,21 @@
 //      Q x B table out.  For the 16-column DNA table the LDS columns are XOR-swizzled by the row
 //      ((row >> 1) & 15): DNA reads use 4 of 16 columns, which would pile a half-wave onto 8 of
 //      the 32 8-byte bank slots.
+//   2b. DNA fast path (k_preplace_pairs): queries whose windows hold only A/C/G/T/N-or-gap use a
+//      second table T2[b][s][36] = T[b][s][c0] + T[b][s+1][c1] over {A,C,G,T,N,none}^2: one
+//      ds_read_b64 per TWO sites, and the value is exactly the (a0 + a1) the reference forms
+//      first, so the association order ((a0+a1)+(a2+a3)) and the results stay bit-identical to
+//      the generic path.  Queries are additionally split by window-start parity (a group stages
+//      only the pair rows of its own parity) and their per-pair LDS offsets are precomputed once
+//      per chunk of queries (k_pack_pairs); queries with other ambiguity codes take the generic
+//      kernel.
 //   3. k_select (dynamic heuristic) works on the table in HBM: one wave per query, the row lives
 //      in registers, candidates go to a per-query staging row; an exclusive scan of the counts
 //      gives every query its output offset (no atomics on a shared counter, deterministic
 //      order); the keys (branch << 32 | query) are radix-sorted into Work's branch-major order.
 #include "epa_dev_internal.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -40,8 +49,8 @@ constexpr int CW = CH / 4;   // packed code words per chunk
 struct Group {
   uint32_t start;      // first index into the sorted order
   uint32_t count;      // 0 = unused slot of the over-provisioned group table
-  uint32_t min_begin;  // bucket start
-  uint32_t pad;
+  uint32_t min_begin;  // bucket start (key space)
+  uint32_t cls;        // 0 = site-pair fast path (or the only class), 1 = generic kernel
 };
 
 __global__ void k_iota(uint32_t* v, uint32_t n) {
@@ -49,12 +58,15 @@ __global__ void k_iota(uint32_t* v, uint32_t n) {
   if (i < n) v[i] = i;
 }
 
-// One workgroup.  sorted_begin ascending.  Bucket k = starts in [k*SPREAD, (k+1)*SPREAD); every
-// bucket is cut into groups of <= GQ queries.  Also validates the windows (error word).
+// One workgroup.  sorted_begin = ascending sort keys (window start, or class / parity / start
+// composed by k_pack_pairs).  Bucket k = keys in [k*SPREAD, (k+1)*SPREAD); every bucket is cut
+// into groups of <= gq0 (class 0) or gq1 (class 1: buckets >= class_buckets) queries.  Also validates the
+// windows (error word).
 __global__ void __launch_bounds__(256) k_make_groups(const uint32_t* __restrict__ sorted_begin,
                                                      const uint32_t* __restrict__ win_begin,
                                                      const uint32_t* __restrict__ win_span, uint32_t Q,
                                                      uint32_t W, uint32_t n_buckets,
+                                                     uint32_t class_buckets, uint32_t gq0, uint32_t gq1,
                                                      Group* __restrict__ groups, uint32_t max_groups,
                                                      uint32_t* __restrict__ status) {
   extern __shared__ uint32_t lo[];  // [n_buckets + 1] first sorted index of each bucket
@@ -78,8 +90,9 @@ __global__ void __launch_bounds__(256) k_make_groups(const uint32_t* __restrict_
   if (threadIdx.x == 0) {
     uint32_t g = 0;
     for (uint32_t k = 0; k < n_buckets; ++k) {
-      for (uint32_t s = lo[k]; s < lo[k + 1]; s += GQ) {
-        if (g < max_groups) groups[g] = Group{s, min((uint32_t)GQ, lo[k + 1] - s), k * SPREAD, 0};
+      const uint32_t cls = k >= class_buckets ? 1u : 0u, gq = cls ? gq1 : gq0;
+      for (uint32_t s = lo[k]; s < lo[k + 1]; s += gq) {
+        if (g < max_groups) groups[g] = Group{s, min(gq, lo[k + 1] - s), k * SPREAD, cls};
         ++g;
       }
     }
@@ -96,7 +109,7 @@ __global__ void __launch_bounds__(GQ, ACC ? 2 : 4) k_preplace(const double* __re
                                                  const uint32_t* __restrict__ win_span,
                                                  const uint32_t* __restrict__ perm,
                                                  const Group* __restrict__ groups, uint32_t W,
-                                                 uint32_t B, size_t codes_bytes,
+                                                 uint32_t B, size_t codes_bytes, uint32_t want_cls,
                                                  double* __restrict__ lnl) {
   constexpr bool SWZ = NCOLS == 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,7 +117,7 @@ __global__ void __launch_bounds__(GQ, ACC ? 2 : 4) k_preplace(const double* __re
   double* accs = tile + (size_t)TROWS * NCOLS;                     // [NB][GQ] (ACC only)
   __shared__ uint32_t s_maxspan;
   const Group g = groups[blockIdx.x];
-  if (g.count == 0) return;
+  if (g.count == 0 || g.cls != want_cls) return;
   const uint32_t b0 = blockIdx.y * NB;
   const uint32_t nb = min((uint32_t)NB, B - b0);
   const int t = threadIdx.x;
@@ -262,6 +275,230 @@ __global__ void __launch_bounds__(GQ, ACC ? 2 : 4) k_preplace(const double* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// Site-pair fast path (DNA).
+// ---------------------------------------------------------------------------------------------
+constexpr int NSYM = 6;                 // A C G T N(or gap) none
+constexpr int PE = NSYM * NSYM;         // entries per pair row: e = sym(site) * 6 + sym(site + 1)
+constexpr int PROWB = PE * 8;           // 288 bytes per pair row
+constexpr int CP = CH / 2;              // pair slots per chunk
+constexpr int PW = CP / 2;              // packed words (2 x 16-bit LDS offsets) per chunk
+constexpr int TROWS2 = TROWS / 2;       // pair rows staged per (branch, chunk)
+constexpr int GQ2 = 1024;               // queries (threads) per group of the pair path: one
+                                        // workgroup per CU, the staged slice is shared by 1024 queries
+constexpr int NB2_ACC = 8;              // branches per workgroup when partial sums live in LDS
+constexpr uint32_t ZERO_OFF = (PE - 1) * 8;  // (none, none) of the thread's own first row: exact +0.0
+
+// state-set code (4-bit mask) -> symbol; 6 = any other ambiguity code (generic kernel)
+__device__ __forceinline__ uint32_t dna_sym(uint32_t code) {
+  if (code == 15) return 4;
+  if (code == 1 || code == 2 || code == 4 || code == 8) return (uint32_t)__ffs((int)code) - 1;
+  return 6;
+}
+
+// T2[b][s][e] = (i0 < 5 ? T[b][s][code(i0)] : 0) + (i1 < 5 ? T[b][s+1][code(i1)] : 0).  The sum is
+// the very `a0 + a1` the reference's 4-way unrolled loop forms first (Lookup_Store.hpp:120-131),
+// x + 0.0 == x covers the singles of the tail.
+__global__ void __launch_bounds__(256) k_build_lookup2(const double* __restrict__ lookup, uint32_t W,
+                                                       double* __restrict__ lookup2) {
+  const uint32_t b = blockIdx.y;
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= W * PE) return;
+  const uint32_t s = i / PE, e = i - s * PE, i0 = e / NSYM, i1 = e - i0 * NSYM;
+  const uint32_t code[5] = {1, 2, 4, 8, 15};
+  const double* T = lookup + (size_t)b * W * 16;
+  const double v0 = i0 < 5 ? T[(size_t)s * 16 + code[i0]] : 0.0;
+  const double v1 = (i1 < 5 && s + 1 < W) ? T[(size_t)(s + 1) * 16 + code[i1]] : 0.0;
+  lookup2[((size_t)b * W + s) * PE + e] = v0 + v1;
+}
+
+// One wave per query: per-pair LDS offsets relative to the query's first pair row, 16 bit each
+// (pair p of the window sits in chunk p / CP at row p % CP), the three tail singles, the sort key
+// (class, window-start parity, window start) for the grouping.
+__global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ codes,
+                                                    const uint32_t* __restrict__ win_begin,
+                                                    const uint32_t* __restrict__ win_span, uint32_t Q,
+                                                    uint32_t W, uint32_t Wp, uint32_t NP16,
+                                                    uint16_t* __restrict__ packed,
+                                                    uint16_t* __restrict__ tails,
+                                                    uint32_t* __restrict__ keys) {
+  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  if (q >= Q) return;
+  const uint32_t begin = win_begin[q];
+  uint32_t span = win_span[q];
+  if ((uint64_t)begin + span > W) span = 0;  // invalid window: flagged by k_make_groups
+  const uint8_t* c = codes + (size_t)q * W + begin;
+  const uint32_t nfull = span >> 2, ntail = span & 3, npairs = 2 * nfull;
+  bool rare = false;
+  for (uint32_t p = lane; p < NP16; p += 64) {
+    uint32_t v = ZERO_OFF;
+    if (p < npairs) {
+      const uint32_t s0 = dna_sym(c[2 * p]), s1 = dna_sym(c[2 * p + 1]);
+      rare |= (s0 > 4) | (s1 > 4);
+      v = (p % CP) * PROWB + (min(s0, 5u) * NSYM + min(s1, 5u)) * 8;
+    }
+    packed[(size_t)q * NP16 + p] = (uint16_t)v;
+  }
+  if (lane < 4) {
+    uint32_t v = ZERO_OFF;
+    if (lane < ntail) {
+      uint32_t sy = dna_sym(c[4 * nfull + lane]);
+      rare |= sy > 4;
+      sy = min(sy, 5u);
+      const uint32_t kt = npairs % CP;  // row of the first tail site inside its chunk (even)
+      const uint32_t e = lane == 1 ? 5 * NSYM + sy : sy * NSYM + 5;
+      v = (kt + (lane == 2 ? 1u : 0u)) * PROWB + e * 8;
+    }
+    tails[(size_t)q * 4 + lane] = (uint16_t)v;
+  }
+  const bool any_rare = __ballot(rare) != 0ull;
+  if (lane == 0) keys[q] = (any_rare ? 2 * Wp : 0) + (begin & 1u) * Wp + begin;
+}
+
+template <bool ACC>
+__global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
+    const double* __restrict__ lookup2, const uint16_t* __restrict__ packed,
+    const uint16_t* __restrict__ tails, const uint32_t* __restrict__ win_begin,
+    const uint32_t* __restrict__ win_span, const uint32_t* __restrict__ perm,
+    const Group* __restrict__ groups, uint32_t W, uint32_t B, uint32_t NP16,
+    double* __restrict__ lnl) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [TROWS2][PE] doubles, then accs
+  double* accs = reinterpret_cast<double*>(smem + (size_t)TROWS2 * PROWB);  // [NB2_ACC][GQ2] (ACC only)
+  __shared__ uint32_t s_maxspan;
+  constexpr uint32_t NBP = ACC ? NB2_ACC : NB;
+  const Group g = groups[blockIdx.x];
+  if (g.count == 0 || g.cls != 0) return;
+  const uint32_t b0 = blockIdx.y * NBP;
+  if (b0 >= B) return;
+  const uint32_t nb = min(NBP, B - b0);
+  const int t = threadIdx.x;
+  const bool active = t < (int)g.count;
+  uint32_t qi = 0, begin = 0, span = 0;
+  if (active) {
+    qi = perm[g.start + t];
+    begin = win_begin[qi];
+    span = win_span[qi];
+    if ((uint64_t)begin + span > W) span = 0;
+  }
+  if (t == 0) s_maxspan = 0;
+  __syncthreads();
+  atomicMax(&s_maxspan, span);
+  if (ACC) for (uint32_t j = 0; j < nb; ++j) accs[j * GQ2 + t] = 0.0;
+  __syncthreads();
+  // all members share the parity of their window start: rel is even, pair rows line up
+  const uint32_t gmin = win_begin[perm[g.start]];
+  const uint32_t gspread = win_begin[perm[g.start + g.count - 1]] - gmin;  // < SPREAD
+  const uint32_t rowoff = ((begin - gmin) >> 1) * PROWB;
+  const uint32_t rowoff2 = rowoff | (rowoff << 16);
+  const uint32_t nchunks = ACC ? (s_maxspan + CH - 1) / CH : 1;
+  uint32_t t0 = 0, t1 = 0, t2 = 0, tailchunk = 0xffffffffu;
+  if (active && (span & 3)) {
+    const uint16_t* tq = tails + (size_t)qi * 4;
+    t0 = tq[0] + rowoff; t1 = tq[1] + rowoff; t2 = tq[2] + rowoff;
+    tailchunk = ((span >> 2) * 2) / CP;
+  }
+  auto at = [&](uint32_t off) -> double { return *reinterpret_cast<const double*>(smem + off); };
+
+  for (uint32_t c = 0; c < nchunks; ++c) {
+    const uint32_t cbase = c * CH;
+    const bool mine = active && cbase < span;
+    uint32_t cw[PW];  // two 16-bit LDS byte offsets per word = one group of 4 sites
+    if (mine) {
+      // 160 B per (query, chunk), 16 B aligned (NP16 is a multiple of CP = 80)
+      const uint4* p = reinterpret_cast<const uint4*>(packed + (size_t)qi * NP16 + (size_t)c * CP);
+#pragma unroll
+      for (int i = 0; i < PW / 4; ++i) {  // no carry between the halves: offsets stay below 2^16
+        const uint4 v = p[i];
+        cw[4 * i] = v.x + rowoff2;
+        cw[4 * i + 1] = v.y + rowoff2;
+        cw[4 * i + 2] = v.z + rowoff2;
+        cw[4 * i + 3] = v.w + rowoff2;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PW; ++i) cw[i] = 0;
+    }
+    const uint32_t row0 = gmin + cbase;  // alignment site of pair row 0 of the staged slice
+    const uint32_t need = min((uint32_t)TROWS2, (gspread >> 1) + (min((uint32_t)CH, s_maxspan - cbase) + 1) / 2);
+    // The slice of branch j+1 is requested (into registers) before the gathers of branch j start
+    // and written to LDS after them: its HBM latency hides under the gather phase.
+    const uint32_t rows = (row0 < W) ? min(need, (W - row0 + 1) / 2) : 0;
+    const uint32_t n2 = rows * (PE / 2);
+    constexpr int PF = (TROWS2 * (PE / 2) + GQ2 - 1) / GQ2;
+    double2 pf[PF];
+    auto request = [&](uint32_t j) {
+      // pair row r = table row (row0 + 2r): 18 double2 each, consecutive pair rows 36 apart
+      const double2* src = reinterpret_cast<const double2*>(lookup2 + ((size_t)(b0 + j) * W + row0) * PE);
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const uint32_t i = u * GQ2 + t;
+        const uint32_t r = i / (PE / 2);
+        pf[u] = make_double2(0.0, 0.0);
+        if (i < n2) pf[u] = src[(size_t)i + (size_t)r * (PE / 2)];
+      }
+    };
+    request(0);
+    for (uint32_t j = 0; j < nb; ++j) {
+      __syncthreads();  // previous consumers of the tile are done
+      {
+        double2* dst = reinterpret_cast<double2*>(smem);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          const uint32_t i = u * GQ2 + t;
+          if (i < n2) dst[i] = pf[u];
+        }
+      }
+      __syncthreads();
+      if (j + 1 < nb) request(j + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (mine) {
+        double sum = ACC ? accs[j * GQ2 + t] : 0.0;
+        // the offsets are invariant over the branches: without this hipcc hoists the 80 extracted
+        // addresses out of the j loop into VGPRs (the kernel has to fit 4 workgroups per CU)
+#pragma unroll
+        for (int i = 0; i < PW; ++i) asm volatile("" : "+v"(cw[i]));
+        // Software pipeline as in k_preplace: batch k+1 (4 words = 8 ds_read_b64) is issued
+        // before batch k is summed.  Slots past the window read an exact +0.0.
+        constexpr int WPB = 4, NBATCH = PW / WPB;
+        double rb[2][WPB * 2];
+        auto issue = [&](int bt) {
+#pragma unroll
+          for (int w = 0; w < WPB; ++w) {
+            const uint32_t v = cw[bt * WPB + w];
+            rb[bt & 1][2 * w] = at(v & 0xffffu);
+            rb[bt & 1][2 * w + 1] = at(v >> 16);
+          }
+        };
+        issue(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int bt = 0; bt < NBATCH; ++bt) {
+          if (bt + 1 < NBATCH) issue(bt + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int w = 0; w < WPB; ++w) {
+            const double s1 = rb[bt & 1][2 * w] + rb[bt & 1][2 * w + 1];  // (a0+a1) + (a2+a3)
+            sum += s1;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c == tailchunk) {  // singles of the window tail, in order
+          sum += at(t0);
+          sum += at(t1);
+          sum += at(t2);
+        }
+        if (ACC) accs[j * GQ2 + t] = sum;
+        else lnl[(size_t)qi * B + b0 + j] = sum;
+      }
+    }
+  }
+  if (ACC && active) {
+    double* out = lnl + (size_t)qi * B + b0;
+    for (uint32_t j = 0; j < nb; ++j) out[j] = accs[j * GQ2 + t];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_select: dynamic heuristic on device (apply_heuristic -> dynamic_heuristic,
 // src/core/heuristics.hpp:40-68; compute_and_set_lwr src/set_manipulators.cpp:43-69;
 // until_accumulated_reached :90-114).  One wave per query, the row of B log-likelihoods in
@@ -356,43 +593,87 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
+int launch_build_lookup2(epa_ctx* ctx) {
+  if (!ctx->lookup2)
+    EPA_HIP(ctx, hipMalloc(&ctx->lookup2, sizeof(double) * (size_t)ctx->B * ctx->W * PE));
+  dim3 grid((ctx->W * PE + 255) / 256, ctx->B);
+  hipLaunchKernelGGL(k_build_lookup2, grid, dim3(256), 0, ctx->stream, ctx->lookup, ctx->W, ctx->lookup2);
+  EPA_HIP(ctx, hipGetLastError());
+  return EPA_OK;
+}
+
 int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin,
                     const uint32_t* d_span, uint32_t Q, double* d_lnl, uint32_t max_span) {
+  const bool pairs = ctx->s == 4 && ctx->lookup2 && !getenv("EPA_PREPLACE_GENERIC");
   const uint32_t n_buckets = (ctx->W + SPREAD - 1) / SPREAD;
-  const uint32_t max_groups = (Q + GQ - 1) / GQ + n_buckets;
-  // scratch 6: [status 256 B | iota Q | sorted_begin Q | perm Q | groups | rocprim temp]
+  const uint32_t Wp = n_buckets * SPREAD;                       // key space of one (class, parity)
+  const uint32_t key_buckets = pairs ? 4 * n_buckets : n_buckets;
+  const uint32_t class_buckets = pairs ? 2 * n_buckets : 0xffffffffu;
+  const uint32_t max_groups = (Q + GQ - 1) / GQ + key_buckets;
+  // pair offsets per query: whole chunks of CP, enough for the longest window
+  const uint32_t span_bound = (max_span == 0 || max_span > ctx->W) ? ctx->W : max_span;
+  const uint32_t NP16 = pairs ? ((span_bound + 1) / 2 + CP - 1) / CP * CP : 0;
+  // scratch 6: [status 256 B | iota Q | sorted_keys Q | perm Q | keys Q | groups | packed | tails | rocprim temp]
   size_t temp_bytes = 0;
   (void)rocprim::radix_sort_pairs(nullptr, temp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                   (uint32_t*)nullptr, (uint32_t*)nullptr, Q, 0, 32, ctx->stream);
   const size_t qb = align256(sizeof(uint32_t) * Q);
-  const size_t need = 256 + 3 * qb + align256(sizeof(Group) * max_groups) + temp_bytes;
+  const size_t gb = align256(sizeof(Group) * max_groups);
+  const size_t pb = align256(sizeof(uint16_t) * (size_t)Q * NP16);
+  const size_t tb = pairs ? align256(sizeof(uint16_t) * 4 * (size_t)Q) : 0;
+  const size_t need = 256 + 4 * qb + gb + pb + tb + temp_bytes;
   char* base = (char*)epa_scratch(ctx, 6, need);
   if (!base) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(preplace scratch)");
   uint32_t* status = reinterpret_cast<uint32_t*>(base);
   uint32_t* iota = reinterpret_cast<uint32_t*>(base + 256);
-  uint32_t* sorted_begin = reinterpret_cast<uint32_t*>(base + 256 + qb);
+  uint32_t* sorted_keys = reinterpret_cast<uint32_t*>(base + 256 + qb);
   uint32_t* perm = reinterpret_cast<uint32_t*>(base + 256 + 2 * qb);
-  Group* groups = reinterpret_cast<Group*>(base + 256 + 3 * qb);
-  void* temp = base + 256 + 3 * qb + align256(sizeof(Group) * max_groups);
+  uint32_t* keys = reinterpret_cast<uint32_t*>(base + 256 + 3 * qb);
+  Group* groups = reinterpret_cast<Group*>(base + 256 + 4 * qb);
+  uint16_t* packed = reinterpret_cast<uint16_t*>(base + 256 + 4 * qb + gb);
+  uint16_t* tails = reinterpret_cast<uint16_t*>(base + 256 + 4 * qb + gb + pb);
+  void* temp = base + 256 + 4 * qb + gb + pb + tb;
   ctx->d_status = status;
   EPA_HIP(ctx, hipMemsetAsync(status, 0, 256, ctx->stream));
   hipLaunchKernelGGL(k_iota, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, iota, Q);
-  EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, d_begin, sorted_begin, iota, perm, Q, 0, 32,
-                                         ctx->stream));
-  hipLaunchKernelGGL(k_make_groups, dim3(1), dim3(256), sizeof(uint32_t) * (n_buckets + 1), ctx->stream,
-                     sorted_begin, d_begin, d_span, Q, ctx->W, n_buckets, groups, max_groups, status);
+  int key_bits = 1;
+  while (key_bits < 32 && (1ull << key_bits) < (uint64_t)key_buckets * SPREAD) ++key_bits;
+  if (pairs) {
+    hipLaunchKernelGGL(k_pack_pairs, dim3((Q + 3) / 4), dim3(256), 0, ctx->stream, d_codes, d_begin,
+                       d_span, Q, ctx->W, Wp, NP16, packed, tails, keys);
+    EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, keys, sorted_keys, iota, perm, Q, 0,
+                                           key_bits, ctx->stream));
+  } else {
+    EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, d_begin, sorted_keys, iota, perm, Q, 0, 32,
+                                           ctx->stream));
+  }
+  hipLaunchKernelGGL(k_make_groups, dim3(1), dim3(256), sizeof(uint32_t) * (key_buckets + 1), ctx->stream,
+                     sorted_keys, d_begin, d_span, Q, ctx->W, key_buckets, class_buckets,
+                     (uint32_t)(pairs ? GQ2 : GQ), (uint32_t)GQ, groups, max_groups, status);
   dim3 grid(max_groups, (ctx->B + NB - 1) / NB);
   // max_span: upper bound of the window spans when the caller knows it (0 = unknown)
   const bool acc = max_span == 0 || max_span > (uint32_t)CH;
   const size_t lds = sizeof(double) * ((size_t)TROWS * ctx->ncols + (acc ? (size_t)NB * GQ : 0));
+  const size_t lds2 = (size_t)TROWS2 * PROWB + (acc ? sizeof(double) * NB2_ACC * GQ2 : 0);
+  const dim3 grid2(max_groups, (ctx->B + (acc ? NB2_ACC : NB) - 1) / (acc ? NB2_ACC : NB));
   const size_t codes_bytes = (size_t)Q * ctx->W;
+  const uint32_t want_cls = pairs ? 1u : 0u;
   epa_timer_start(ctx, ctx->t_preplace);
+#define PRE2(A)                                                                                      \
+  do {                                                                                               \
+    EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<A>,                               \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));        \
+    hipLaunchKernelGGL((k_preplace_pairs<A>), grid2, dim3(GQ2), lds2, ctx->stream, ctx->lookup2, packed, \
+                       tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, NP16, d_lnl);           \
+  } while (0)
+  if (pairs) { if (acc) PRE2(true); else PRE2(false); }
+#undef PRE2
 #define PRE(NC, A)                                                                                  \
   do {                                                                                              \
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace<NC, A>,                                \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
     hipLaunchKernelGGL((k_preplace<NC, A>), grid, dim3(GQ), lds, ctx->stream, ctx->lookup, d_codes, \
-                       d_begin, d_span, perm, groups, ctx->W, ctx->B, codes_bytes, d_lnl);          \
+                       d_begin, d_span, perm, groups, ctx->W, ctx->B, codes_bytes, want_cls, d_lnl); \
   } while (0)
   if (ctx->ncols == 16) { if (acc) PRE(16, true); else PRE(16, false); }
   else { if (acc) PRE(24, true); else PRE(24, false); }

@@ -190,3 +190,35 @@ def test_single_rate_category_model():
     tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
     assert np.max(np.abs(res["lnl"] - tl)) < LNL_TOL
     assert np.max(np.abs(res["distal_length"] - td)) < 1e-6
+
+
+def test_preplace_pair_path_bitwise_equals_generic(monkeypatch):
+    """DNA fast path (site-pair table, k_preplace_pairs) vs the generic gather kernel vs the
+    oracle: every window length mod 4 (the reference's 4-way unrolled sum + singles), both parities
+    of the window start, windows longer than one 160-site chunk, N / gap inside the window, and
+    queries with other ambiguity codes (routed to the generic kernel) mixed into the same call."""
+    w = synth_case(24, 700, 8, 100, seeds=(31, 32, 33))
+    o = Oracle(w["newick"], w["labels"], w["seqs"], 4, w["subst"], w["freqs"], w["rates"])
+    e = evaluator_from_oracle(o, w["rates"], w["freqs"])
+    rng = np.random.RandomState(77)
+    W = 700
+    reads = []
+    for i in range(1500):
+        span = int(rng.choice([1, 2, 3, 4, 5, 7, 37, 150, 151, 158, 159, 160, 161, 162, 163, 323, 480, 699]))
+        begin = int(rng.randint(0, W - span + 1))
+        body = rng.choice(list("ACGT"), span)
+        if i % 3 == 0:  # N and gaps inside the window (stay on the fast path)
+            k = rng.randint(0, span, max(1, span // 10))
+            body[k] = rng.choice(list("N-"), len(k))
+            body[0] = "A"; body[-1] = "C"
+        if i % 7 == 0:  # other ambiguity codes: generic kernel
+            body[rng.randint(0, span)] = rng.choice(list("RYKMSWBDHV"))
+        reads.append("-" * begin + "".join(body) + "-" * (W - begin - span))
+    codes, wb, ws = epa.encode_queries(4, reads)
+    assert len(set(wb % 2)) == 2 and len(set(ws % 4)) == 4
+    fast = e.preplace(codes, wb, ws)
+    monkeypatch.setenv("EPA_PREPLACE_GENERIC", "1")
+    generic = e.preplace(codes, wb, ws)
+    monkeypatch.delenv("EPA_PREPLACE_GENERIC")
+    assert np.array_equal(fast, generic)  # same association order, bit for bit
+    assert np.max(np.abs(fast - o.preplace(reads))) < LNL_TOL
