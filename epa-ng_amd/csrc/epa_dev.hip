@@ -344,6 +344,11 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx) {
   ctx->ncols = s == 4 ? 16 : 24;
   ctx->aa_x_as_n = (int)d->aa_x_as_n;
   EPA_HIP(ctx, hipSetDevice(device));
+  {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0)
+      ctx->n_cu = n;
+  }
 
   ModelDev& m = ctx->hmodel;
   memset(&m, 0, sizeof(m));

@@ -51,6 +51,7 @@ struct EvTimer {
 
 struct epa_ctx {
   int device = 0;
+  int n_cu = 256;  // compute units of the device (persistent-grid sizing)
   hipStream_t stream = nullptr;
   std::string err;
 

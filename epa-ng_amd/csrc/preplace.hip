@@ -58,42 +58,86 @@ __global__ void k_iota(uint32_t* v, uint32_t n) {
   if (i < n) v[i] = i;
 }
 
-// One workgroup.  sorted_begin = ascending sort keys (window start, or class / parity / start
-// composed by k_pack_pairs).  Bucket k = keys in [k*SPREAD, (k+1)*SPREAD); every bucket is cut
-// into groups of <= gq0 (class 0) or gq1 (class 1: buckets >= class_buckets) queries.  Also validates the
-// windows (error word).
-__global__ void __launch_bounds__(256) k_make_groups(const uint32_t* __restrict__ sorted_begin,
+// One workgroup.  sorted_keys ascending (window start, or class / parity / start composed by
+// k_pack_pairs: block = key / Wp, blocks >= class_blocks are class 1).  Every block is cut into
+// runs of gq0 (class 0) / gq1 (class 1) consecutive queries; a run whose window starts spread over
+// SPREAD sites or more (sparse data) is subdivided along the fixed SPREAD grid, so every group
+// fits the staged slice.  Also validates the windows (error words).
+__global__ void __launch_bounds__(256) k_make_groups(const uint32_t* __restrict__ sorted_keys,
                                                      const uint32_t* __restrict__ win_begin,
                                                      const uint32_t* __restrict__ win_span, uint32_t Q,
-                                                     uint32_t W, uint32_t n_buckets,
-                                                     uint32_t class_buckets, uint32_t gq0, uint32_t gq1,
-                                                     Group* __restrict__ groups, uint32_t max_groups,
-                                                     uint32_t* __restrict__ status) {
-  extern __shared__ uint32_t lo[];  // [n_buckets + 1] first sorted index of each bucket
+                                                     uint32_t W, uint32_t Wp, uint32_t n_blocks,
+                                                     uint32_t class_blocks, uint32_t gq0, uint32_t gq1,
+                                                     uint32_t max_runs, Group* __restrict__ groups,
+                                                     uint32_t max_groups, uint32_t* __restrict__ status) {
+  extern __shared__ uint32_t sh[];
+  uint32_t* lo = sh;                       // [n_blocks + 1] first sorted index of each block
+  uint32_t* runbase = lo + n_blocks + 1;   // [n_blocks + 1] first run of each block
+  uint32_t* run_start = runbase + n_blocks + 1;  // [max_runs]
+  uint32_t* run_end = run_start + max_runs;
+  uint32_t* run_off = run_end + max_runs;        // first group slot of the run
   for (uint32_t i = threadIdx.x; i < Q; i += blockDim.x) {
     const uint32_t s = win_span[i];
     if (s == 0) atomicMax(&status[0], 0x80000000u | i);                    // all-gap query
     else if ((uint64_t)win_begin[i] + s > W) atomicMax(&status[1], 0x80000000u | i);  // width
   }
-  for (uint32_t k = threadIdx.x; k <= n_buckets; k += blockDim.x) {
-    const uint32_t key = k * SPREAD;  // lower_bound(sorted_begin, key)
-    uint32_t a = 0, b = Q;
+  auto lower_bound = [&](uint32_t a, uint32_t b, uint64_t key) {
     while (a < b) {
       const uint32_t m = (a + b) >> 1;
-      if (sorted_begin[m] < key) a = m + 1; else b = m;
+      if ((uint64_t)sorted_keys[m] < key) a = m + 1; else b = m;
     }
-    lo[k] = a;
-  }
-  __syncthreads();
+    return a;
+  };
+  for (uint32_t k = threadIdx.x; k <= n_blocks; k += blockDim.x)
+    lo[k] = k == n_blocks ? Q : lower_bound(0, Q, (uint64_t)k * Wp);
   for (uint32_t i = threadIdx.x; i < max_groups; i += blockDim.x) groups[i] = Group{0, 0, 0, 0};
   __syncthreads();
   if (threadIdx.x == 0) {
+    uint32_t r = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+      const uint32_t gq = b >= class_blocks ? gq1 : gq0;
+      runbase[b] = r;
+      r += (lo[b + 1] - lo[b] + gq - 1) / gq;
+    }
+    runbase[n_blocks] = r;
+  }
+  __syncthreads();
+  const uint32_t nruns = min(runbase[n_blocks], max_runs);
+  for (uint32_t r = threadIdx.x; r < nruns; r += blockDim.x) {
+    uint32_t b = 0;
+    while (b + 1 < n_blocks && r >= runbase[b + 1]) ++b;
+    const uint32_t gq = b >= class_blocks ? gq1 : gq0;
+    const uint32_t start = lo[b] + (r - runbase[b]) * gq, end = min(lo[b + 1], start + gq);
+    const uint32_t k0 = sorted_keys[start], k1 = sorted_keys[end - 1];
+    run_start[r] = start;
+    run_end[r] = end;
+    run_off[r] = (k1 - k0 < (uint32_t)SPREAD) ? 1u : (k1 / SPREAD - k0 / SPREAD + 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // exclusive scan of the group counts (a few hundred runs)
     uint32_t g = 0;
-    for (uint32_t k = 0; k < n_buckets; ++k) {
-      const uint32_t cls = k >= class_buckets ? 1u : 0u, gq = cls ? gq1 : gq0;
-      for (uint32_t s = lo[k]; s < lo[k + 1]; s += gq) {
-        if (g < max_groups) groups[g] = Group{s, min(gq, lo[k + 1] - s), k * SPREAD, cls};
-        ++g;
+    for (uint32_t r = 0; r < nruns; ++r) { const uint32_t n = run_off[r]; run_off[r] = g; g += n; }
+    run_off[nruns] = g;
+    // group ranges for the persistent kernels: class 0 = [0, status[5]), class 1 = [status[5], status[4])
+    const uint32_t r1 = class_blocks < n_blocks ? min(runbase[class_blocks], nruns) : nruns;
+    status[4] = min(g, max_groups);
+    status[5] = min(run_off[r1], max_groups);
+  }
+  __syncthreads();
+  for (uint32_t r = threadIdx.x; r < nruns; r += blockDim.x) {
+    uint32_t b = 0;
+    while (b + 1 < n_blocks && r >= runbase[b + 1]) ++b;
+    const uint32_t cls = b >= class_blocks ? 1u : 0u;
+    const uint32_t start = run_start[r], end = run_end[r], g0 = run_off[r], n = run_off[r + 1] - g0;
+    if (n == 1) {
+      if (g0 < max_groups) groups[g0] = Group{start, end - start, 0, cls};
+    } else {
+      const uint32_t kb = sorted_keys[start] / SPREAD;
+      uint32_t a = start;
+      for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t e = k + 1 == n ? end : lower_bound(a, end, (uint64_t)(kb + k + 1) * SPREAD);
+        if (g0 + k < max_groups) groups[g0 + k] = Group{a, e - a, 0, cls};
+        a = e;
       }
     }
   }
@@ -110,17 +154,25 @@ __global__ void __launch_bounds__(GQ, ACC ? 2 : 4) k_preplace(const double* __re
                                                  const uint32_t* __restrict__ perm,
                                                  const Group* __restrict__ groups, uint32_t W,
                                                  uint32_t B, size_t codes_bytes, uint32_t want_cls,
+                                                 const uint32_t* __restrict__ status,
                                                  double* __restrict__ lnl) {
   constexpr bool SWZ = NCOLS == 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* tile = reinterpret_cast<double*>(smem);                  // [TROWS][NCOLS]
   double* accs = tile + (size_t)TROWS * NCOLS;                     // [NB][GQ] (ACC only)
   __shared__ uint32_t s_maxspan;
-  const Group g = groups[blockIdx.x];
-  if (g.count == 0 || g.cls != want_cls) return;
-  const uint32_t b0 = blockIdx.y * NB;
-  const uint32_t nb = min((uint32_t)NB, B - b0);
+  // Persistent grid: work item = (group, tile of NB branches), groups fastest (neighbouring groups
+  // overlap in the rows of T they stage: L2 reuse).  The group range of this kernel's class comes
+  // from k_make_groups (status[4], status[5]); no workgroup is launched for an empty slot.
+  const uint32_t gbeg = want_cls ? status[5] : 0, gend = want_cls ? status[4] : status[5];
+  const uint32_t ng = gend - gbeg, ntiles = (B + NB - 1) / NB;
   const int t = threadIdx.x;
+  for (uint32_t item = blockIdx.x; item < ng * ntiles; item += gridDim.x) {
+  const Group g = groups[gbeg + item % ng];
+  const uint32_t b0 = (item / ng) * NB;
+  const uint32_t nb = min((uint32_t)NB, B - b0);
+  __syncthreads();  // the previous item's readers of s_maxspan / accs / tile are done
+  if (g.count == 0) continue;
   const bool active = t < (int)g.count;
   uint32_t qi = 0, begin = 0, span = 0;
   if (active) {
@@ -272,6 +324,7 @@ __global__ void __launch_bounds__(GQ, ACC ? 2 : 4) k_preplace(const double* __re
     double* out = lnl + (size_t)qi * B + b0;
     for (uint32_t j = 0; j < nb; ++j) out[j] = accs[j * GQ + t];
   }
+  }  // work items
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -361,17 +414,20 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     const uint16_t* __restrict__ tails, const uint32_t* __restrict__ win_begin,
     const uint32_t* __restrict__ win_span, const uint32_t* __restrict__ perm,
     const Group* __restrict__ groups, uint32_t W, uint32_t B, uint32_t NP16,
-    double* __restrict__ lnl) {
+    const uint32_t* __restrict__ status, double* __restrict__ lnl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [TROWS2][PE] doubles, then accs
   double* accs = reinterpret_cast<double*>(smem + (size_t)TROWS2 * PROWB);  // [NB2_ACC][GQ2] (ACC only)
   __shared__ uint32_t s_maxspan;
   constexpr uint32_t NBP = ACC ? NB2_ACC : NB;
-  const Group g = groups[blockIdx.x];
-  if (g.count == 0 || g.cls != 0) return;
-  const uint32_t b0 = blockIdx.y * NBP;
-  if (b0 >= B) return;
-  const uint32_t nb = min(NBP, B - b0);
+  // persistent grid over (group, branch tile) items of class 0, see k_preplace
+  const uint32_t ng = status[5], ntiles = (B + NBP - 1) / NBP;
   const int t = threadIdx.x;
+  for (uint32_t item = blockIdx.x; item < ng * ntiles; item += gridDim.x) {
+  const Group g = groups[item % ng];
+  const uint32_t b0 = (item / ng) * NBP;
+  const uint32_t nb = min(NBP, B - b0);
+  __syncthreads();  // the previous item's readers of s_maxspan / accs / the tile are done
+  if (g.count == 0) continue;
   const bool active = t < (int)g.count;
   uint32_t qi = 0, begin = 0, span = 0;
   if (active) {
@@ -496,6 +552,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     double* out = lnl + (size_t)qi * B + b0;
     for (uint32_t j = 0; j < nb; ++j) out[j] = accs[j * GQ2 + t];
   }
+  }  // work items
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -606,10 +663,11 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
                     const uint32_t* d_span, uint32_t Q, double* d_lnl, uint32_t max_span) {
   const bool pairs = ctx->s == 4 && ctx->lookup2 && !getenv("EPA_PREPLACE_GENERIC");
   const uint32_t n_buckets = (ctx->W + SPREAD - 1) / SPREAD;
-  const uint32_t Wp = n_buckets * SPREAD;                       // key space of one (class, parity)
-  const uint32_t key_buckets = pairs ? 4 * n_buckets : n_buckets;
-  const uint32_t class_buckets = pairs ? 2 * n_buckets : 0xffffffffu;
-  const uint32_t max_groups = (Q + GQ - 1) / GQ + key_buckets;
+  const uint32_t Wp = n_buckets * SPREAD;  // key space of one (class, parity) block
+  const uint32_t n_blocks = pairs ? 4 : 1, class_blocks = pairs ? 2 : 1;
+  const uint32_t gq0 = pairs ? GQ2 : GQ, gq1 = GQ;
+  const uint32_t max_runs = (Q + GQ - 1) / GQ + n_blocks;
+  const uint32_t max_groups = max_runs + n_blocks * n_buckets;  // + one split per SPREAD boundary
   // pair offsets per query: whole chunks of CP, enough for the longest window
   const uint32_t span_bound = (max_span == 0 || max_span > ctx->W) ? ctx->W : max_span;
   const uint32_t NP16 = pairs ? ((span_bound + 1) / 2 + CP - 1) / CP * CP : 0;
@@ -637,7 +695,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   EPA_HIP(ctx, hipMemsetAsync(status, 0, 256, ctx->stream));
   hipLaunchKernelGGL(k_iota, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, iota, Q);
   int key_bits = 1;
-  while (key_bits < 32 && (1ull << key_bits) < (uint64_t)key_buckets * SPREAD) ++key_bits;
+  while (key_bits < 32 && (1ull << key_bits) < (uint64_t)n_blocks * Wp) ++key_bits;
   if (pairs) {
     hipLaunchKernelGGL(k_pack_pairs, dim3((Q + 3) / 4), dim3(256), 0, ctx->stream, d_codes, d_begin,
                        d_span, Q, ctx->W, Wp, NP16, packed, tails, keys);
@@ -647,15 +705,23 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, d_begin, sorted_keys, iota, perm, Q, 0, 32,
                                            ctx->stream));
   }
-  hipLaunchKernelGGL(k_make_groups, dim3(1), dim3(256), sizeof(uint32_t) * (key_buckets + 1), ctx->stream,
-                     sorted_keys, d_begin, d_span, Q, ctx->W, key_buckets, class_buckets,
-                     (uint32_t)(pairs ? GQ2 : GQ), (uint32_t)GQ, groups, max_groups, status);
-  dim3 grid(max_groups, (ctx->B + NB - 1) / NB);
+  hipLaunchKernelGGL(k_make_groups, dim3(1), dim3(256),
+                     sizeof(uint32_t) * (2 * (n_blocks + 1) + 3 * (size_t)max_runs + 1), ctx->stream,
+                     sorted_keys, d_begin, d_span, Q, ctx->W, pairs ? Wp : 0xffffffffu, n_blocks,
+                     class_blocks, gq0, gq1, max_runs, groups, max_groups, status);
+  // persistent grids: every resident workgroup slot of the device, work items strided over them
+  const uint32_t ntiles = (ctx->B + NB - 1) / NB;
   // max_span: upper bound of the window spans when the caller knows it (0 = unknown)
-  const bool acc = max_span == 0 || max_span > (uint32_t)CH;
+  const bool acc = max_span == 0 || max_span > (uint32_t)CH || getenv("EPA_PREPLACE_ACC");
   const size_t lds = sizeof(double) * ((size_t)TROWS * ctx->ncols + (acc ? (size_t)NB * GQ : 0));
   const size_t lds2 = (size_t)TROWS2 * PROWB + (acc ? sizeof(double) * NB2_ACC * GQ2 : 0);
-  const dim3 grid2(max_groups, (ctx->B + (acc ? NB2_ACC : NB) - 1) / (acc ? NB2_ACC : NB));
+  const uint32_t ntiles2 = (ctx->B + (acc ? NB2_ACC : NB) - 1) / (acc ? NB2_ACC : NB);
+  const dim3 grid2((uint32_t)std::min<uint64_t>((uint64_t)max_groups * ntiles2, (uint64_t)ctx->n_cu));  // 1 per CU
+  // generic kernel: with the pair path on it only sees the few groups of queries with rare
+  // ambiguity codes -> persistent grid; as the only kernel (20 states) one workgroup per item,
+  // dispatched dynamically (items differ in cost, partial groups are cheaper)
+  const dim3 grid(pairs ? (uint32_t)std::min<uint64_t>((uint64_t)max_groups * ntiles, (uint64_t)ctx->n_cu * (acc ? 2 : 4))
+                        : max_groups * ntiles);
   const size_t codes_bytes = (size_t)Q * ctx->W;
   const uint32_t want_cls = pairs ? 1u : 0u;
   epa_timer_start(ctx, ctx->t_preplace);
@@ -664,7 +730,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<A>,                               \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));        \
     hipLaunchKernelGGL((k_preplace_pairs<A>), grid2, dim3(GQ2), lds2, ctx->stream, ctx->lookup2, packed, \
-                       tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, NP16, d_lnl);           \
+                       tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, NP16, status, d_lnl);           \
   } while (0)
   if (pairs) { if (acc) PRE2(true); else PRE2(false); }
 #undef PRE2
@@ -673,7 +739,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace<NC, A>,                                \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
     hipLaunchKernelGGL((k_preplace<NC, A>), grid, dim3(GQ), lds, ctx->stream, ctx->lookup, d_codes, \
-                       d_begin, d_span, perm, groups, ctx->W, ctx->B, codes_bytes, want_cls, d_lnl); \
+                       d_begin, d_span, perm, groups, ctx->W, ctx->B, codes_bytes, want_cls, status, d_lnl); \
   } while (0)
   if (ctx->ncols == 16) { if (acc) PRE(16, true); else PRE(16, false); }
   else { if (acc) PRE(24, true); else PRE(24, false); }
