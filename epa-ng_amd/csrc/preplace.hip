@@ -53,6 +53,18 @@ struct Group {
   uint32_t cls;        // 0 = site-pair fast path (or the only class), 1 = generic kernel
 };
 
+// window validation (error words read back by preplace_check_status)
+__device__ __forceinline__ void validate_window(uint32_t i, uint32_t begin, uint32_t span, uint32_t W,
+                                                uint32_t* status) {
+  if (span == 0) atomicMax(&status[0], 0x80000000u | i);                          // all-gap query
+  else if ((uint64_t)begin + span > W) atomicMax(&status[1], 0x80000000u | i);    // width
+}
+__global__ void k_validate(const uint32_t* __restrict__ win_begin, const uint32_t* __restrict__ win_span,
+                           uint32_t Q, uint32_t W, uint32_t* __restrict__ status) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < Q) validate_window(i, win_begin[i], win_span[i], W, status);
+}
+
 __global__ void k_iota(uint32_t* v, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = i;
@@ -62,11 +74,9 @@ __global__ void k_iota(uint32_t* v, uint32_t n) {
 // k_pack_pairs: block = key / Wp, blocks >= class_blocks are class 1).  Every block is cut into
 // runs of gq0 (class 0) / gq1 (class 1) consecutive queries; a run whose window starts spread over
 // SPREAD sites or more (sparse data) is subdivided along the fixed SPREAD grid, so every group
-// fits the staged slice.  Also validates the windows (error words).
-__global__ void __launch_bounds__(256) k_make_groups(const uint32_t* __restrict__ sorted_keys,
-                                                     const uint32_t* __restrict__ win_begin,
-                                                     const uint32_t* __restrict__ win_span, uint32_t Q,
-                                                     uint32_t W, uint32_t Wp, uint32_t n_blocks,
+// fits the staged slice.
+__global__ void __launch_bounds__(256) k_make_groups(const uint32_t* __restrict__ sorted_keys, uint32_t Q,
+                                                     uint32_t Wp, uint32_t n_blocks,
                                                      uint32_t class_blocks, uint32_t gq0, uint32_t gq1,
                                                      uint32_t max_runs, Group* __restrict__ groups,
                                                      uint32_t max_groups, uint32_t* __restrict__ status) {
@@ -76,11 +86,6 @@ __global__ void __launch_bounds__(256) k_make_groups(const uint32_t* __restrict_
   uint32_t* run_start = runbase + n_blocks + 1;  // [max_runs]
   uint32_t* run_end = run_start + max_runs;
   uint32_t* run_off = run_end + max_runs;        // first group slot of the run
-  for (uint32_t i = threadIdx.x; i < Q; i += blockDim.x) {
-    const uint32_t s = win_span[i];
-    if (s == 0) atomicMax(&status[0], 0x80000000u | i);                    // all-gap query
-    else if ((uint64_t)win_begin[i] + s > W) atomicMax(&status[1], 0x80000000u | i);  // width
-  }
   auto lower_bound = [&](uint32_t a, uint32_t b, uint64_t key) {
     while (a < b) {
       const uint32_t m = (a + b) >> 1;
@@ -114,16 +119,22 @@ __global__ void __launch_bounds__(256) k_make_groups(const uint32_t* __restrict_
     run_off[r] = (k1 - k0 < (uint32_t)SPREAD) ? 1u : (k1 / SPREAD - k0 / SPREAD + 1);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {  // exclusive scan of the group counts (a few hundred runs)
+  // exclusive scan of the group counts: a few hundred runs, every thread sums its own prefix
+  uint32_t* cnt = run_off + max_runs + 1;  // [max_runs] copy of the counts
+  for (uint32_t r = threadIdx.x; r < nruns; r += blockDim.x) cnt[r] = run_off[r];
+  __syncthreads();
+  for (uint32_t r = threadIdx.x; r <= nruns; r += blockDim.x) {
     uint32_t g = 0;
-    for (uint32_t r = 0; r < nruns; ++r) { const uint32_t n = run_off[r]; run_off[r] = g; g += n; }
-    run_off[nruns] = g;
-    // group ranges for the persistent kernels: class 0 = [0, status[5]), class 1 = [status[5], status[4])
-    const uint32_t r1 = class_blocks < n_blocks ? min(runbase[class_blocks], nruns) : nruns;
-    status[4] = min(g, max_groups);
-    status[5] = min(run_off[r1], max_groups);
+    for (uint32_t i = 0; i < r; ++i) g += cnt[i];
+    run_off[r] = g;
   }
   __syncthreads();
+  if (threadIdx.x == 0) {
+    // group ranges for the persistent kernels: class 0 = [0, status[5]), class 1 = [status[5], status[4])
+    const uint32_t r1 = class_blocks < n_blocks ? min(runbase[class_blocks], nruns) : nruns;
+    status[4] = min(run_off[nruns], max_groups);
+    status[5] = min(run_off[r1], max_groups);
+  }
   for (uint32_t r = threadIdx.x; r < nruns; r += blockDim.x) {
     uint32_t b = 0;
     while (b + 1 < n_blocks && r >= runbase[b + 1]) ++b;
@@ -179,7 +190,7 @@ __global__ void __launch_bounds__(GQ, ACC ? 2 : 4) k_preplace(const double* __re
     qi = perm[g.start + t];
     begin = win_begin[qi];
     span = win_span[qi];
-    if ((uint64_t)begin + span > W) span = 0;  // invalid window: flagged by k_make_groups
+    if ((uint64_t)begin + span > W) span = 0;  // invalid window: flagged by the validation pass
   }
   if (t == 0) s_maxspan = 0;
   __syncthreads();
@@ -373,13 +384,15 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
                                                     uint32_t W, uint32_t Wp, uint32_t NP16,
                                                     uint16_t* __restrict__ packed,
                                                     uint16_t* __restrict__ tails,
-                                                    uint32_t* __restrict__ keys) {
+                                                    uint32_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ status) {
   const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63;
   if (q >= Q) return;
   const uint32_t begin = win_begin[q];
   uint32_t span = win_span[q];
-  if ((uint64_t)begin + span > W) span = 0;  // invalid window: flagged by k_make_groups
+  if (lane == 0) validate_window(q, begin, span, W, status);
+  if ((uint64_t)begin + span > W) span = 0;  // invalid window (flagged above)
   const uint8_t* c = codes + (size_t)q * W + begin;
   const uint32_t nfull = span >> 2, ntail = span & 3, npairs = 2 * nfull;
   bool rare = false;
@@ -698,17 +711,21 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   while (key_bits < 32 && (1ull << key_bits) < (uint64_t)n_blocks * Wp) ++key_bits;
   if (pairs) {
     hipLaunchKernelGGL(k_pack_pairs, dim3((Q + 3) / 4), dim3(256), 0, ctx->stream, d_codes, d_begin,
-                       d_span, Q, ctx->W, Wp, NP16, packed, tails, keys);
+                       d_span, Q, ctx->W, Wp, NP16, packed, tails, keys, status);
     EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, keys, sorted_keys, iota, perm, Q, 0,
                                            key_bits, ctx->stream));
   } else {
-    EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, d_begin, sorted_keys, iota, perm, Q, 0, 32,
+    hipLaunchKernelGGL(k_validate, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, d_begin, d_span, Q,
+                       ctx->W, status);
+    int wbits = 1;
+    while (wbits < 32 && (1ull << wbits) <= (uint64_t)ctx->W) ++wbits;
+    EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, d_begin, sorted_keys, iota, perm, Q, 0, wbits,
                                            ctx->stream));
   }
   hipLaunchKernelGGL(k_make_groups, dim3(1), dim3(256),
-                     sizeof(uint32_t) * (2 * (n_blocks + 1) + 3 * (size_t)max_runs + 1), ctx->stream,
-                     sorted_keys, d_begin, d_span, Q, ctx->W, pairs ? Wp : 0xffffffffu, n_blocks,
-                     class_blocks, gq0, gq1, max_runs, groups, max_groups, status);
+                     sizeof(uint32_t) * (2 * (n_blocks + 1) + 4 * (size_t)max_runs + 2), ctx->stream,
+                     sorted_keys, Q, pairs ? Wp : 0xffffffffu, n_blocks, class_blocks, gq0, gq1, max_runs,
+                     groups, max_groups, status);
   // persistent grids: every resident workgroup slot of the device, work items strided over them
   const uint32_t ntiles = (ctx->B + NB - 1) / NB;
   // max_span: upper bound of the window spans when the caller knows it (0 = unknown)
