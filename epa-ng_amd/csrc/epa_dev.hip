@@ -116,7 +116,9 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
                                                       const uint32_t* __restrict__ scSum,
                                                       const double* __restrict__ blen,
                                                       double pendant, uint32_t W,
-                                                      double* __restrict__ lookup) {
+                                                      double* __restrict__ lookup,
+                                                      double* __restrict__ refI,
+                                                      uint8_t* __restrict__ resc0) {
   __shared__ double U[S * S], Ui[S * S];
   __shared__ double Eh[EPA_MAX_CATS * S], Ep[EPA_MAX_CATS * S];  // exp tables: half branch, pendant
   const int c = m->c, ncols = m->ncols;
@@ -159,6 +161,7 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
   // per-site scaling of pll_update_partials: every entry below 2^-256 -> multiply by 2^256
   const bool resc = mx < 0x1p-256;
   if (resc) sc += 1;
+  if (resc0) resc0[(size_t)b * W + site] = resc ? 1 : 0;
   const double mult = resc ? 0x1p+256 : 1.0;
   // g[k][i] = pi_i * (P_pendant I)_i  via the eigenbasis: P I = U (e o (Ui I))
   double g[EPA_MAX_CATS][S];
@@ -169,6 +172,8 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
       double acc = 0.0;
 #pragma unroll
       for (int i = 0; i < S; ++i) acc = fma(Ui[x * S + i], I[k][i] * mult, acc);
+      // the thorough kernel starts every pair from exactly this vector (same lengths): keep it
+      if (refI) refI[((size_t)b * c * S + (size_t)(k * S + x)) * W + site] = acc;
       it[x] = acc * Ep[k * S + x];
     }
 #pragma unroll
@@ -202,10 +207,12 @@ int launch_build_lookup(epa_ctx* ctx) {
   epa_timer_start(ctx, ctx->t_lookup);
   if (ctx->s == 4)
     hipLaunchKernelGGL(k_build_lookup<4>, grid, dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT,
-                       ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup);
+                       ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup, ctx->refI,
+                       ctx->resc0);
   else
     hipLaunchKernelGGL(k_build_lookup<20>, grid, dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT,
-                       ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup);
+                       ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup,
+                       (double*)nullptr, (uint8_t*)nullptr);
   EPA_HIP(ctx, hipGetLastError());
   if (ctx->s == 4) {
     int rc = launch_build_lookup2(ctx);
@@ -317,6 +324,8 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
   if (ctx->blen) (void)hipFree(ctx->blen);
   if (ctx->lookup) (void)hipFree(ctx->lookup);
   if (ctx->lookup2) (void)hipFree(ctx->lookup2);
+  if (ctx->refI) (void)hipFree(ctx->refI);
+  if (ctx->resc0) (void)hipFree(ctx->resc0);
   if (ctx->dmodel) (void)hipFree(ctx->dmodel);
   EvTimer* ts[4] = {&ctx->t_lookup, &ctx->t_preplace, &ctx->t_thorough, &ctx->t_select};
   for (auto* t : ts) { if (t->a) (void)hipEventDestroy(t->a); if (t->b) (void)hipEventDestroy(t->b); }
@@ -414,6 +423,10 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx) {
   EPA_HIP(ctx, hipMemset(ctx->scSum, 0, sizeof(uint32_t) * B * W));
   EPA_HIP(ctx, hipMalloc(&ctx->blen, sizeof(double) * B));
   EPA_HIP(ctx, hipMalloc(&ctx->lookup, sizeof(double) * B * W * ctx->ncols));
+  if (s == 4 && c == 4) {
+    EPA_HIP(ctx, hipMalloc(&ctx->refI, sizeof(double) * B * cs * W));
+    EPA_HIP(ctx, hipMalloc(&ctx->resc0, B * W));
+  }
   ctx->h_blen.assign(d->branch_length, d->branch_length + B);
   EPA_HIP(ctx, hipMemcpy(ctx->blen, d->branch_length, sizeof(double) * B, hipMemcpyHostToDevice));
 
@@ -553,6 +566,10 @@ extern "C" int epa_dev_thorough(epa_ctx* ctx, const epa_pair* pairs, uint64_t n_
   EPA_HIP(ctx, hipSetDevice(ctx->device));
   if (!(ctx->s == 4 && ctx->c == 4) && !(ctx->s == 20))
     return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "thorough: DNA needs 4 rate categories");
+  if (ctx->refI) {  // per-branch starting vectors of the DNA kernel come with the lookup build
+    int brc = epa_dev_build_lookup(ctx);
+    if (brc) return brc;
+  }
   std::vector<uint32_t> hb_buf, hs_buf;
   const uint32_t* hb = host_view(win_begin, Q, hb_buf, ctx->stream);
   const uint32_t* hs = host_view(win_span, Q, hs_buf, ctx->stream);

@@ -37,6 +37,8 @@ struct ThArgs {
   ModelDNA m;
   BloConsts blo;
   const double* refT;      // [2B][16][W]
+  const double* refI;      // [B][16][W]  U^-1 inner CLV at the starting lengths (k_build_lookup)
+  const uint8_t* resc0;    // [B][W]      its per-site rescale flag
   const uint32_t* scSum;   // [B][W]
   const double* blen;      // [B]
   const double* qt;        // [16 columns][4]   U^-1 image of each column's tip vector
@@ -318,8 +320,41 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     }
   };
 
+  // Initial score at the starting lengths (orig/2, orig/2, default pendant): the inner CLV does
+  // not depend on the query, k_build_lookup stored its U^-1 image per (branch, site) -> 16 loads
+  // and the fold with the query instead of 32 loads and the two 4x4 products per category.
+  auto score_first = [&](double tp_) -> double {
+    table_publish(tab, lane, exp(lc.lr * tp_) * (lc.slot == 2 ? lc.w : 1.0));
+    const char* refi = reinterpret_cast<const char*>(a.refI + (size_t)b * 16 * cW + begin);
+    const uint8_t* r0 = a.resc0 + (size_t)b * cW + begin;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const uint32_t si = st.valid[ch] ? ch * 64 + lane : 0;
+      const uint32_t s = si * 8u + chain;
+      double It[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) It[c] = *reinterpret_cast<const double*>(refi + (s + (uint32_t)c * W8));
+      st.resc[ch] = r0[si];
+      asm volatile("" ::: "memory");
+      const double* qv = qts + st.code[ch] * 4;
+      const double q0 = qv[0], q1 = qv[1], q2 = qv[2], q3 = qv[3];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        st.S[ch][k * 4 + 0] = It[k * 4 + 0] * q0;
+        st.S[ch][k * 4 + 1] = It[k * 4 + 1] * q1;
+        st.S[ch][k * 4 + 2] = It[k * 4 + 2] * q2;
+        st.S[ch][k * 4 + 3] = It[k * 4 + 3] * q3;
+      }
+      chain = zero_after(st.S[ch][15]);
+    }
+    double ew[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
+    return window_lnl<NCH>(st, ew);
+  };
+
   // traverse_update_partials + initial score (optimize.cpp:15-42,111-113)
-  double loglikelihood = -score(td, tx, tp);
+  double loglikelihood = a.refI ? -score_first(tp) : -score(td, tx, tp);
 
   uint32_t smoothings = a.blo.max_rounds;
   while (smoothings) {
@@ -421,6 +456,9 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
   a.m = ctx->dna;
   a.blo = ctx->blo;
   a.refT = ctx->refT;
+  // filled by k_build_lookup; until then every pair computes its own starting vector
+  a.refI = ctx->lookup_built ? ctx->refI : nullptr;
+  a.resc0 = ctx->resc0;
   a.scSum = ctx->scSum;
   a.blen = ctx->blen;
   a.qt = ctx->dmodel->qt;
