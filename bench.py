@@ -165,7 +165,9 @@ def main():
     else:  # same accounting with s = 20: P = c(4s^2+s), E = c(2s^2+2s), D = 6cs
         P_, E_, D_ = 4 * (4 * 400 + 20), 4 * (2 * 400 + 40), 6 * 4 * 20
         flops_pair = nq * ((2 * P_ + E_) + R * (4 * P_ + E_ + 2 * kbar * D_))
-        flops_exec = flops_pair
+        # initial inner CLV from the per-branch precompute: only the fold with the query and the
+        # lnL contraction (3cs flop per site) are executed of the 2P + E
+        flops_exec = nq * (3 * 4 * 20 + R * (4 * P_ + E_ + 2 * kbar * D_))
     cs = 4 * states
     bytes_pair = 2 * nq * cs * 8 + 2 * nq * 4 + nq + 24
     t_th = float(np.mean(th_ms)) * 1e-3

@@ -211,8 +211,8 @@ int launch_build_lookup(epa_ctx* ctx) {
                        ctx->resc0);
   else
     hipLaunchKernelGGL(k_build_lookup<20>, grid, dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT,
-                       ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup,
-                       (double*)nullptr, (uint8_t*)nullptr);
+                       ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup, ctx->refI,
+                       ctx->resc0);
   EPA_HIP(ctx, hipGetLastError());
   if (ctx->s == 4) {
     int rc = launch_build_lookup2(ctx);
@@ -423,7 +423,7 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx) {
   EPA_HIP(ctx, hipMemset(ctx->scSum, 0, sizeof(uint32_t) * B * W));
   EPA_HIP(ctx, hipMalloc(&ctx->blen, sizeof(double) * B));
   EPA_HIP(ctx, hipMalloc(&ctx->lookup, sizeof(double) * B * W * ctx->ncols));
-  if (s == 4 && c == 4) {
+  if (c == 4) {  // starting vectors of the thorough kernels (both are built for 4 categories)
     EPA_HIP(ctx, hipMalloc(&ctx->refI, sizeof(double) * B * cs * W));
     EPA_HIP(ctx, hipMalloc(&ctx->resc0, B * W));
   }

@@ -75,7 +75,7 @@ struct epa_ctx {
   uint32_t* scSum = nullptr;
   double* blen = nullptr;
   double* lookup = nullptr;
-  double* refI = nullptr;     // DNA only: [B][16][W] U^-1 image of the inner CLV toward the query at
+  double* refI = nullptr;     // c == 4: [B][c*s][W] U^-1 image of the inner CLV toward the query at
                               // the starting lengths (orig/2, orig/2), rescaled; resc0 [B][W] its flag
   uint8_t* resc0 = nullptr;
   double* lookup2 = nullptr;  // DNA only: [B][W][36] site-pair sums (preplace.hip, k_preplace_pairs)

@@ -36,6 +36,8 @@ struct ThArgsAA {
   const ModelDev* m;
   BloConsts blo;
   const double* refT;      // [2B][80][W]
+  const double* refI;      // [B][80][W] U^-1 inner CLV at the starting lengths (k_build_lookup), or null
+  const uint8_t* resc0;    // [B][W]     its per-site rescale flag
   const uint32_t* scSum;   // [B][W]
   const double* blen;      // [B]
   const epa_pair* pairs;
@@ -184,8 +186,22 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
         const uint32_t site = p * 64 + lane;
         const bool valid = site < n;
         const uint32_t s = valid ? site : 0;
-        double A[S], E[S], Q[S], I[S];
-        const uint32_t code = qc[s];  // its latency hides under the 40 requests below
+        double E[S], It[S];
+        bool resc;
+        double mult;
+        const uint32_t code = qc[s];  // its latency hides under the requests below
+        if (mode == 2) {
+          // starting lengths: U^-1 inner CLV of this (branch, site) from the per-branch precompute
+          const double* It0 = a.refI + ((size_t)b * 80 + (size_t)k * S) * cW + begin;
+#pragma unroll
+          for (int x = 0; x < S; ++x) It[x] = It0[(size_t)x * cW + s];
+#pragma unroll
+          for (int x = 0; x < S; ++x) E[x] = m->qt[code * S + x];
+          resc = a.resc0[(size_t)b * cW + begin + s] != 0;
+          asm volatile("" ::: "memory");
+          mult = 1.0;  // already applied
+        } else {
+        double A[S], Q[S], I[S];
         request(p, true);
 #pragma unroll
         for (int x = 0; x < S; ++x) Q[x] = m->qt[code * S + x];
@@ -238,9 +254,8 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
         __syncthreads();
         const double mall = fmax(fmax(sh.red[p & 1][0][0][lane], sh.red[p & 1][0][1][lane]),
                                  fmax(sh.red[p & 1][0][2][lane], sh.red[p & 1][0][3][lane]));
-        const bool resc = mall < 0x1p-256;
-        const double mult = resc ? 0x1p+256 : 1.0;
-        double It[S];
+        resc = mall < 0x1p-256;
+        mult = resc ? 0x1p+256 : 1.0;
         {
           ConstD row = Uib + szero(p);
 #pragma unroll
@@ -262,6 +277,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
           asm volatile("" ::"v"(It[i]));
           __builtin_amdgcn_sched_barrier(0);
         }
+        }  // mode != 2
         double l0 = 0.0;
         // LDS slab: lanes past the window write to the spare last column (an `if (valid)` around
         // the stores would let LLVM sink the whole U^-1 product into the branch and wreck the
@@ -271,9 +287,9 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
         for (int x = 0; x < S; ++x) {
           const double sv = It[x] * mult * E[x];
           slab(x * a.Wpad + wsite) = sv;
-          if (mode == 0) l0 = fma(sv, sh.tab[2][k * S + x], l0);
+          if (mode != 1) l0 = fma(sv, sh.tab[2][k * S + x], l0);
         }
-        if (mode == 0) {
+        if (mode != 1) {
           sh.red[p & 1][1][k][lane] = l0;
           __syncthreads();
           if (k == 0) {
@@ -288,7 +304,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
           }
         }
       }
-      if (mode == 0) {
+      if (mode != 1) {
         if (k == 0) {
           const double tot = wave_sum(log(mant) + (double)ex * LOG_2);
           if (lane == 0) sh.bc[2] = tot;
@@ -397,7 +413,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
     uint32_t rounds = 0, reverted = 0;
     double lnl_now = 0.0;
     publish(td, tx, tp);
-    phase(0, lnl_now);
+    if (a.refI) phase(2, lnl_now); else phase(0, lnl_now);
     double loglikelihood = -lnl_now;
     uint32_t smoothings = a.blo.max_rounds;
     while (smoothings) {
@@ -461,6 +477,8 @@ int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, 
   a.m = ctx->dmodel;
   a.blo = ctx->blo;
   a.refT = ctx->refT;
+  a.refI = ctx->lookup_built ? ctx->refI : nullptr;
+  a.resc0 = ctx->resc0;
   a.scSum = ctx->scSum;
   a.blen = ctx->blen;
   a.pairs = d_pairs;
