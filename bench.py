@@ -50,7 +50,7 @@ def main():
     a = parse()
     import torch
     import epa_ng_amd as epa
-    from epa_ng_amd import hostlib, synth
+    from epa_ng_amd import hostlib, parallel, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,7 +102,7 @@ def main():
     cap = Q * 64   # pair capacity per step (dynamic heuristic selects a handful per read)
     d_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
     d_res = torch.zeros((cap, 3), dtype=torch.float64, device=dev)
-    nmax_t = torch.zeros(1, dtype=torch.int64, device=cdev)
+    exch = parallel.AsyncResultGather(dist, min(cap, 8 * Q), dev) if world > 1 else None
 
     th_ms, th_pairs, th_rounds, th_evals, pre_ms, sel_ms = [], [], [], [], [], []
 
@@ -113,14 +113,9 @@ def main():
                            pairs_out=d_pairs, results_out=d_res)
         if world > 1:
             # the path's only exchange: every rank's candidate placements -> rank 0 (RCCL over
-            # xGMI; the reference gathers jplace byte ranges, src/io/jplace_writer.hpp:117-129)
-            nmax_t[0] = n
-            dist.all_reduce(nmax_t, op=dist.ReduceOp.MAX)
-            m = int(nmax_t.item())
-            gp = [torch.empty((m, 2), dtype=torch.int32, device=cdev) for _ in range(world)] if rank == 0 else None
-            gr = [torch.empty((m, 3), dtype=torch.float64, device=cdev) for _ in range(world)] if rank == 0 else None
-            dist.gather(d_pairs[:m].to(cdev), gp, dst=0)
-            dist.gather(d_res[:m].to(cdev), gr, dst=0)
+            # xGMI; the reference gathers jplace byte ranges, src/io/jplace_writer.hpp:117-129).
+            # Posted asynchronously: it overlaps the next chunk's kernels (parallel.py).
+            exch.post(d_pairs, d_res, n)
         if record:
             th_ms.append(ev.kernel_ms("thorough")); pre_ms.append(ev.kernel_ms("preplace"))
             sel_ms.append(ev.kernel_ms("select"))
@@ -136,6 +131,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.warmup, n_chunks):
         step(i, True)
+    if world > 1:
+        exch.finish()   # the last chunks' gathers are part of the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -41,3 +41,76 @@ def gather_results(pairs, results, seq_offset, dist=None, dst=0):
     if rank != dst:
         return None
     return np.concatenate([o[:int(c.item())].cpu().numpy() for o, c in zip(out, counts)], axis=0)
+
+
+class AsyncResultGather:
+    """The path's only exchange, overlapped with compute: after every chunk each rank posts its
+    (pair, result) rows to rank 0 with an asynchronous gather (RCCL runs it on its own stream over
+    xGMI while the next chunk's kernels execute).  Rows are packed as 4 x f64: the 8-byte
+    (branch_id, seq_id) pair reinterpreted as one f64, then lnl, pendant, distal; one extra row
+    carries the rank's row count.  `depth` slots are used round-robin, a slot is reused only after
+    its previous gather has completed.
+
+    post() is collective: every rank calls it once per chunk, in the same order."""
+
+    def __init__(self, dist, max_rows, device, dst=0, depth=2):
+        import torch
+        self.dist, self.dst, self.depth = dist, dst, depth
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.max_rows = int(max_rows)
+        self.cdev = device if dist.get_backend() == "nccl" else torch.device("cpu")
+        mk = lambda: torch.empty((self.max_rows + 1, 4), dtype=torch.float64, device=self.cdev)
+        self.send = [mk() for _ in range(depth)]
+        self.recv = [[mk() for _ in range(self.world)] for _ in range(depth)] if self.rank == dst else None
+        self.work = [None] * depth
+        self.rows = [0] * depth
+        self.nmax = torch.zeros(1, dtype=torch.int64, device=self.cdev)
+        self.step = 0
+        self.collected = []   # dst only: list of (step, [per-rank (n, 4) arrays]) when keep=True
+
+    def post(self, pairs_i32, results_f64, n, keep=False):
+        """pairs_i32: (cap, 2) int32 tensor, results_f64: (cap, 3) float64 tensor, n valid rows."""
+        import torch
+        slot = self.step % self.depth
+        self._retire(slot, keep)
+        self.nmax[0] = n
+        self.dist.all_reduce(self.nmax, op=self.dist.ReduceOp.MAX)   # common row count of this gather
+        m = int(self.nmax.item())
+        if m > self.max_rows:
+            raise RuntimeError("AsyncResultGather: %d rows exceed max_rows %d" % (m, self.max_rows))
+        buf = self.send[slot]
+        if n:
+            buf[:n, 0] = pairs_i32[:n].contiguous().view(torch.int64).view(torch.float64).reshape(-1).to(self.cdev)
+            buf[:n, 1:4] = results_f64[:n].to(self.cdev)
+        buf[m, 0] = float(n)
+        out = [r[:m + 1] for r in self.recv[slot]] if self.rank == self.dst else None
+        self.work[slot] = self.dist.gather(buf[:m + 1], out, dst=self.dst, async_op=True)
+        self.rows[slot] = m
+        self.step += 1
+
+    def _retire(self, slot, keep):
+        w = self.work[slot]
+        if w is None:
+            return
+        w.wait()
+        self.work[slot] = None
+        if keep and self.rank == self.dst:
+            m = self.rows[slot]
+            parts = []
+            for r in self.recv[slot]:
+                k = int(r[m, 0].item())
+                parts.append(r[:k].cpu().numpy().copy())
+            self.collected.append(parts)
+
+    def finish(self, keep=False):
+        """waits for every outstanding gather (oldest first)"""
+        for i in range(self.depth):
+            self._retire((self.step + i) % self.depth, keep)
+
+
+def unpack_rows(rows):
+    """(n, 4) f64 rows of AsyncResultGather -> (branch_id, seq_id, lnl, pendant, distal) arrays"""
+    ids = np.ascontiguousarray(rows[:, 0]).view(np.int64)
+    branch = (ids & 0xffffffff).astype(np.uint32)
+    seq = (ids >> 32).astype(np.uint32)
+    return branch, seq, rows[:, 1], rows[:, 2], rows[:, 3]

@@ -38,6 +38,29 @@ if rank == 0:
     print("GATHER_OK", out.shape[0])
 else:
     assert out is None
+# overlapped exchange used by bench.py: three chunks through two slots
+import torch
+ag = parallel.AsyncResultGather(dist, max_rows=64, device=torch.device("cpu"))
+for step in range(3):
+    n = 5 + 3 * rank + step
+    p = torch.zeros((64, 2), dtype=torch.int32)
+    r = torch.zeros((64, 3), dtype=torch.float64)
+    p[:n, 0] = torch.arange(n, dtype=torch.int32) + 100 * step      # branch_id
+    p[:n, 1] = torch.arange(n, dtype=torch.int32) + 1000 * rank     # seq_id
+    r[:n, 0] = -(p[:n, 0].double() * 7 + p[:n, 1].double())
+    ag.post(p, r, n, keep=True)
+ag.finish(keep=True)
+if rank == 0:
+    assert len(ag.collected) == 3
+    for step, parts in enumerate(ag.collected):
+        assert len(parts) == world
+        for rk, rows in enumerate(parts):
+            assert rows.shape == (5 + 3 * rk + step, 4)
+            b, s_, lnl, _, _ = parallel.unpack_rows(rows)
+            assert np.array_equal(b, np.arange(len(b)) + 100 * step)
+            assert np.array_equal(s_, np.arange(len(b)) + 1000 * rk)
+            assert np.array_equal(lnl, -(b * 7.0 + s_))
+    print("ASYNC_OK")
 dist.destroy_process_group()
 '''
 
@@ -70,4 +93,4 @@ def test_two_rank_gloo_gather(tmp_path):
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
-    assert "GATHER_OK" in outs[0]
+    assert "GATHER_OK" in outs[0] and "ASYNC_OK" in outs[0]
