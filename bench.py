@@ -96,7 +96,8 @@ def main():
 
     chunks = []
     for c in range(n_chunks):
-        codes, wb, ws = epa.encode_queries(states, reads[c * Q:(c + 1) * Q])
+        # compact wire format: one row per read holding only its window (152 B instead of 1500 B)
+        codes, wb, ws = epa.encode_queries(states, reads[c * Q:(c + 1) * Q], compact=True)
         chunks.append((torch.from_numpy(codes).to(dev), torch.from_numpy(wb.view(np.int32)).to(dev),
                        torch.from_numpy(ws.view(np.int32)).to(dev), codes, wb, ws))
     cap = Q * 64   # pair capacity per step (dynamic heuristic selects a handful per read)

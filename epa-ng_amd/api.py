@@ -80,6 +80,11 @@ def dev_lib():
         L.epa_encode_queries.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.epa_encode_queries_compact.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32,
+                                                 C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_uint32,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.POINTER(C.c_uint32)]
+        L.epa_dev_set_query_layout.argtypes = [C.c_void_p, C.c_uint32]
         L.epa_dev_preplace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                        C.c_void_p]
         L.epa_dev_thorough.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
@@ -111,8 +116,11 @@ def _ptr(a):
     return a.data_ptr()  # torch tensor
 
 
-def encode_queries(states, seqs, premasking=True, aa_x_as_n=False):
-    """ASCII query rows -> (codes uint8 [Q][W], win_begin uint32 [Q], win_span uint32 [Q])."""
+def encode_queries(states, seqs, premasking=True, aa_x_as_n=False, compact=False):
+    """ASCII query rows -> (codes uint8, win_begin uint32 [Q], win_span uint32 [Q]).
+    codes is [Q][W] (the aligned rows), or with compact=True [Q][stride] holding only each
+    query's window (stride = longest window rounded up to 16; see epa_encode_queries_compact).
+    The Evaluator methods recognise the layout by the row length."""
     Q = len(seqs)
     W = len(seqs[0])
     arr = (C.c_char_p * Q)()
@@ -120,16 +128,28 @@ def encode_queries(states, seqs, premasking=True, aa_x_as_n=False):
     for s in arr:
         if len(s) != W:
             raise EpaError(-4, "Query sequence length not same as reference alignment!")
-    codes = np.zeros((Q, W), np.uint8)
     wb = np.zeros(Q, np.uint32)
     ws = np.zeros(Q, np.uint32)
     bad = C.c_uint32(0)
-    rc = dev_lib().epa_encode_queries(states, W, Q, arr, int(premasking), int(aa_x_as_n),
-                                      codes.ctypes.data, wb.ctypes.data, ws.ctypes.data,
-                                      C.byref(bad))
-    if rc:
-        raise EpaError(rc, "query %d: %s" % (bad.value, "char is invalid!" if rc == -6 else
-                                             "does not appear to have any non-gap sites!"))
+    L = dev_lib()
+
+    def check(rc):
+        if rc:
+            raise EpaError(rc, "query %d: %s" % (bad.value, "char is invalid!" if rc == -6 else
+                                                 "does not appear to have any non-gap sites!"))
+    if not compact:
+        codes = np.zeros((Q, W), np.uint8)
+        check(L.epa_encode_queries(states, W, Q, arr, int(premasking), int(aa_x_as_n),
+                                   codes.ctypes.data, wb.ctypes.data, ws.ctypes.data, C.byref(bad)))
+        return codes, wb, ws
+    check(L.epa_encode_queries_compact(states, W, Q, arr, int(premasking), int(aa_x_as_n), 0, None,
+                                       wb.ctypes.data, ws.ctypes.data, C.byref(bad)))
+    stride = (int(ws.max()) + 15) // 16 * 16
+    if stride == W:       # keep the two layouts distinguishable by their row length
+        stride += 16
+    codes = np.zeros((Q, stride), np.uint8)
+    check(L.epa_encode_queries_compact(states, W, Q, arr, int(premasking), int(aa_x_as_n), stride,
+                                       codes.ctypes.data, wb.ctypes.data, ws.ctypes.data, C.byref(bad)))
     return codes, wb, ws
 
 
@@ -212,11 +232,17 @@ class Evaluator:
     def build_lookup(self):
         self._check(self.L.epa_dev_build_lookup(self.h))
 
+    def _layout(self, codes):
+        """tells the context whether `codes` rows are aligned rows (W bytes) or compact windows"""
+        row = int(codes.shape[1]) if len(codes.shape) == 2 else self.W
+        self._check(self.L.epa_dev_set_query_layout(self.h, 0 if row == self.W else row))
+
     def preplace(self, codes, win_begin, win_span, Q=None, out=None):
         """-> lnl [Q][B].  Inputs numpy (host) or torch cuda tensors (HBM-resident)."""
         Q = len(win_begin) if Q is None else Q
         if out is None:
             out = np.empty((Q, self.B), np.float64)
+        self._layout(codes)
         self._check(self.L.epa_dev_preplace(self.h, _ptr(codes), _ptr(win_begin), _ptr(win_span),
                                             Q, _ptr(out)))
         return out
@@ -228,6 +254,7 @@ class Evaluator:
         if out is None:
             out = np.empty(n, RESULT_DTYPE)
         st = _Stats()
+        self._layout(codes)
         self._check(self.L.epa_dev_thorough(self.h, _ptr(pairs), n, _ptr(codes), _ptr(win_begin),
                                             _ptr(win_span), Q, _ptr(out), C.byref(st)))
         self.last_stats = {"pairs": st.pairs, "rounds": st.rounds,
@@ -259,6 +286,7 @@ class Evaluator:
             results_out = np.empty(max_pairs, RESULT_DTYPE)
         n = C.c_uint64(0)
         st = _Stats()
+        self._layout(codes)
         self._check(self.L.epa_dev_place_chunk(self.h, _ptr(codes), _ptr(win_begin), _ptr(win_span),
                                                Q, max_span, threshold, _ptr(pairs_out),
                                                _ptr(results_out), max_pairs, C.byref(n),

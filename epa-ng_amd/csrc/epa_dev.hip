@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <numeric>
+#include <thread>
 
 static thread_local std::string g_create_err;
 
@@ -255,10 +256,9 @@ static uint32_t column_mask(int s, int col) {
   return (1u << 20) - 1;  // '-' and 'X'
 }
 
-extern "C" int epa_encode_queries(uint32_t states, uint32_t sites, uint32_t Q,
-                                  const char* const* seqs, int premasking, int aa_x_as_n,
-                                  uint8_t* codes, uint32_t* win_begin, uint32_t* win_span,
-                                  uint32_t* bad_query) {
+static int encode_impl(uint32_t states, uint32_t sites, uint32_t Q, const char* const* seqs,
+                       int premasking, int aa_x_as_n, bool compact, uint32_t stride, uint8_t* codes,
+                       uint32_t* win_begin, uint32_t* win_span, uint32_t* bad_query) {
   int8_t map[256];
   memset(map, -1, sizeof(map));
   const bool dna = states == 4;
@@ -275,24 +275,64 @@ extern "C" int epa_encode_queries(uint32_t states, uint32_t sites, uint32_t Q,
     map['X'] = map['x'] = map['N'];
   }
   map['?'] = map['-'];
-  for (uint32_t q = 0; q < Q; ++q) {
-    const char* sq = seqs[q];
-    uint8_t* out = codes + (size_t)q * sites;
-    for (uint32_t w = 0; w < sites; ++w) {
-      const int8_t v = map[(unsigned char)sq[w]];
-      if (v < 0) { if (bad_query) *bad_query = q; return EPA_ERR_INVALID_CHAR; }
-      out[w] = (uint8_t)v;
+  // queries are independent: a few host threads (the first offender in query order is reported)
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned nt = (unsigned)std::min<uint64_t>(std::min(hw, 32u), std::max<uint64_t>(1, (uint64_t)Q * sites >> 20));
+  std::vector<uint32_t> bad(nt, 0xffffffffu);
+  std::vector<int> code(nt, EPA_OK);
+  auto work = [&](unsigned t) {
+    const uint32_t q0 = (uint32_t)((uint64_t)Q * t / nt), q1 = (uint32_t)((uint64_t)Q * (t + 1) / nt);
+    for (uint32_t q = q0; q < q1; ++q) {
+      const char* sq = seqs[q];
+      uint32_t lo = 0, hi = sites;
+      if (premasking) {  // get_valid_range, src/util/Range.hpp:34-49: only the literal '-'
+        while (lo < hi && sq[lo] == '-') ++lo;
+        while (hi > lo && sq[hi - 1] == '-') --hi;
+      }
+      // every character of the row is validated, as the reference does (Lookup_Store.hpp:100-108)
+      for (uint32_t w = 0; w < sites; ++w)
+        if (map[(unsigned char)sq[w]] < 0) { bad[t] = q; code[t] = EPA_ERR_INVALID_CHAR; return; }
+      if (hi == lo) { bad[t] = q; code[t] = EPA_ERR_QUERY_ALL_GAP; return; }
+      win_begin[q] = lo;
+      win_span[q] = hi - lo;
+      if (!compact) {
+        uint8_t* out = codes + (size_t)q * sites;
+        for (uint32_t w = 0; w < sites; ++w) out[w] = (uint8_t)map[(unsigned char)sq[w]];
+      } else if (stride) {
+        if (hi - lo > stride) { bad[t] = q; code[t] = EPA_ERR_INVALID_ARG; return; }
+        uint8_t* out = codes + (size_t)q * stride;
+        for (uint32_t w = lo; w < hi; ++w) out[w - lo] = (uint8_t)map[(unsigned char)sq[w]];
+        memset(out + (hi - lo), 0, stride - (hi - lo));
+      }
     }
-    uint32_t lo = 0, hi = sites;
-    if (premasking) {  // get_valid_range, src/util/Range.hpp:34-49: only the literal '-'
-      while (lo < hi && sq[lo] == '-') ++lo;
-      while (hi > lo && sq[hi - 1] == '-') --hi;
-      if (hi == lo) { if (bad_query) *bad_query = q; return EPA_ERR_QUERY_ALL_GAP; }
-    }
-    win_begin[q] = lo;
-    win_span[q] = hi - lo;
+  };
+  if (nt == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
   }
+  for (unsigned t = 0; t < nt; ++t)
+    if (code[t] != EPA_OK) { if (bad_query) *bad_query = bad[t]; return code[t]; }
   return EPA_OK;
+}
+
+extern "C" int epa_encode_queries(uint32_t states, uint32_t sites, uint32_t Q,
+                                  const char* const* seqs, int premasking, int aa_x_as_n,
+                                  uint8_t* codes, uint32_t* win_begin, uint32_t* win_span,
+                                  uint32_t* bad_query) {
+  return encode_impl(states, sites, Q, seqs, premasking, aa_x_as_n, false, 0, codes, win_begin, win_span,
+                     bad_query);
+}
+
+extern "C" int epa_encode_queries_compact(uint32_t states, uint32_t sites, uint32_t Q,
+                                          const char* const* seqs, int premasking, int aa_x_as_n,
+                                          uint32_t stride, uint8_t* codes, uint32_t* win_begin,
+                                          uint32_t* win_span, uint32_t* bad_query) {
+  if (stride && !codes) return EPA_ERR_INVALID_ARG;
+  return encode_impl(states, sites, Q, seqs, premasking, aa_x_as_n, true, stride, codes, win_begin,
+                     win_span, bad_query);
 }
 
 // =============================================================================================
@@ -306,6 +346,12 @@ extern "C" int epa_dev_device_count(void) {
 
 extern "C" const char* epa_dev_last_error(const epa_ctx* ctx) {
   return ctx ? ctx->err.c_str() : g_create_err.c_str();
+}
+
+extern "C" int epa_dev_set_query_layout(epa_ctx* ctx, uint32_t code_stride) {
+  if (!ctx) return EPA_ERR_INVALID_ARG;
+  ctx->code_stride = code_stride;
+  return EPA_OK;
 }
 
 extern "C" int epa_dev_set_stream(epa_ctx* ctx, void* s) {
@@ -527,6 +573,8 @@ static int check_windows(epa_ctx* ctx, const uint32_t* hb, const uint32_t* hs, u
                       "Query sequence length not same as reference alignment!");
     mx = std::max(mx, hs[q]);
   }
+  if (ctx->code_stride && mx > ctx->code_stride)
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "a window is longer than the compact code stride");
   *max_span = mx;
   return EPA_OK;
 }
@@ -539,7 +587,7 @@ extern "C" int epa_dev_preplace(epa_ctx* ctx, const uint8_t* q_codes, const uint
   EPA_HIP(ctx, hipSetDevice(ctx->device));
   int rc = epa_dev_build_lookup(ctx);
   if (rc) return rc;
-  const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * ctx->W);
+  const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * (ctx->code_stride ? ctx->code_stride : ctx->W));
   const uint32_t* d_begin = (const uint32_t*)epa_to_device(ctx, 1, win_begin, sizeof(uint32_t) * Q);
   const uint32_t* d_span = (const uint32_t*)epa_to_device(ctx, 2, win_span, sizeof(uint32_t) * Q);
   if (!d_codes || !d_begin || !d_span) return epa_fail(ctx, EPA_ERR_HIP, "query upload failed");
@@ -582,7 +630,7 @@ extern "C" int epa_dev_thorough(epa_ctx* ctx, const epa_pair* pairs, uint64_t n_
       if (pairs[i].branch_id >= ctx->B || pairs[i].seq_id >= Q)
         return epa_fail(ctx, EPA_ERR_INVALID_ARG, "pair index out of range");
   }
-  const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * ctx->W);
+  const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * (ctx->code_stride ? ctx->code_stride : ctx->W));
   const uint32_t* d_begin = (const uint32_t*)epa_to_device(ctx, 1, win_begin, sizeof(uint32_t) * Q);
   const uint32_t* d_span = (const uint32_t*)epa_to_device(ctx, 2, win_span, sizeof(uint32_t) * Q);
   const epa_pair* d_pairs = (const epa_pair*)epa_to_device(ctx, 4, pairs, sizeof(epa_pair) * n_pairs);
@@ -660,7 +708,7 @@ extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const u
     for (uint32_t q = 0; q < Q; ++q) max_span = std::max(max_span, hs[q]);
   }
   if (max_span > ctx->W) max_span = ctx->W;
-  const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * ctx->W);
+  const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * (ctx->code_stride ? ctx->code_stride : ctx->W));
   const uint32_t* d_begin = (const uint32_t*)epa_to_device(ctx, 1, win_begin, sizeof(uint32_t) * Q);
   const uint32_t* d_span = (const uint32_t*)epa_to_device(ctx, 2, win_span, sizeof(uint32_t) * Q);
   if (!d_codes || !d_begin || !d_span) return epa_fail(ctx, EPA_ERR_HIP, "query upload failed");

@@ -64,6 +64,7 @@ struct epa_ctx {
   bool dna_zero0 = false;   // eigenvalue 0 is the (exactly) zero one after the create-time reorder
   BloConsts blo;
   int aa_x_as_n = 0;
+  uint32_t code_stride = 0;  // 0: query codes are Q x W rows; S: compact rows of S bytes (window only)
 
   // HBM-resident reference data
   //   refT   [2B][c*s][W]  eigen-transformed CLVs, component-major (side 0 proximal, 1 distal)

@@ -205,8 +205,9 @@ private:
 
 // encoded chunk of queries (what crosses the C-ABI)
 struct Encoded_Chunk {
-  std::vector<uint8_t> codes;
+  std::vector<uint8_t> codes;  // compact layout: row q = the window of query q, `stride` bytes
   std::vector<uint32_t> win_begin, win_span;
+  uint32_t stride = 0;
 };
 Encoded_Chunk encode_chunk(const MSA& chunk, const Tree& tree, const Options& options);
 

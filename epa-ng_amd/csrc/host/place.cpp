@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <fstream>
+#include <future>
 #include <limits>
 #include <numeric>
 
@@ -40,7 +41,6 @@ Device_Evaluator::~Device_Evaluator() { epa_dev_destroy(ctx_); }
 Encoded_Chunk encode_chunk(const MSA& chunk, const Tree& tree, const Options& options) {
   Encoded_Chunk e;
   const size_t Q = chunk.size(), W = tree.num_sites();
-  e.codes.resize(Q * W);
   e.win_begin.resize(Q);
   e.win_span.resize(Q);
   std::vector<const char*> rows(Q);
@@ -50,14 +50,25 @@ Encoded_Chunk encode_chunk(const MSA& chunk, const Tree& tree, const Options& op
     rows[q] = chunk[q].sequence().c_str();
   }
   uint32_t bad = 0;
-  const int rc = epa_encode_queries((uint32_t)tree.model().num_states(), (uint32_t)W, (uint32_t)Q,
-                                    rows.data(), options.premasking, options.aa_x_as_n,
-                                    e.codes.data(), e.win_begin.data(), e.win_span.data(), &bad);
-  if (rc == EPA_ERR_QUERY_ALL_GAP)  // Tiny_Tree.cpp:153-156
-    throw std::runtime_error{std::string() + "Sequence with header '" + chunk[bad].header() +
-                             "' does not appear to have any non-gap sites!"};
-  if (rc == EPA_ERR_INVALID_CHAR)  // Lookup_Store.hpp:100-108
-    throw std::runtime_error{"char is invalid! (sequence '" + chunk[bad].header() + "')"};
+  auto check = [&](int rc) {
+    if (rc == EPA_ERR_QUERY_ALL_GAP)  // Tiny_Tree.cpp:153-156
+      throw std::runtime_error{std::string() + "Sequence with header '" + chunk[bad].header() +
+                               "' does not appear to have any non-gap sites!"};
+    if (rc == EPA_ERR_INVALID_CHAR)  // Lookup_Store.hpp:100-108
+      throw std::runtime_error{"char is invalid! (sequence '" + chunk[bad].header() + "')"};
+    if (rc != EPA_OK) throw std::runtime_error{"query encoding failed"};
+  };
+  // compact wire format: pass 1 finds the windows, pass 2 writes only the window columns
+  check(epa_encode_queries_compact((uint32_t)tree.model().num_states(), (uint32_t)W, (uint32_t)Q,
+                                   rows.data(), options.premasking, options.aa_x_as_n, 0, nullptr,
+                                   e.win_begin.data(), e.win_span.data(), &bad));
+  uint32_t mx = 1;
+  for (uint32_t s : e.win_span) mx = std::max(mx, s);
+  e.stride = (mx + 15) / 16 * 16;
+  e.codes.resize(Q * (size_t)e.stride);
+  check(epa_encode_queries_compact((uint32_t)tree.model().num_states(), (uint32_t)W, (uint32_t)Q,
+                                   rows.data(), options.premasking, options.aa_x_as_n, e.stride,
+                                   e.codes.data(), e.win_begin.data(), e.win_span.data(), &bad));
   return e;
 }
 
@@ -65,6 +76,7 @@ void place(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, Device_
            std::vector<double>& lnl, const Options&) {
   const size_t Q = chunk.size(), B = tree.num_branches();
   lnl.resize(Q * B);
+  epa_dev_set_query_layout(dev.ctx(), enc.stride);
   const int rc = epa_dev_preplace(dev.ctx(), enc.codes.data(), enc.win_begin.data(),
                                   enc.win_span.data(), (uint32_t)Q, lnl.data());
   if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
@@ -155,6 +167,7 @@ void place_thorough(const Work& to_place, const MSA& chunk, const Encoded_Chunk&
   for (size_t i = 0; i < n; ++i)
     pairs[i] = epa_pair{(uint32_t)to_place[i].branch_id, (uint32_t)to_place[i].sequence_id};
   std::vector<epa_result> res(n);
+  epa_dev_set_query_layout(dev.ctx(), enc.stride);
   const int rc = epa_dev_thorough(dev.ctx(), pairs.data(), n, enc.codes.data(), enc.win_begin.data(),
                                   enc.win_span.data(), (uint32_t)Q, res.data(), nullptr);
   if (rc == EPA_ERR_NEG_INF)  // Tiny_Tree.cpp:209-212
@@ -175,6 +188,7 @@ void place_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, D
   for (;;) {
     pairs.resize(cap);
     res.resize(cap);
+    epa_dev_set_query_layout(dev.ctx(), enc.stride);
     const int rc = epa_dev_place_chunk(dev.ctx(), enc.codes.data(), enc.win_begin.data(),
                                        enc.win_span.data(), (uint32_t)Q, max_span,
                                        options.prescoring_threshold, pairs.data(), res.data(), cap, &n,
@@ -248,10 +262,24 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
   std::vector<Sample> results;
   std::vector<double> lnl;
   size_t done = 0;
+  // The next chunk is sliced and encoded on a host thread while the device works on the current
+  // one (the reference prefetches its next chunk the same way, src/core/place.cpp:190-215).
+  struct Staged { MSA chunk; Encoded_Chunk enc; };
+  auto stage = [&](size_t from) {
+    Staged s;
+    const size_t n = std::min<size_t>(options.chunk_size, all.size() - from);
+    s.chunk.assign(all.begin() + from, all.begin() + from + n);
+    s.enc = encode_chunk(s.chunk, tree, options);
+    return s;
+  };
+  std::future<Staged> next;
+  if (!all.empty()) next = std::async(std::launch::async, stage, (size_t)0);
   while (done < all.size()) {
-    const size_t n = std::min<size_t>(options.chunk_size, all.size() - done);
-    MSA chunk(all.begin() + done, all.begin() + done + n);
-    const Encoded_Chunk enc = encode_chunk(chunk, tree, options);
+    Staged cur = next.get();
+    const MSA& chunk = cur.chunk;
+    const Encoded_Chunk& enc = cur.enc;
+    const size_t n = chunk.size();
+    if (done + n < all.size()) next = std::async(std::launch::async, stage, done + n);
     Work blo_work;
     Sample blo_sample;
     auto t0 = clk::now();

@@ -55,14 +55,14 @@ struct Group {
 
 // window validation (error words read back by preplace_check_status)
 __device__ __forceinline__ void validate_window(uint32_t i, uint32_t begin, uint32_t span, uint32_t W,
-                                                uint32_t* status) {
+                                                uint32_t cmax, uint32_t* status) {
   if (span == 0) atomicMax(&status[0], 0x80000000u | i);                          // all-gap query
-  else if ((uint64_t)begin + span > W) atomicMax(&status[1], 0x80000000u | i);    // width
+  else if ((uint64_t)begin + span > W || span > cmax) atomicMax(&status[1], 0x80000000u | i);  // width
 }
 __global__ void k_validate(const uint32_t* __restrict__ win_begin, const uint32_t* __restrict__ win_span,
-                           uint32_t Q, uint32_t W, uint32_t* __restrict__ status) {
+                           uint32_t Q, uint32_t W, uint32_t cmax, uint32_t* __restrict__ status) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < Q) validate_window(i, win_begin[i], win_span[i], W, status);
+  if (i < Q) validate_window(i, win_begin[i], win_span[i], W, cmax, status);
 }
 
 __global__ void k_iota(uint32_t* v, uint32_t n) {
@@ -164,6 +164,7 @@ __global__ void __launch_bounds__(GQ, ACC ? 2 : 4) k_preplace(const double* __re
                                                  const uint32_t* __restrict__ win_span,
                                                  const uint32_t* __restrict__ perm,
                                                  const Group* __restrict__ groups, uint32_t W,
+                                                 uint32_t cstride, uint32_t crel,
                                                  uint32_t B, size_t codes_bytes, uint32_t want_cls,
                                                  const uint32_t* __restrict__ status,
                                                  double* __restrict__ lnl) {
@@ -190,7 +191,7 @@ __global__ void __launch_bounds__(GQ, ACC ? 2 : 4) k_preplace(const double* __re
     qi = perm[g.start + t];
     begin = win_begin[qi];
     span = win_span[qi];
-    if ((uint64_t)begin + span > W) span = 0;  // invalid window: flagged by the validation pass
+    if ((uint64_t)begin + span > W || (crel && span > cstride)) span = 0;  // invalid window: flagged by the validation pass
   }
   if (t == 0) s_maxspan = 0;
   __syncthreads();
@@ -211,7 +212,8 @@ __global__ void __launch_bounds__(GQ, ACC ? 2 : 4) k_preplace(const double* __re
     // ---- my CH codes as byte offsets (code * 8), packed 4 per register
     uint32_t cw[CW];
     if (mine) {
-      const size_t addr = (size_t)qi * W + begin + cbase;
+      // row of query qi: Q x W layout (window at +begin) or compact (window at 0)
+      const size_t addr = (size_t)qi * cstride + (crel ? 0u : begin) + cbase;
       const size_t a0 = addr & ~(size_t)3;
       const uint32_t sh = (uint32_t)(addr & 3) * 8;
       const size_t last = (codes_bytes - 1) & ~(size_t)3;
@@ -381,7 +383,8 @@ __global__ void __launch_bounds__(256) k_build_lookup2(const double* __restrict_
 __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ codes,
                                                     const uint32_t* __restrict__ win_begin,
                                                     const uint32_t* __restrict__ win_span, uint32_t Q,
-                                                    uint32_t W, uint32_t Wp, uint32_t NP16,
+                                                    uint32_t W, uint32_t cstride, uint32_t crel,
+                                                    uint32_t Wp, uint32_t NP16,
                                                     uint16_t* __restrict__ packed,
                                                     uint16_t* __restrict__ tails,
                                                     uint32_t* __restrict__ keys,
@@ -391,9 +394,10 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
   if (q >= Q) return;
   const uint32_t begin = win_begin[q];
   uint32_t span = win_span[q];
-  if (lane == 0) validate_window(q, begin, span, W, status);
-  if ((uint64_t)begin + span > W) span = 0;  // invalid window (flagged above)
-  const uint8_t* c = codes + (size_t)q * W + begin;
+  const uint32_t cmax = crel ? cstride : 0xffffffffu;
+  if (lane == 0) validate_window(q, begin, span, W, cmax, status);
+  if ((uint64_t)begin + span > W || span > cmax) span = 0;  // invalid window (flagged above)
+  const uint8_t* c = codes + (size_t)q * cstride + (crel ? 0u : begin);
   const uint32_t nfull = span >> 2, ntail = span & 3, npairs = 2 * nfull;
   bool rare = false;
   for (uint32_t p = lane; p < NP16; p += 64) {
@@ -675,6 +679,7 @@ int launch_build_lookup2(epa_ctx* ctx) {
 int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin,
                     const uint32_t* d_span, uint32_t Q, double* d_lnl, uint32_t max_span) {
   const bool pairs = ctx->s == 4 && ctx->lookup2 && !getenv("EPA_PREPLACE_GENERIC");
+  const uint32_t crel = ctx->code_stride ? 1u : 0u, cstride = crel ? ctx->code_stride : ctx->W;
   const uint32_t n_buckets = (ctx->W + SPREAD - 1) / SPREAD;
   const uint32_t Wp = n_buckets * SPREAD;  // key space of one (class, parity) block
   const uint32_t n_blocks = pairs ? 4 : 1, class_blocks = pairs ? 2 : 1;
@@ -711,12 +716,12 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   while (key_bits < 32 && (1ull << key_bits) < (uint64_t)n_blocks * Wp) ++key_bits;
   if (pairs) {
     hipLaunchKernelGGL(k_pack_pairs, dim3((Q + 3) / 4), dim3(256), 0, ctx->stream, d_codes, d_begin,
-                       d_span, Q, ctx->W, Wp, NP16, packed, tails, keys, status);
+                       d_span, Q, ctx->W, cstride, crel, Wp, NP16, packed, tails, keys, status);
     EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, keys, sorted_keys, iota, perm, Q, 0,
                                            key_bits, ctx->stream));
   } else {
     hipLaunchKernelGGL(k_validate, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, d_begin, d_span, Q,
-                       ctx->W, status);
+                       ctx->W, crel ? cstride : 0xffffffffu, status);
     int wbits = 1;
     while (wbits < 32 && (1ull << wbits) <= (uint64_t)ctx->W) ++wbits;
     EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, d_begin, sorted_keys, iota, perm, Q, 0, wbits,
@@ -739,7 +744,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   // dispatched dynamically (items differ in cost, partial groups are cheaper)
   const dim3 grid(pairs ? (uint32_t)std::min<uint64_t>((uint64_t)max_groups * ntiles, (uint64_t)ctx->n_cu * (acc ? 2 : 4))
                         : max_groups * ntiles);
-  const size_t codes_bytes = (size_t)Q * ctx->W;
+  const size_t codes_bytes = (size_t)Q * cstride;
   const uint32_t want_cls = pairs ? 1u : 0u;
   epa_timer_start(ctx, ctx->t_preplace);
 #define PRE2(A)                                                                                      \
@@ -756,7 +761,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace<NC, A>,                                \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
     hipLaunchKernelGGL((k_preplace<NC, A>), grid, dim3(GQ), lds, ctx->stream, ctx->lookup, d_codes, \
-                       d_begin, d_span, perm, groups, ctx->W, ctx->B, codes_bytes, want_cls, status, d_lnl); \
+                       d_begin, d_span, perm, groups, ctx->W, cstride, crel, ctx->B, codes_bytes, want_cls, status, d_lnl); \
   } while (0)
   if (ctx->ncols == 16) { if (acc) PRE(16, true); else PRE(16, false); }
   else { if (acc) PRE(24, true); else PRE(24, false); }

@@ -41,7 +41,8 @@ struct ThArgsAA {
   const uint32_t* scSum;   // [B][W]
   const double* blen;      // [B]
   const epa_pair* pairs;
-  const uint8_t* codes;    // [Q][W]
+  const uint8_t* codes;    // [Q][cstride]; window at +begin (crel == 0, cstride == W) or at 0 (compact)
+  uint32_t cstride, crel;
   const uint32_t* win_begin;
   const uint32_t* win_span;
   epa_result* out;
@@ -146,7 +147,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
     const double* Xt = a.refT + ((size_t)(2 * b) * 80 + (size_t)k * S) * cW + begin;
     const double* Dt = a.refT + ((size_t)(2 * b + 1) * 80 + (size_t)k * S) * cW + begin;
     const uint32_t* scp = a.scSum + (size_t)b * cW + begin;
-    const uint8_t* qc = a.codes + (size_t)q * cW + begin;
+    const uint8_t* qc = a.codes + (size_t)q * a.cstride + (a.crel ? 0u : begin);
     const double orig = a.blen[b];
     const uint32_t npass = (n + 63) / 64;
 
@@ -483,6 +484,8 @@ int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, 
   a.blen = ctx->blen;
   a.pairs = d_pairs;
   a.codes = d_codes;
+  a.crel = ctx->code_stride ? 1u : 0u;
+  a.cstride = a.crel ? ctx->code_stride : ctx->W;
   a.win_begin = d_begin;
   a.win_span = d_span;
   a.out = d_out;

@@ -43,7 +43,8 @@ struct ThArgs {
   const double* blen;      // [B]
   const double* qt;        // [16 columns][4]   U^-1 image of each column's tip vector
   const epa_pair* pairs;
-  const uint8_t* codes;    // [Q][W]
+  const uint8_t* codes;    // [Q][cstride]; window at +begin (crel == 0, cstride == W) or at 0 (compact)
+  uint32_t cstride, crel;
   const uint32_t* win_begin;
   const uint32_t* win_span;
   epa_result* out;
@@ -247,7 +248,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   auto ldX = [&](int c, uint32_t soff) { return *reinterpret_cast<const double*>(ref + (soff + (uint32_t)c * W8)); };
   auto ldD = [&](int c, uint32_t soff) { return *reinterpret_cast<const double*>(ref + (soff + (uint32_t)(16 + c) * W8)); };
   const uint32_t* scp = a.scSum + (size_t)b * cW + begin;
-  const uint8_t* qc = a.codes + (size_t)q * cW + begin;
+  const uint8_t* qc = a.codes + (size_t)q * a.cstride + (a.crel ? 0u : begin);
   const double orig = a.blen[b];
 
   SiteState<NCH> st;
@@ -464,6 +465,8 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
   a.qt = ctx->dmodel->qt;
   a.pairs = d_pairs;
   a.codes = d_codes;
+  a.crel = ctx->code_stride ? 1u : 0u;
+  a.cstride = a.crel ? ctx->code_stride : ctx->W;
   a.win_begin = d_begin;
   a.win_span = d_span;
   a.out = d_out;

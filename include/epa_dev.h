@@ -161,6 +161,21 @@ int epa_encode_queries(uint32_t states, uint32_t sites, uint32_t Q, const char* 
                        uint32_t* win_span, uint32_t* bad_query);
 
 /*
+ * Compact query layout (the wire format for real runs: a 150-column read of a 1500-column
+ * alignment is 150 bytes instead of 1500).  Row q holds ONLY the window of query q:
+ * codes[q*stride + i] = code of alignment column win_begin[q] + i, i < win_span[q] <= stride;
+ * the rest of the row is padding.  Two passes: call with stride == 0 (codes may be NULL) to get
+ * the windows, pick stride >= max(win_span) (a multiple of 16 keeps rows aligned), call again.
+ * epa_dev_set_query_layout() tells a context which layout the q_codes of the following
+ * preplace / thorough / place_chunk calls use: 0 (default) = Q x W rows as produced by
+ * epa_encode_queries(), S > 0 = compact rows of S bytes.  Results are identical.
+ */
+int epa_encode_queries_compact(uint32_t states, uint32_t sites, uint32_t Q, const char* const* seqs,
+                               int premasking, int aa_x_as_n, uint32_t stride, uint8_t* codes,
+                               uint32_t* win_begin, uint32_t* win_span, uint32_t* bad_query);
+int epa_dev_set_query_layout(epa_ctx* ctx, uint32_t code_stride);
+
+/*
  * Replaces place() (src/core/place.cpp:41-95): lnl[q*B + b] = sum over the query's window of
  * T[b][site][code(q,site)]  (Lookup_Store::sum_precomputed_sitelk, Lookup_Store.hpp:110-141,
  * same summation order).  pendant = pendant_default and distal = branch_length/2 are implied.

@@ -216,3 +216,39 @@ def test_full_size_cfg2_properties():
     assert np.allclose(lw.sum(1), 1.0)
     p2, r2 = ev.place_chunk(codes, wb, ws, max_span=150)
     assert np.array_equal(p2, pairs) and np.array_equal(r2["lnl"], res["lnl"])
+
+
+@pytest.mark.parametrize("states", [4, 20])
+def test_compact_query_layout_gives_identical_results(states):
+    """q_codes as compact window rows (epa_dev_set_query_layout) vs aligned Q x W rows: the three
+    device calls return bit-identical tables / pairs / results (host and device buffers)."""
+    import torch
+    from epa_ng_amd import synth
+    if states == 4:
+        w = synth.dna_workload(32, 500, 700, 120, (41, 42, 43))
+    else:
+        w = synth.aa_workload(16, 260, 150, 70, (44, 45, 46))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=states, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    reads = list(w["reads"])
+    reads[3] = reads[3].replace("A", "N", 2)
+    full = epa.encode_queries(states, reads)
+    comp = epa.encode_queries(states, reads, compact=True)
+    assert comp[0].shape[1] < full[0].shape[1]
+    t_full = ev.preplace(*full)
+    t_comp = ev.preplace(*comp)
+    assert np.array_equal(t_full, t_comp)
+    pf, rf = ev.place_chunk(*full)
+    pc, rc = ev.place_chunk(*comp)
+    assert np.array_equal(pf, pc)
+    for k in ("lnl", "pendant_length", "distal_length"):
+        assert np.array_equal(rf[k], rc[k])
+    r2 = ev.thorough(pc, *comp)
+    assert np.array_equal(r2["lnl"], rc["lnl"])
+    # device-resident compact buffers
+    dc = torch.from_numpy(comp[0]).cuda()
+    db = torch.from_numpy(comp[1].view(np.int32)).cuda()
+    ds = torch.from_numpy(comp[2].view(np.int32)).cuda()
+    t_dev = ev.preplace(dc, db, ds)
+    assert np.array_equal(t_dev, t_full)

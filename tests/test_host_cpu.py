@@ -123,3 +123,31 @@ def test_heuristics_against_numpy():
     assert len(pb) == 50 * int(np.ceil(0.1 * 37))
     pb, ps = hostlib.heuristic(lnl, "baseball")
     assert np.all(np.bincount(ps) <= 40) and np.all(np.bincount(ps) >= 6)
+
+
+def test_compact_query_encoding_matches_aligned_rows():
+    """epa_encode_queries_compact (the wire format of the host pipeline): same windows, row q =
+    the window columns of the aligned row; multi-threaded encode reports the first offender."""
+    import epa_ng_amd as epa
+    rng = np.random.RandomState(3)
+    W = 300
+    rows = []
+    for i in range(4000):
+        span = int(rng.randint(1, 120))
+        begin = int(rng.randint(0, W - span + 1))
+        body = "".join(rng.choice(list("ACGTNRY-"), span))
+        body = "A" + body[1:-1] + ("C" if span > 1 else "")
+        rows.append("-" * begin + body[:span] + "-" * (W - begin - span))
+    full, wb, ws = epa.encode_queries(4, rows)
+    comp, wb2, ws2 = epa.encode_queries(4, rows, compact=True)
+    assert np.array_equal(wb, wb2) and np.array_equal(ws, ws2)
+    assert comp.shape[1] % 16 == 0 and comp.shape[1] >= ws.max() and comp.shape[1] < W
+    for q in range(0, len(rows), 37):
+        assert np.array_equal(comp[q, :ws[q]], full[q, wb[q]:wb[q] + ws[q]])
+        assert not comp[q, ws[q]:].any()
+    big = rows * 3                                  # > 1 MiB of characters: several encoder threads
+    big[7000] = "-" * W
+    big[9000] = "J" + "A" * (W - 1)
+    with pytest.raises(epa.EpaError) as ei:
+        epa.encode_queries(4, big, compact=True)
+    assert "query 7000" in str(ei.value)
