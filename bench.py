@@ -191,6 +191,9 @@ def main():
     cpu = None
     parity = None
     if not a.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (bench contract)
+        # the oracle's OpenMP threads = the CPUs this process may really use (a container can see
+        # 256 CPUs and be limited to 16 by its cgroup quota: oversubscribing would slow the baseline)
+        eff = hostlib.configure_threads()
         from oracle_lib import Oracle, lib as orc_lib
         ns = min(a.cpu_sample, Q)
         sample = reads[a.warmup * Q: a.warmup * Q + ns]
@@ -204,7 +207,7 @@ def main():
         lnl_cpu = o.preplace(sample)
         tl, tp, td = o.thorough(prs["branch_id"], prs["seq_id"], sample)
         cpu_t = time.perf_counter() - c0
-        cores = orc_lib().orc_max_threads()
+        cores = min(eff, orc_lib().orc_max_threads())
         cpu = {"value": round(ns / cpu_t, 2), "unit": "placements/s", "cores": cores, "kind": "port",
                "sample": "%d reads of step 0 through the oracle's OpenMP preplace (B=%d) + thorough "
                          "(%d pairs), lookups prebuilt" % (ns, B, len(prs))}

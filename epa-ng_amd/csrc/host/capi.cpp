@@ -49,6 +49,9 @@ void* epa_host_ref_create(const char* newick, int n_seqs, const char* const* lab
 
 void epa_host_ref_destroy(void* h) { delete static_cast<Ref*>(h); }
 
+// OpenMP thread cap of this process (affinity + cgroup quota); returns the count in effect
+int epa_host_configure_threads() { return epa::configure_host_threads(); }
+
 void epa_host_ref_dims(void* h, uint32_t* states, uint32_t* cats, uint32_t* sites, uint32_t* branches) {
   const Tree& t = *static_cast<Ref*>(h)->tree;
   *states = t.model().num_states(); *cats = t.model().num_ratecats();

@@ -171,7 +171,7 @@ private:
   struct Rec { int next = -1, back = -1, tip = -1; double length = 0.0; };
   int new_rec();
   int parse_subtree(const char*& p, double& len);
-  void compute_clv(int rec);
+  void compute_all_clvs();
   void side(int rec, const double*& clv, const uint8_t*& tip, const uint32_t*& sc) const;
 
   Model model_;
@@ -186,6 +186,11 @@ private:
   std::vector<std::vector<uint32_t>> scaler_;    // per record
   std::vector<uint32_t> tipmap_;
 };
+
+// Caps OpenMP at the CPUs this process may really use (affinity mask and cgroup cpu.max quota:
+// a container that sees 256 CPUs but is limited to 16 crawls with 256 spinning threads).
+// Called once by the entry points; returns the thread count in effect.
+int configure_host_threads();
 
 // ---- readers / writers
 MSA read_fasta(const std::string& path);
@@ -237,7 +242,11 @@ void filter(Sample& sample, const Options& options);  // :192-204
 // The chunk loop (src/core/place.cpp:173-251): reads `query_file` in chunks, writes
 // <outdir>/epa_result.jplace.  rank/world: contiguous query sharding as local_seq_package
 // (src/net/epa_mpi_util.cpp:10-30); every rank returns its own samples, rank 0 writes.
-struct Run_Stats { size_t queries = 0, pairs = 0; double seconds_place = 0, seconds_thorough = 0; };
+struct Run_Stats {
+  size_t queries = 0, pairs = 0;
+  double seconds_place = 0, seconds_thorough = 0;  // device calls (fused path: all in seconds_place)
+  double seconds_setup = 0, seconds_read = 0, seconds_stage_wait = 0, seconds_post = 0, seconds_write = 0;
+};
 Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std::string& outdir,
                      const Options& options, const std::string& invocation, int device = 0);
 

@@ -10,9 +10,28 @@
 #include <limits>
 #include <numeric>
 
+#include <omp.h>
+#include <sched.h>
+
 #include "epa_host.hpp"
 
 namespace epa {
+
+int configure_host_threads() {
+  static int configured = 0;
+  if (configured) return configured;
+  int n = omp_get_max_threads();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+  std::ifstream f("/sys/fs/cgroup/cpu.max");  // cgroup v2: "<quota> <period>" or "max <period>"
+  std::string quota;
+  double period = 0;
+  if (f >> quota >> period && quota != "max" && period > 0)
+    n = std::min(n, std::max(1, (int)std::ceil(std::stod(quota) / period)));
+  omp_set_num_threads(n);
+  configured = n;
+  return n;
+}
 
 namespace {
 const double kDefaultBranchLength = -std::log(0.9);
@@ -93,6 +112,7 @@ static void row_lwr(const double* row, size_t B, std::vector<double>& lwr) {
 }
 
 Work apply_heuristic(const std::vector<double>& lnl, size_t Q, size_t B, const Options& options) {
+  configure_host_threads();
   std::vector<std::vector<uint32_t>> keep(Q);
 #pragma omp parallel
   {
@@ -208,6 +228,7 @@ void place_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, D
 }
 
 void compute_and_set_lwr(Sample& sample) {
+  configure_host_threads();
 #pragma omp parallel for schedule(dynamic)
   for (long j = 0; j < (long)sample.size(); ++j) {
     auto& pq = sample[j];
@@ -226,6 +247,7 @@ static void sort_by_lwr(PQuery& pq) {
 }
 
 void filter(Sample& sample, const Options& options) {
+  configure_host_threads();
   const double thresh = options.support_threshold;
   if (thresh < 0.0 || thresh > 1.0)
     throw std::range_error{"thresh is not a valid likelihood weight ratio (outside of [0,1])"};
@@ -256,9 +278,14 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
                      const Options& options, const std::string& invocation, int device) {
   using clk = std::chrono::steady_clock;
   Run_Stats st;
+  configure_host_threads();
   const size_t B = tree.num_branches();
+  auto ts = clk::now();
   Device_Evaluator dev(tree, options, device);
+  st.seconds_setup = std::chrono::duration<double>(clk::now() - ts).count();
+  ts = clk::now();
   MSA all = read_fasta(query_file);
+  st.seconds_read = std::chrono::duration<double>(clk::now() - ts).count();
   std::vector<Sample> results;
   std::vector<double> lnl;
   size_t done = 0;
@@ -275,7 +302,9 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
   std::future<Staged> next;
   if (!all.empty()) next = std::async(std::launch::async, stage, (size_t)0);
   while (done < all.size()) {
+    auto tw = clk::now();
     Staged cur = next.get();
+    st.seconds_stage_wait += std::chrono::duration<double>(clk::now() - tw).count();
     const MSA& chunk = cur.chunk;
     const Encoded_Chunk& enc = cur.enc;
     const size_t n = chunk.size();
@@ -307,6 +336,7 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
     compute_and_set_lwr(blo_sample);
     filter(blo_sample, options);
     results.push_back(std::move(blo_sample));
+    st.seconds_post += std::chrono::duration<double>(clk::now() - t2).count();
     st.pairs += blo_work.size();
     st.seconds_place += std::chrono::duration<double>(t1 - t0).count();
     st.seconds_thorough += std::chrono::duration<double>(t2 - t1).count();
@@ -315,9 +345,12 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
   st.queries = done;
   std::string dir = outdir;
   if (!dir.empty() && dir.back() != '/') dir += "/";
+  ts = clk::now();
   std::ofstream os(dir + "epa_result.jplace");
   if (!os) throw std::runtime_error{"cannot open " + dir + "epa_result.jplace"};
   write_jplace(os, results, tree.numbered_newick(options.precision), invocation, options.precision);
+  os.flush();
+  st.seconds_write = std::chrono::duration<double>(clk::now() - ts).count();
   return st;
 }
 

@@ -26,6 +26,7 @@ def host_lib():
                                           C.POINTER(C.c_char_p), C.c_char_p, C.c_int, dp, dp,
                                           C.c_int, dp, dp]
         L.epa_host_ref_destroy.argtypes = [C.c_void_p]
+        L.epa_host_configure_threads.restype = C.c_int
         u32p = C.POINTER(C.c_uint32)
         L.epa_host_ref_dims.argtypes = [C.c_void_p, u32p, u32p, u32p, u32p]
         L.epa_host_ref_tree_logl.restype = C.c_double
@@ -57,6 +58,12 @@ def _strs(lst):
     arr = (C.c_char_p * len(lst))()
     arr[:] = [s if isinstance(s, bytes) else s.encode() for s in lst]
     return arr
+
+
+def configure_threads():
+    """caps this process's OpenMP threads at the CPUs it may really use (affinity mask and cgroup
+    quota); returns the count.  Shared runtime: also governs the test oracle's OpenMP loops."""
+    return host_lib().epa_host_configure_threads()
 
 
 class Reference:
