@@ -14,6 +14,7 @@
 #pragma once
 
 #include <cstddef>
+#include <cstdio>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -194,6 +195,23 @@ int configure_host_threads();
 
 // ---- readers / writers
 MSA read_fasta(const std::string& path);
+// chunked FASTA reader of the query file (the reference's MSA_Stream, src/seq/MSA_Stream.hpp)
+class Fasta_Stream {
+public:
+  explicit Fasta_Stream(const std::string& path);
+  ~Fasta_Stream();
+  Fasta_Stream(const Fasta_Stream&) = delete;
+  // appends up to max_seqs sequences to `out`; returns how many (0 = end of file)
+  size_t read_next(MSA& out, size_t max_seqs);
+private:
+  bool next_line(const char*& b, const char*& e);
+  std::FILE* f_ = nullptr;
+  std::vector<char> buf_;
+  size_t pos_ = 0, len_ = 0;
+  bool eof_ = false, pending_header_ = false;
+  std::string header_, seq_;
+  char up_[256];
+};
 void write_jplace(std::ostream& os, const std::vector<Sample>& chunks, const std::string& newick,
                   const std::string& invocation, unsigned int precision);
 

@@ -283,32 +283,32 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
   auto ts = clk::now();
   Device_Evaluator dev(tree, options, device);
   st.seconds_setup = std::chrono::duration<double>(clk::now() - ts).count();
-  ts = clk::now();
-  MSA all = read_fasta(query_file);
-  st.seconds_read = std::chrono::duration<double>(clk::now() - ts).count();
+  Fasta_Stream reader(query_file);
   std::vector<Sample> results;
   std::vector<double> lnl;
   size_t done = 0;
-  // The next chunk is sliced and encoded on a host thread while the device works on the current
+  // The next chunk is read and encoded on a host thread while the device works on the current
   // one (the reference prefetches its next chunk the same way, src/core/place.cpp:190-215).
-  struct Staged { MSA chunk; Encoded_Chunk enc; };
-  auto stage = [&](size_t from) {
+  struct Staged { MSA chunk; Encoded_Chunk enc; double seconds_read = 0; };
+  auto stage = [&]() {
     Staged s;
-    const size_t n = std::min<size_t>(options.chunk_size, all.size() - from);
-    s.chunk.assign(all.begin() + from, all.begin() + from + n);
-    s.enc = encode_chunk(s.chunk, tree, options);
+    const auto r0 = clk::now();
+    reader.read_next(s.chunk, options.chunk_size);
+    s.seconds_read = std::chrono::duration<double>(clk::now() - r0).count();
+    if (!s.chunk.empty()) s.enc = encode_chunk(s.chunk, tree, options);
     return s;
   };
-  std::future<Staged> next;
-  if (!all.empty()) next = std::async(std::launch::async, stage, (size_t)0);
-  while (done < all.size()) {
+  std::future<Staged> next = std::async(std::launch::async, stage);
+  for (;;) {
     auto tw = clk::now();
     Staged cur = next.get();
     st.seconds_stage_wait += std::chrono::duration<double>(clk::now() - tw).count();
+    st.seconds_read += cur.seconds_read;
+    if (cur.chunk.empty()) break;
     const MSA& chunk = cur.chunk;
     const Encoded_Chunk& enc = cur.enc;
     const size_t n = chunk.size();
-    if (done + n < all.size()) next = std::async(std::launch::async, stage, done + n);
+    next = std::async(std::launch::async, stage);
     Work blo_work;
     Sample blo_sample;
     auto t0 = clk::now();

@@ -151,3 +151,48 @@ def test_compact_query_encoding_matches_aligned_rows():
     with pytest.raises(epa.EpaError) as ei:
         epa.encode_queries(4, big, compact=True)
     assert "query 7000" in str(ei.value)
+
+
+def test_fasta_stream_chunked_reader(tmp_path):
+    """Fasta_Stream (the query reader of the chunk loop): multi-line records, CRLF, lower case,
+    blank lines, header comments, no trailing newline; chunk boundaries must not lose or split
+    records.  Driven through a tiny C++ program linked against libepa_host.so."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include "epa_host.hpp"
+#include <cstdio>
+#include <cstdlib>
+int main(int argc, char** argv) {
+  epa::Fasta_Stream in(argv[1]);
+  const size_t chunk = std::strtoul(argv[2], nullptr, 10);
+  for (;;) {
+    epa::MSA m;
+    const size_t n = in.read_next(m, chunk);
+    if (!n) break;
+    std::printf("CHUNK %zu\n", n);
+    for (auto& s : m) std::printf("%s %s\n", s.header().c_str(), s.sequence().c_str());
+  }
+}
+''')
+    exe = tmp_path / "t"
+    pkg = os.path.join(root, "epa-ng_amd")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"),
+                    "-I", os.path.join(pkg, "csrc", "host"), str(src), "-o", str(exe),
+                    "-L", pkg, "-lepa_host", "-lepa_dev", "-Wl,-rpath," + pkg], check=True)
+    recs = [("q%d" % i, "ACGT-" * (3 + i % 4) + "nnac"[: i % 5]) for i in range(11)]
+    text = ""
+    for i, (h, s) in enumerate(recs):
+        text += ">%s some comment\r\n" % h
+        half = len(s) // 2
+        text += s[:half].lower() + "\r\n\r\n" + s[half:] + ("\n" if i + 1 < len(recs) else "")
+    fa = tmp_path / "q.fasta"
+    fa.write_bytes(text.encode())
+    for chunk in (1, 3, 4, 11, 50):
+        out = subprocess.run([str(exe), str(fa), str(chunk)], check=True, capture_output=True, text=True).stdout
+        lines = out.strip().split("\n")
+        sizes = [int(l.split()[1]) for l in lines if l.startswith("CHUNK")]
+        got = [tuple(l.split()) for l in lines if not l.startswith("CHUNK")]
+        assert sizes == [min(chunk, len(recs) - k) for k in range(0, len(recs), chunk)]
+        assert got == [(h, s.upper()) for h, s in recs]
