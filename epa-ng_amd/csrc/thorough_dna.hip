@@ -442,6 +442,224 @@ __global__ void __launch_bounds__(64, 2) k_thorough_dna(const ThArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Long windows (more than 24 x 64 sites): same algorithm, the sumtable lives in an HBM slab
+// ([17][Wpad] doubles per resident wave: 16 components + the per-site scaler count) instead of
+// registers, the site chunks are a runtime loop.  Throughput is secondary here: the path exists
+// so that full-length queries of long alignments are placed at all.
+// ---------------------------------------------------------------------------------------------
+template <class Deriv>
+__device__ __forceinline__ double newton_fn(Deriv&& deriv, double x1, double xguess, double x2, double tol,
+                                            int max_iters, uint32_t& evals) {
+  double rts = xguess, f, df, xl, xh, dx;
+  if (rts < x1) rts = x1;
+  if (rts > x2) rts = x2;
+  deriv(rts, f, df);
+  ++evals;
+  if (!isfinite(f) || !isfinite(df)) return NAN;
+  if (df >= 0.0 && fabs(f) < tol) return rts;
+  if (f < 0.0) { xl = rts; xh = x2; } else { xh = rts; xl = x1; }
+  for (int i = 1; i <= max_iters; ++i) {
+    if (df <= 0.0 || (((rts - xh) * df - f) * ((rts - xl) * df - f) >= 0.0)) {
+      dx = 0.5 * (xh - xl);
+      rts = xl + dx;
+      if (xl == rts) return rts;
+    } else {
+      dx = f / df;
+      const double temp = rts;
+      rts -= dx;
+      if (temp == rts) return rts;
+    }
+    if (fabs(dx) < tol || i == max_iters) return rts;
+    if (rts < x1) rts = x1;
+    deriv(rts, f, df);
+    ++evals;
+    if (!isfinite(f) || !isfinite(df)) return NAN;
+    if (df > 0.0 && fabs(f) < tol) return rts;
+    if (f < 0.0) xl = rts; else xh = rts;
+  }
+  return NAN;
+}
+
+template <bool ZERO0>
+__global__ void __launch_bounds__(64, 2) k_thorough_dna_long(const ThArgs a) {
+  __shared__ double tab[64];
+  __shared__ double qts[64];
+  const int lane = threadIdx.x;
+  qts[lane] = a.qt[lane];
+  LaneConst lc;
+  {
+    const int lk = (lane >> 2) & 3, lx = lane & 3;
+    lc.slot = lane >> 4;
+    lc.lr = a.m.lam[lx] * a.m.rate[lk];
+    lc.w = a.m.w[lk];
+    lc.cN = lc.slot == 0 ? lc.w : (lc.slot == 1 ? lc.w * lc.lr : (lc.slot == 2 ? lc.w * lc.lr * lc.lr : 0.0));
+  }
+  __syncthreads();
+  const ModelDNA& m = a.m;
+  double* slab = a.sscratch + (size_t)blockIdx.x * 17 * a.Wpad;  // [17][Wpad]
+  const size_t cW = a.W;
+  uint32_t wrounds = 0, wevals = 0, wreverts = 0;
+  for (uint64_t pid = blockIdx.x; pid < a.n_pairs; pid += gridDim.x) {
+    const epa_pair pr = a.pairs[pid];
+    const uint32_t b = pr.branch_id, q = pr.seq_id;
+    const uint32_t begin = a.win_begin[q], n = a.win_span[q];
+    const uint32_t nch = (n + 63) / 64;
+    const double* Xt = a.refT + (size_t)(2 * b) * 16 * cW + begin;
+    const double* Dt = a.refT + (size_t)(2 * b + 1) * 16 * cW + begin;
+    const uint32_t* scp = a.scSum + (size_t)b * cW + begin;
+    const uint8_t* qc = a.codes + (size_t)q * a.cstride + (a.crel ? 0u : begin);
+    const double orig = a.blen[b];
+
+    // inner CLV toward the query at (td, tx), S = (U^-1 I) o qt -> slab; returns the window lnL
+    auto score = [&](double td_, double tx_, double tp_, bool first) -> double {
+      const double tl = lc.slot == 0 ? td_ : (lc.slot == 1 ? tx_ : tp_);
+      table_publish(tab, lane, exp(lc.lr * tl) * (lc.slot == 2 ? lc.w : 1.0));
+      double ew[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
+      double mant = 1.0;
+      int ex = 0;
+      for (uint32_t ch = 0; ch < nch; ++ch) {
+        const uint32_t site = ch * 64 + lane;
+        const bool valid = site < n;
+        const uint32_t s = valid ? site : 0;
+        double It[16];
+        uint32_t resc;
+        if (first) {
+          const double* It0 = a.refI + (size_t)b * 16 * cW + begin;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) It[c] = It0[(size_t)c * cW + s];
+          resc = a.resc0[(size_t)b * cW + begin + s];
+        } else {
+          double D[16], X[16];
+#pragma unroll
+          for (int c = 0; c < 16; ++c) { D[c] = Dt[(size_t)c * cW + s]; X[c] = Xt[(size_t)c * cW + s]; }
+          inner_site(m, D, tab, X, tab + 16, It, resc);
+        }
+        const double* qv = qts + qc[s] * 4;
+        double l0 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            const double sv = It[k * 4 + x] * qv[x];
+            if (valid) slab[(size_t)(k * 4 + x) * a.Wpad + site] = sv;
+            l0 = fma(sv, ew[k * 4 + x], l0);
+          }
+        const uint32_t sc = scp[s] + resc;
+        if (valid) slab[(size_t)16 * a.Wpad + site] = (double)sc;
+        if (!valid) l0 = 1.0;
+        mant *= __builtin_amdgcn_frexp_mant(l0);
+        ex += __builtin_amdgcn_frexp_exp(l0) - (valid ? 256 * (int)sc : 0);
+        ex += __builtin_amdgcn_frexp_exp(mant);
+        mant = __builtin_amdgcn_frexp_mant(mant);
+      }
+      __threadfence_block();
+      return wave_sum(log(mant) + (double)ex * 0.6931471805599453094);
+    };
+    // inner CLV toward distal: I' = (P_pend q) o (P_prox X); S = Dt o (U^-1 I') -> slab
+    auto distal_sumtable = [&](double tp_, double tx_) {
+      table_publish(tab, lane, exp(lc.lr * (lc.slot == 0 ? tp_ : tx_)));
+      for (uint32_t ch = 0; ch < nch; ++ch) {
+        const uint32_t site = ch * 64 + lane;
+        const bool valid = site < n;
+        const uint32_t s = valid ? site : 0;
+        double Qv[16], X[16], D[16], It[16];
+        const double* qv = qts + qc[s] * 4;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const double v = qv[x];
+          Qv[x] = v; Qv[4 + x] = v; Qv[8 + x] = v; Qv[12 + x] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { X[c] = Xt[(size_t)c * cW + s]; D[c] = Dt[(size_t)c * cW + s]; }
+        uint32_t r;
+        inner_site(m, Qv, tab, X, tab + 16, It, r);
+        if (valid) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) slab[(size_t)c * a.Wpad + site] = D[c] * It[c];
+        }
+      }
+      __threadfence_block();
+    };
+    auto deriv = [&](double t, double& f, double& df) {
+      table_publish(tab, lane, exp(lc.lr * t) * lc.cN);
+      double e[16], e1[16], e2[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { e[i] = tab[i]; e1[i] = tab[16 + i]; e2[i] = tab[32 + i]; }
+      double fl = 0.0, dfl = 0.0;
+      for (uint32_t ch = 0; ch < nch; ++ch) {
+        const uint32_t site = ch * 64 + lane;
+        const bool valid = site < n;
+        const uint32_t s = valid ? site : 0;
+        double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const double sv = slab[(size_t)i * a.Wpad + s];
+          l0 = fma(sv, e[i], l0);
+          if (!(ZERO0 && (i & 3) == 0)) { l1 = fma(sv, e1[i], l1); l2 = fma(sv, e2[i], l2); }
+        }
+        const double inv = fast_rcp(l0);
+        const double d1 = -l1 * inv;
+        const double d2 = fma(d1, d1, -l2 * inv);
+        if (valid) { fl += d1; dfl += d2; }
+      }
+      f = wave_sum(fl);
+      df = wave_sum(dfl);
+    };
+
+    double tp = a.blo.pendant_default, td = orig * 0.5, tx = orig * 0.5;
+    uint32_t evals = 0, rounds = 0, reverted = 0;
+    double loglikelihood = -score(td, tx, tp, a.refI != nullptr);
+    uint32_t smoothings = a.blo.max_rounds;
+    while (smoothings) {
+      const double old_td = td, old_tp = tp;
+      double xmin = a.blo.min_branch, xmax = a.blo.max_branch, xtol = xmin / 10.0;
+      double xguess = tp;
+      if (xguess < xmin || xguess > xmax) xguess = a.blo.default_branch;
+      double xres = newton_fn(deriv, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
+      if (xres > 0.0) tp = xres;
+      distal_sumtable(tp, tx);
+      xguess = td;
+      xmin = fmin(a.blo.min_branch / 2.0, orig / 2.0);
+      xtol = xmin / 10.0;
+      xmax = orig - xtol;
+      if (xguess < xmin || xguess > xmax) xguess = orig / 2.0;
+      xres = newton_fn(deriv, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
+      if (xres > 0.0) { td = xres; tx = orig - xres; }
+      const double new_ll = -score(td, tx, tp, false);
+      ++rounds;
+      if (new_ll - loglikelihood > new_ll * 1e-14) {
+        tp = old_tp; td = old_td; tx = orig - old_td;
+        reverted = 1;
+        break;
+      }
+      --smoothings;
+      if (fabs(new_ll - loglikelihood) < a.blo.epsilon) smoothings = 0;
+      loglikelihood = new_ll;
+    }
+    if (lane == 0) {
+      const double lnl = -loglikelihood;
+      epa_result r;
+      r.lnl = lnl;
+      r.pendant_length = tp;
+      r.distal_length = (orig / (td + tx)) * td;
+      a.out[pid] = r;
+      if (!isfinite(lnl)) {
+        if (atomicAdd(&a.stats[3], 1ull) == 0) a.stats[4] = ((unsigned long long)b << 32) | q;
+      }
+    }
+    wrounds += rounds; wevals += evals; wreverts += reverted;
+  }
+  if (lane == 0) {
+    atomicAdd(&a.stats[0], (unsigned long long)wrounds);
+    atomicAdd(&a.stats[1], (unsigned long long)wevals);
+    atomicAdd(&a.stats[2], (unsigned long long)wreverts);
+  }
+}
+
 }  // namespace
 
 int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
@@ -501,8 +719,16 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
   else if (nch <= 16) LAUNCH(16);
   else if (nch <= 24) LAUNCH(24);
   else {
-    epa_timer_stop(ctx, ctx->t_thorough);
-    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "thorough: query windows longer than 1536 sites");
+    // long windows: sumtable slab in HBM, one resident wave per slab
+    const uint32_t nlong = (uint32_t)std::min<uint64_t>(n_pairs, 2048);
+    a.Wpad = nch * 64;
+    a.sscratch = (double*)epa_scratch(ctx, 7, sizeof(double) * (size_t)nlong * 17 * a.Wpad);
+    if (!a.sscratch) {
+      epa_timer_stop(ctx, ctx->t_thorough);
+      return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(long-window sumtable scratch)");
+    }
+    if (ctx->dna_zero0) hipLaunchKernelGGL((k_thorough_dna_long<true>), dim3(nlong), dim3(64), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_thorough_dna_long<false>), dim3(nlong), dim3(64), 0, ctx->stream, a);
   }
 #undef LAUNCH
   epa_timer_stop(ctx, ctx->t_thorough);

@@ -222,3 +222,26 @@ def test_preplace_pair_path_bitwise_equals_generic(monkeypatch):
     monkeypatch.delenv("EPA_PREPLACE_GENERIC")
     assert np.array_equal(fast, generic)  # same association order, bit for bit
     assert np.max(np.abs(fast - o.preplace(reads))) < LNL_TOL
+
+
+def test_thorough_long_windows_hbm_slab():
+    """windows longer than 24 x 64 sites take k_thorough_dna_long (sumtable in an HBM slab);
+    mixed with a short query in the same call (the launch is sized by the longest window)."""
+    w = synth_case(12, 2100, 10, 1700, seeds=(51, 52, 53))
+    short = synth_case(12, 2100, 3, 90, seeds=(51, 52, 54))["reads"]
+    o = Oracle(w["newick"], w["labels"], w["seqs"], 4, w["subst"], w["freqs"], w["rates"])
+    e = evaluator_from_oracle(o, w["rates"], w["freqs"])
+    reads = list(w["reads"]) + list(short)
+    for compact in (False, True):
+        codes, wb, ws = epa.encode_queries(4, reads, compact=compact)
+        assert ws.max() > 1536 and ws.min() < 100
+        lnl = e.preplace(codes, wb, ws)
+        assert np.max(np.abs(lnl - o.preplace(reads))) < LNL_TOL
+        pairs = all_pairs(o.B, len(reads))
+        res = e.thorough(pairs, codes, wb, ws)
+        tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
+        assert np.max(np.abs(res["lnl"] - tl)) < LNL_TOL
+        assert np.max(np.abs(res["pendant_length"] - tp) / np.maximum(1.0, tp)) < 1e-6
+        assert np.max(np.abs(res["distal_length"] - td)) < 1e-6
+        assert e.last_stats["rounds"] == o.last_stats["rounds"]
+        assert e.last_stats["reverts"] == o.last_stats["reverts"]
