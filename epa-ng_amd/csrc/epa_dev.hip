@@ -364,7 +364,7 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
-  for (int i = 0; i < 8; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+  for (int i = 0; i < epa_ctx::N_SCRATCH; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
   if (ctx->refT) (void)hipFree(ctx->refT);
   if (ctx->scSum) (void)hipFree(ctx->scSum);
   if (ctx->blen) (void)hipFree(ctx->blen);
@@ -720,7 +720,7 @@ extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const u
   rc = launch_preplace(ctx, d_codes, d_begin, d_span, Q, d_lnl, max_span);
   if (rc) return rc;
   uint64_t n = 0;
-  rc = launch_select(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, &n);  // syncs once
+  rc = launch_select(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, &n, d_span);  // syncs once
   if (rc) return rc;
   rc = preplace_check_status(ctx);
   if (rc) return rc;

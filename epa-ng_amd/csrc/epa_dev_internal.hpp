@@ -84,10 +84,15 @@ struct epa_ctx {
   std::vector<double> h_blen;
 
   // per-call scratch (grown on demand)
-  void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t scratch_sz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static constexpr int N_SCRATCH = 10;
+  void* scratch[N_SCRATCH] = {};
+  size_t scratch_sz[N_SCRATCH] = {};
 
   uint32_t* d_status = nullptr;   // window-validation words of the last preplace (in scratch 6)
+  // span-class histogram of the candidate pairs of the last select (valid for the thorough call
+  // that follows it in the fused path: saves one device round trip)
+  uint32_t cls_hist[16] = {};
+  uint64_t cls_hist_pairs = 0;  // 0 = not valid
   uint32_t select_cap = 64;       // staging slots per query of the candidate selection
 
   EvTimer t_lookup, t_preplace, t_thorough, t_select;
@@ -110,6 +115,18 @@ void epa_timer_stop(epa_ctx* ctx, EvTimer& t);
       return epa_fail(ctx, EPA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
   } while (0)
 
+// ---- span classes of the thorough kernels: a launch covers pairs whose window needs the same
+// kernel instantiation, so one long window does not drag a whole chunk onto the big-register
+// variant.  DNA: sites per lane NCH in {1,2,3,4,6,8,12,16,24} (class 0..8), 9 = HBM-slab kernel;
+// 20 states: 0 = LDS-resident slab (window <= EPA_AA_LDS_MAX_SPAN), 1 = HBM slab.
+constexpr int EPA_N_CLS = 10;
+constexpr uint32_t EPA_AA_LDS_MAX_SPAN = 102;
+__host__ __device__ inline int epa_span_class(int states, uint32_t span) {
+  if (states != 4) return span <= EPA_AA_LDS_MAX_SPAN ? 0 : 1;
+  const uint32_t nch = (span + 63) / 64;
+  return nch <= 4 ? (nch ? (int)nch - 1 : 0) : nch <= 6 ? 4 : nch <= 8 ? 5 : nch <= 12 ? 6 : nch <= 16 ? 7 : nch <= 24 ? 8 : 9;
+}
+
 // ---- kernel launchers
 int launch_transform(epa_ctx* ctx, const double* d_clv_or_null, const uint8_t* d_tip_or_null,
                      const uint32_t* d_tipmap, uint32_t tipmap_size, double* dst);
@@ -121,5 +138,9 @@ int preplace_check_status(epa_ctx* ctx);
 int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
                     const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
                     epa_result* d_out, unsigned long long* d_stats);
+int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_order, uint64_t n_pairs,
+                       const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span,
+                       uint32_t max_span, bool want_lds, epa_result* d_out, unsigned long long* d_stats);
 int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshold,
-                  epa_pair* d_pairs, uint64_t max_pairs, uint64_t* n_pairs);
+                  epa_pair* d_pairs, uint64_t max_pairs, uint64_t* n_pairs,
+                  const uint32_t* d_span = nullptr);  // d_span: also histogram the span classes

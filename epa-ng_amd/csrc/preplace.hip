@@ -643,6 +643,23 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
   if (lane == 0) counts[q] = min(taken, cap);
 }
 
+// span-class histogram of the selected pairs: sum of the per-query candidate counts by the class
+// of the query's window (one atomic per wave and class present)
+__global__ void __launch_bounds__(256) k_class_hist(const uint32_t* __restrict__ counts,
+                                                   const uint32_t* __restrict__ win_span, uint32_t Q,
+                                                   int states, uint32_t* __restrict__ hist) {
+  const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  const int cls = q < Q ? epa_span_class(states, win_span[q]) : -1;
+  const uint32_t n = q < Q ? counts[q] : 0;
+  for (int c = 0; c < EPA_N_CLS; ++c) {
+    if (__ballot(cls == c) == 0ull) continue;
+    uint32_t v = cls == c ? n : 0;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&hist[c], v);
+  }
+}
+
 __global__ void __launch_bounds__(256) k_compact(const unsigned long long* __restrict__ stage,
                                                  const uint32_t* __restrict__ counts,
                                                  const uint32_t* __restrict__ offsets, uint32_t Q,
@@ -785,7 +802,8 @@ int preplace_check_status(epa_ctx* ctx) {
 }
 
 int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshold,
-                  epa_pair* d_pairs, uint64_t max_pairs, uint64_t* n_pairs) {
+                  epa_pair* d_pairs, uint64_t max_pairs, uint64_t* n_pairs, const uint32_t* d_span) {
+  ctx->cls_hist_pairs = 0;
   const uint32_t B = ctx->B;
   if (B > 64 * 64)
     return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "select_candidates: more than 4096 branches");
@@ -822,7 +840,10 @@ int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshol
 #undef SEL
     EPA_HIP(ctx, rocprim::exclusive_scan(temp, scan_bytes, counts, offsets, 0u, Q + 1,
                                          rocprim::plus<uint32_t>(), ctx->stream));
-    uint32_t hst[4] = {0, 0, 0, 0}, total = 0;
+    uint32_t hst[8 + EPA_N_CLS] = {}, total = 0;
+    if (d_span)  // class histogram in status[8 ..]: read back with the total, no extra round trip
+      hipLaunchKernelGGL(k_class_hist, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, counts, d_span, Q,
+                         ctx->s, status + 8);
     EPA_HIP(ctx, hipMemcpyAsync(&total, offsets + Q, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     EPA_HIP(ctx, hipMemcpyAsync(hst, status, sizeof(hst), hipMemcpyDeviceToHost, ctx->stream));
     EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -846,6 +867,10 @@ int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshol
     epa_timer_stop(ctx, ctx->t_select);
     EPA_HIP(ctx, hipGetLastError());
     *n_pairs = total;
+    if (d_span) {
+      for (int c = 0; c < EPA_N_CLS; ++c) ctx->cls_hist[c] = hst[8 + c];
+      ctx->cls_hist_pairs = total;
+    }
     return EPA_OK;
   }
 }

@@ -41,6 +41,7 @@ struct ThArgsAA {
   const uint32_t* scSum;   // [B][W]
   const double* blen;      // [B]
   const epa_pair* pairs;
+  const uint32_t* order;   // pair indices of this launch (span class), or null = 0..n_pairs-1
   const uint8_t* codes;    // [Q][cstride]; window at +begin (crel == 0, cstride == W) or at 0 (compact)
   uint32_t cstride, crel;
   const uint32_t* win_begin;
@@ -139,7 +140,8 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
   }
 
   uint32_t wrounds = 0, wevals = 0, wreverts = 0;
-  for (uint64_t pid = blockIdx.x; pid < a.n_pairs; pid += gridDim.x) {
+  for (uint64_t pidx = blockIdx.x; pidx < a.n_pairs; pidx += gridDim.x) {
+    const uint64_t pid = a.order ? a.order[pidx] : pidx;
     const epa_pair pr = a.pairs[pid];
     const uint32_t b = pr.branch_id, q = pr.seq_id;
     const uint32_t begin = a.win_begin[q], n = a.win_span[q];
@@ -469,9 +471,9 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
 
 }  // namespace
 
-int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
-                       const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
-                       epa_result* d_out, unsigned long long* d_stats) {
+int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_order, uint64_t n_pairs,
+                       const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span,
+                       uint32_t max_span, bool want_lds, epa_result* d_out, unsigned long long* d_stats) {
   if (ctx->c != 4)
     return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "thorough (20 states): needs 4 rate categories");
   ThArgsAA a;
@@ -483,6 +485,7 @@ int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, 
   a.scSum = ctx->scSum;
   a.blen = ctx->blen;
   a.pairs = d_pairs;
+  a.order = d_order;
   a.codes = d_codes;
   a.crel = ctx->code_stride ? 1u : 0u;
   a.cstride = a.crel ? ctx->code_stride : ctx->W;
@@ -495,7 +498,9 @@ int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, 
   uint32_t nwg = (uint32_t)std::min<uint64_t>(n_pairs, 512);  // 2 resident workgroups per CU
   const uint32_t wpad_lds = (max_span + 1) / 2 * 2 + 2;  // + spare column for lanes past the window
   // two workgroups per CU: static + dynamic LDS <= 80 KB each
-  const bool lds_slab = sizeof(Shared) + sizeof(double) * 80 * wpad_lds <= 80 * 1024 && !getenv("EPA_AA_HBM_SLAB");
+  static_assert(sizeof(Shared) + sizeof(double) * 80 * ((EPA_AA_LDS_MAX_SPAN + 1) / 2 * 2 + 2) <= 80 * 1024,
+                "EPA_AA_LDS_MAX_SPAN does not fit two workgroups per CU");
+  const bool lds_slab = want_lds && max_span <= EPA_AA_LDS_MAX_SPAN && !getenv("EPA_AA_HBM_SLAB");
   if (lds_slab) {
     a.Wpad = wpad_lds;
     a.sscratch = nullptr;
@@ -508,12 +513,10 @@ int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, 
     const int dyn = (int)(sizeof(double) * 80 * a.Wpad);
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_thorough_aa<true>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
   }
-  epa_timer_start(ctx, ctx->t_thorough);
   if (lds_slab)
     hipLaunchKernelGGL(k_thorough_aa<true>, dim3(nwg), dim3(256), sizeof(double) * 80 * a.Wpad, ctx->stream, a);
   else
     hipLaunchKernelGGL(k_thorough_aa<false>, dim3(nwg), dim3(256), 0, ctx->stream, a);
-  epa_timer_stop(ctx, ctx->t_thorough);
   EPA_HIP(ctx, hipGetLastError());
   return EPA_OK;
 }

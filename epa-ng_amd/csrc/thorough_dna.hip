@@ -26,6 +26,9 @@
 #include "epa_dev_internal.hpp"
 #include "wave_util.hpp"
 
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -43,6 +46,7 @@ struct ThArgs {
   const double* blen;      // [B]
   const double* qt;        // [16 columns][4]   U^-1 image of each column's tip vector
   const epa_pair* pairs;
+  const uint32_t* order;   // pair indices of this launch (span class), or null = 0..n_pairs-1
   const uint8_t* codes;    // [Q][cstride]; window at +begin (crel == 0, cstride == W) or at 0 (compact)
   uint32_t cstride, crel;
   const uint32_t* win_begin;
@@ -232,10 +236,11 @@ __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, 
 }
 
 template <int NCH, bool ZERO0>
-__device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid, const int lane,
+__device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pidx, const int lane,
                                              double* tab, const double* qts, const LaneConst& lc,
                                              uint32_t (&wstat)[3]) {
   const ModelDNA& m = a.m;
+  const uint64_t pid = a.order ? a.order[pidx] : pidx;
   const epa_pair pr = a.pairs[pid];
   const uint32_t b = pr.branch_id, q = pr.seq_id;
   const uint32_t begin = a.win_begin[q], n = a.win_span[q];
@@ -501,7 +506,8 @@ __global__ void __launch_bounds__(64, 2) k_thorough_dna_long(const ThArgs a) {
   double* slab = a.sscratch + (size_t)blockIdx.x * 17 * a.Wpad;  // [17][Wpad]
   const size_t cW = a.W;
   uint32_t wrounds = 0, wevals = 0, wreverts = 0;
-  for (uint64_t pid = blockIdx.x; pid < a.n_pairs; pid += gridDim.x) {
+  for (uint64_t pidx = blockIdx.x; pidx < a.n_pairs; pidx += gridDim.x) {
+    const uint64_t pid = a.order ? a.order[pidx] : pidx;
     const epa_pair pr = a.pairs[pid];
     const uint32_t b = pr.branch_id, q = pr.seq_id;
     const uint32_t begin = a.win_begin[q], n = a.win_span[q];
@@ -662,38 +668,31 @@ __global__ void __launch_bounds__(64, 2) k_thorough_dna_long(const ThArgs a) {
 
 }  // namespace
 
-int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
-                       const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
-                       epa_result* d_out, unsigned long long* d_stats);
+namespace {
 
-int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
-                    const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
-                    epa_result* d_out, unsigned long long* d_stats) {
-  if (ctx->s == 20)
-    return launch_thorough_aa(ctx, d_pairs, n_pairs, d_codes, d_begin, d_span, max_span, d_out, d_stats);
-  ThArgs a;
-  a.m = ctx->dna;
-  a.blo = ctx->blo;
-  a.refT = ctx->refT;
-  // filled by k_build_lookup; until then every pair computes its own starting vector
-  a.refI = ctx->lookup_built ? ctx->refI : nullptr;
-  a.resc0 = ctx->resc0;
-  a.scSum = ctx->scSum;
-  a.blen = ctx->blen;
-  a.qt = ctx->dmodel->qt;
-  a.pairs = d_pairs;
-  a.codes = d_codes;
-  a.crel = ctx->code_stride ? 1u : 0u;
-  a.cstride = a.crel ? ctx->code_stride : ctx->W;
-  a.win_begin = d_begin;
-  a.win_span = d_span;
-  a.out = d_out;
-  a.stats = d_stats;
-  a.sscratch = nullptr;
-  a.n_pairs = n_pairs;
-  a.W = ctx->W;
-  a.Wpad = 0;
-  const uint32_t nch = (max_span + 63) / 64;
+__global__ void __launch_bounds__(256) k_pair_class(const epa_pair* __restrict__ pairs, uint64_t n,
+                                                   const uint32_t* __restrict__ win_span, int states,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ idx,
+                                                   uint32_t* __restrict__ hist) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cls = i < n ? epa_span_class(states, win_span[pairs[i].seq_id]) : -1;
+  if (i < n) {
+    if (keys) { keys[i] = (uint32_t)cls; idx[i] = (uint32_t)i; }
+  }
+  if (hist) {
+    for (int c = 0; c < EPA_N_CLS; ++c) {
+      const unsigned long long bal = __ballot(cls == c);
+      if (bal && (threadIdx.x & 63) == 0) atomicAdd(&hist[c], (uint32_t)__popcll(bal));
+    }
+  }
+}
+
+}  // namespace
+
+// One launch per span class present (see epa_span_class).  `order` = this class's pair indices
+// in their original (branch-major) order, null when the launch covers all pairs.
+static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t max_span) {
+  const uint64_t n_pairs = a.n_pairs;
   // Grid: single-wave workgroups, 2048 of them are resident (8 per CU, 2 per SIMD at this
   // kernel's VGPR budget).  Oversubscribing the resident set lets the hardware dispatcher do the
   // load balancing (pairs differ 10x in cost): a finished wave's slot is refilled at once.
@@ -703,35 +702,132 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
   uint64_t want = (uint64_t)256 * 8 * per_slot;
   if (want > n_pairs) want = n_pairs;
   uint32_t nwg = (uint32_t)((want + 7) / 8 * 8);
-  epa_timer_start(ctx, ctx->t_thorough);
 #define LAUNCH(N)                                                                              \
   do {                                                                                         \
     if (ctx->dna_zero0) hipLaunchKernelGGL((k_thorough_dna<N, true>), dim3(nwg), dim3(64), 0, ctx->stream, a); \
     else hipLaunchKernelGGL((k_thorough_dna<N, false>), dim3(nwg), dim3(64), 0, ctx->stream, a); \
   } while (0)
-  if (nch <= 1) LAUNCH(1);
-  else if (nch <= 2) LAUNCH(2);
-  else if (nch <= 3) LAUNCH(3);
-  else if (nch <= 4) LAUNCH(4);
-  else if (nch <= 6) LAUNCH(6);
-  else if (nch <= 8) LAUNCH(8);
-  else if (nch <= 12) LAUNCH(12);
-  else if (nch <= 16) LAUNCH(16);
-  else if (nch <= 24) LAUNCH(24);
-  else {
-    // long windows: sumtable slab in HBM, one resident wave per slab
-    const uint32_t nlong = (uint32_t)std::min<uint64_t>(n_pairs, 2048);
-    a.Wpad = nch * 64;
-    a.sscratch = (double*)epa_scratch(ctx, 7, sizeof(double) * (size_t)nlong * 17 * a.Wpad);
-    if (!a.sscratch) {
-      epa_timer_stop(ctx, ctx->t_thorough);
-      return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(long-window sumtable scratch)");
+  switch (cls) {
+    case 0: LAUNCH(1); break;
+    case 1: LAUNCH(2); break;
+    case 2: LAUNCH(3); break;
+    case 3: LAUNCH(4); break;
+    case 4: LAUNCH(6); break;
+    case 5: LAUNCH(8); break;
+    case 6: LAUNCH(12); break;
+    case 7: LAUNCH(16); break;
+    case 8: LAUNCH(24); break;
+    default: {
+      // long windows: sumtable slab in HBM, one resident wave per slab
+      const uint32_t nlong = (uint32_t)std::min<uint64_t>(n_pairs, 2048);
+      a.Wpad = (max_span + 63) / 64 * 64;
+      a.sscratch = (double*)epa_scratch(ctx, 7, sizeof(double) * (size_t)nlong * 17 * a.Wpad);
+      if (!a.sscratch) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(long-window sumtable scratch)");
+      if (ctx->dna_zero0) hipLaunchKernelGGL((k_thorough_dna_long<true>), dim3(nlong), dim3(64), 0, ctx->stream, a);
+      else hipLaunchKernelGGL((k_thorough_dna_long<false>), dim3(nlong), dim3(64), 0, ctx->stream, a);
     }
-    if (ctx->dna_zero0) hipLaunchKernelGGL((k_thorough_dna_long<true>), dim3(nlong), dim3(64), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((k_thorough_dna_long<false>), dim3(nlong), dim3(64), 0, ctx->stream, a);
   }
 #undef LAUNCH
+  return EPA_OK;
+}
+
+int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
+                    const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
+                    epa_result* d_out, unsigned long long* d_stats) {
+  if (n_pairs > 0xffffffffull) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "thorough: more than 2^32 pairs per call");
+  // ---- span classes present in this call
+  uint32_t hist[EPA_N_CLS] = {};
+  const int cmax = epa_span_class(ctx->s, max_span);
+  const bool cached = ctx->cls_hist_pairs == n_pairs && n_pairs != 0;
+  if (cached) {
+    for (int c = 0; c < EPA_N_CLS; ++c) hist[c] = ctx->cls_hist[c];
+  } else if (cmax == 0) {
+    hist[0] = (uint32_t)n_pairs;  // every window is in the smallest class
+  }
+  ctx->cls_hist_pairs = 0;
+  // scratch 8: [hist 64 B | keys n | idx n | keys_out n | order n | rocprim temp]
+  size_t temp_bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, temp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                  (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n_pairs, 0, 4, ctx->stream);
+  const size_t nb = (sizeof(uint32_t) * n_pairs + 255) & ~(size_t)255;
+  uint32_t* d_hist = nullptr;
+  uint32_t *d_keys = nullptr, *d_idx = nullptr, *d_keys2 = nullptr, *d_order = nullptr;
+  auto carve = [&]() -> int {
+    char* base = (char*)epa_scratch(ctx, 8, 256 + 4 * nb + temp_bytes);
+    if (!base) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(span-class scratch)");
+    d_hist = (uint32_t*)base;
+    d_keys = (uint32_t*)(base + 256); d_idx = (uint32_t*)(base + 256 + nb);
+    d_keys2 = (uint32_t*)(base + 256 + 2 * nb); d_order = (uint32_t*)(base + 256 + 3 * nb);
+    return EPA_OK;
+  };
+  const dim3 cgrid((uint32_t)((n_pairs + 255) / 256));
+  bool have_keys = false;
+  if (!cached && cmax != 0) {  // pairs from the caller: histogram (and keys) in one pass, one round trip
+    int rc = carve();
+    if (rc) return rc;
+    EPA_HIP(ctx, hipMemsetAsync(d_hist, 0, 64, ctx->stream));
+    hipLaunchKernelGGL(k_pair_class, cgrid, dim3(256), 0, ctx->stream, d_pairs, n_pairs, d_span, ctx->s, d_keys,
+                       d_idx, d_hist);
+    EPA_HIP(ctx, hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, ctx->stream));
+    EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    have_keys = true;
+  }
+  int present = 0;
+  for (int c = 0; c < EPA_N_CLS; ++c) present += hist[c] != 0;
+  const uint32_t* order = nullptr;
+  if (present > 1) {  // stable partition by class: branch-major order survives inside a class
+    if (!have_keys) {
+      int rc = carve();
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_pair_class, cgrid, dim3(256), 0, ctx->stream, d_pairs, n_pairs, d_span, ctx->s,
+                         d_keys, d_idx, (uint32_t*)nullptr);
+    }
+    void* temp = (char*)d_order + nb;
+    EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, d_keys, d_keys2, d_idx, d_order, (size_t)n_pairs, 0, 4,
+                                           ctx->stream));
+    order = d_order;
+  }
+  epa_timer_start(ctx, ctx->t_thorough);
+  int rc = EPA_OK;
+  uint64_t off = 0;
+  // window bound of a class (slab sizing of the 20-state LDS kernel, the long-window kernel)
+  static const uint32_t dna_bound[EPA_N_CLS] = {64, 128, 192, 256, 384, 512, 768, 1024, 1536, 0xffffffffu};
+  for (int c = 0; c < EPA_N_CLS && rc == EPA_OK; ++c) {
+    if (!hist[c]) continue;
+    const uint32_t* ord = order ? order + off : nullptr;
+    off += hist[c];
+    if (ctx->s == 20) {
+      const uint32_t bound = c == 0 ? std::min(max_span, EPA_AA_LDS_MAX_SPAN) : max_span;
+      rc = launch_thorough_aa(ctx, d_pairs, ord, hist[c], d_codes, d_begin, d_span, bound, c == 0, d_out, d_stats);
+      continue;
+    }
+    ThArgs a;
+    a.m = ctx->dna;
+    a.blo = ctx->blo;
+    a.refT = ctx->refT;
+    // filled by k_build_lookup; until then every pair computes its own starting vector
+    a.refI = ctx->lookup_built ? ctx->refI : nullptr;
+    a.resc0 = ctx->resc0;
+    a.scSum = ctx->scSum;
+    a.blen = ctx->blen;
+    a.qt = ctx->dmodel->qt;
+    a.pairs = d_pairs;
+    a.order = ord;
+    a.codes = d_codes;
+    a.crel = ctx->code_stride ? 1u : 0u;
+    a.cstride = a.crel ? ctx->code_stride : ctx->W;
+    a.win_begin = d_begin;
+    a.win_span = d_span;
+    a.out = d_out;
+    a.stats = d_stats;
+    a.sscratch = nullptr;
+    a.n_pairs = hist[c];
+    a.W = ctx->W;
+    a.Wpad = 0;
+    rc = launch_thorough_dna_class(ctx, a, c, std::min(max_span, dna_bound[c]));
+  }
   epa_timer_stop(ctx, ctx->t_thorough);
+  if (rc) return rc;
   EPA_HIP(ctx, hipGetLastError());
   return EPA_OK;
 }

@@ -252,3 +252,38 @@ def test_compact_query_layout_gives_identical_results(states):
     ds = torch.from_numpy(comp[2].view(np.int32)).cuda()
     t_dev = ev.preplace(dc, db, ds)
     assert np.array_equal(t_dev, t_full)
+
+
+@pytest.mark.parametrize("states", [4, 20])
+def test_mixed_window_lengths_dispatch_by_span_class(states):
+    """One chunk whose windows span several kernel classes (DNA: 1..24 sites per lane and the
+    HBM-slab kernel; 20 states: LDS and HBM slab): pairs are partitioned by class on the device,
+    results come back in pair order and equal the oracle's."""
+    from epa_ng_amd import synth
+    rng = np.random.RandomState(9)
+    if states == 4:
+        W, lens = 1900, [20, 70, 130, 200, 300, 420, 700, 900, 1300, 1700]
+        base = synth.dna_workload(10, W, 2, 100, (61, 62, 63))
+    else:
+        W, lens = 330, [30, 64, 100, 102, 103, 128, 200, 300]
+        base = synth.aa_workload(10, W, 2, 50, (64, 65, 66))
+    reads = []
+    for i, n in enumerate(lens * 2):
+        r, _ = synth.make_reads(base["seqs"], 1, n, 0.05, 700 + i, states=states)
+        reads.append(r[0])
+    o = Oracle(base["newick"], base["labels"], base["seqs"], states, base["subst"], base["freqs"], base["rates"])
+    ref = hostlib.Reference(base["newick"], base["labels"], base["seqs"], states=states, subst=base["subst"],
+                            freqs=base["freqs"], rates=base["rates"])
+    ev = ref.evaluator()
+    codes, wb, ws = epa.encode_queries(states, reads, compact=True)
+    pairs, res = ev.place_chunk(codes, wb, ws)                      # class histogram from the select
+    assert np.all(np.diff(pairs["branch_id"].astype(np.int64)) >= 0)
+    tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
+    assert np.max(np.abs(res["lnl"] - tl)) < 1e-6
+    assert np.max(np.abs(res["distal_length"] - td)) < 1e-6
+    rounds = o.last_stats["rounds"]
+    assert ev.last_stats["rounds"] == rounds
+    perm = rng.permutation(len(pairs))                              # caller-supplied pairs, any order
+    r2 = ev.thorough(pairs[perm], codes, wb, ws)
+    assert np.array_equal(r2["lnl"], res["lnl"][perm])
+    assert ev.last_stats["rounds"] == rounds
