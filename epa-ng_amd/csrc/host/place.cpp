@@ -314,7 +314,7 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
     auto t0 = clk::now();
     auto t1 = t0;
     const bool fused = options.prescoring && options.device_select && !options.baseball &&
-                       !options.prescoring_by_percentage && B <= 4096;
+                       !options.prescoring_by_percentage && B <= 65536;
     if (fused) {
       // default configuration: the whole chunk body runs on the GPU (epa_dev_place_chunk), the
       // Q x B table never crosses PCIe

@@ -643,6 +643,63 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
   if (lane == 0) counts[q] = min(taken, cap);
 }
 
+// Same selection for references with more than 4096 branches: the row does not fit the register
+// file, so it is streamed from HBM/L2 once per pass (max, total, then one pass per selected
+// branch: 3-4 on typical data); taken branches are remembered in a per-lane bitmask
+// (element i lives in lane i % 64, bit i / 64; up to 64 x 64 x NW branches).
+template <int NW>
+__global__ void __launch_bounds__(256) k_select_big(const double* __restrict__ lnl, uint32_t Q, uint32_t B,
+                                                    double threshold, uint32_t cap,
+                                                    unsigned long long* __restrict__ stage,
+                                                    uint32_t* __restrict__ counts,
+                                                    uint32_t* __restrict__ status) {
+  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  if (q >= Q) return;
+  const double* src = lnl + (size_t)q * B;
+  unsigned long long takenmask[NW];
+#pragma unroll
+  for (int w = 0; w < NW; ++w) takenmask[w] = 0ull;
+  double mx = -INFINITY;
+  for (uint32_t i = lane; i < B; i += 64) mx = fmax(mx, src[i]);
+  mx = wave_max(mx);
+  double tot = 0.0;
+  for (uint32_t i = lane; i < B; i += 64) tot += exp(src[i] - mx);
+  tot = wave_add(tot);
+  double sum = 0.0;
+  uint32_t taken = 0;
+  unsigned long long* out = stage + (size_t)q * cap;
+  while (taken < B && sum < threshold) {
+    double best = -INFINITY;
+    uint32_t bi = 0xffffffffu;
+    for (uint32_t i = lane, r = 0; i < B; i += 64, ++r) {
+      const double v = src[i];
+      const bool free_ = !((takenmask[r >> 6] >> (r & 63)) & 1ull);
+      if (free_ && v > best) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+      const double ob = __shfl_xor(best, o);
+      const uint32_t oi = __shfl_xor(bi, o);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (bi == 0xffffffffu) break;
+    sum += exp(best - mx) / tot;
+    if ((bi & 63u) == lane) {
+      const uint32_t r = bi >> 6;
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        if ((uint32_t)w == (r >> 6)) takenmask[w] |= 1ull << (r & 63);
+    }
+    if (lane == 0) {
+      if (taken < cap) out[taken] = ((unsigned long long)bi << 32) | q;
+      else atomicMax(&status[2], taken + 1);
+    }
+    ++taken;
+  }
+  if (lane == 0) counts[q] = min(taken, cap);
+}
+
 // span-class histogram of the selected pairs: sum of the per-query candidate counts by the class
 // of the query's window (one atomic per wave and class present)
 __global__ void __launch_bounds__(256) k_class_hist(const uint32_t* __restrict__ counts,
@@ -805,8 +862,8 @@ int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshol
                   epa_pair* d_pairs, uint64_t max_pairs, uint64_t* n_pairs, const uint32_t* d_span) {
   ctx->cls_hist_pairs = 0;
   const uint32_t B = ctx->B;
-  if (B > 64 * 64)
-    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "select_candidates: more than 4096 branches");
+  if (B > 64 * 64 * 16)
+    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "select_candidates: more than 65536 branches");
   for (;;) {
     const uint32_t cap = ctx->select_cap;
     size_t scan_bytes = 0, sort_bytes = 0;
@@ -835,8 +892,11 @@ int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshol
     const dim3 grid((Q + 3) / 4);
     const int nr = (int)((B + 63) / 64);
 #define SEL(N) hipLaunchKernelGGL(k_select<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, cap, stage, counts, status)
+#define SELBIG(N) hipLaunchKernelGGL(k_select_big<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, cap, stage, counts, status)
     if (nr <= 2) SEL(2); else if (nr <= 4) SEL(4); else if (nr <= 8) SEL(8); else if (nr <= 16) SEL(16);
-    else if (nr <= 32) SEL(32); else SEL(64);
+    else if (nr <= 32) SEL(32); else if (nr <= 64) SEL(64);
+    else if (nr <= 128) SELBIG(2); else if (nr <= 256) SELBIG(4); else SELBIG(16);
+#undef SELBIG
 #undef SEL
     EPA_HIP(ctx, rocprim::exclusive_scan(temp, scan_bytes, counts, offsets, 0u, Q + 1,
                                          rocprim::plus<uint32_t>(), ctx->stream));

@@ -287,3 +287,25 @@ def test_mixed_window_lengths_dispatch_by_span_class(states):
     r2 = ev.thorough(pairs[perm], codes, wb, ws)
     assert np.array_equal(r2["lnl"], res["lnl"][perm])
     assert ev.last_stats["rounds"] == rounds
+
+
+def test_large_reference_more_than_4096_branches():
+    """B = 4397 (> 64 x 64): candidate selection streams the row instead of holding it in
+    registers (k_select_big); fused chunk vs the oracle and vs the host restatement."""
+    from epa_ng_amd import synth
+    w = synth.dna_workload(2200, 64, 48, 40, (71, 72, 73))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    assert ref.B == 2 * 2200 - 3
+    ev = ref.evaluator()
+    o = Oracle(w["newick"], w["labels"], w["seqs"], 4, w["subst"], w["freqs"], w["rates"])
+    codes, wb, ws = epa.encode_queries(4, w["reads"], compact=True)
+    lnl = ev.preplace(codes, wb, ws)
+    assert np.max(np.abs(lnl - o.preplace(w["reads"]))) < 1e-6
+    # 40-column reads against 4397 branches: flat likelihoods, > 100 candidates per read
+    pairs, res = ev.place_chunk(codes, wb, ws, max_pairs=len(w["reads"]) * ref.B)
+    hb, hs = hostlib.heuristic(lnl, "dynamic", 0.99999)
+    assert sorted(zip(hb.tolist(), hs.tolist())) == sorted(zip(pairs["branch_id"].tolist(), pairs["seq_id"].tolist()))
+    assert np.all(np.diff(pairs["branch_id"].astype(np.int64)) >= 0)
+    tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], w["reads"])
+    assert np.max(np.abs(res["lnl"] - tl)) < 1e-6
