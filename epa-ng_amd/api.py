@@ -94,6 +94,7 @@ def dev_lib():
         L.epa_dev_place_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                           C.c_uint32, C.c_double, C.c_void_p, C.c_void_p,
                                           C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(_Stats)]
+        L.epa_dev_tree_logl.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
         L.epa_dev_last_kernel_ms.restype = C.c_double
         L.epa_dev_last_kernel_ms.argtypes = [C.c_void_p, C.c_char_p]
         _LIB = L
@@ -296,6 +297,12 @@ class Evaluator:
         if host:
             return pairs_out[:n.value], results_out[:n.value]
         return n.value
+
+    def tree_logl(self, branch=0):
+        """log-likelihood of the reference tree evaluated on the device at `branch`"""
+        v = C.c_double(0.0)
+        self._check(self.L.epa_dev_tree_logl(self.h, branch, C.byref(v)))
+        return v.value
 
     def kernel_ms(self, which):
         return self.L.epa_dev_last_kernel_ms(self.h, which.encode())

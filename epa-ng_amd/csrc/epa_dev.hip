@@ -378,7 +378,9 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
   delete ctx;
 }
 
-static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx) {
+static int precompute_from_tree(epa_ctx* ctx, const epa_tree_desc* t, const uint32_t* d_tipmap);
+
+static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const epa_tree_desc* tree = nullptr) {
   const int s = (int)d->states, c_in = (int)d->rate_cats;
   if (!(s == 4 || s == 20)) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "states must be 4 or 20");
   if (c_in < 1 || c_in > EPA_MAX_CATS) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "rate_cats out of range");
@@ -390,9 +392,9 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx) {
   if (d->prop_invar != 0.0)
     return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "prop_invar > 0 (+I) is not implemented yet");
   if (!d->eigenvals || !d->eigenvecs_u || !d->eigenvecs_uinv || !d->freqs || !d->rates ||
-      !d->rate_weights || !d->prox_clv || !d->branch_length)
+      !d->rate_weights || (!tree && !d->prox_clv) || !d->branch_length)
     return epa_fail(ctx, EPA_ERR_INVALID_ARG, "null model / reference pointer in descriptor");
-  if (!d->dist_clv && !d->dist_tipchars)
+  if (!tree && !d->dist_clv && !d->dist_tipchars)
     return epa_fail(ctx, EPA_ERR_INVALID_ARG, "descriptor has neither dist_clv nor dist_tipchars");
   ctx->device = device;
   ctx->s = s; ctx->c = c; ctx->W = d->sites; ctx->B = d->branches;
@@ -483,6 +485,7 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx) {
     EPA_HIP(ctx, hipMemcpy(d_tipmap, d->tipmap, sizeof(uint32_t) * d->tipmap_size,
                            hipMemcpyHostToDevice));
   }
+  if (tree) return precompute_from_tree(ctx, tree, d_tipmap);
   // upload + transform, one CLV at a time through two alternating staging buffers
   for (size_t b = 0; b < B; ++b) {
     for (int side = 0; side < 2; ++side) {
@@ -520,6 +523,321 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx) {
     }
   }
   EPA_HIP(ctx, hipGetLastError());
+  return EPA_OK;
+}
+
+// =============================================================================================
+// Reference precompute on device (epa_dev_create_from_tree).
+// One directional CLV = (P(la) child_a) o (P(lb) child_b), computed in the eigenbasis:
+//   I_ki = (U (e^{lam r_k la} o a~_k))_i (U (e^{lam r_k lb} o b~_k))_i,  out~ = U^-1 I
+// with the per-site 2^256 rescale of pll_update_partials; children are read from, and the result
+// is written to, the refT slot of the branch side the record belongs to (every record is the
+// proximal or distal side of exactly one branch), so no state-space CLV is ever stored.
+// Thread per site, blockIdx.y = record inside a dependency level.
+// =============================================================================================
+struct RecDev {
+  uint32_t side;    // destination: branch side index (2b or 2b+1)
+  uint32_t ca, cb;  // operands: side index of an inner child, or EPA_TIP | tip
+  uint32_t pad;
+  double la, lb;
+};
+
+template <int S>
+__global__ void __launch_bounds__(256) k_clv_level(const ModelDev* __restrict__ m,
+                                                   const RecDev* __restrict__ recs,
+                                                   const uint8_t* __restrict__ tipchars,
+                                                   const uint32_t* __restrict__ tipmap, uint32_t W,
+                                                   double* __restrict__ refT,
+                                                   uint32_t* __restrict__ sc_side) {
+  __shared__ double U[S * S], Ui[S * S];
+  __shared__ double Ea[EPA_MAX_CATS * S], Eb[EPA_MAX_CATS * S];
+  const int c = m->c;
+  const RecDev r = recs[blockIdx.y];
+  for (int i = threadIdx.x; i < S * S; i += blockDim.x) { U[i] = m->U[i]; Ui[i] = m->Ui[i]; }
+  for (int i = threadIdx.x; i < c * S; i += blockDim.x) {
+    const int k = i / S, x = i % S;
+    Ea[i] = exp(m->lam[x] * m->rate[k] * r.la);
+    Eb[i] = exp(m->lam[x] * m->rate[k] * r.lb);
+  }
+  __syncthreads();
+  const uint32_t site = blockIdx.x * blockDim.x + threadIdx.x;
+  if (site >= W) return;
+  const size_t cs = (size_t)c * S;
+  const bool tip_a = r.ca & EPA_TIP, tip_b = r.cb & EPA_TIP;
+  const double* A = tip_a ? nullptr : refT + (size_t)r.ca * cs * W + site;
+  const double* Bv = tip_b ? nullptr : refT + (size_t)r.cb * cs * W + site;
+  double ta[S], tb[S];  // U^-1 image of a tip's state set (category independent)
+  if (tip_a) {
+    const uint32_t mask = tipmap[tipchars[(size_t)(r.ca & ~EPA_TIP) * W + site]];
+    for (int x = 0; x < S; ++x) {
+      double acc = 0.0;
+      for (int i = 0; i < S; ++i) if ((mask >> i) & 1u) acc += Ui[x * S + i];
+      ta[x] = acc;
+    }
+  }
+  if (tip_b) {
+    const uint32_t mask = tipmap[tipchars[(size_t)(r.cb & ~EPA_TIP) * W + site]];
+    for (int x = 0; x < S; ++x) {
+      double acc = 0.0;
+      for (int i = 0; i < S; ++i) if ((mask >> i) & 1u) acc += Ui[x * S + i];
+      tb[x] = acc;
+    }
+  }
+  double I[EPA_MAX_CATS][S];
+  double mx = 0.0;
+  for (int k = 0; k < c; ++k) {
+    double av[S], bv[S];
+#pragma unroll
+    for (int x = 0; x < S; ++x) {
+      av[x] = (tip_a ? ta[x] : A[(size_t)(k * S + x) * W]) * Ea[k * S + x];
+      bv[x] = (tip_b ? tb[x] : Bv[(size_t)(k * S + x) * W]) * Eb[k * S + x];
+    }
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int x = 0; x < S; ++x) {
+        a = fma(U[i * S + x], av[x], a);
+        b = fma(U[i * S + x], bv[x], b);
+      }
+      const double v = a * b;
+      I[k][i] = v;
+      mx = fmax(mx, v);
+    }
+  }
+  const bool resc = mx < 0x1p-256;
+  const double mult = resc ? 0x1p+256 : 1.0;
+  double* out = refT + (size_t)r.side * cs * W + site;
+  for (int k = 0; k < c; ++k)
+#pragma unroll
+    for (int x = 0; x < S; ++x) {
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < S; ++i) acc = fma(Ui[x * S + i], I[k][i] * mult, acc);
+      out[(size_t)(k * S + x) * W] = acc;
+    }
+  const uint32_t sa = tip_a ? 0u : sc_side[(size_t)r.ca * W + site];
+  const uint32_t sb = tip_b ? 0u : sc_side[(size_t)r.cb * W + site];
+  sc_side[(size_t)r.side * W + site] = sa + sb + (resc ? 1u : 0u);
+}
+
+// tip sides of the branches: U^-1 image of the tip's state set, replicated over the categories
+__global__ void __launch_bounds__(256) k_tip_sides(const ModelDev* __restrict__ m,
+                                                   const uint32_t* __restrict__ tip_of_branch,
+                                                   const uint8_t* __restrict__ tipchars,
+                                                   const uint32_t* __restrict__ tipmap, uint32_t W,
+                                                   double* __restrict__ refT) {
+  const uint32_t b = blockIdx.y;
+  const uint32_t t = tip_of_branch[b];
+  if (t == 0xffffffffu) return;
+  const uint32_t site = blockIdx.x * blockDim.x + threadIdx.x;
+  if (site >= W) return;
+  const int s = m->s, c = m->c;
+  const uint32_t mask = tipmap[tipchars[(size_t)t * W + site]];
+  double* out = refT + (size_t)(2 * b + 1) * c * s * W + site;
+  for (int x = 0; x < s; ++x) {
+    double acc = 0.0;
+    for (int i = 0; i < s; ++i) if ((mask >> i) & 1u) acc += m->Ui[x * s + i];
+    for (int k = 0; k < c; ++k) out[(size_t)(k * s + x) * W] = acc;
+  }
+}
+
+__global__ void k_scaler_sum(const uint32_t* __restrict__ sc_side, uint32_t* __restrict__ scSum, size_t n,
+                             uint32_t W) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // i = b * W + site
+  if (i >= n) return;
+  const size_t b = i / W, w = i % W;
+  scSum[i] = sc_side[(2 * b) * W + w] + sc_side[(2 * b + 1) * W + w];
+}
+
+static int precompute_from_tree(epa_ctx* ctx, const epa_tree_desc* t, const uint32_t* d_tipmap) {
+  const uint32_t n = t->tips, R = t->inner_records, B = ctx->B, W = ctx->W;
+  if (!t->tipchars || !t->rec_child_a || !t->rec_child_b || !t->rec_length_a || !t->rec_length_b ||
+      !t->branch_prox || !t->branch_dist || !d_tipmap)
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "null pointer in tree descriptor");
+  if (n < 3 || R != 3 * (n - 2) || B != 2 * n - 3)
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "tree descriptor: sizes are not those of an unrooted binary tree");
+  // record -> branch side
+  std::vector<uint32_t> side_of(R, 0xffffffffu), tip_of_branch(B, 0xffffffffu);
+  for (uint32_t b = 0; b < B; ++b) {
+    const uint32_t p = t->branch_prox[b], d = t->branch_dist[b];
+    if ((p & EPA_TIP) || p >= R || side_of[p] != 0xffffffffu)
+      return epa_fail(ctx, EPA_ERR_INVALID_ARG, "tree descriptor: bad proximal record");
+    side_of[p] = 2 * b;
+    if (d & EPA_TIP) {
+      if ((d & ~EPA_TIP) >= n) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "tree descriptor: bad tip id");
+      tip_of_branch[b] = d & ~EPA_TIP;
+    } else {
+      if (d >= R || side_of[d] != 0xffffffffu)
+        return epa_fail(ctx, EPA_ERR_INVALID_ARG, "tree descriptor: bad distal record");
+      side_of[d] = 2 * b + 1;
+    }
+  }
+  for (uint32_t r = 0; r < R; ++r)
+    if (side_of[r] == 0xffffffffu)
+      return epa_fail(ctx, EPA_ERR_INVALID_ARG, "tree descriptor: a record is not a side of any branch");
+  // dependency levels (explicit stack: the dependency chain of a caterpillar tree is n long)
+  std::vector<int> level(R, -1);
+  auto child_level = [&](uint32_t op) { return (op & EPA_TIP) ? 0 : level[op]; };
+  for (uint32_t root = 0; root < R; ++root) {
+    if (level[root] >= 0) continue;
+    std::vector<uint32_t> st{root};
+    while (!st.empty()) {
+      const uint32_t r = st.back();
+      if (level[r] >= 0) { st.pop_back(); continue; }
+      const uint32_t a = t->rec_child_a[r], b = t->rec_child_b[r];
+      if ((!(a & EPA_TIP) && a >= R) || (!(b & EPA_TIP) && b >= R) || ((a & EPA_TIP) && (a & ~EPA_TIP) >= n) ||
+          ((b & EPA_TIP) && (b & ~EPA_TIP) >= n))
+        return epa_fail(ctx, EPA_ERR_INVALID_ARG, "tree descriptor: bad child operand");
+      if (st.size() > (size_t)R + 1) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "tree descriptor: cyclic records");
+      const bool na = !(a & EPA_TIP) && level[a] < 0, nb = !(b & EPA_TIP) && level[b] < 0;
+      if (na) st.push_back(a);
+      if (nb) st.push_back(b);
+      if (na || nb) continue;
+      level[r] = 1 + std::max(child_level(a), child_level(b));
+      st.pop_back();
+    }
+  }
+  int nlev = 0;
+  for (uint32_t r = 0; r < R; ++r) nlev = std::max(nlev, level[r]);
+  std::vector<std::vector<uint32_t>> by_level(nlev + 1);
+  for (uint32_t r = 0; r < R; ++r) by_level[level[r]].push_back(r);
+  std::vector<RecDev> recs;
+  recs.reserve(R);
+  std::vector<uint32_t> lev_begin;
+  auto opnd = [&](uint32_t op) { return (op & EPA_TIP) ? op : side_of[op]; };
+  for (int l = 1; l <= nlev; ++l) {
+    lev_begin.push_back((uint32_t)recs.size());
+    for (uint32_t r : by_level[l])
+      recs.push_back(RecDev{side_of[r], opnd(t->rec_child_a[r]), opnd(t->rec_child_b[r]), 0, t->rec_length_a[r],
+                            t->rec_length_b[r]});
+  }
+  lev_begin.push_back((uint32_t)recs.size());
+  // device buffers (freed at the end: only refT / scSum persist)
+  uint8_t* d_tips = nullptr;
+  RecDev* d_recs = nullptr;
+  uint32_t *d_sc = nullptr, *d_tob = nullptr;
+  auto cleanup = [&]() {
+    if (d_tips) (void)hipFree(d_tips);
+    if (d_recs) (void)hipFree(d_recs);
+    if (d_sc) (void)hipFree(d_sc);
+    if (d_tob) (void)hipFree(d_tob);
+  };
+#define TREE_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return epa_fail(ctx, EPA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); } } while (0)
+  TREE_HIP(hipMalloc(&d_tips, (size_t)n * W));
+  TREE_HIP(hipMemcpy(d_tips, t->tipchars, (size_t)n * W, hipMemcpyHostToDevice));
+  TREE_HIP(hipMalloc(&d_recs, sizeof(RecDev) * recs.size()));
+  TREE_HIP(hipMemcpy(d_recs, recs.data(), sizeof(RecDev) * recs.size(), hipMemcpyHostToDevice));
+  TREE_HIP(hipMalloc(&d_sc, sizeof(uint32_t) * 2 * (size_t)B * W));
+  TREE_HIP(hipMemset(d_sc, 0, sizeof(uint32_t) * 2 * (size_t)B * W));
+  TREE_HIP(hipMalloc(&d_tob, sizeof(uint32_t) * B));
+  TREE_HIP(hipMemcpy(d_tob, tip_of_branch.data(), sizeof(uint32_t) * B, hipMemcpyHostToDevice));
+  const dim3 blk(256);
+  hipLaunchKernelGGL(k_tip_sides, dim3((W + 255) / 256, B), blk, 0, ctx->stream, ctx->dmodel, d_tob, d_tips,
+                     d_tipmap, W, ctx->refT);
+  for (size_t l = 0; l + 1 < lev_begin.size(); ++l) {
+    const uint32_t cnt = lev_begin[l + 1] - lev_begin[l];
+    if (!cnt) continue;
+    for (uint32_t off = 0; off < cnt; off += 65535) {  // grid.y limit
+      const dim3 grid((W + 255) / 256, std::min<uint32_t>(65535, cnt - off));
+      if (ctx->s == 4)
+        hipLaunchKernelGGL(k_clv_level<4>, grid, blk, 0, ctx->stream, ctx->dmodel, d_recs + lev_begin[l] + off,
+                           d_tips, d_tipmap, W, ctx->refT, d_sc);
+      else
+        hipLaunchKernelGGL(k_clv_level<20>, grid, blk, 0, ctx->stream, ctx->dmodel, d_recs + lev_begin[l] + off,
+                           d_tips, d_tipmap, W, ctx->refT, d_sc);
+    }
+  }
+  const size_t nbw = (size_t)B * W;
+  hipLaunchKernelGGL(k_scaler_sum, dim3((uint32_t)((nbw + 255) / 256)), blk, 0, ctx->stream, d_sc, ctx->scSum, nbw, W);
+  TREE_HIP(hipStreamSynchronize(ctx->stream));
+  TREE_HIP(hipGetLastError());
+#undef TREE_HIP
+  cleanup();
+  return EPA_OK;
+}
+
+// edge log-likelihood of the reference tree at branch b from the two stored sides
+template <int S>
+__global__ void __launch_bounds__(256) k_tree_logl(const ModelDev* __restrict__ m,
+                                                  const double* __restrict__ refT,
+                                                  const uint32_t* __restrict__ scSum, uint32_t b, double len,
+                                                  uint32_t W, double* __restrict__ partial) {
+  __shared__ double U[S * S];
+  __shared__ double E[EPA_MAX_CATS * S];
+  __shared__ double red[256];
+  const int c = m->c;
+  for (int i = threadIdx.x; i < S * S; i += blockDim.x) U[i] = m->U[i];
+  for (int i = threadIdx.x; i < c * S; i += blockDim.x) E[i] = exp(m->lam[i % S] * m->rate[i / S] * len);
+  __syncthreads();
+  const uint32_t site = blockIdx.x * blockDim.x + threadIdx.x;
+  double v = 0.0;
+  if (site < W) {
+    const size_t cs = (size_t)c * S;
+    const double* X = refT + (size_t)(2 * b) * cs * W + site;
+    const double* D = refT + (size_t)(2 * b + 1) * cs * W + site;
+    double L = 0.0;
+    for (int k = 0; k < c; ++k) {
+      double xv[S], dv[S];
+#pragma unroll
+      for (int x = 0; x < S; ++x) { xv[x] = X[(size_t)(k * S + x) * W]; dv[x] = D[(size_t)(k * S + x) * W] * E[k * S + x]; }
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < S; ++i) {
+        double a = 0.0, d = 0.0;
+#pragma unroll
+        for (int x = 0; x < S; ++x) { a = fma(U[i * S + x], xv[x], a); d = fma(U[i * S + x], dv[x], d); }
+        t = fma(m->pi[i] * a, d, t);
+      }
+      L = fma(m->w[k], t, L);
+    }
+    v = log(L) + (double)scSum[(size_t)b * W + site] * (-256.0 * 0.6931471805599453094);
+  }
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+extern "C" int epa_dev_tree_logl(epa_ctx* ctx, uint32_t branch, double* lnl) {
+  if (!ctx || !lnl || branch >= ctx->B) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "bad argument");
+  EPA_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t nblk = (ctx->W + 255) / 256;
+  double* d_part = (double*)epa_scratch(ctx, 9, sizeof(double) * nblk);
+  if (!d_part) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(tree lnL partials)");
+  const double len = ctx->h_blen[branch];
+  if (ctx->s == 4)
+    hipLaunchKernelGGL(k_tree_logl<4>, dim3(nblk), dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT, ctx->scSum,
+                       branch, len, ctx->W, d_part);
+  else
+    hipLaunchKernelGGL(k_tree_logl<20>, dim3(nblk), dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT, ctx->scSum,
+                       branch, len, ctx->W, d_part);
+  std::vector<double> part(nblk);
+  EPA_HIP(ctx, hipMemcpyAsync(part.data(), d_part, sizeof(double) * nblk, hipMemcpyDeviceToHost, ctx->stream));
+  EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double s = 0.0;
+  for (double p : part) s += p;  // fixed order: deterministic
+  *lnl = s;
+  return EPA_OK;
+}
+
+extern "C" int epa_dev_create_from_tree(const epa_tree_desc* tree, int device, epa_ctx** out) {
+  if (!tree || !out) return epa_fail(nullptr, EPA_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  if (epa_dev_device_count() <= 0)
+    return epa_fail(nullptr, EPA_ERR_NO_DEVICE,
+                    "no HIP device visible: libepa_dev has no CPU fallback by design");
+  epa_ctx* ctx = new epa_ctx();
+  int rc = create_impl(&tree->ref, device, ctx, tree);
+  if (rc != EPA_OK) {
+    g_create_err = ctx->err;
+    epa_dev_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
   return EPA_OK;
 }
 

@@ -96,19 +96,32 @@ uint32_t epa_host_ref_tipmap(void* h, uint32_t* out, uint32_t cap) {
   return (uint32_t)tm.size();
 }
 
-// creates the device context straight from the host tree (what simple_mpi does internally)
-int epa_host_dev_create(void* h, int device, int aa_x_as_n, epa_ctx** out) {
+// creates the device context straight from the host tree (what simple_mpi does internally).
+// device_precompute != 0: reference CLVs computed on the GPU from the tree; 0: host CLVs uploaded.
+int epa_host_dev_create_ex(void* h, int device, int aa_x_as_n, int device_precompute, epa_ctx** out) {
   const Tree& t = *static_cast<Ref*>(h)->tree;
-  epa_ref_desc d;
-  std::vector<const double*> pc, dc;
-  std::vector<const uint32_t*> ps, ds;
-  std::vector<const uint8_t*> dt;
-  std::vector<double> bl;
-  t.fill_desc(d, pc, ps, dc, dt, ds, bl);
-  d.aa_x_as_n = aa_x_as_n;
-  const int rc = epa_dev_create(&d, device, out);
+  int rc;
+  if (device_precompute) {
+    epa_tree_desc d;
+    Tree::Tree_Desc_Storage store;
+    t.fill_tree_desc(d, store);
+    d.ref.aa_x_as_n = aa_x_as_n;
+    rc = epa_dev_create_from_tree(&d, device, out);
+  } else {
+    epa_ref_desc d;
+    std::vector<const double*> pc, dc;
+    std::vector<const uint32_t*> ps, ds;
+    std::vector<const uint8_t*> dt;
+    std::vector<double> bl;
+    t.fill_desc(d, pc, ps, dc, dt, ds, bl);
+    d.aa_x_as_n = aa_x_as_n;
+    rc = epa_dev_create(&d, device, out);
+  }
   if (rc) g_err = epa_dev_last_error(nullptr);
   return rc;
+}
+int epa_host_dev_create(void* h, int device, int aa_x_as_n, epa_ctx** out) {
+  return epa_host_dev_create_ex(h, device, aa_x_as_n, 1, out);
 }
 
 // the whole pipeline: query fasta -> <outdir>/epa_result.jplace

@@ -42,6 +42,7 @@ struct Options {  // defaults: src/util/Options.hpp:13-34
   unsigned int precision = 10;
   bool aa_x_as_n = false;   // quirk D4 switch
   bool device_select = true;  // run the dynamic heuristic on the GPU (default heuristic only)
+  bool device_precompute = true;  // reference CLVs computed on the GPU from the tree (no host CLVs)
 };
 
 class Sequence {
@@ -167,12 +168,24 @@ public:
   void fill_desc(epa_ref_desc& d, std::vector<const double*>& pc, std::vector<const uint32_t*>& ps,
                  std::vector<const double*>& dc, std::vector<const uint8_t*>& dt,
                  std::vector<const uint32_t*>& ds, std::vector<double>& bl) const;
+  // tree + tip sequences for the device-side reference precompute (epa_dev_create_from_tree);
+  // needs no host CLVs.  `store` owns the arrays the descriptor points to.
+  struct Tree_Desc_Storage {
+    std::vector<uint8_t> tipchars;
+    std::vector<uint32_t> child_a, child_b, prox, dist;
+    std::vector<double> len_a, len_b, blen;
+  };
+  void fill_tree_desc(epa_tree_desc& d, Tree_Desc_Storage& store) const;
+  // host CLVs are computed on first use (Tree::branch / ref_tree_logl / fill_desc): the device
+  // path of the product never needs them
+  void ensure_host_clvs() const;
 
 private:
   struct Rec { int next = -1, back = -1, tip = -1; double length = 0.0; };
   int new_rec();
   int parse_subtree(const char*& p, double& len);
   void compute_all_clvs();
+  mutable bool host_clvs_ready_ = false;
   void side(int rec, const double*& clv, const uint8_t*& tip, const uint32_t*& sc) const;
 
   Model model_;
@@ -222,6 +235,7 @@ public:
   ~Device_Evaluator();
   Device_Evaluator(const Device_Evaluator&) = delete;
   epa_ctx* ctx() const { return ctx_; }
+  double ref_tree_logl(size_t branch = 0) const;  // Tree::ref_tree_logl evaluated on the device
 private:
   epa_ctx* ctx_ = nullptr;
 };
@@ -262,6 +276,7 @@ void filter(Sample& sample, const Options& options);  // :192-204
 // (src/net/epa_mpi_util.cpp:10-30); every rank returns its own samples, rank 0 writes.
 struct Run_Stats {
   size_t queries = 0, pairs = 0;
+  double ref_tree_logl = 0;  // of the reference tree, evaluated on the device at branch 0
   double seconds_place = 0, seconds_thorough = 0;  // device calls (fused path: all in seconds_place)
   double seconds_setup = 0, seconds_read = 0, seconds_stage_wait = 0, seconds_post = 0, seconds_write = 0;
 };

@@ -78,11 +78,11 @@ int main(int argc, char** argv) {
     const auto t_tree = std::chrono::steady_clock::now();
     const Tree tree(ss.str(), ref, model, opt);
     const double secs_tree = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tree).count();
-    std::cout << "Reference tree log-likelihood: " << tree.ref_tree_logl() << std::endl;
     const Run_Stats st = simple_mpi(tree, query_file, outdir, opt, invocation, device);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+    std::cout << "Reference tree log-likelihood: " << st.ref_tree_logl << "\n";
     std::cout << st.queries << " Sequences done! (" << st.pairs << " thorough pairs)\n"
-              << "Time breakdown [s]: reference CLVs " << secs_tree << ", device setup " << st.seconds_setup
+              << "Time breakdown [s]: tree + MSA " << secs_tree << ", device setup " << st.seconds_setup
               << ", read queries " << st.seconds_read << ", wait for encoded chunk " << st.seconds_stage_wait
               << ", device " << st.seconds_place + st.seconds_thorough << ", lwr+filter " << st.seconds_post
               << ", write jplace " << st.seconds_write << "\n"

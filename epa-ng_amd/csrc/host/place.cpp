@@ -43,16 +43,35 @@ const double kDefaultBranchLength = -std::log(0.9);
 }  // namespace
 
 Device_Evaluator::Device_Evaluator(const Tree& tree, const Options& options, int device) {
-  epa_ref_desc d;
-  std::vector<const double*> pc, dc;
-  std::vector<const uint32_t*> ps, ds;
-  std::vector<const uint8_t*> dt;
-  std::vector<double> bl;
-  tree.fill_desc(d, pc, ps, dc, dt, ds, bl);
-  d.flags = options.sliding_blo ? EPA_FLAG_SLIDING_BLO : 0x80000000u;  // non-sliding: rejected
-  d.aa_x_as_n = options.aa_x_as_n ? 1 : 0;
-  const int rc = epa_dev_create(&d, device, &ctx_);
+  const uint32_t flags = options.sliding_blo ? EPA_FLAG_SLIDING_BLO : 0x80000000u;  // non-sliding: rejected
+  int rc;
+  if (options.device_precompute) {
+    // tree + tip sequences go to the device, all directional CLVs are computed there
+    epa_tree_desc d;
+    Tree::Tree_Desc_Storage store;
+    tree.fill_tree_desc(d, store);
+    d.ref.flags = flags;
+    d.ref.aa_x_as_n = options.aa_x_as_n ? 1 : 0;
+    rc = epa_dev_create_from_tree(&d, device, &ctx_);
+  } else {
+    epa_ref_desc d;
+    std::vector<const double*> pc, dc;
+    std::vector<const uint32_t*> ps, ds;
+    std::vector<const uint8_t*> dt;
+    std::vector<double> bl;
+    tree.fill_desc(d, pc, ps, dc, dt, ds, bl);
+    d.flags = flags;
+    d.aa_x_as_n = options.aa_x_as_n ? 1 : 0;
+    rc = epa_dev_create(&d, device, &ctx_);
+  }
   if (rc != EPA_OK) throw_dev(nullptr, rc);
+}
+
+double Device_Evaluator::ref_tree_logl(size_t branch) const {
+  double v = 0.0;
+  const int rc = epa_dev_tree_logl(ctx_, (uint32_t)branch, &v);
+  if (rc != EPA_OK) throw_dev(ctx_, rc);
+  return v;
 }
 
 Device_Evaluator::~Device_Evaluator() { epa_dev_destroy(ctx_); }
@@ -282,6 +301,7 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
   const size_t B = tree.num_branches();
   auto ts = clk::now();
   Device_Evaluator dev(tree, options, device);
+  st.ref_tree_logl = dev.ref_tree_logl(0);
   st.seconds_setup = std::chrono::duration<double>(clk::now() - ts).count();
   Fasta_Stream reader(query_file);
   std::vector<Sample> results;

@@ -174,7 +174,68 @@ Tree::Tree(const std::string& newick, const MSA& ref_msa, const Model& model, co
   // precompute_clvs (src/core/pll/epa_pll_util.cpp:62-107): all three directions per inner node
   clv_.resize(recs_.size());
   scaler_.resize(recs_.size());
-  compute_all_clvs();
+}
+
+void Tree::ensure_host_clvs() const {
+  if (host_clvs_ready_) return;
+#pragma omp critical(epa_host_clvs)
+  {
+    if (!host_clvs_ready_) {
+      const_cast<Tree*>(this)->compute_all_clvs();
+      host_clvs_ready_ = true;
+    }
+  }
+}
+
+void Tree::fill_tree_desc(epa_tree_desc& d, Tree_Desc_Storage& st) const {
+  std::memset(&d, 0, sizeof(d));
+  const size_t B = nums_.branches, n = nums_.tip_nodes;
+  // dense ids of the inner records
+  std::vector<uint32_t> id(recs_.size(), 0xffffffffu);
+  uint32_t R = 0;
+  for (size_t r = 0; r < recs_.size(); ++r)
+    if (recs_[r].tip < 0) id[r] = R++;
+  auto operand = [&](int rec) -> uint32_t {
+    return recs_[rec].tip >= 0 ? (EPA_TIP | (uint32_t)recs_[rec].tip) : id[rec];
+  };
+  st.child_a.assign(R, 0); st.child_b.assign(R, 0); st.len_a.assign(R, 0.0); st.len_b.assign(R, 0.0);
+  for (size_t r = 0; r < recs_.size(); ++r) {
+    if (recs_[r].tip >= 0) continue;
+    const int n1 = recs_[r].next, n2 = recs_[n1].next;
+    const int c1 = recs_[n1].back, c2 = recs_[n2].back;
+    st.child_a[id[r]] = operand(c1); st.len_a[id[r]] = recs_[c1].length;
+    st.child_b[id[r]] = operand(c2); st.len_b[id[r]] = recs_[c2].length;
+  }
+  st.prox.resize(B); st.dist.resize(B); st.blen.resize(B);
+  for (size_t b = 0; b < B; ++b) {
+    int dd = branch_rec_.at(b), p = recs_[dd].back;
+    st.blen[b] = recs_[dd].length;
+    if (recs_[dd].tip < 0 && recs_[p].tip >= 0) std::swap(dd, p);  // the tip is always DISTAL
+    st.prox[b] = operand(p);
+    st.dist[b] = operand(dd);
+  }
+  st.tipchars.resize(n * sites_);
+  for (size_t t = 0; t < n; ++t) std::memcpy(&st.tipchars[t * sites_], tipchars_[t].data(), sites_);
+  epa_ref_desc& rd = d.ref;
+  rd.states = (uint32_t)model_.num_states();
+  rd.rate_cats = (uint32_t)model_.num_ratecats();
+  rd.sites = (uint32_t)sites_;
+  rd.branches = (uint32_t)B;
+  rd.eigenvals = model_.eigenvals().data();
+  rd.eigenvecs_u = model_.eigenvecs_u().data();
+  rd.eigenvecs_uinv = model_.eigenvecs_uinv().data();
+  rd.freqs = model_.base_freqs().data();
+  rd.rates = model_.ratecat_rates().data();
+  rd.rate_weights = model_.ratecat_weights().data();
+  rd.branch_length = st.blen.data();
+  rd.tipmap = tipmap_.data();
+  rd.tipmap_size = (uint32_t)tipmap_.size();
+  d.tips = (uint32_t)n;
+  d.inner_records = R;
+  d.tipchars = st.tipchars.data();
+  d.rec_child_a = st.child_a.data(); d.rec_child_b = st.child_b.data();
+  d.rec_length_a = st.len_a.data(); d.rec_length_b = st.len_b.data();
+  d.branch_prox = st.prox.data(); d.branch_dist = st.dist.data();
 }
 
 void Tree::side(int rec, const double*& clv, const uint8_t*& tip, const uint32_t*& sc) const {
@@ -274,6 +335,7 @@ void Tree::compute_all_clvs() {
 }
 
 Tree::Branch Tree::branch(size_t b) const {
+  ensure_host_clvs();
   int d = branch_rec_.at(b), p = recs_[d].back;
   const double len = recs_[d].length;
   // the reference tip is always DISTAL (src/tree/Tiny_Tree.cpp:64-74)
@@ -318,6 +380,7 @@ void Tree::fill_desc(epa_ref_desc& d, std::vector<const double*>& pc,
 }
 
 double Tree::ref_tree_logl(size_t b) const {
+  ensure_host_clvs();
   const int d = branch_rec_.at(b), p = recs_[d].back;
   const int s = model_.num_states(), c = model_.num_ratecats();
   const size_t cs = (size_t)c * s;

@@ -103,6 +103,32 @@ typedef struct {
                               *    Lookup_Store.hpp:63-66); 0 (default): 'X' = any             */
 } epa_ref_desc;
 
+/*
+ * Reference precompute ON the device: instead of 2B host CLVs the caller hands over the tree and
+ * the tip sequences and the library computes all 3(n-2) directional CLVs itself (the job of
+ * precompute_clvs, src/core/pll/epa_pll_util.cpp:62-107 / Tree::Tree, src/tree/Tree.cpp:16-56),
+ * level by level, directly in the eigen-transformed layout the kernels use (nothing but n x W
+ * tip codes crosses PCIe).  `ref` carries the model, sizes, tip map, branch lengths and optimiser
+ * constants; its per-branch CLV / scaler pointer arrays are ignored.
+ * A directional CLV record r is the partial likelihood of the subtree seen from one end of a
+ * branch; it is the product of its two children propagated over their branches.  Operand ids:
+ * value < inner_records = record, EPA_TIP | t = tip t.  Every inner record must be the proximal
+ * or distal side of exactly one branch; a tip end is always passed as the DISTAL side.
+ */
+#define EPA_TIP 0x80000000u
+typedef struct {
+  epa_ref_desc ref;
+  uint32_t tips;                  /* n                                                          */
+  uint32_t inner_records;         /* 3 (n - 2)                                                  */
+  const uint8_t* tipchars;        /* [n][sites] tip codes (index into ref.tipmap)               */
+  const uint32_t* rec_child_a;    /* [inner_records] operand ids of the two children            */
+  const uint32_t* rec_child_b;
+  const double* rec_length_a;     /* [inner_records] branch length toward each child            */
+  const double* rec_length_b;
+  const uint32_t* branch_prox;    /* [B] operand id of the proximal side (an inner record)      */
+  const uint32_t* branch_dist;    /* [B] operand id of the distal side (record or tip)          */
+} epa_tree_desc;
+
 /* one unit of Work (src/core/Work.hpp:31-34 Work_Pair) */
 typedef struct {
   uint32_t branch_id;
@@ -137,6 +163,13 @@ int epa_dev_device_count(void);
 int epa_dev_create(const epa_ref_desc* desc, int device, epa_ctx** out);
 void epa_dev_destroy(epa_ctx* ctx);
 const char* epa_dev_last_error(const epa_ctx* ctx); /* ctx may be NULL: last create() error */
+
+/* Same context, reference CLVs computed on the device from the tree (see epa_tree_desc). */
+int epa_dev_create_from_tree(const epa_tree_desc* tree, int device, epa_ctx** out);
+
+/* Log-likelihood of the reference tree evaluated at branch `branch` (Tree::ref_tree_logl,
+ * src/tree/Tree.cpp:119-131; equal on every branch up to rounding). */
+int epa_dev_tree_logl(epa_ctx* ctx, uint32_t branch, double* lnl);
 
 /* Optional: run all kernels of `ctx` on this hipStream_t (passed as void*). Default stream 0. */
 int epa_dev_set_stream(epa_ctx* ctx, void* hip_stream);

@@ -309,3 +309,66 @@ def test_large_reference_more_than_4096_branches():
     assert np.all(np.diff(pairs["branch_id"].astype(np.int64)) >= 0)
     tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], w["reads"])
     assert np.max(np.abs(res["lnl"] - tl)) < 1e-6
+
+
+@pytest.mark.parametrize("states", [4, 20])
+def test_device_reference_precompute_matches_host_clvs(states):
+    """epa_dev_create_from_tree (all directional CLVs computed on the GPU from the tree and the tip
+    sequences) vs epa_dev_create fed with the host-computed CLVs: tree lnL on every kind of
+    branch, the preplacement table and the thorough results agree to rounding; golden tree lnL."""
+    from epa_ng_amd import synth
+    if states == 4:
+        g = load_case("dna8_gtr_g_default")
+        labels = [a for a, _ in g["msa"]]
+        seqs = [b for _, b in g["msa"]]
+        ref = hostlib.Reference(g["newick"], labels, seqs, states=4, subst=g["subst"], freqs=g["freqs"],
+                                rates=g["gamma_rates"])
+        ev = ref.evaluator()
+        for b in range(ref.B):   # the reference's property: equal on every edge
+            assert abs(ev.tree_logl(b) - (-4620.363834217626)) < 1e-7
+        w = synth.dna_workload(200, 420, 300, 110, (81, 82, 83))   # deep enough to need rescaling? no, but many levels
+    else:
+        w = synth.aa_workload(40, 260, 120, 80, (84, 85, 86))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=states, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    e_dev = ref.evaluator(device_precompute=True)
+    e_host = ref.evaluator(device_precompute=False)
+    host_lnl = ref.tree_lnl(0)
+    for b in (0, 1, ref.B // 2, ref.B - 1):
+        assert abs(e_dev.tree_logl(b) - host_lnl) < 1e-6 * max(1.0, abs(host_lnl)) * 1e-3 + 1e-6
+        assert abs(e_host.tree_logl(b) - host_lnl) < 1e-6 * max(1.0, abs(host_lnl)) * 1e-3 + 1e-6
+    codes, wb, ws = epa.encode_queries(states, w["reads"], compact=True)
+    t_dev, t_host = e_dev.preplace(codes, wb, ws), e_host.preplace(codes, wb, ws)
+    assert np.max(np.abs(t_dev - t_host)) < 1e-8
+    p_dev, r_dev = e_dev.place_chunk(codes, wb, ws)
+    p_host, r_host = e_host.place_chunk(codes, wb, ws)
+    assert np.array_equal(p_dev, p_host)
+    assert np.max(np.abs(r_dev["lnl"] - r_host["lnl"])) < 1e-8
+    assert np.max(np.abs(r_dev["distal_length"] - r_host["distal_length"])) < 1e-7
+
+
+def test_device_reference_precompute_rescaling_deep_tree():
+    """caterpillar-like 700-tip tree with long branches: the per-site 2^256 rescale triggers
+    inside the device recursion; scaler counts must agree with the host precompute (tree lnL and
+    preplacement equal)."""
+    from epa_ng_amd import synth
+    rng = np.random.RandomState(4)
+    n = 700
+    nwk = "(t0:0.9,t1:0.9"
+    for i in range(2, n - 1):
+        nwk = "(" + nwk + "):0.9,t%d:0.9" % i
+    nwk = nwk + ",t%d:0.9);" % (n - 1)
+    W = 96
+    labels = ["t%d" % i for i in range(n)]
+    seqs = ["".join(rng.choice(list("ACGT"), W)) for _ in range(n)]
+    ref = hostlib.Reference(nwk, labels, seqs, states=4, subst=synth.CFG2_SUBST, freqs=synth.CFG2_FREQS,
+                            rates=synth.gamma_rates(0.5))
+    e_dev = ref.evaluator(device_precompute=True)
+    e_host = ref.evaluator(device_precompute=False)
+    host_lnl = ref.tree_lnl(0)
+    assert host_lnl < -256 * np.log(2.0) * 10     # scaled many times over
+    for b in (0, ref.B // 3, ref.B - 1):
+        assert abs(e_dev.tree_logl(b) - host_lnl) < 1e-6
+    reads = ["".join(rng.choice(list("ACGT"), W)) for _ in range(20)]
+    codes, wb, ws = epa.encode_queries(4, reads, compact=True)
+    assert np.max(np.abs(e_dev.preplace(codes, wb, ws) - e_host.preplace(codes, wb, ws))) < 1e-7
