@@ -149,6 +149,7 @@ public:
   const Model& model() const { return model_; }
   size_t num_sites() const { return sites_; }
   size_t num_branches() const { return nums_.branches; }
+  bool rooted_input() const { return rooted_input_; }  // the newick had a bifurcating root (removed)
   double ref_tree_logl(size_t branch = 0) const;  // edge lnL (Tree::ref_tree_logl :119-131)
   // numbered newick, edge ids in utree_query_branches order (pll_util.cpp:182-259)
   std::string numbered_newick(unsigned int precision) const;
@@ -194,6 +195,7 @@ private:
   std::vector<Rec> recs_;
   std::vector<std::string> labels_;
   int vroot_ = -1;
+  bool rooted_input_ = false;
   std::vector<int> branch_rec_;
   std::vector<std::vector<uint8_t>> tipchars_;   // per tip
   std::vector<std::vector<double>> clv_;         // per record (empty for tips)

@@ -77,6 +77,9 @@ int main(int argc, char** argv) {
     std::cout << "Using model parameters: " << model.to_string() << std::endl;
     const auto t_tree = std::chrono::steady_clock::now();
     const Tree tree(ss.str(), ref, model, opt);
+    if (tree.rooted_input())
+      std::cout << "WARNING: rooted reference tree: the root was removed, placements are reported on the "
+                   "unrooted tree in the jplace (no --preserve-rooting in this build)." << std::endl;
     const double secs_tree = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tree).count();
     const Run_Stats st = simple_mpi(tree, query_file, outdir, opt, invocation, device);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();

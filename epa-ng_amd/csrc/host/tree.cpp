@@ -91,9 +91,20 @@ Tree::Tree(const std::string& newick, const MSA& ref_msa, const Model& model, co
     if (*p == ')') { ++p; break; }
     throw std::runtime_error{"Treeparsing failed! expected ',' or ')'"};
   }
-  if (nk == 2)
-    throw std::runtime_error{"Rooted reference trees are not supported by this build yet "
-                             "(SURVEY.md section 8f-4): please unroot the tree"};
+  if (nk == 2) {
+    // Rooted input: the root is removed and its two edges become one (what pll_rtree_unroot does
+    // for the reference, src/io/file_io.cpp:129-171).  Placements are reported on the unrooted
+    // tree written to the jplace; the reference's --preserve-rooting edge renumbering
+    // (rtree_mapper) depends on libpll internals and is not reproduced.
+    int top = kids[0], other = kids[1];
+    if (recs_[top].next < 0) std::swap(top, other);
+    if (recs_[top].next < 0) throw std::runtime_error{"Number of tip nodes too small"};
+    recs_[top].back = other;
+    recs_[other].back = top;
+    recs_[top].length = recs_[other].length = kl[0] + kl[1];
+    rooted_input_ = true;
+    vroot_ = top;
+  } else {
   const int a = new_rec(), b = new_rec(), c = new_rec();
   recs_[a].next = b; recs_[b].next = c; recs_[c].next = a;
   const int ring[3] = {a, b, c};
@@ -103,6 +114,7 @@ Tree::Tree(const std::string& newick, const MSA& ref_msa, const Model& model, co
     recs_[ring[i]].length = recs_[kids[i]].length = kl[i];
   }
   vroot_ = a;
+  }
   if (labels_.size() < 3) throw std::runtime_error{"Number of tip nodes too small"};
   // set_missing_branch_lengths (src/core/pll/pll_util.cpp:13-39): a zero length counts as missing
   for (auto& r : recs_)

@@ -196,3 +196,33 @@ int main(int argc, char** argv) {
         got = [tuple(l.split()) for l in lines if not l.startswith("CHUNK")]
         assert sizes == [min(chunk, len(recs) - k) for k in range(0, len(recs), chunk)]
         assert got == [(h, s.upper()) for h, s in recs]
+
+
+def test_rooted_reference_tree_is_unrooted():
+    """a bifurcating root is removed (its two edges merge): same branch count and the same tree
+    log-likelihood as the equivalent unrooted newick (pulley principle)."""
+    from epa_ng_amd import synth
+    root = synth.random_tree(9, 5)
+    rates = synth.gamma_rates(0.7)
+    labels, seqs = synth.simulate_msa(root, 120, synth.CFG2_SUBST, synth.CFG2_FREQS, rates, 6)
+    unrooted = synth.newick(root)
+    k0, k1, k2 = root.kids
+
+    def sub(node):
+        r = synth.Node()
+        r.kids = [node]
+        s = synth.newick(r)            # "(<node>:len);"
+        return s[1:-2]
+    l2 = k2.length
+    k2.length = 0.7 * l2
+    rooted = "((%s,%s):%r,%s);" % (sub(k0), sub(k1), 0.3 * l2, sub(k2))
+    k2.length = l2
+    kw = dict(states=4, subst=synth.CFG2_SUBST, freqs=synth.CFG2_FREQS, rates=rates)
+    a = hostlib.Reference(unrooted, labels, seqs, **kw)
+    b = hostlib.Reference(rooted, labels, seqs, **kw)
+    assert a.B == b.B == 2 * 9 - 3
+    la = a.tree_lnl(0)
+    for e in range(b.B):
+        assert abs(b.tree_lnl(e) - la) < 1e-8
+    nw = b.numbered_newick()
+    assert nw.count("{") == b.B and nw.endswith(";")
