@@ -917,10 +917,12 @@ int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshol
                       "select_candidates: " + std::to_string(total) + " candidates exceed max_pairs");
     if (total) {
       hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, ctx->stream, stage, counts, offsets, Q, cap, keys_a);
-      // branch-major order == Work iteration order (std::map<branch, vector<seq>>)
+      // branch-major order == Work iteration order (std::map<branch, vector<seq>>).  The compacted
+      // list is already ascending in the query id (and a query names a branch at most once), so a
+      // STABLE sort on the branch bits alone gives (branch, query) order: 2 digit passes, not 6.
       int bits = 33;
       while ((1ull << (bits - 32)) <= B && bits < 64) ++bits;
-      EPA_HIP(ctx, rocprim::radix_sort_keys(temp, sort_bytes, keys_a, keys_b, (size_t)total, 0, bits, ctx->stream));
+      EPA_HIP(ctx, rocprim::radix_sort_keys(temp, sort_bytes, keys_a, keys_b, (size_t)total, 32, bits, ctx->stream));
       hipLaunchKernelGGL(k_keys_to_pairs, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, keys_b,
                          (uint64_t)total, d_pairs);
     }
