@@ -42,7 +42,8 @@ class _RefDesc(C.Structure):
                 ("blo_min_branch", C.c_double), ("blo_max_branch", C.c_double),
                 ("blo_default_branch", C.c_double), ("blo_epsilon", C.c_double),
                 ("pendant_default", C.c_double), ("blo_max_rounds", C.c_uint32),
-                ("blo_max_newton", C.c_uint32), ("flags", C.c_uint32), ("aa_x_as_n", C.c_uint32)]
+                ("blo_max_newton", C.c_uint32), ("flags", C.c_uint32), ("aa_x_as_n", C.c_uint32),
+                ("invariant_state", C.c_void_p)]
 
 
 class _Stats(C.Structure):
@@ -161,7 +162,7 @@ class Evaluator:
 
     def __init__(self, states, rates, weights, eigenvals, u, uinv, freqs, branch_length,
                  prox_clv, dist_clv, prox_scaler=None, dist_scaler=None, dist_tip=None,
-                 tipmap=None, device=0, aa_x_as_n=False):
+                 tipmap=None, device=0, aa_x_as_n=False, pinv=0.0, invariant_state=None):
         L = dev_lib()
         B = len(branch_length)
         self.B, self.s, self.c = B, states, len(rates)
@@ -197,7 +198,11 @@ class Evaluator:
         d.eigenvals, d.eigenvecs_u, d.eigenvecs_uinv = (keep[0].ctypes.data, keep[1].ctypes.data,
                                                        keep[2].ctypes.data)
         d.freqs, d.rates, d.rate_weights = keep[3].ctypes.data, keep[4].ctypes.data, keep[5].ctypes.data
-        d.prop_invar = 0.0
+        d.prop_invar = float(pinv)
+        inv = None
+        if invariant_state is not None:
+            inv = np.ascontiguousarray(invariant_state, dtype=np.int8)
+            d.invariant_state = inv.ctypes.data
         d.prox_clv = C.cast(pc, C.c_void_p)
         d.prox_scaler = C.cast(ps, C.c_void_p)
         d.dist_clv = C.cast(dc, C.c_void_p)

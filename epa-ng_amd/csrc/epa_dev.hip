@@ -119,7 +119,8 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
                                                       double pendant, uint32_t W,
                                                       double* __restrict__ lookup,
                                                       double* __restrict__ refI,
-                                                      uint8_t* __restrict__ resc0) {
+                                                      uint8_t* __restrict__ resc0,
+                                                      const double* __restrict__ cinv) {
   __shared__ double U[S * S], Ui[S * S];
   __shared__ double Eh[EPA_MAX_CATS * S], Ep[EPA_MAX_CATS * S];  // exp tables: half branch, pendant
   const int c = m->c, ncols = m->ncols;
@@ -197,6 +198,7 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
         if ((mask >> i) & 1u) tr += g[k][i];
       terma += tr * m->w[k];
     }
+    if (cinv) terma += cinv[site];  // +I: p * pi_inv, unscaled and independent of the query char
     double v = log(terma);
     if (sc) v += sc * log_thr;
     out[col] = v;
@@ -209,11 +211,11 @@ int launch_build_lookup(epa_ctx* ctx) {
   if (ctx->s == 4)
     hipLaunchKernelGGL(k_build_lookup<4>, grid, dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT,
                        ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup, ctx->refI,
-                       ctx->resc0);
+                       ctx->resc0, ctx->cinv);
   else
     hipLaunchKernelGGL(k_build_lookup<20>, grid, dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT,
                        ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup, ctx->refI,
-                       ctx->resc0);
+                       ctx->resc0, ctx->cinv);
   EPA_HIP(ctx, hipGetLastError());
   if (ctx->s == 4) {
     int rc = launch_build_lookup2(ctx);
@@ -371,6 +373,7 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
   if (ctx->lookup) (void)hipFree(ctx->lookup);
   if (ctx->lookup2) (void)hipFree(ctx->lookup2);
   if (ctx->refI) (void)hipFree(ctx->refI);
+  if (ctx->cinv) (void)hipFree(ctx->cinv);
   if (ctx->resc0) (void)hipFree(ctx->resc0);
   if (ctx->dmodel) (void)hipFree(ctx->dmodel);
   EvTimer* ts[4] = {&ctx->t_lookup, &ctx->t_preplace, &ctx->t_thorough, &ctx->t_select};
@@ -389,8 +392,10 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   const int c = (c_in == 1 || c_in == 2) ? 4 : c_in;
   ctx->c_in = c_in;
   if (!d->sites || !d->branches) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "empty reference");
-  if (d->prop_invar != 0.0)
-    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "prop_invar > 0 (+I) is not implemented yet");
+  const double pinv = d->prop_invar;
+  if (!(pinv >= 0.0 && pinv < 1.0)) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "prop_invar must be in [0, 1)");
+  if (pinv > 0.0 && !tree && !d->invariant_state)
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "prop_invar > 0 needs invariant_state");
   if (!d->eigenvals || !d->eigenvecs_u || !d->eigenvecs_uinv || !d->freqs || !d->rates ||
       !d->rate_weights || (!tree && !d->prox_clv) || !d->branch_length)
     return epa_fail(ctx, EPA_ERR_INVALID_ARG, "null model / reference pointer in descriptor");
@@ -413,8 +418,10 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   for (int i = 0; i < s * s; ++i) { m.U[i] = d->eigenvecs_u[i]; m.Ui[i] = d->eigenvecs_uinv[i]; }
   for (int i = 0; i < s; ++i) { m.lam[i] = d->eigenvals[i]; m.pi[i] = d->freqs[i]; }
   for (int k = 0; k < c; ++k) {
-    m.rate[k] = d->rates[k % c_in];
-    m.w[k] = d->rate_weights[k % c_in] * (double)c_in / (double)c;
+    // +I (libpll): every P-matrix uses r / (1 - p); the (1 - p) factor of the site likelihood
+    // (1-p) sum_k w_k L_k + p pi_inv is folded into the weights
+    m.rate[k] = d->rates[k % c_in] / (1.0 - pinv);
+    m.w[k] = d->rate_weights[k % c_in] * (double)c_in / (double)c * (1.0 - pinv);
   }
   {
     // Internal convention: eigenvalue 0 is the stationary (zero) one.  Swap the largest
@@ -433,6 +440,8 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
     }
     ctx->dna_zero0 = fabs(m.lam[0]) <= 1e-9 * amax;
     if (ctx->dna_zero0) m.lam[0] = 0.0;
+    if (pinv > 0.0 && !ctx->dna_zero0)
+      return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "+I needs a rate matrix with a zero eigenvalue (any proper GTR)");
   }
   for (int col = 0; col < ctx->ncols; ++col) {
     m.colmask[col] = column_mask(s, col);
@@ -484,6 +493,36 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
     if (!d_tipmap) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(tipmap)");
     EPA_HIP(ctx, hipMemcpy(d_tipmap, d->tipmap, sizeof(uint32_t) * d->tipmap_size,
                            hipMemcpyHostToDevice));
+  }
+  if (pinv > 0.0) {
+    // per-site constant of the +I term: p * pi[state] for sites invariant over the reference tips
+    std::vector<int8_t> inv_buf;
+    const int8_t* inv = d->invariant_state;
+    if (!inv) {  // tree path: derive it from the tip sequences (pll_update_invariant_sites)
+      if (!tree->tipchars || !d->tipmap)
+        return epa_fail(ctx, EPA_ERR_INVALID_ARG, "prop_invar > 0: no tip sequences to derive invariant sites from");
+      inv_buf.resize(W);
+      for (size_t w = 0; w < W; ++w) {
+        uint32_t all = s == 4 ? 15u : ((1u << 20) - 1);
+        for (uint32_t t = 0; t < tree->tips; ++t) {
+          const uint8_t code = tree->tipchars[(size_t)t * W + w];
+          if (code >= d->tipmap_size) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "tip code outside the tip map");
+          all &= d->tipmap[code];
+        }
+        int st = -1;
+        if (all && !(all & (all - 1))) { st = 0; while (!((all >> st) & 1u)) ++st; }
+        inv_buf[w] = (int8_t)st;
+      }
+      inv = inv_buf.data();
+    }
+    std::vector<double> cinv(W);
+    for (size_t w = 0; w < W; ++w) {
+      if (inv[w] >= s) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "invariant_state out of range");
+      cinv[w] = inv[w] >= 0 ? pinv * d->freqs[inv[w]] : 0.0;
+    }
+    EPA_HIP(ctx, hipMalloc(&ctx->cinv, sizeof(double) * W));
+    EPA_HIP(ctx, hipMemcpy(ctx->cinv, cinv.data(), sizeof(double) * W, hipMemcpyHostToDevice));
+    ctx->inv_w0 = 1.0 / m.w[0];
   }
   if (tree) return precompute_from_tree(ctx, tree, d_tipmap);
   // upload + transform, one CLV at a time through two alternating staging buffers
@@ -762,7 +801,8 @@ template <int S>
 __global__ void __launch_bounds__(256) k_tree_logl(const ModelDev* __restrict__ m,
                                                   const double* __restrict__ refT,
                                                   const uint32_t* __restrict__ scSum, uint32_t b, double len,
-                                                  uint32_t W, double* __restrict__ partial) {
+                                                  uint32_t W, const double* __restrict__ cinv,
+                                                  double* __restrict__ partial) {
   __shared__ double U[S * S];
   __shared__ double E[EPA_MAX_CATS * S];
   __shared__ double red[256];
@@ -791,6 +831,7 @@ __global__ void __launch_bounds__(256) k_tree_logl(const ModelDev* __restrict__ 
       }
       L = fma(m->w[k], t, L);
     }
+    if (cinv) L += cinv[site];
     v = log(L) + (double)scSum[(size_t)b * W + site] * (-256.0 * 0.6931471805599453094);
   }
   red[threadIdx.x] = v;
@@ -811,10 +852,10 @@ extern "C" int epa_dev_tree_logl(epa_ctx* ctx, uint32_t branch, double* lnl) {
   const double len = ctx->h_blen[branch];
   if (ctx->s == 4)
     hipLaunchKernelGGL(k_tree_logl<4>, dim3(nblk), dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT, ctx->scSum,
-                       branch, len, ctx->W, d_part);
+                       branch, len, ctx->W, ctx->cinv, d_part);
   else
     hipLaunchKernelGGL(k_tree_logl<20>, dim3(nblk), dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT, ctx->scSum,
-                       branch, len, ctx->W, d_part);
+                       branch, len, ctx->W, ctx->cinv, d_part);
   std::vector<double> part(nblk);
   EPA_HIP(ctx, hipMemcpyAsync(part.data(), d_part, sizeof(double) * nblk, hipMemcpyDeviceToHost, ctx->stream));
   EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));

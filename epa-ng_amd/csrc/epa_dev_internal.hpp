@@ -79,6 +79,8 @@ struct epa_ctx {
   double* refI = nullptr;     // c == 4: [B][c*s][W] U^-1 image of the inner CLV toward the query at
                               // the starting lengths (orig/2, orig/2), rescaled; resc0 [B][W] its flag
   uint8_t* resc0 = nullptr;
+  double* cinv = nullptr;     // +I only: [W] p * pi[invariant state of the site] (0 where not invariant)
+  double inv_w0 = 0.0;        // 1 / w_0: folds cinv into the zero-eigenvalue sumtable entry (thorough)
   double* lookup2 = nullptr;  // DNA only: [B][W][36] site-pair sums (preplace.hip, k_preplace_pairs)
   bool lookup_built = false;
   std::vector<double> h_blen;

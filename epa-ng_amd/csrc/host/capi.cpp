@@ -26,10 +26,10 @@ extern "C" {
 const char* epa_host_last_error() { return g_err.c_str(); }
 
 // model given either as descriptor string (model_desc != NULL) or explicit arrays
-void* epa_host_ref_create(const char* newick, int n_seqs, const char* const* labels,
-                          const char* const* seqs, const char* model_desc, int states,
-                          const double* subst, const double* freqs, int cats, const double* rates,
-                          const double* weights) {
+void* epa_host_ref_create_ex(const char* newick, int n_seqs, const char* const* labels,
+                             const char* const* seqs, const char* model_desc, int states,
+                             const double* subst, const double* freqs, int cats, const double* rates,
+                             const double* weights, double pinv) {
   Ref* r = nullptr;
   if (guarded([&] {
         MSA msa;
@@ -39,12 +39,21 @@ void* epa_host_ref_create(const char* newick, int n_seqs, const char* const* lab
                                      std::vector<double>(freqs, freqs + states),
                                      std::vector<double>(rates, rates + cats),
                                      weights ? std::vector<double>(weights, weights + cats)
-                                             : std::vector<double>());
+                                             : std::vector<double>(),
+                                     pinv);
         r = new Ref();
         r->tree.reset(new Tree(newick, msa, m, r->opt));
       }))
     return nullptr;
   return r;
+}
+
+void* epa_host_ref_create(const char* newick, int n_seqs, const char* const* labels,
+                          const char* const* seqs, const char* model_desc, int states,
+                          const double* subst, const double* freqs, int cats, const double* rates,
+                          const double* weights) {
+  return epa_host_ref_create_ex(newick, n_seqs, labels, seqs, model_desc, states, subst, freqs, cats, rates,
+                                weights, 0.0);
 }
 
 void epa_host_ref_destroy(void* h) { delete static_cast<Ref*>(h); }

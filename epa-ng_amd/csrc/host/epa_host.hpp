@@ -111,7 +111,7 @@ public:
   //   GTR | PROTGTR  [{r1/r2/...}]  [+FU{f1/..} | +FE | +FO(->equal)]  [+G[n][{alpha}]]
   explicit Model(const std::string& descriptor);
   Model(int states, std::vector<double> subst, std::vector<double> freqs, std::vector<double> rates,
-        std::vector<double> weights);
+        std::vector<double> weights, double pinv = 0.0);
   int num_states() const { return states_; }
   int num_ratecats() const { return (int)rates_.size(); }
   const std::vector<double>& subst_rates() const { return subst_; }
@@ -119,6 +119,7 @@ public:
   const std::vector<double>& ratecat_rates() const { return rates_; }
   const std::vector<double>& ratecat_weights() const { return weights_; }
   double alpha() const { return alpha_; }
+  double pinv() const { return pinv_; }  // +I: proportion of invariant sites
   const std::vector<double>& eigenvals() const { return eigenvals_; }
   const std::vector<double>& eigenvecs_u() const { return u_; }       // libpll inv_eigenvecs
   const std::vector<double>& eigenvecs_uinv() const { return uinv_; }  // libpll eigenvecs
@@ -130,7 +131,7 @@ public:
 private:
   void update_eigen();
   int states_ = 4;
-  double alpha_ = 1.0;
+  double alpha_ = 1.0, pinv_ = 0.0;
   std::vector<double> subst_, freqs_, rates_, weights_, eigenvals_, u_, uinv_;
 };
 
@@ -165,6 +166,8 @@ public:
   };
   Branch branch(size_t b) const;
   const std::vector<uint32_t>& tipmap() const { return tipmap_; }
+  // +I: state of the sites invariant over the reference tips, -1 otherwise (pll_update_invariant_sites)
+  const std::vector<int8_t>& invariant_state() const { return invariant_; }
   // fills an epa_ref_desc that borrows this tree's buffers (valid while *this lives)
   void fill_desc(epa_ref_desc& d, std::vector<const double*>& pc, std::vector<const uint32_t*>& ps,
                  std::vector<const double*>& dc, std::vector<const uint8_t*>& dt,
@@ -201,6 +204,7 @@ private:
   std::vector<std::vector<double>> clv_;         // per record (empty for tips)
   std::vector<std::vector<uint32_t>> scaler_;    // per record
   std::vector<uint32_t> tipmap_;
+  std::vector<int8_t> invariant_;
 };
 
 // Caps OpenMP at the CPUs this process may really use (affinity mask and cgroup cpu.max quota:

@@ -118,9 +118,10 @@ std::vector<double> compute_gamma_cats(double alpha, int k) {
 }
 
 Model::Model(int states, std::vector<double> subst, std::vector<double> freqs,
-             std::vector<double> rates, std::vector<double> weights)
-    : states_(states), subst_(std::move(subst)), freqs_(std::move(freqs)), rates_(std::move(rates)),
-      weights_(std::move(weights)) {
+             std::vector<double> rates, std::vector<double> weights, double pinv)
+    : states_(states), pinv_(pinv), subst_(std::move(subst)), freqs_(std::move(freqs)),
+      rates_(std::move(rates)), weights_(std::move(weights)) {
+  if (!(pinv_ >= 0.0 && pinv_ < 1.0)) throw std::runtime_error{"Model: p-inv must be in [0, 1)"};
   if ((int)subst_.size() != states * (states - 1) / 2 || (int)freqs_.size() != states)
     throw std::runtime_error{"Model: wrong number of substitution rates / frequencies"};
   if (weights_.empty()) weights_.assign(rates_.size(), 1.0 / rates_.size());
@@ -189,6 +190,12 @@ Model::Model(const std::string& descriptor) {
       while (i < rest.size() && std::isdigit((unsigned char)rest[i])) ++i;
       if (i > nb) cats = std::stoi(rest.substr(nb, i - nb));
       if (braces(arg)) alpha_ = std::stod(arg);
+    } else if (opt == "I" || opt == "IU" || opt == "IO" || opt == "IC") {
+      // +I{p} / +IU{p}: user-defined proportion of invariant sites (Model.cpp:355-375); +IO / +IC
+      // (ML / empirical estimate) need the optimiser EPA-ng never runs: a value must be given
+      if (!braces(arg)) throw std::runtime_error{"Model: +" + opt + " needs an explicit value, e.g. +I{0.1}"};
+      pinv_ = std::stod(arg);
+      if (!(pinv_ >= 0.0 && pinv_ < 1.0)) throw std::runtime_error{"Model: p-inv must be in [0, 1)"};
     } else {
       throw std::runtime_error{"Model: option +" + opt + " is not supported by this build"};
     }
@@ -239,7 +246,8 @@ void Model::update_eigen() {
 void Model::pmatrix(double t, int k, double* P) const {
   const int s = states_;
   std::vector<double> e(s);
-  for (int x = 0; x < s; ++x) e[x] = std::exp(eigenvals_[x] * rates_[k] * t);
+  // +I: libpll divides the rate by (1 - p-inv) in every P-matrix
+  for (int x = 0; x < s; ++x) e[x] = std::exp(eigenvals_[x] * rates_[k] * t / (1.0 - pinv_));
   for (int i = 0; i < s; ++i)
     for (int j = 0; j < s; ++j) {
       double acc = 0.0;
@@ -278,6 +286,7 @@ std::string Model::to_string() const {
   s << "}+FU{";
   for (size_t i = 0; i < freqs_.size(); ++i) s << (i ? "/" : "") << freqs_[i];
   s << "}";
+  if (pinv_ > 0.0) s << "+IU{" << pinv_ << "}";
   if (rates_.size() > 1) s << "+G" << rates_.size() << "{" << alpha_ << "}";
   return s.str();
 }

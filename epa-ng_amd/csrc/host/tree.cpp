@@ -183,6 +183,18 @@ Tree::Tree(const std::string& newick, const MSA& ref_msa, const Model& model, co
       tipchars_[t][w] = c->second;
     }
   }
+  // pll_update_invariant_sites over the reference tips (the array the tiny partition borrows,
+  // src/tree/tiny_util.cpp:153-156): AND of the tips' state sets is a single state -> that state
+  invariant_.assign(sites_, (int8_t)-1);
+  for (size_t w = 0; w < sites_; ++w) {
+    uint32_t all = s == 4 ? 15u : ((1u << 20) - 1);
+    for (unsigned t = 0; t < n; ++t) all &= tipmap_[tipchars_[t][w]];
+    if (all && !(all & (all - 1))) {
+      int st = 0;
+      while (!((all >> st) & 1u)) ++st;
+      invariant_[w] = (int8_t)st;
+    }
+  }
   // precompute_clvs (src/core/pll/epa_pll_util.cpp:62-107): all three directions per inner node
   clv_.resize(recs_.size());
   scaler_.resize(recs_.size());
@@ -240,6 +252,8 @@ void Tree::fill_tree_desc(epa_tree_desc& d, Tree_Desc_Storage& st) const {
   rd.rates = model_.ratecat_rates().data();
   rd.rate_weights = model_.ratecat_weights().data();
   rd.branch_length = st.blen.data();
+  rd.prop_invar = model_.pinv();
+  rd.invariant_state = model_.pinv() > 0.0 ? invariant_.data() : nullptr;
   rd.tipmap = tipmap_.data();
   rd.tipmap_size = (uint32_t)tipmap_.size();
   d.tips = (uint32_t)n;
@@ -383,7 +397,8 @@ void Tree::fill_desc(epa_ref_desc& d, std::vector<const double*>& pc,
   d.freqs = model_.base_freqs().data();
   d.rates = model_.ratecat_rates().data();
   d.rate_weights = model_.ratecat_weights().data();
-  d.prop_invar = 0.0;
+  d.prop_invar = model_.pinv();
+  d.invariant_state = model_.pinv() > 0.0 ? invariant_.data() : nullptr;
   d.prox_clv = pc.data(); d.prox_scaler = ps.data();
   d.dist_clv = dc.data(); d.dist_tipchars = dt.data(); d.dist_scaler = ds.data();
   d.branch_length = bl.data();
@@ -421,6 +436,9 @@ double Tree::ref_tree_logl(size_t b) const {
       }
       site += cat * model_.ratecat_weights()[k];
     }
+    if (model_.pinv() > 0.0)  // +I: (1 - p) L + p pi_inv (libpll, unscaled invariant term)
+      site = site * (1.0 - model_.pinv()) +
+             (invariant_[w] >= 0 ? model_.pinv() * model_.base_freqs()[invariant_[w]] : 0.0);
     const uint32_t cnt = (sp ? sp[w] : 0) + (sd ? sd[w] : 0);
     logl += std::log(site) + cnt * log_thr;
   }

@@ -38,6 +38,8 @@ struct ThArgsAA {
   const double* refT;      // [2B][80][W]
   const double* refI;      // [B][80][W] U^-1 inner CLV at the starting lengths (k_build_lookup), or null
   const uint8_t* resc0;    // [B][W]     its per-site rescale flag
+  const double* cinv;      // +I: [W] p * pi_inv per site, or null
+  double inv_w0;           // +I: 1 / w_0 (folded into sumtable entry (category 0, eigen index 0))
   const uint32_t* scSum;   // [B][W]
   const double* blen;      // [B]
   const epa_pair* pairs;
@@ -288,7 +290,10 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa(const ThArgsAA a) {
         const uint32_t wsite = (LDS_SLAB && !valid) ? a.Wpad - 1 : site;
 #pragma unroll
         for (int x = 0; x < S; ++x) {
-          const double sv = It[x] * mult * E[x];
+          double sv = It[x] * mult * E[x];
+          // +I: p * pi_inv enters L_0 only: eigenvalue 0 is exactly 0, its order-1/2 table entries
+          // vanish, so the term is folded into the sumtable entry (category 0, eigen index 0)
+          if (x == 0 && k == 0 && a.cinv) sv += a.cinv[begin + s] * a.inv_w0;
           slab(x * a.Wpad + wsite) = sv;
           if (mode != 1) l0 = fma(sv, sh.tab[2][k * S + x], l0);
         }
@@ -482,6 +487,8 @@ int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_
   a.refT = ctx->refT;
   a.refI = ctx->lookup_built ? ctx->refI : nullptr;
   a.resc0 = ctx->resc0;
+  a.cinv = ctx->cinv;
+  a.inv_w0 = ctx->inv_w0;
   a.scSum = ctx->scSum;
   a.blen = ctx->blen;
   a.pairs = d_pairs;

@@ -42,6 +42,8 @@ struct ThArgs {
   const double* refT;      // [2B][16][W]
   const double* refI;      // [B][16][W]  U^-1 inner CLV at the starting lengths (k_build_lookup)
   const uint8_t* resc0;    // [B][W]      its per-site rescale flag
+  const double* cinv;      // +I: [W] p * pi_inv per site, or null
+  double inv_w0;           // +I: 1 / w_0
   const uint32_t* scSum;   // [B][W]
   const double* blen;      // [B]
   const double* qt;        // [16 columns][4]   U^-1 image of each column's tip vector
@@ -235,7 +237,7 @@ __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, 
   return NAN;
 }
 
-template <int NCH, bool ZERO0>
+template <int NCH, bool ZERO0, bool INV>
 __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pidx, const int lane,
                                              double* tab, const double* qts, const LaneConst& lc,
                                              uint32_t (&wstat)[3]) {
@@ -271,6 +273,13 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   uint32_t evals = 0, rounds = 0, reverted = 0;
   uint32_t chain = 0;  // zero_after() token: serialises load batches behind the preceding math
 
+  // +I: the site's invariant term p * pi_inv enters the site likelihood L_0 only.  Eigenvalue 0
+  // is exactly 0 (ZERO0), so its table entries are w_0 (order 0) and 0 (orders 1, 2): adding
+  // c / w_0 to sumtable entry (category 0, eigen index 0) adds c to L_0 and nothing to L_1, L_2.
+  auto cinv_of = [&](int ch) -> double {
+    const uint32_t s = st.valid[ch] ? ch * 64 + lane : 0;
+    return a.cinv[begin + s] * a.inv_w0;
+  };
   // Inner CLV toward the query at (td, tx) folded with the query, S = (U^-1 I) o qt, and the
   // window lnL at pendant length tp_.  One table pass: slot 0 -> exp(lr td), slot 1 ->
   // exp(lr tx), slot 2 -> w exp(lr tp).
@@ -295,6 +304,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
         st.S[ch][k * 4 + 2] = It[k * 4 + 2] * q2;
         st.S[ch][k * 4 + 3] = It[k * 4 + 3] * q3;
       }
+      if constexpr (INV) st.S[ch][0] += cinv_of(ch);
       chain = zero_after(st.S[ch][15]);
     }
     double ew[16];
@@ -322,6 +332,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
       inner_site(m, Qv, tab, X, tab + 16, It, r);
 #pragma unroll
       for (int c = 0; c < 16; ++c) st.S[ch][c] = D[c] * It[c];
+      if constexpr (INV) st.S[ch][0] += cinv_of(ch);
       chain = zero_after(st.S[ch][15]);
     }
   };
@@ -351,6 +362,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
         st.S[ch][k * 4 + 2] = It[k * 4 + 2] * q2;
         st.S[ch][k * 4 + 3] = It[k * 4 + 3] * q3;
       }
+      if constexpr (INV) st.S[ch][0] += cinv_of(ch);
       chain = zero_after(st.S[ch][15]);
     }
     double ew[16];
@@ -418,7 +430,9 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 // windows are served by one 4 MiB L2.  Inside its XCD slice a wave takes pairs round-robin
 // (wave, wave + stride, ...): neighbouring waves work on neighbouring pairs = the same branch,
 // and every wave gets a ~25-pair random sample of the 10x cost spread (1..32 NR rounds).
-template <int NCH, bool ZERO0>
+// INV: the model has +I (instantiated for ZERO0 only; a separate instantiation so that the
+// default kernel's register allocation is untouched: the runtime-flag version cost 40 more spills)
+template <int NCH, bool ZERO0, bool INV>
 __global__ void __launch_bounds__(64, 2) k_thorough_dna(const ThArgs a) {
   __shared__ double tab[64];   // broadcast table of the wave
   __shared__ double qts[64];   // U^-1 image of the 16 query column codes
@@ -439,7 +453,7 @@ __global__ void __launch_bounds__(64, 2) k_thorough_dna(const ThArgs a) {
   const uint64_t lo = (uint64_t)x * per;
   const uint64_t hi = lo + per < a.n_pairs ? lo + per : a.n_pairs;
   uint32_t wstat[3] = {0, 0, 0};
-  for (uint64_t p = lo + w; p < hi; p += stride) process_pair<NCH, ZERO0>(a, p, lane, tab, qts, lc, wstat);
+  for (uint64_t p = lo + w; p < hi; p += stride) process_pair<NCH, ZERO0, INV>(a, p, lane, tab, qts, lc, wstat);
   if (lane == 0) {
     atomicAdd(&a.stats[0], (unsigned long long)wstat[0]);
     atomicAdd(&a.stats[1], (unsigned long long)wstat[1]);
@@ -550,7 +564,8 @@ __global__ void __launch_bounds__(64, 2) k_thorough_dna_long(const ThArgs a) {
         for (int k = 0; k < 4; ++k)
 #pragma unroll
           for (int x = 0; x < 4; ++x) {
-            const double sv = It[k * 4 + x] * qv[x];
+            double sv = It[k * 4 + x] * qv[x];
+            if (a.cinv && k == 0 && x == 0) sv += a.cinv[begin + s] * a.inv_w0;  // +I, see process_pair
             if (valid) slab[(size_t)(k * 4 + x) * a.Wpad + site] = sv;
             l0 = fma(sv, ew[k * 4 + x], l0);
           }
@@ -585,7 +600,8 @@ __global__ void __launch_bounds__(64, 2) k_thorough_dna_long(const ThArgs a) {
         inner_site(m, Qv, tab, X, tab + 16, It, r);
         if (valid) {
 #pragma unroll
-          for (int c = 0; c < 16; ++c) slab[(size_t)c * a.Wpad + site] = D[c] * It[c];
+          for (int c = 0; c < 16; ++c)
+            slab[(size_t)c * a.Wpad + site] = D[c] * It[c] + ((a.cinv && c == 0) ? a.cinv[begin + s] * a.inv_w0 : 0.0);
         }
       }
       __threadfence_block();
@@ -704,8 +720,9 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
   uint32_t nwg = (uint32_t)((want + 7) / 8 * 8);
 #define LAUNCH(N)                                                                              \
   do {                                                                                         \
-    if (ctx->dna_zero0) hipLaunchKernelGGL((k_thorough_dna<N, true>), dim3(nwg), dim3(64), 0, ctx->stream, a); \
-    else hipLaunchKernelGGL((k_thorough_dna<N, false>), dim3(nwg), dim3(64), 0, ctx->stream, a); \
+    if (a.cinv) hipLaunchKernelGGL((k_thorough_dna<N, true, true>), dim3(nwg), dim3(64), 0, ctx->stream, a); \
+    else if (ctx->dna_zero0) hipLaunchKernelGGL((k_thorough_dna<N, true, false>), dim3(nwg), dim3(64), 0, ctx->stream, a); \
+    else hipLaunchKernelGGL((k_thorough_dna<N, false, false>), dim3(nwg), dim3(64), 0, ctx->stream, a); \
   } while (0)
   switch (cls) {
     case 0: LAUNCH(1); break;
@@ -808,6 +825,8 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
     // filled by k_build_lookup; until then every pair computes its own starting vector
     a.refI = ctx->lookup_built ? ctx->refI : nullptr;
     a.resc0 = ctx->resc0;
+  a.cinv = ctx->cinv;
+  a.inv_w0 = ctx->inv_w0;
     a.scSum = ctx->scSum;
     a.blen = ctx->blen;
     a.qt = ctx->dmodel->qt;

@@ -25,6 +25,10 @@ def host_lib():
         L.epa_host_ref_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p),
                                           C.POINTER(C.c_char_p), C.c_char_p, C.c_int, dp, dp,
                                           C.c_int, dp, dp]
+        L.epa_host_ref_create_ex.restype = C.c_void_p
+        L.epa_host_ref_create_ex.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p),
+                                             C.POINTER(C.c_char_p), C.c_char_p, C.c_int, dp, dp,
+                                             C.c_int, dp, dp, C.c_double]
         L.epa_host_ref_destroy.argtypes = [C.c_void_p]
         L.epa_host_configure_threads.restype = C.c_int
         u32p = C.POINTER(C.c_uint32)
@@ -72,7 +76,7 @@ class Reference:
     (mirror of the reference's `Tree`, src/tree/Tree.cpp:16-56)."""
 
     def __init__(self, newick, labels, seqs, model=None, states=None, subst=None, freqs=None,
-                 rates=None, weights=None):
+                 rates=None, weights=None, pinv=0.0):
         L = host_lib()
         self._keep = (_strs(labels), _strs(seqs))
         if model is not None:
@@ -84,9 +88,10 @@ class Reference:
             freqs = np.ascontiguousarray(freqs, np.float64)
             rates = np.ascontiguousarray(rates, np.float64)
             w = None if weights is None else np.ascontiguousarray(weights, np.float64)
-            self.h = L.epa_host_ref_create(newick.encode(), len(labels), self._keep[0],
-                                           self._keep[1], None, states, _dp(subst), _dp(freqs),
-                                           len(rates), _dp(rates), None if w is None else _dp(w))
+            self.h = L.epa_host_ref_create_ex(newick.encode(), len(labels), self._keep[0],
+                                              self._keep[1], None, states, _dp(subst), _dp(freqs),
+                                              len(rates), _dp(rates), None if w is None else _dp(w),
+                                              float(pinv))
         if not self.h:
             raise RuntimeError(L.epa_host_last_error().decode())
         s, c, w_, b = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()

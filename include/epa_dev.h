@@ -74,7 +74,7 @@ typedef struct {
   const double* freqs;       /* [states] stationary frequencies                                */
   const double* rates;       /* [rate_cats]                                                    */
   const double* rate_weights;/* [rate_cats]                                                    */
-  double prop_invar;         /* must be 0.0 (+I is "next")                                     */
+  double prop_invar;         /* proportion of invariant sites (+I), 0 <= p < 1; see invariant_state */
 
   /* per branch: B pointers each */
   const double* const* prox_clv;       /* [B] -> [W][c][s]                                     */
@@ -101,6 +101,14 @@ typedef struct {
   uint32_t flags;            /* EPA_FLAG_*; 0 selects EPA_FLAG_SLIDING_BLO                     */
   uint32_t aa_x_as_n;        /* 1: reproduce quirk D4 (AA 'X' preplaced in the 'N' column,      *
                               *    Lookup_Store.hpp:63-66); 0 (default): 'X' = any             */
+  /* +I: state of every site that is invariant over the REFERENCE tips (libpll
+   * pll_update_invariant_sites: AND of the tips' state sets is a single state), -1 otherwise;
+   * the array the tiny partition borrows at src/tree/tiny_util.cpp:153-156.  [sites]; required
+   * by epa_dev_create when prop_invar > 0, optional for epa_dev_create_from_tree (derived from
+   * the tip sequences when NULL).  With +I the library follows libpll: rates are divided by
+   * (1 - p) in every P-matrix, a site's likelihood is (1-p) L + p pi_state (the second term is
+   * added unscaled and regardless of the query's character, as libpll does).                  */
+  const int8_t* invariant_state;
 } epa_ref_desc;
 
 /*

@@ -372,3 +372,63 @@ def test_device_reference_precompute_rescaling_deep_tree():
     reads = ["".join(rng.choice(list("ACGT"), W)) for _ in range(20)]
     codes, wb, ws = epa.encode_queries(4, reads, compact=True)
     assert np.max(np.abs(e_dev.preplace(codes, wb, ws) - e_host.preplace(codes, wb, ws))) < 1e-7
+
+
+@pytest.mark.parametrize("states", [4, 20])
+def test_prop_invariant_sites_device_vs_oracle(states):
+    """+I through the whole device path (device reference precompute, lookup, pair / generic
+    preplacement, first-phase vectors, thorough kernels incl. the long-window one): tree lnL,
+    preplacement table and thorough results equal the oracle's +I restatement."""
+    from epa_ng_amd import synth
+    pinv = 0.23
+    if states == 4:
+        w = synth.dna_workload(24, 330, 60, 90, (91, 92, 93))
+        const_cols = "ACGTTGCA" * 5
+    else:
+        w = synth.aa_workload(14, 230, 40, 60, (94, 95, 96))
+        const_cols = "ARNDCQEGHI" * 3
+    k = len(const_cols)
+    seqs = [s[:-k] + const_cols for s in w["seqs"]]           # a block of invariant columns
+    reads = [r[:-k] + (const_cols if i % 2 else "-" * k) for i, r in enumerate(w["reads"])]
+    reads += [r[:60] + "-" * (len(r) - 60 - k) + const_cols for r in w["reads"][:6]]   # long windows
+    if states == 4:
+        reads[0] = reads[0].replace("A", "R", 1)                 # generic preplace kernel
+    o = Oracle(w["newick"], w["labels"], seqs, states, w["subst"], w["freqs"], w["rates"], pinv=pinv)
+    ref = hostlib.Reference(w["newick"], w["labels"], seqs, states=states, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"], pinv=pinv)
+    for dev_pre in (True, False):
+        ev = ref.evaluator(device_precompute=dev_pre)
+        assert abs(ev.tree_logl(0) - o.tree_lnl(0)) < 1e-7
+        codes, wb, ws = epa.encode_queries(states, reads, compact=True)
+        lnl = ev.preplace(codes, wb, ws)
+        assert np.max(np.abs(lnl - o.preplace(reads))) < 1e-6
+        pairs, res = ev.place_chunk(codes, wb, ws, max_pairs=len(reads) * ref.B)
+        tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
+        assert np.max(np.abs(res["lnl"] - tl)) < 1e-6
+        assert np.max(np.abs(res["distal_length"] - td)) < 1e-6
+        assert np.max(np.abs(res["pendant_length"] - tp) / np.maximum(1.0, tp)) < 1e-6
+        assert ev.last_stats["rounds"] == o.last_stats["rounds"]
+    # and the +I term really matters on this data
+    o0 = Oracle(w["newick"], w["labels"], seqs, states, w["subst"], w["freqs"], w["rates"])
+    assert np.max(np.abs(o0.preplace(reads[:4]) - o.preplace(reads[:4]))) > 0.1
+
+
+def test_prop_invariant_sites_long_window_kernel():
+    """+I in k_thorough_dna_long (windows > 1536 sites)"""
+    from epa_ng_amd import synth
+    w = synth.dna_workload(10, 1800, 4, 1700, (97, 98, 99))
+    seqs = [s[:-40] + "ACGT" * 10 for s in w["seqs"]]
+    reads = [r[:-40] + "ACGT" * 10 for r in w["reads"]]
+    o = Oracle(w["newick"], w["labels"], seqs, 4, w["subst"], w["freqs"], w["rates"], pinv=0.3)
+    ref = hostlib.Reference(w["newick"], w["labels"], seqs, states=4, subst=w["subst"], freqs=w["freqs"],
+                            rates=w["rates"], pinv=0.3)
+    ev = ref.evaluator()
+    codes, wb, ws = epa.encode_queries(4, reads, compact=True)
+    assert ws.max() > 1536
+    pairs = np.zeros(ref.B * len(reads), epa.PAIR_DTYPE)
+    pairs["branch_id"] = np.repeat(np.arange(ref.B), len(reads))
+    pairs["seq_id"] = np.tile(np.arange(len(reads)), ref.B)
+    res = ev.thorough(pairs, codes, wb, ws)
+    tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
+    assert np.max(np.abs(res["lnl"] - tl)) < 1e-6
+    assert np.max(np.abs(res["distal_length"] - td)) < 1e-6

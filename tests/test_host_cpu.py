@@ -226,3 +226,29 @@ def test_rooted_reference_tree_is_unrooted():
         assert abs(b.tree_lnl(e) - la) < 1e-8
     nw = b.numbered_newick()
     assert nw.count("{") == b.B and nw.endswith(";")
+
+
+def test_prop_invariant_sites_host_vs_oracle():
+    """+I on the host side: model string +I{p}, rates / (1 - p) in the P-matrices, invariant
+    sites from the reference tips, (1-p) L + p pi_inv per site: tree lnL == oracle on every edge
+    and differs from the p = 0 value."""
+    from epa_ng_amd import synth
+    root = synth.random_tree(14, 21)
+    rates = synth.gamma_rates(0.6)
+    labels, seqs = synth.simulate_msa(root, 200, synth.CFG2_SUBST, synth.CFG2_FREQS, rates, 22)
+    seqs = [s[:150] + "ACGTA" * 10 for s in seqs]           # 50 invariant columns
+    seqs[3] = seqs[3][:160] + "-N" + seqs[3][162:]          # gaps / N do not break invariance
+    nwk = synth.newick(root)
+    pinv = 0.17
+    o = Oracle(nwk, labels, seqs, 4, synth.CFG2_SUBST, synth.CFG2_FREQS, rates, pinv=pinv)
+    ref = hostlib.Reference(nwk, labels, seqs, states=4, subst=synth.CFG2_SUBST, freqs=synth.CFG2_FREQS,
+                            rates=rates, pinv=pinv)
+    ref0 = hostlib.Reference(nwk, labels, seqs, states=4, subst=synth.CFG2_SUBST, freqs=synth.CFG2_FREQS,
+                             rates=rates)
+    for b in range(ref.B):
+        assert abs(ref.tree_lnl(b) - o.tree_lnl(b)) < 1e-8
+    assert abs(ref.tree_lnl(0) - ref0.tree_lnl(0)) > 1.0
+    desc = ("GTR{%s}+FU{%s}+I{%r}+G4{0.6}" % ("/".join(map(repr, synth.CFG2_SUBST)),
+                                             "/".join(map(repr, synth.CFG2_FREQS)), pinv))
+    ref2 = hostlib.Reference(nwk, labels, seqs, model=desc)
+    assert abs(ref2.tree_lnl(0) - ref.tree_lnl(0)) < 1e-6
