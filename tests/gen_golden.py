@@ -154,8 +154,10 @@ def numbered_newick(root, prec):
 
 # ---------------------------------------------------------------- model
 class Model:
-    def __init__(self, s, subst, freqs, alpha, cats=4, rates=None):
+    def __init__(self, s, subst, freqs, alpha, cats=4, rates=None, pinv=0.0):
         self.s = s
+        self.pinv = pinv          # +I: rates / (1 - p) in P(t); site lk = (1-p) L + p pi_inv
+        self.cinv = None          # [W] p * pi_inv per site (set by make_case from the reference tips)
         self.freqs = np.asarray(freqs, float)
         R = np.zeros((s, s))
         R[np.triu_indices(s, 1)] = subst
@@ -175,7 +177,7 @@ class Model:
         self.weights = np.full(len(self.rates), 1.0 / len(self.rates))
 
     def P(self, t):
-        return np.stack([expm(self.Q * (r * t)) for r in self.rates])  # [c][i][j]
+        return np.stack([expm(self.Q * (r * t / (1.0 - self.pinv))) for r in self.rates])  # [c][i][j]
 
 
 # ---------------------------------------------------------------- likelihood (log-normalised)
@@ -199,9 +201,16 @@ def prune(model, node, seqs):
     return acc / mx[:, None, None], logf + np.log(mx)
 
 
+def mix_inv(model, l0, logf):
+    """+I: true site likelihood (1 - p) L + p pi_inv; l0 is normalised by exp(logf)"""
+    if model.pinv == 0.0:
+        return np.log(l0) + logf
+    return np.log((1.0 - model.pinv) * l0 * np.exp(logf) + model.cinv[:len(l0)])
+
+
 def root_lnl_sites(model, partial, logf):
     site = np.einsum("c,wci,i->w", model.weights, partial, model.freqs)
-    return np.log(site) + logf
+    return mix_inv(model, site, logf)
 
 
 def tree_lnl(model, root, seqs):
@@ -250,7 +259,7 @@ def star_terms(model, tipp, dist, prox, tp, td, tx, order=(0, 0, 0)):
     def branch(p, t, k):
         P = model.P(t)
         for _ in range(k):
-            P = np.einsum("c,ij,cjk->cik", model.rates, model.Q, P)
+            P = np.einsum("c,ij,cjk->cik", model.rates / (1.0 - model.pinv), model.Q, P)
         return np.einsum("cij,wcj->wci", P, p)
 
     a = branch(tipp, tp, order[0])
@@ -261,7 +270,7 @@ def star_terms(model, tipp, dist, prox, tp, td, tx, order=(0, 0, 0)):
 
 def star_lnl(model, tipp, dist, prox, tp, td, tx, lo, n):
     l0 = star_terms(model, tipp, dist, prox, tp, td, tx)
-    return float((np.log(l0) + dist[1] + prox[1])[lo:lo + n].sum())
+    return float(mix_inv(model, l0, dist[1] + prox[1])[lo:lo + n].sum())
 
 
 def newton(x1, xguess, x2, tol, max_iters, deriv):
@@ -312,6 +321,11 @@ def thorough(model, tipp, dist, prox, orig, lo, n):
             l0 = star_terms(model, tipp, dist, prox, *args)[sl]
             l1 = star_terms(model, tipp, dist, prox, *args, order=tuple(o1))[sl]
             l2 = star_terms(model, tipp, dist, prox, *args, order=tuple(o2))[sl]
+            if model.pinv > 0.0:   # derivatives of (1-p) L + p pi_inv: only L depends on t
+                sc = np.exp((dist[1] + prox[1])[sl])
+                l0 = (1.0 - model.pinv) * l0 * sc + model.cinv[sl]
+                l1 = (1.0 - model.pinv) * l1 * sc
+                l2 = (1.0 - model.pinv) * l2 * sc
             d1 = -l1 / l0
             return float(d1.sum()), float((d1 * d1 - l2 / l0).sum())
         return deriv
@@ -344,15 +358,23 @@ def thorough(model, tipp, dist, prox, orig, lo, n):
 
 
 # ---------------------------------------------------------------- cases
-def make_case(name, tree_file, aln_file, queries, s, subst, freqs, alpha, full_pairs=True):
+def make_case(name, tree_file, aln_file, queries, s, subst, freqs, alpha, full_pairs=True, pinv=0.0):
     newick = open(os.path.join(DATA, tree_file)).read().strip()
     root = parse_newick(newick)
     seqs = dict(read_fasta(os.path.join(DATA, aln_file)))
-    model = Model(s, subst, freqs, alpha)
+    model = Model(s, subst, freqs, alpha, pinv=pinv)
     brs = branches_postorder(root)
     W = len(next(iter(seqs.values())))
+    # sites invariant over the reference tips (a tip's ambiguity / gap does not break it): the
+    # intersection of the tips' state sets is a single state
+    inter = np.ones((W, s), bool)
+    for sq in seqs.values():
+        inter &= np.stack([char_vec(s, ch) for ch in sq]) > 0
+    inv_state = np.where(inter.sum(1) == 1, inter.argmax(1), -1)
+    model.cinv = np.where(inv_state >= 0, pinv * model.freqs[np.maximum(inv_state, 0)], 0.0)
     out = {"name": name, "tree_file": tree_file, "aln_file": aln_file, "states": s,
-           "subst": list(subst), "freqs": list(freqs), "alpha": alpha,
+           "subst": list(subst), "freqs": list(freqs), "alpha": alpha, "pinv": pinv,
+           "invariant_state": inv_state.tolist(),
            "gamma_rates": model.rates.tolist(),
            "numbered_newick_p2": numbered_newick(root, 2),
            "tree_lnl": tree_lnl(model, root, seqs),
@@ -425,14 +447,24 @@ def main():
 
     q = read_fasta(os.path.join(DATA, "query.fasta"))
     dnaq = derive_queries([(a, b) for a, b in q])
+    only = set(sys.argv[1:])   # optional: regenerate just the named cases
     cases = []
+    _make = make_case
+
+    def make_case_sel(name, *a, **kw):
+        return _make(name, *a, **kw) if (not only or name in only) else None
     # GTR+G defaults of raxml::Model("GTR+G") (Model.cpp:190-193,470,487-488)
-    cases.append(make_case("dna8_gtr_g_default", "ref.tre", "aln.fasta", dnaq, 4,
+    cases.append(make_case_sel("dna8_gtr_g_default", "ref.tre", "aln.fasta", dnaq, 4,
                            [0.5, 0.5, 0.5, 0.5, 0.5, 1.0], [0.25] * 4, 1.0))
     # model string pinned by test/src/parse_model.cpp:10-11
-    cases.append(make_case("dna8_gtr_fu_g4", "ref.tre", "aln.fasta", dnaq, 4,
+    cases.append(make_case_sel("dna8_gtr_fu_g4", "ref.tre", "aln.fasta", dnaq, 4,
                            [0.787874, 1.821672, 1.294006, 0.698421, 3.034135, 1.0],
                            [0.256465, 0.222535, 0.308594, 0.212406], 0.478218))
+    # +I on the same data (model GTR+FU+I{0.2}+G4): pins the oracle's restatement of libpll's
+    # invariant-site handling against the brute force (no scaling occurs on 8 taxa)
+    cases.append(make_case_sel("dna8_gtr_fu_i_g4", "ref.tre", "aln.fasta", dnaq[:4], 4,
+                           [0.787874, 1.821672, 1.294006, 0.698421, 3.034135, 1.0],
+                           [0.256465, 0.222535, 0.308594, 0.212406], 0.478218, pinv=0.2))
     # 20-state: a deterministic pseudo-random PROTGTR (190 rates) + non-uniform freqs
     rng = np.random.RandomState(7)
     aasub = np.round(rng.gamma(1.0, 2.0, 190) + 0.01, 6).tolist()
@@ -446,9 +478,9 @@ def main():
     w = list("-" * 200 + s0[200:320] + "-" * (W - 320))
     w[210], w[211], w[212] = "X", "B", "Z"
     aaq.append((aaq[0][0] + "_win200_320_amb", "".join(w)))
-    cases.append(make_case("aa8_protgtr_g4", "aa_ref.tre", "AA_aln.fasta", aaq, 20, aasub,
+    cases.append(make_case_sel("aa8_protgtr_g4", "aa_ref.tre", "AA_aln.fasta", aaq, 20, aasub,
                            aaf.tolist(), 0.563473))
-    for c in cases:
+    for c in [c for c in cases if c is not None]:
         path = os.path.join(HERE, "golden", c["name"] + ".json")
         with open(path, "w") as f:
             json.dump(c, f, indent=0)

@@ -432,3 +432,27 @@ def test_prop_invariant_sites_long_window_kernel():
     tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
     assert np.max(np.abs(res["lnl"] - tl)) < 1e-6
     assert np.max(np.abs(res["distal_length"] - td)) < 1e-6
+
+
+def test_prop_invariant_sites_golden_on_device():
+    """the +I golden case (independent brute force) straight through the device path"""
+    g = load_case("dna8_gtr_fu_i_g4")
+    labels = [a for a, _ in g["msa"]]
+    seqs = [b for _, b in g["msa"]]
+    ref = hostlib.Reference(g["newick"], labels, seqs, states=4, subst=g["subst"], freqs=g["freqs"],
+                            rates=g["gamma_rates"], pinv=g["pinv"])
+    assert abs(ref.tree_lnl(0) - g["tree_lnl"]) < 1e-8
+    ev = ref.evaluator()
+    assert abs(ev.tree_logl(3) - g["tree_lnl"]) < 1e-7
+    qs = [q["seq"] for q in g["queries"]]
+    codes, wb, ws = epa.encode_queries(4, qs)
+    assert np.max(np.abs(ev.preplace(codes, wb, ws) - np.array(g["preplace"]))) < 1e-6
+    pairs = np.zeros(ref.B * len(qs), epa.PAIR_DTYPE)
+    pairs["branch_id"] = np.repeat(np.arange(ref.B), len(qs))
+    pairs["seq_id"] = np.tile(np.arange(len(qs)), ref.B)
+    res = ev.thorough(pairs, codes, wb, ws)
+    for i, p in enumerate(pairs):
+        e = g["thorough"][p["seq_id"]][p["branch_id"]]
+        assert abs(res["lnl"][i] - e["lnl"]) < 1e-6
+        assert abs(res["distal_length"][i] - e["distal"]) < 1e-6
+        assert abs(res["pendant_length"][i] - e["pendant"]) < 1e-6 * max(1.0, e["pendant"])

@@ -131,3 +131,28 @@ def test_error_codes():
         o.preplace(["!" + "A" * (o.W - 1)])
     assert lib().orc_char_column(4, b"u", 0) == 1 and lib().orc_char_column(4, b"x", 0) == 0
     assert lib().orc_char_column(20, b"X", 1) == 11 and lib().orc_char_column(20, b"X", 0) == 21
+
+
+def test_prop_invariant_sites_matches_bruteforce():
+    """+I (GTR+FU+I{0.2}+G4 on the reference's data): the oracle's restatement of libpll's
+    invariant-site handling (rates / (1-p) in P(t), (1-p) L + p pi_inv, invariant sites from the
+    reference tips only) against the independent brute force of tests/gen_golden.py."""
+    g = load_case("dna8_gtr_fu_i_g4")
+    assert g["pinv"] == 0.2 and sum(1 for v in g["invariant_state"] if v >= 0) > 50
+    labels = [a for a, _ in g["msa"]]
+    seqs = [b for _, b in g["msa"]]
+    o = Oracle(g["newick"], labels, seqs, 4, g["subst"], g["freqs"], g["gamma_rates"], pinv=g["pinv"])
+    for b in range(o.B):
+        assert abs(o.tree_lnl(b) - g["tree_lnl"]) < 1e-8
+    qs = [q["seq"] for q in g["queries"]]
+    assert np.max(np.abs(o.preplace(qs) - np.array(g["preplace"]))) < 1e-8
+    pb = [b for b in range(o.B) for _ in qs]
+    ps = [qi for _ in range(o.B) for qi in range(len(qs))]
+    lnl, pen, dis = o.thorough(pb, ps, qs)
+    for i, (b, qi) in enumerate(zip(pb, ps)):
+        e = g["thorough"][qi][b]
+        assert abs(lnl[i] - e["lnl"]) < 1e-7, (b, qi, lnl[i], e)
+        assert abs(pen[i] - e["pendant"]) < 1e-7 * max(1.0, e["pendant"])
+        assert abs(dis[i] - e["distal"]) < 1e-7
+    assert o.last_stats["rounds"] == sum(e["rounds"] for row in g["thorough"] for e in row)
+    assert o.last_stats["reverts"] == sum(e["reverted"] for row in g["thorough"] for e in row)
