@@ -108,7 +108,8 @@ class Model {
 public:
   Model() = default;
   // raxml-ng style descriptor, subset (src/core/raxml/Model.cpp:123-538):
-  //   GTR | PROTGTR  [{r1/r2/...}]  [+FU{f1/..} | +FE | +FO(->equal)]  [+G[n][{alpha}]]
+  //   GTR | PROTGTR  [{r1/r2/...}]  [+FU{f1/..} | +FE | +FO(->equal)]  [+I{p}]
+  //                  [+G[n][{alpha}] | +R[n]{rates}{weights}]
   explicit Model(const std::string& descriptor);
   Model(int states, std::vector<double> subst, std::vector<double> freqs, std::vector<double> rates,
         std::vector<double> weights, double pinv = 0.0);
@@ -132,6 +133,7 @@ private:
   void update_eigen();
   int states_ = 4;
   double alpha_ = 1.0, pinv_ = 0.0;
+  bool free_rates_ = false;
   std::vector<double> subst_, freqs_, rates_, weights_, eigenvals_, u_, uinv_;
 };
 

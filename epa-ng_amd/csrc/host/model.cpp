@@ -146,7 +146,7 @@ Model::Model(const std::string& descriptor) {
   freqs_.assign(states_, 1.0 / states_);
   int cats = 1;
   alpha_ = 1.0;
-  bool gamma = false;
+  bool gamma = false, free_rates = false;
   std::string rest = pos == std::string::npos ? "" : descriptor.substr(pos);
   size_t i = 0;
   auto braces = [&](std::string& out) {
@@ -190,6 +190,33 @@ Model::Model(const std::string& descriptor) {
       while (i < rest.size() && std::isdigit((unsigned char)rest[i])) ++i;
       if (i > nb) cats = std::stoi(rest.substr(nb, i - nb));
       if (braces(arg)) alpha_ = std::stod(arg);
+    } else if (opt == "R") {
+      // free rates: +R<n>{r1/../rn}{w1/../wn} (Model.cpp:405-455): weights normalised to sum 1
+      // (equal if omitted), then rates divided by sum_k w_k r_k
+      free_rates = true;
+      cats = 4;
+      size_t nb = i;
+      while (i < rest.size() && std::isdigit((unsigned char)rest[i])) ++i;
+      if (i > nb) cats = std::stoi(rest.substr(nb, i - nb));
+      if (!braces(arg)) throw std::runtime_error{"Model: +R needs explicit rates, e.g. +R4{0.1/0.5/1/3}{0.25/0.25/0.25/0.25}"};
+      rates_ = parse_list(arg);
+      if ((int)rates_.size() != cats)
+        throw std::runtime_error{"Invalid number of free rates specified: " + std::to_string(rates_.size()) +
+                                 " (expected: " + std::to_string(cats) + ")"};
+      if (braces(arg)) {
+        weights_ = parse_list(arg);
+        if ((int)weights_.size() != cats)
+          throw std::runtime_error{"Invalid number of rate weights specified: " + std::to_string(weights_.size()) +
+                                   " (expected: " + std::to_string(cats) + ")"};
+        double sum = 0;
+        for (double w : weights_) sum += w;
+        for (double& w : weights_) w /= sum;
+      } else {
+        weights_.assign(cats, 1.0 / cats);
+      }
+      double swr = 0;
+      for (int k = 0; k < cats; ++k) swr += rates_[k] * weights_[k];
+      for (double& r : rates_) r /= swr;
     } else if (opt == "I" || opt == "IU" || opt == "IO" || opt == "IC") {
       // +I{p} / +IU{p}: user-defined proportion of invariant sites (Model.cpp:355-375); +IO / +IC
       // (ML / empirical estimate) need the optimiser EPA-ng never runs: a value must be given
@@ -200,9 +227,13 @@ Model::Model(const std::string& descriptor) {
       throw std::runtime_error{"Model: option +" + opt + " is not supported by this build"};
     }
   }
-  if (gamma) rates_ = compute_gamma_cats(alpha_, cats);
-  else rates_.assign(1, 1.0);
-  weights_.assign(rates_.size(), 1.0 / rates_.size());
+  if (gamma && free_rates) throw std::runtime_error{"Model: +G and +R are mutually exclusive"};
+  if (!free_rates) {
+    if (gamma) rates_ = compute_gamma_cats(alpha_, cats);
+    else rates_.assign(1, 1.0);
+    weights_.assign(rates_.size(), 1.0 / rates_.size());
+  }
+  free_rates_ = free_rates;
   update_eigen();
 }
 
@@ -287,7 +318,13 @@ std::string Model::to_string() const {
   for (size_t i = 0; i < freqs_.size(); ++i) s << (i ? "/" : "") << freqs_[i];
   s << "}";
   if (pinv_ > 0.0) s << "+IU{" << pinv_ << "}";
-  if (rates_.size() > 1) s << "+G" << rates_.size() << "{" << alpha_ << "}";
+  if (free_rates_) {
+    s << "+R" << rates_.size() << "{";
+    for (size_t k = 0; k < rates_.size(); ++k) s << (k ? "/" : "") << rates_[k];
+    s << "}{";
+    for (size_t k = 0; k < weights_.size(); ++k) s << (k ? "/" : "") << weights_[k];
+    s << "}";
+  } else if (rates_.size() > 1) s << "+G" << rates_.size() << "{" << alpha_ << "}";
   return s.str();
 }
 

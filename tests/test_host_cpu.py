@@ -252,3 +252,25 @@ def test_prop_invariant_sites_host_vs_oracle():
                                              "/".join(map(repr, synth.CFG2_FREQS)), pinv))
     ref2 = hostlib.Reference(nwk, labels, seqs, model=desc)
     assert abs(ref2.tree_lnl(0) - ref.tree_lnl(0)) < 1e-6
+
+
+def test_free_rate_model_string():
+    """+R4{rates}{weights}: weights normalised, rates divided by sum w r (Model.cpp:405-455);
+    tree lnL equals the explicit-parameter construction and the oracle's."""
+    from epa_ng_amd import synth
+    root = synth.random_tree(10, 31)
+    labels, seqs = synth.simulate_msa(root, 150, synth.CFG2_SUBST, synth.CFG2_FREQS, [0.2, 0.7, 1.1, 2.0], 32)
+    nwk = synth.newick(root)
+    raw_r, raw_w = np.array([0.3, 1.0, 2.0, 5.0]), np.array([2.0, 1.0, 0.5, 0.5])
+    w = raw_w / raw_w.sum()
+    r = raw_r / (raw_r * w).sum()
+    desc = "GTR{%s}+FU{%s}+R4{0.3/1.0/2.0/5.0}{2.0/1.0/0.5/0.5}" % (
+        "/".join(map(repr, synth.CFG2_SUBST)), "/".join(map(repr, synth.CFG2_FREQS)))
+    a = hostlib.Reference(nwk, labels, seqs, model=desc)
+    b = hostlib.Reference(nwk, labels, seqs, states=4, subst=synth.CFG2_SUBST, freqs=synth.CFG2_FREQS,
+                          rates=r, weights=w)
+    o = Oracle(nwk, labels, seqs, 4, synth.CFG2_SUBST, synth.CFG2_FREQS, r, weights=w)
+    m = a.model()
+    assert np.allclose(m["rates"], r, rtol=1e-12) and np.allclose(m["weights"], w, rtol=1e-12)
+    assert abs(a.tree_lnl(0) - b.tree_lnl(0)) < 1e-9
+    assert abs(a.tree_lnl(0) - o.tree_lnl(0)) < 1e-8
