@@ -141,13 +141,39 @@ struct SiteState {
   bool valid[NCH];
 };
 
+// Windows longer than 3 x 64 sites are spread over the NW wavefronts of a workgroup (wave w owns
+// sites [w * NCH * 64, (w + 1) * NCH * 64) of the window, its sumtable stays in ITS registers);
+// the per-wave sums of f, f' and lnL are combined through LDS with one barrier per Newton
+// evaluation (double-buffered: a wave can be at most one barrier ahead of the slowest one).
+// All waves then hold identical scalars and walk the optimiser's control flow in lock step.
+template <int NW>
+struct Comb {
+  double* red;  // LDS [2][NW][2]
+  int wv;
+  int phase;
+  __device__ __forceinline__ void sum2(double& a, double& b, int lane) {
+    if constexpr (NW > 1) {
+      double* r = red + phase * NW * 2;
+      if (lane == 0) { r[wv * 2] = a; r[wv * 2 + 1] = b; }
+      __syncthreads();
+      double sa = 0.0, sb = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { sa += r[w * 2]; sb += r[w * 2 + 1]; }
+      a = sa;
+      b = sb;
+      phase ^= 1;
+    }
+  }
+};
+
 // Newton tables for proposal t: e = w exp(lr t), e1 = w lr exp(lr t), e2 = w lr^2 exp(lr t).
 // ZERO0: eigenvalue 0 is exactly 0 (stationary mode) -> its e1/e2 columns vanish.
 // Then  f = sum_sites -l1/l0,  f' = sum_sites (l1/l0)^2 - l2/l0   (pll_compute_likelihood_
 // derivatives): 40 (48) FMAs per site.
-template <int NCH, bool ZERO0>
+template <int NCH, bool ZERO0, int NW>
 __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* tab, int lane,
-                                            const LaneConst& lc, double t, double& f, double& df) {
+                                            const LaneConst& lc, Comb<NW>& cb, double t, double& f,
+                                            double& df) {
   table_publish(tab, lane, exp(lc.lr * t) * lc.cN);
   double e[16], e1[16], e2[16];
 #pragma unroll
@@ -174,6 +200,7 @@ __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* ta
   }
   f = wave_sum(fl);
   df = wave_sum(dfl);
+  cb.sum2(f, df, lane);
 }
 
 // sum over the window of log L_site + scalers * log(2^-256)  (pll_compute_edge_loglikelihood);
@@ -181,8 +208,9 @@ __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* ta
 // and exponent (v_frexp_*), mantissas multiplied, exponents and scaler counts added as integers:
 //   sum_ch log(L_ch) + sc_ch log 2^-256  =  log(prod mant) + ln2 * (sum exp - 256 sum sc)
 // -> ONE log() per lane instead of NCH.
-template <int NCH>
-__device__ __forceinline__ double window_lnl(const SiteState<NCH>& st, const double (&ew)[16]) {
+template <int NCH, int NW>
+__device__ __forceinline__ double window_lnl(const SiteState<NCH>& st, const double (&ew)[16], Comb<NW>& cb,
+                                             int lane) {
   double mant = 1.0;
   int ex = 0;
 #pragma unroll
@@ -199,18 +227,20 @@ __device__ __forceinline__ double window_lnl(const SiteState<NCH>& st, const dou
       mant = __builtin_amdgcn_frexp_mant(mant);
     }
   }
-  return wave_sum(log(mant) + (double)ex * 0.6931471805599453094);
+  double v = wave_sum(log(mant) + (double)ex * 0.6931471805599453094), z = 0.0;
+  cb.sum2(v, z, lane);
+  return v;
 }
 
 // pllmod_opt_minimize_newton (pll-modules; rtsafe-style safeguarded Newton).  Wave-uniform.
-template <int NCH, bool ZERO0>
+template <int NCH, bool ZERO0, int NW>
 __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, int lane,
-                                         const LaneConst& lc, double x1, double xguess, double x2,
-                                         double tol, int max_iters, uint32_t& evals) {
+                                         const LaneConst& lc, Comb<NW>& cb, double x1, double xguess,
+                                         double x2, double tol, int max_iters, uint32_t& evals) {
   double rts = xguess, f, df, xl, xh, dx;
   if (rts < x1) rts = x1;
   if (rts > x2) rts = x2;
-  derivatives<NCH, ZERO0>(st, tab, lane, lc, rts, f, df);
+  derivatives<NCH, ZERO0, NW>(st, tab, lane, lc, cb, rts, f, df);
   ++evals;
   if (!isfinite(f) || !isfinite(df)) return NAN;
   if (df >= 0.0 && fabs(f) < tol) return rts;
@@ -228,7 +258,7 @@ __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, 
     }
     if (fabs(dx) < tol || i == max_iters) return rts;
     if (rts < x1) rts = x1;
-    derivatives<NCH, ZERO0>(st, tab, lane, lc, rts, f, df);
+    derivatives<NCH, ZERO0, NW>(st, tab, lane, lc, cb, rts, f, df);
     ++evals;
     if (!isfinite(f) || !isfinite(df)) return NAN;
     if (df > 0.0 && fabs(f) < tol) return rts;
@@ -237,10 +267,11 @@ __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, 
   return NAN;
 }
 
-template <int NCH, bool ZERO0, bool INV>
+template <int NCH, bool ZERO0, bool INV, int NW>
 __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pidx, const int lane,
                                              double* tab, const double* qts, const LaneConst& lc,
-                                             uint32_t (&wstat)[3]) {
+                                             Comb<NW>& cb, uint32_t (&wstat)[3]) {
+  const uint32_t site0 = NW > 1 ? (uint32_t)cb.wv * NCH * 64 : 0u;  // first window site of this wave
   const ModelDNA& m = a.m;
   const uint64_t pid = a.order ? a.order[pidx] : pidx;
   const epa_pair pr = a.pairs[pid];
@@ -261,7 +292,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   SiteState<NCH> st;
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
-    const uint32_t s = ch * 64 + lane;
+    const uint32_t s = site0 + ch * 64 + lane;
     st.valid[ch] = s < n;
     const uint32_t sc = st.valid[ch] ? s : 0;  // clamp: inactive lanes recompute site 0
     st.sc[ch] = scp[sc];
@@ -277,7 +308,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   // is exactly 0 (ZERO0), so its table entries are w_0 (order 0) and 0 (orders 1, 2): adding
   // c / w_0 to sumtable entry (category 0, eigen index 0) adds c to L_0 and nothing to L_1, L_2.
   auto cinv_of = [&](int ch) -> double {
-    const uint32_t s = st.valid[ch] ? ch * 64 + lane : 0;
+    const uint32_t s = st.valid[ch] ? site0 + ch * 64 + lane : 0;
     return a.cinv[begin + s] * a.inv_w0;
   };
   // Inner CLV toward the query at (td, tx) folded with the query, S = (U^-1 I) o qt, and the
@@ -289,7 +320,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       // one chunk's 32 loads in flight at a time (VGPR budget)
-      const uint32_t s = (st.valid[ch] ? ch * 64 + lane : 0) * 8u + chain;
+      const uint32_t s = (st.valid[ch] ? site0 + ch * 64 + lane : 0) * 8u + chain;
       double D[16], X[16], It[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) { D[c] = ldD(c, s); X[c] = ldX(c, s); }
@@ -310,14 +341,14 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     double ew[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
-    return window_lnl<NCH>(st, ew);
+    return window_lnl<NCH, NW>(st, ew, cb, lane);
   };
   // inner CLV toward distal: I' = (P_pend q) o (P_prox X); S = Dt o (U^-1 I')
   auto distal_sumtable = [&](double tp_, double tx_) {
     table_publish(tab, lane, exp(lc.lr * (lc.slot == 0 ? tp_ : tx_)));
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      const uint32_t s = (st.valid[ch] ? ch * 64 + lane : 0) * 8u + chain;
+      const uint32_t s = (st.valid[ch] ? site0 + ch * 64 + lane : 0) * 8u + chain;
       double Qv[16], X[16], D[16], It[16];
       const double* qv = qts + st.code[ch] * 4;
 #pragma unroll
@@ -346,7 +377,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     const uint8_t* r0 = a.resc0 + (size_t)b * cW + begin;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      const uint32_t si = st.valid[ch] ? ch * 64 + lane : 0;
+      const uint32_t si = st.valid[ch] ? site0 + ch * 64 + lane : 0;
       const uint32_t s = si * 8u + chain;
       double It[16];
 #pragma unroll
@@ -368,7 +399,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     double ew[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
-    return window_lnl<NCH>(st, ew);
+    return window_lnl<NCH, NW>(st, ew, cb, lane);
   };
 
   // traverse_update_partials + initial score (optimize.cpp:15-42,111-113)
@@ -381,7 +412,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     double xmin = a.blo.min_branch, xmax = a.blo.max_branch, xtol = xmin / 10.0;
     double xguess = tp;
     if (xguess < xmin || xguess > xmax) xguess = a.blo.default_branch;
-    double xres = newton<NCH, ZERO0>(st, tab, lane, lc, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
+    double xres = newton<NCH, ZERO0, NW>(st, tab, lane, lc, cb, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
     if (xres > 0.0) tp = xres;
     chain = zero_after(tp);
     // ---- NR for the distal length with the proximal P-matrix held fixed (:170-211)
@@ -391,7 +422,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     xtol = xmin / 10.0;
     xmax = orig - xtol;
     if (xguess < xmin || xguess > xmax) xguess = orig / 2.0;
-    xres = newton<NCH, ZERO0>(st, tab, lane, lc, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
+    xres = newton<NCH, ZERO0, NW>(st, tab, lane, lc, cb, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
     if (xres > 0.0) { td = xres; tx = orig - xres; }
     chain = zero_after(td);
     // ---- score (:217-222)
@@ -407,7 +438,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     loglikelihood = new_ll;
   }
 
-  if (lane == 0) {
+  if (lane == 0 && (NW == 1 || cb.wv == 0)) {
     const double lnl = -loglikelihood;
     epa_result r;
     r.lnl = lnl;
@@ -432,12 +463,14 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 // and every wave gets a ~25-pair random sample of the 10x cost spread (1..32 NR rounds).
 // INV: the model has +I (instantiated for ZERO0 only; a separate instantiation so that the
 // default kernel's register allocation is untouched: the runtime-flag version cost 40 more spills)
-template <int NCH, bool ZERO0, bool INV>
-__global__ void __launch_bounds__(64, 2) k_thorough_dna(const ThArgs a) {
-  __shared__ double tab[64];   // broadcast table of the wave
-  __shared__ double qts[64];   // U^-1 image of the 16 query column codes
-  const int lane = threadIdx.x;
-  qts[lane] = a.qt[lane];
+template <int NCH, bool ZERO0, bool INV, int NW>
+__global__ void __launch_bounds__(64 * NW, 2) k_thorough_dna(const ThArgs a) {
+  __shared__ double tab[64 * NW];  // broadcast table of each wave
+  __shared__ double qts[64];       // U^-1 image of the 16 query column codes
+  __shared__ double red[2 * NW * 2];
+  const int lane = threadIdx.x & 63;
+  Comb<NW> cb{red, (int)(threadIdx.x >> 6), 0};
+  if (threadIdx.x < 64) qts[lane] = a.qt[lane];
   LaneConst lc;
   {
     const int lk = (lane >> 2) & 3, lx = lane & 3;
@@ -453,14 +486,14 @@ __global__ void __launch_bounds__(64, 2) k_thorough_dna(const ThArgs a) {
   const uint64_t lo = (uint64_t)x * per;
   const uint64_t hi = lo + per < a.n_pairs ? lo + per : a.n_pairs;
   uint32_t wstat[3] = {0, 0, 0};
-  for (uint64_t p = lo + w; p < hi; p += stride) process_pair<NCH, ZERO0, INV>(a, p, lane, tab, qts, lc, wstat);
-  if (lane == 0) {
+  for (uint64_t p = lo + w; p < hi; p += stride)
+    process_pair<NCH, ZERO0, INV, NW>(a, p, lane, tab + cb.wv * 64, qts, lc, cb, wstat);
+  if (threadIdx.x == 0) {
     atomicAdd(&a.stats[0], (unsigned long long)wstat[0]);
     atomicAdd(&a.stats[1], (unsigned long long)wstat[1]);
     atomicAdd(&a.stats[2], (unsigned long long)wstat[2]);
   }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Long windows (more than 24 x 64 sites): same algorithm, the sumtable lives in an HBM slab
@@ -709,31 +742,34 @@ __global__ void __launch_bounds__(256) k_pair_class(const epa_pair* __restrict__
 // in their original (branch-major) order, null when the launch covers all pairs.
 static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t max_span) {
   const uint64_t n_pairs = a.n_pairs;
-  // Grid: single-wave workgroups, 2048 of them are resident (8 per CU, 2 per SIMD at this
-  // kernel's VGPR budget).  Oversubscribing the resident set lets the hardware dispatcher do the
-  // load balancing (pairs differ 10x in cost): a finished wave's slot is refilled at once.
+  // Grid: 2048 wavefronts are resident (8 per CU, 2 per SIMD at this kernel's VGPR budget), i.e.
+  // 2048 / NW workgroups.  Oversubscribing the resident set lets the hardware dispatcher do the
+  // load balancing (pairs differ 10x in cost): a finished workgroup's slot is refilled at once.
   // EPA_TH_WAVES_PER_SLOT tunes it (default 8 -> ~3 pairs per wave at 50k pairs).
   uint32_t per_slot = 8;
   if (const char* e = getenv("EPA_TH_WAVES_PER_SLOT")) per_slot = (uint32_t)std::max(1, atoi(e));
-  uint64_t want = (uint64_t)256 * 8 * per_slot;
-  if (want > n_pairs) want = n_pairs;
-  uint32_t nwg = (uint32_t)((want + 7) / 8 * 8);
-#define LAUNCH(N)                                                                              \
-  do {                                                                                         \
-    if (a.cinv) hipLaunchKernelGGL((k_thorough_dna<N, true, true>), dim3(nwg), dim3(64), 0, ctx->stream, a); \
-    else if (ctx->dna_zero0) hipLaunchKernelGGL((k_thorough_dna<N, true, false>), dim3(nwg), dim3(64), 0, ctx->stream, a); \
-    else hipLaunchKernelGGL((k_thorough_dna<N, false, false>), dim3(nwg), dim3(64), 0, ctx->stream, a); \
+  // class -> (wavefronts per pair NW, 64-site chunks per wavefront NCH): windows up to 192 sites
+  // are one wave's job; longer ones are spread over 2 / 4 / 8 waves of a workgroup, each keeping
+  // its part of the sumtable in registers (NCH stays <= 3: the kernel's register budget)
+#define LAUNCH(N, NW_)                                                                            \
+  do {                                                                                            \
+    uint64_t want = (uint64_t)256 * 8 * per_slot / (NW_);                                          \
+    if (want > n_pairs) want = n_pairs;                                                            \
+    const uint32_t nwg = (uint32_t)((want + 7) / 8 * 8);                                           \
+    if (a.cinv) hipLaunchKernelGGL((k_thorough_dna<N, true, true, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
+    else if (ctx->dna_zero0) hipLaunchKernelGGL((k_thorough_dna<N, true, false, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
+    else hipLaunchKernelGGL((k_thorough_dna<N, false, false, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
   } while (0)
   switch (cls) {
-    case 0: LAUNCH(1); break;
-    case 1: LAUNCH(2); break;
-    case 2: LAUNCH(3); break;
-    case 3: LAUNCH(4); break;
-    case 4: LAUNCH(6); break;
-    case 5: LAUNCH(8); break;
-    case 6: LAUNCH(12); break;
-    case 7: LAUNCH(16); break;
-    case 8: LAUNCH(24); break;
+    case 0: LAUNCH(1, 1); break;
+    case 1: LAUNCH(2, 1); break;
+    case 2: LAUNCH(3, 1); break;
+    case 3: LAUNCH(2, 2); break;   // <= 256 sites
+    case 4: LAUNCH(3, 2); break;   // <= 384
+    case 5: LAUNCH(2, 4); break;   // <= 512
+    case 6: LAUNCH(3, 4); break;   // <= 768
+    case 7: LAUNCH(2, 8); break;   // <= 1024
+    case 8: LAUNCH(3, 8); break;   // <= 1536
     default: {
       // long windows: sumtable slab in HBM, one resident wave per slab
       const uint32_t nlong = (uint32_t)std::min<uint64_t>(n_pairs, 2048);
