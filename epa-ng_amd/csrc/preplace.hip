@@ -643,7 +643,88 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
   if (lane == 0) counts[q] = min(taken, cap);
 }
 
-// Same selection for references with more than 4096 branches: the row does not fit the register
+// Same selection, workgroup per query (4 waves): the row of up to 256 x NRT branches lives in the
+// registers of the whole workgroup (element i in thread i % 256, slot i / 256), so the table is
+// read exactly once; wave-level (max, argmax, sum) results are combined across the four waves
+// through LDS.  Used for 4096 < B <= 16384.
+template <int NRT>
+__global__ void __launch_bounds__(256) k_select_wg(const double* __restrict__ lnl, uint32_t Q, uint32_t B,
+                                                   double threshold, uint32_t cap,
+                                                   unsigned long long* __restrict__ stage,
+                                                   uint32_t* __restrict__ counts,
+                                                   uint32_t* __restrict__ status) {
+  __shared__ double s_val[2][4];
+  __shared__ uint32_t s_idx[2][4];
+  const uint32_t q = blockIdx.x;
+  const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const double* src = lnl + (size_t)q * B;
+  double v[NRT];
+  double mx = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < NRT; ++r) {
+    const uint32_t i = r * 256 + t;
+    v[r] = i < B ? src[i] : -INFINITY;
+    mx = fmax(mx, v[r]);
+  }
+  int ph = 0;
+  auto block_max = [&](double x) {
+    x = wave_max(x);
+    if (lane == 0) s_val[ph][wv] = x;
+    __syncthreads();
+    x = fmax(fmax(s_val[ph][0], s_val[ph][1]), fmax(s_val[ph][2], s_val[ph][3]));
+    ph ^= 1;
+    return x;
+  };
+  mx = block_max(mx);
+  double tot = 0.0;
+#pragma unroll
+  for (int r = 0; r < NRT; ++r) tot += exp(v[r] - mx);  // exp(-inf) == 0 for the padding
+  tot = wave_add(tot);
+  if (lane == 0) s_val[ph][wv] = tot;
+  __syncthreads();
+  tot = (s_val[ph][0] + s_val[ph][1]) + (s_val[ph][2] + s_val[ph][3]);
+  ph ^= 1;
+  double sum = 0.0;
+  uint32_t taken = 0;
+  unsigned long long* out = stage + (size_t)q * cap;
+  while (taken < B && sum < threshold) {
+    double best = -INFINITY;
+    uint32_t bi = 0xffffffffu;
+#pragma unroll
+    for (int r = 0; r < NRT; ++r)
+      if (v[r] > best) { best = v[r]; bi = r * 256 + t; }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+      const double ob = __shfl_xor(best, o);
+      const uint32_t oi = __shfl_xor(bi, o);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { s_val[ph][wv] = best; s_idx[ph][wv] = bi; }
+    __syncthreads();
+    best = s_val[ph][0];
+    bi = s_idx[ph][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const double ob = s_val[ph][w];
+      const uint32_t oi = s_idx[ph][w];
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    ph ^= 1;
+    if (bi == 0xffffffffu) break;
+    sum += exp(best - mx) / tot;
+#pragma unroll
+    for (int r = 0; r < NRT; ++r)
+      if ((uint32_t)(r * 256) + t == bi) v[r] = -INFINITY;
+    if (t == 0) {
+      if (taken < cap) out[taken] = ((unsigned long long)bi << 32) | q;
+      else atomicMax(&status[2], taken + 1);
+    }
+    ++taken;
+  }
+  if (t == 0) counts[q] = min(taken, cap);
+}
+
+// Same selection for references with more than 16384 branches: the row does not fit the register
 // file, so it is streamed from HBM/L2 once per pass (max, total, then one pass per selected
 // branch: 3-4 on typical data); taken branches are remembered in a per-lane bitmask
 // (element i lives in lane i % 64, bit i / 64; up to 64 x 64 x NW branches).
@@ -895,7 +976,9 @@ int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshol
 #define SELBIG(N) hipLaunchKernelGGL(k_select_big<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, cap, stage, counts, status)
     if (nr <= 2) SEL(2); else if (nr <= 4) SEL(4); else if (nr <= 8) SEL(8); else if (nr <= 16) SEL(16);
     else if (nr <= 32) SEL(32); else if (nr <= 64) SEL(64);
-    else if (nr <= 128) SELBIG(2); else if (nr <= 256) SELBIG(4); else SELBIG(16);
+    else if (nr <= 128) hipLaunchKernelGGL(k_select_wg<32>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, cap, stage, counts, status);
+    else if (nr <= 256) hipLaunchKernelGGL(k_select_wg<64>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, cap, stage, counts, status);
+    else SELBIG(16);
 #undef SELBIG
 #undef SEL
     EPA_HIP(ctx, rocprim::exclusive_scan(temp, scan_bytes, counts, offsets, 0u, Q + 1,

@@ -456,3 +456,20 @@ def test_prop_invariant_sites_golden_on_device():
         assert abs(res["lnl"][i] - e["lnl"]) < 1e-6
         assert abs(res["distal_length"][i] - e["distal"]) < 1e-6
         assert abs(res["pendant_length"][i] - e["pendant"]) < 1e-6 * max(1.0, e["pendant"])
+
+
+def test_very_large_reference_streamed_select():
+    """B = 16597 (> 16384): the candidate selection streams the row (k_select_big); checked against
+    the host restatement of the dynamic heuristic on the same table."""
+    from epa_ng_amd import synth
+    w = synth.dna_workload(8300, 24, 6, 24, (75, 76, 77))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    assert ref.B == 2 * 8300 - 3
+    ev = ref.evaluator()
+    codes, wb, ws = epa.encode_queries(4, w["reads"], compact=True)
+    lnl = ev.preplace(codes, wb, ws)
+    pairs = ev.select(lnl, len(w["reads"]), 0.99999, max_pairs=len(w["reads"]) * ref.B)
+    hb, hs = hostlib.heuristic(lnl, "dynamic", 0.99999)
+    assert sorted(zip(hb.tolist(), hs.tolist())) == sorted(zip(pairs["branch_id"].tolist(), pairs["seq_id"].tolist()))
+    assert np.all(np.diff(pairs["branch_id"].astype(np.int64)) >= 0)
