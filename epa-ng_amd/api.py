@@ -96,6 +96,10 @@ def dev_lib():
                                           C.c_uint32, C.c_double, C.c_void_p, C.c_void_p,
                                           C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(_Stats)]
         L.epa_dev_tree_logl.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
+        L.epa_dev_place_all.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                        C.c_uint32, C.c_double, C.c_int, C.c_uint32, C.c_uint32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(_Stats)]
         L.epa_dev_last_kernel_ms.restype = C.c_double
         L.epa_dev_last_kernel_ms.argtypes = [C.c_void_p, C.c_char_p]
         _LIB = L
@@ -302,6 +306,31 @@ class Evaluator:
         if host:
             return pairs_out[:n.value], results_out[:n.value]
         return n.value
+
+    def place_all(self, codes, win_begin, win_span, Q=None, min_lwr=0.01, acc=False, filter_min=1,
+                  filter_max=7, max_span=0):
+        """--no-heur on device: thorough placement on every branch, LWR over all of them, filter.
+        Returns a list (one entry per query) of (branch_id, lnl, pendant, distal, lwr) arrays,
+        best placement first."""
+        Q = len(win_begin) if Q is None else Q
+        pairs = np.zeros(Q * filter_max, PAIR_DTYPE)
+        res = np.zeros(Q * filter_max, RESULT_DTYPE)
+        lwr = np.zeros(Q * filter_max, np.float64)
+        counts = np.zeros(Q, np.uint32)
+        st = _Stats()
+        self._layout(codes)
+        self._check(self.L.epa_dev_place_all(self.h, _ptr(codes), _ptr(win_begin), _ptr(win_span), Q,
+                                             max_span, min_lwr, int(acc), filter_min, filter_max,
+                                             _ptr(pairs), _ptr(res), _ptr(lwr), _ptr(counts), C.byref(st)))
+        self.last_stats = {"pairs": st.pairs, "rounds": st.rounds,
+                           "newton_evals": st.newton_evals, "reverts": st.reverts}
+        out = []
+        for q in range(Q):
+            sl = slice(q * filter_max, q * filter_max + int(counts[q]))
+            assert np.all(pairs["seq_id"][sl] == q)
+            out.append((pairs["branch_id"][sl].copy(), res["lnl"][sl].copy(), res["pendant_length"][sl].copy(),
+                        res["distal_length"][sl].copy(), lwr[sl].copy()))
+        return out
 
     def tree_logl(self, branch=0):
         """log-likelihood of the reference tree evaluated on the device at `branch`"""

@@ -1110,6 +1110,186 @@ extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const u
   return EPA_OK;
 }
 
+// =============================================================================================
+// --no-heur: all B x Q pairs on the device, then LWR + filter per query on the device.
+// =============================================================================================
+__global__ void __launch_bounds__(256) k_all_pairs(epa_pair* __restrict__ pairs, uint32_t B, uint32_t Q) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (uint64_t)B * Q) return;
+  const uint32_t b = (uint32_t)(i / Q);
+  pairs[i].branch_id = b;                          // branch-major: Work's iteration order
+  pairs[i].seq_id = (uint32_t)(i - (uint64_t)b * Q);
+}
+
+// One 256-thread workgroup per query.  res is branch-major: the placement of (b, q) is res[b*Q+q].
+// compute_and_set_lwr over all B placements, then the best placements one by one (largest lnL
+// first, ties: lowest branch id) until filter() would stop.
+__global__ void __launch_bounds__(256) k_lwr_filter(const epa_result* __restrict__ res, uint32_t B, uint32_t Q,
+                                                   double min_lwr, int acc, uint32_t keep_min, uint32_t keep_max,
+                                                   epa_pair* __restrict__ out_pairs,
+                                                   epa_result* __restrict__ out_res,
+                                                   double* __restrict__ out_lwr,
+                                                   uint32_t* __restrict__ counts) {
+  __shared__ double s_val[2][4];
+  __shared__ uint32_t s_idx[2][4];
+  __shared__ uint32_t s_taken[64];
+  const uint32_t q = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  auto lnl_of = [&](uint32_t b) { return res[(size_t)b * Q + q].lnl; };
+  auto wmax = [](double v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+  };
+  auto wadd = [](double v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  int ph = 0;
+  double mx = -INFINITY;
+  for (uint32_t b = t; b < B; b += 256) mx = fmax(mx, lnl_of(b));
+  mx = wmax(mx);
+  if (lane == 0) s_val[ph][wv] = mx;
+  __syncthreads();
+  mx = fmax(fmax(s_val[ph][0], s_val[ph][1]), fmax(s_val[ph][2], s_val[ph][3]));
+  ph ^= 1;
+  double tot = 0.0;
+  for (uint32_t b = t; b < B; b += 256) tot += exp(lnl_of(b) - mx);
+  tot = wadd(tot);
+  if (lane == 0) s_val[ph][wv] = tot;
+  __syncthreads();
+  tot = (s_val[ph][0] + s_val[ph][1]) + (s_val[ph][2] + s_val[ph][3]);
+  ph ^= 1;
+  uint32_t taken = 0;
+  double sum = 0.0;
+  const uint32_t limit = min(B, keep_max);
+  for (;;) {
+    if (taken >= limit) break;
+    if (acc && !(sum < min_lwr) && taken + 1 >= keep_min) break;  // accumulated mode: quota reached
+    double best = -INFINITY;
+    uint32_t bi = 0xffffffffu;
+    for (uint32_t b = t; b < B; b += 256) {
+      bool used = false;
+      for (uint32_t k = 0; k < taken; ++k) used |= s_taken[k] == b;
+      const double v = lnl_of(b);
+      if (!used && v > best) { best = v; bi = b; }
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+      const double ob = __shfl_xor(best, o);
+      const uint32_t oi = __shfl_xor(bi, o);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { s_val[ph][wv] = best; s_idx[ph][wv] = bi; }
+    __syncthreads();
+    best = s_val[ph][0];
+    bi = s_idx[ph][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const double ob = s_val[ph][w];
+      const uint32_t oi = s_idx[ph][w];
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    ph ^= 1;
+    if (bi == 0xffffffffu) break;
+    const double lw = exp(best - mx) / tot;
+    if (!acc) {
+      // discard_by_support_threshold: keep lwr > thresh, but at least keep_min
+      if (!(lw > min_lwr) && taken >= keep_min) break;
+    } else {
+      // discard_by_accumulated_threshold: while sum < thresh take; top-up to keep_min - 1 (quirk)
+      if (!(sum < min_lwr) && taken + 1 >= keep_min) break;
+      sum += lw;
+    }
+    if (t == 0) {
+      const size_t o = (size_t)q * keep_max + taken;
+      out_pairs[o].branch_id = bi;
+      out_pairs[o].seq_id = q;
+      out_res[o] = res[(size_t)bi * Q + q];
+      out_lwr[o] = lw;
+      s_taken[taken] = bi;
+    }
+    ++taken;
+    __syncthreads();  // s_taken visible to the next scan
+  }
+  if (t == 0) counts[q] = taken;
+}
+
+extern "C" int epa_dev_place_all(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_begin,
+                                 const uint32_t* win_span, uint32_t Q, uint32_t max_span, double min_lwr,
+                                 int acc_threshold, uint32_t filter_min, uint32_t filter_max,
+                                 epa_pair* pairs, epa_result* results, double* lwr, uint32_t* counts,
+                                 epa_thorough_stats* stats) {
+  if (!ctx || !q_codes || !win_begin || !win_span || !pairs || !results || !lwr || !counts)
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "null argument");
+  if (filter_min < 1 || filter_max < filter_min || filter_max > 64)
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "place_all: need 1 <= filter_min <= filter_max <= 64");
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (Q == 0) return EPA_OK;
+  EPA_HIP(ctx, hipSetDevice(ctx->device));
+  if (!(ctx->s == 4 && ctx->c == 4) && !(ctx->s == 20))
+    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "thorough: DNA needs 4 rate categories");
+  int rc = epa_dev_build_lookup(ctx);  // starting vectors of the thorough kernels
+  if (rc) return rc;
+  std::vector<uint32_t> hb_buf, hs_buf;
+  const uint32_t* hb = host_view(win_begin, Q, hb_buf, ctx->stream);
+  const uint32_t* hs = host_view(win_span, Q, hs_buf, ctx->stream);
+  if (!hb || !hs) return epa_fail(ctx, EPA_ERR_HIP, "cannot read window arrays");
+  uint32_t ms = 0;
+  rc = check_windows(ctx, hb, hs, Q, &ms);
+  if (rc) return rc;
+  if (max_span == 0 || max_span < ms) max_span = ms;
+  const uint64_t n = (uint64_t)ctx->B * Q;
+  if (n > 0xffffffffull) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "place_all: more than 2^32 pairs per chunk");
+  const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * (ctx->code_stride ? ctx->code_stride : ctx->W));
+  const uint32_t* d_begin = (const uint32_t*)epa_to_device(ctx, 1, win_begin, sizeof(uint32_t) * Q);
+  const uint32_t* d_span = (const uint32_t*)epa_to_device(ctx, 2, win_span, sizeof(uint32_t) * Q);
+  if (!d_codes || !d_begin || !d_span) return epa_fail(ctx, EPA_ERR_HIP, "query upload failed");
+  epa_pair* d_all = (epa_pair*)epa_scratch(ctx, 4, sizeof(epa_pair) * n);
+  epa_result* d_res = (epa_result*)epa_scratch(ctx, 5, sizeof(epa_result) * n);
+  unsigned long long* d_stats = (unsigned long long*)epa_scratch(ctx, 6, 256);
+  if (!d_all || !d_res || !d_stats) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(all-pairs buffers)");
+  ctx->d_status = nullptr;
+  EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 256, ctx->stream));
+  hipLaunchKernelGGL(k_all_pairs, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_all, ctx->B, Q);
+  ctx->cls_hist_pairs = 0;
+  rc = launch_thorough(ctx, d_all, n, d_codes, d_begin, d_span, max_span, d_res, d_stats);
+  if (rc) return rc;
+  // filtered output: Q x filter_max slots, staged in scratch 3 when the caller's buffers are on the host
+  const size_t slots = (size_t)Q * filter_max;
+  const bool p_dev = epa_is_device_ptr(pairs), r_dev = epa_is_device_ptr(results), l_dev = epa_is_device_ptr(lwr),
+             c_dev = epa_is_device_ptr(counts);
+  const size_t off_r = (sizeof(epa_pair) * slots + 255) & ~(size_t)255;
+  const size_t off_l = off_r + ((sizeof(epa_result) * slots + 255) & ~(size_t)255);
+  const size_t off_c = off_l + ((sizeof(double) * slots + 255) & ~(size_t)255);
+  char* stage = (char*)epa_scratch(ctx, 3, off_c + sizeof(uint32_t) * Q);
+  if (!stage) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(filter output)");
+  epa_pair* o_p = p_dev ? pairs : (epa_pair*)stage;
+  epa_result* o_r = r_dev ? results : (epa_result*)(stage + off_r);
+  double* o_l = l_dev ? lwr : (double*)(stage + off_l);
+  uint32_t* o_c = c_dev ? counts : (uint32_t*)(stage + off_c);
+  hipLaunchKernelGGL(k_lwr_filter, dim3(Q), dim3(256), 0, ctx->stream, d_res, ctx->B, Q, min_lwr, acc_threshold,
+                     filter_min, filter_max, o_p, o_r, o_l, o_c);
+  if (!p_dev) EPA_HIP(ctx, hipMemcpyAsync(pairs, o_p, sizeof(epa_pair) * slots, hipMemcpyDeviceToHost, ctx->stream));
+  if (!r_dev) EPA_HIP(ctx, hipMemcpyAsync(results, o_r, sizeof(epa_result) * slots, hipMemcpyDeviceToHost, ctx->stream));
+  if (!l_dev) EPA_HIP(ctx, hipMemcpyAsync(lwr, o_l, sizeof(double) * slots, hipMemcpyDeviceToHost, ctx->stream));
+  if (!c_dev) EPA_HIP(ctx, hipMemcpyAsync(counts, o_c, sizeof(uint32_t) * Q, hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long hst[8];
+  EPA_HIP(ctx, hipMemcpyAsync(hst, d_stats, 64, hipMemcpyDeviceToHost, ctx->stream));
+  EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  EPA_HIP(ctx, hipGetLastError());
+  ctx->last_stats.pairs = n;
+  ctx->last_stats.rounds = hst[0];
+  ctx->last_stats.newton_evals = hst[1];
+  ctx->last_stats.reverts = hst[2];
+  if (stats) *stats = ctx->last_stats;
+  if (hst[3])
+    return epa_fail(ctx, EPA_ERR_NEG_INF,
+                    "-INF logl at branch " + std::to_string((uint32_t)(hst[4] >> 32)) +
+                        " with sequence " + std::to_string((uint32_t)(hst[4] & 0xffffffffu)));
+  return EPA_OK;
+}
+
 extern "C" double epa_dev_last_kernel_ms(const epa_ctx* ctx, const char* which) {
   if (!ctx || !which) return -1.0;
   const EvTimer* t = nullptr;

@@ -276,6 +276,12 @@ void place_thorough(const Work& to_place, const MSA& chunk, const Encoded_Chunk&
 void place_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, Device_Evaluator& dev,
                  Work& work, Sample& sample, const Options& options, size_t seq_id_offset = 0);
 
+// --no-heur with the chunk's post-processing on the device (epa_dev_place_all): thorough
+// placement on every branch, compute_and_set_lwr over all of them and filter(); `sample` comes
+// back final (LWR set, filtered, best first).  Returns the number of pairs evaluated.
+size_t place_all(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, Device_Evaluator& dev,
+                 Sample& sample, const Options& options, size_t seq_id_offset = 0);
+
 void compute_and_set_lwr(Sample& sample);            // src/set_manipulators.cpp:43-69
 void filter(Sample& sample, const Options& options);  // :192-204
 

@@ -246,6 +246,36 @@ void place_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, D
   build_sample(work, res, chunk, sample, seq_id_offset);
 }
 
+size_t place_all(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, Device_Evaluator& dev,
+                 Sample& sample, const Options& options, size_t seq_id_offset) {
+  const size_t Q = chunk.size(), fm = options.filter_max;
+  std::vector<epa_pair> pairs(Q * fm);
+  std::vector<epa_result> res(Q * fm);
+  std::vector<double> lwr(Q * fm);
+  std::vector<uint32_t> counts(Q);
+  uint32_t max_span = 0;
+  for (uint32_t s : enc.win_span) max_span = std::max(max_span, s);
+  epa_dev_set_query_layout(dev.ctx(), enc.stride);
+  const int rc = epa_dev_place_all(dev.ctx(), enc.codes.data(), enc.win_begin.data(), enc.win_span.data(),
+                                   (uint32_t)Q, max_span, options.support_threshold,
+                                   options.acc_threshold ? 1 : 0, options.filter_min, options.filter_max,
+                                   pairs.data(), res.data(), lwr.data(), counts.data(), nullptr);
+  if (rc == EPA_ERR_NEG_INF) throw std::runtime_error{epa_dev_last_error(dev.ctx())};
+  if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
+  sample.clear();
+  sample.reserve(Q);
+  for (size_t q = 0; q < Q; ++q) {
+    sample.emplace_back(seq_id_offset + q, chunk[q].header());
+    auto& pq = sample.back();
+    for (uint32_t k = 0; k < counts[q]; ++k) {
+      const size_t o = q * fm + k;
+      pq.emplace_back(pairs[o].branch_id, res[o].lnl, res[o].pendant_length, res[o].distal_length);
+      pq[pq.size() - 1].lwr(lwr[o]);
+    }
+  }
+  return Q * tree.num_branches();
+}
+
 void compute_and_set_lwr(Sample& sample) {
   configure_host_threads();
 #pragma omp parallel for schedule(dynamic)
@@ -333,9 +363,17 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
     Sample blo_sample;
     auto t0 = clk::now();
     auto t1 = t0;
+    // --no-heur: pairs, thorough placement, LWR and filter all on the device (epa_dev_place_all)
+    const bool all_on_device = !options.prescoring && options.filter_min >= 1 &&
+                               options.filter_max >= options.filter_min && options.filter_max <= 64 &&
+                               (uint64_t)n * B <= 0xffffffffull;
     const bool fused = options.prescoring && options.device_select && !options.baseball &&
                        !options.prescoring_by_percentage && B <= 65536;
-    if (fused) {
+    size_t pairs_done = 0;
+    if (all_on_device) {
+      pairs_done = place_all(chunk, enc, tree, dev, blo_sample, options, done);
+      t1 = clk::now();
+    } else if (fused) {
       // default configuration: the whole chunk body runs on the GPU (epa_dev_place_chunk), the
       // Q x B table never crosses PCIe
       place_chunk(chunk, enc, tree, dev, blo_work, blo_sample, options, done);
@@ -353,11 +391,14 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
       place_thorough(blo_work, chunk, enc, tree, dev, blo_sample, options, done);
     }
     auto t2 = clk::now();
-    compute_and_set_lwr(blo_sample);
-    filter(blo_sample, options);
+    if (!all_on_device) {
+      compute_and_set_lwr(blo_sample);
+      filter(blo_sample, options);
+      pairs_done = blo_work.size();
+    }
     results.push_back(std::move(blo_sample));
     st.seconds_post += std::chrono::duration<double>(clk::now() - t2).count();
-    st.pairs += blo_work.size();
+    st.pairs += pairs_done;
     st.seconds_place += std::chrono::duration<double>(t1 - t0).count();
     st.seconds_thorough += std::chrono::duration<double>(t2 - t1).count();
     done += n;

@@ -257,6 +257,23 @@ int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* wi
                         epa_pair* pairs, epa_result* results, uint64_t max_pairs,
                         uint64_t* n_pairs, epa_thorough_stats* stats);
 
+/*
+ * --no-heur (src/core/place.cpp:189,228: every branch gets a thorough placement) with the
+ * post-processing of the chunk loop fused in: thorough optimisation of all B x Q pairs (pairs are
+ * generated on the device), then per query compute_and_set_lwr over all B placements and filter()
+ * (src/set_manipulators.cpp:43-69,131-204) on the device, so that only the surviving placements
+ * cross PCIe.  acc_threshold == 0: discard_by_support_threshold (keep lwr > min_lwr, at least
+ * filter_min, at most filter_max); != 0: discard_by_accumulated_threshold (the reference's
+ * min - 1 top-up quirk included).  1 <= filter_min <= filter_max <= 64.
+ * Outputs (host or device buffers): query q owns slots [q*filter_max, q*filter_max + counts[q]) of
+ * pairs / results / lwr, best placement first.
+ */
+int epa_dev_place_all(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_begin,
+                      const uint32_t* win_span, uint32_t Q, uint32_t max_span, double min_lwr,
+                      int acc_threshold, uint32_t filter_min, uint32_t filter_max, epa_pair* pairs,
+                      epa_result* results, double* lwr, uint32_t* counts,
+                      epa_thorough_stats* stats);
+
 /* duration in milliseconds of the last launch of the named kernel family on ctx's stream,
  * measured with HIP events ("preplace", "thorough", "lookup", "select"); < 0 if never run. */
 double epa_dev_last_kernel_ms(const epa_ctx* ctx, const char* which);

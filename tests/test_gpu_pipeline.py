@@ -473,3 +473,53 @@ def test_very_large_reference_streamed_select():
     hb, hs = hostlib.heuristic(lnl, "dynamic", 0.99999)
     assert sorted(zip(hb.tolist(), hs.tolist())) == sorted(zip(pairs["branch_id"].tolist(), pairs["seq_id"].tolist()))
     assert np.all(np.diff(pairs["branch_id"].astype(np.int64)) >= 0)
+
+
+@pytest.mark.parametrize("states,acc", [(4, False), (4, True), (20, False)])
+def test_no_heur_all_pairs_lwr_and_filter_on_device(states, acc):
+    """epa_dev_place_all (--no-heur: pairs generated, placed, LWR'd and filtered on the device) vs
+    thorough placement of all pairs + the reference's compute_and_set_lwr / filter restated in
+    numpy (support-threshold and accumulated mode, min / max clamps, the min - 1 top-up quirk)."""
+    from epa_ng_amd import synth
+    if states == 4:
+        w = synth.dna_workload(40, 300, 90, 80, (111, 112, 113))
+    else:
+        w = synth.aa_workload(12, 200, 30, 60, (114, 115, 116))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=states, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    reads = list(w["reads"])
+    codes, wb, ws = epa.encode_queries(states, reads, compact=True)
+    Q, B = len(reads), ref.B
+    pairs = np.zeros(B * Q, epa.PAIR_DTYPE)
+    pairs["branch_id"] = np.repeat(np.arange(B), Q)
+    pairs["seq_id"] = np.tile(np.arange(Q), B)
+    full = ev.thorough(pairs, codes, wb, ws)
+    lnl = full["lnl"].reshape(B, Q)
+    for (thr, mn, mx) in ((0.01, 1, 7), (0.3, 3, 5), (0.9999, 1, 2)) if not acc else ((0.95, 1, 7), (0.5, 4, 6)):
+        got = ev.place_all(codes, wb, ws, min_lwr=thr, acc=acc, filter_min=mn, filter_max=mx)
+        assert ev.last_stats["pairs"] == B * Q
+        for q in range(Q):
+            col = lnl[:, q]
+            e = np.exp(col - col.max())
+            lw = e / e.sum()
+            order = np.lexsort((np.arange(B), -col))
+            if not acc:
+                k = 0
+                while k < B and lw[order[k]] > thr:
+                    k += 1
+                if k < mn:
+                    k = min(B, mn)
+                k = min(k, mx)
+            else:
+                k, s_ = 0, 0.0
+                while k < B and k < mx and s_ < thr:
+                    s_ += lw[order[k]]
+                    k += 1
+                if k + 1 < mn:
+                    k = min(B, mn - 1)
+            b_, l_, p_, d_, w_ = got[q]
+            assert list(b_) == list(order[:k]), (q, thr, mn, mx, list(b_), list(order[:k + 1]), lw[order[:k + 2]])
+            assert np.array_equal(l_, col[order[:k]])
+            assert np.max(np.abs(w_ - lw[order[:k]])) < 1e-12
+            assert np.array_equal(p_, full["pendant_length"].reshape(B, Q)[order[:k], q])
