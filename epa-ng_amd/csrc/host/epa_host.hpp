@@ -296,5 +296,8 @@ struct Run_Stats {
 };
 Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std::string& outdir,
                      const Options& options, const std::string& invocation, int device = 0);
+// same, one worker thread per listed GPU; the jplace does not depend on the device count
+Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std::string& outdir,
+                     const Options& options, const std::string& invocation, const std::vector<int>& devices);
 
 }  // namespace epa

@@ -28,7 +28,8 @@ static void usage() {
       "  --precision N         output digits (default 10)\n"
       "  --chunk-size N        queries per chunk (default 50000; EPA-ng's CPU default is 5000)\n"
       "  --no-pre-mask         evaluate all sites of every query\n"
-      "  --device N            GPU ordinal (default 0)\n";
+      "  --device N            GPU ordinal (default 0)\n"
+      "  --devices a,b,..      place on several GPUs of the node (chunks are dealt to them in turn)\n";
 }
 
 int main(int argc, char** argv) {
@@ -38,6 +39,7 @@ int main(int argc, char** argv) {
   std::string tree_file, ref_file, query_file, outdir = "./", model_desc = "GTR+G";
   Options opt;
   int device = 0;
+  std::vector<int> devices;
   auto need = [&](int& i) -> std::string {
     if (i + 1 >= argc) { std::cerr << "missing value for " << argv[i] << "\n"; std::exit(1); }
     return argv[++i];
@@ -62,6 +64,11 @@ int main(int argc, char** argv) {
     else if (a == "--no-pre-mask") opt.premasking = false;
     else if (a == "-T" || a == "--threads") opt.num_threads = (unsigned)std::stoul(need(i));
     else if (a == "--device") device = std::stoi(need(i));
+    else if (a == "--devices") {
+      std::stringstream ls(need(i));
+      std::string tok;
+      while (std::getline(ls, tok, ',')) if (!tok.empty()) devices.push_back(std::stoi(tok));
+    }
     else if (a == "--redo" || a == "--verbose") {}
     else if (a == "-h" || a == "--help") { usage(); return 0; }
     else { std::cerr << "option " << a << " is outside the placement hot path of this build\n"; return 1; }
@@ -81,7 +88,8 @@ int main(int argc, char** argv) {
       std::cout << "WARNING: rooted reference tree: the root was removed, placements are reported on the "
                    "unrooted tree in the jplace (no --preserve-rooting in this build)." << std::endl;
     const double secs_tree = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tree).count();
-    const Run_Stats st = simple_mpi(tree, query_file, outdir, opt, invocation, device);
+    if (devices.empty()) devices.push_back(device);
+    const Run_Stats st = simple_mpi(tree, query_file, outdir, opt, invocation, devices);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
     std::cout << "Reference tree log-likelihood: " << st.ref_tree_logl << "\n";
     std::cout << st.queries << " Sequences done! (" << st.pairs << " thorough pairs)\n"

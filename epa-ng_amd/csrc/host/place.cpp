@@ -5,8 +5,11 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
 #include <fstream>
-#include <future>
+#include <mutex>
+#include <thread>
 #include <limits>
 #include <numeric>
 
@@ -18,18 +21,18 @@
 namespace epa {
 
 int configure_host_threads() {
-  static int configured = 0;
-  if (configured) return configured;
-  int n = omp_get_max_threads();
-  cpu_set_t set;
-  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
-  std::ifstream f("/sys/fs/cgroup/cpu.max");  // cgroup v2: "<quota> <period>" or "max <period>"
-  std::string quota;
-  double period = 0;
-  if (f >> quota >> period && quota != "max" && period > 0)
-    n = std::min(n, std::max(1, (int)std::ceil(std::stod(quota) / period)));
-  omp_set_num_threads(n);
-  configured = n;
+  static const int n = [] {
+    int v = omp_get_max_threads();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) v = std::min(v, std::max(1, CPU_COUNT(&set)));
+    std::ifstream f("/sys/fs/cgroup/cpu.max");  // cgroup v2: "<quota> <period>" or "max <period>"
+    std::string quota;
+    double period = 0;
+    if (f >> quota >> period && quota != "max" && period > 0)
+      v = std::min(v, std::max(1, (int)std::ceil(std::stod(quota) / period)));
+    return v;
+  }();
+  omp_set_num_threads(n);  // per calling thread (the device workers are separate host threads)
   return n;
 }
 
@@ -323,87 +326,162 @@ void filter(Sample& sample, const Options& options) {
   }
 }
 
+namespace {
+struct Chunk_Timing { double place = 0, thorough = 0, post = 0; size_t pairs = 0; };
+
+// the body of the reference's chunk loop (src/core/place.cpp:219-246) for one chunk on one device
+Sample process_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, Device_Evaluator& dev,
+                     const Options& options, size_t seq_id_offset, Chunk_Timing& tm) {
+  using clk = std::chrono::steady_clock;
+  const size_t B = tree.num_branches(), n = chunk.size();
+  Work blo_work;
+  Sample blo_sample;
+  auto t0 = clk::now();
+  auto t1 = t0;
+  // --no-heur: pairs, thorough placement, LWR and filter all on the device (epa_dev_place_all)
+  const bool all_on_device = !options.prescoring && options.filter_min >= 1 &&
+                             options.filter_max >= options.filter_min && options.filter_max <= 64 &&
+                             (uint64_t)n * B <= 0xffffffffull;
+  const bool fused = options.prescoring && options.device_select && !options.baseball &&
+                     !options.prescoring_by_percentage && B <= 65536;
+  if (all_on_device) {
+    tm.pairs = place_all(chunk, enc, tree, dev, blo_sample, options, seq_id_offset);
+    t1 = clk::now();
+  } else if (fused) {
+    // default configuration: the whole chunk body runs on the GPU (epa_dev_place_chunk), the
+    // Q x B table never crosses PCIe
+    place_chunk(chunk, enc, tree, dev, blo_work, blo_sample, options, seq_id_offset);
+    t1 = clk::now();
+  } else {
+    if (options.prescoring) {
+      std::vector<double> lnl;
+      place(chunk, enc, tree, dev, lnl, options);
+      blo_work = apply_heuristic(lnl, n, B, options);
+    } else {  // --no-heur: all B x Q pairs (src/core/place.cpp:189,228)
+      blo_work.reserve(n * B);
+      for (size_t b = 0; b < B; ++b)
+        for (size_t q = 0; q < n; ++q) blo_work.push_back(Work_Pair{b, q});
+    }
+    t1 = clk::now();
+    place_thorough(blo_work, chunk, enc, tree, dev, blo_sample, options, seq_id_offset);
+  }
+  auto t2 = clk::now();
+  if (!all_on_device) {
+    compute_and_set_lwr(blo_sample);
+    filter(blo_sample, options);
+    tm.pairs = blo_work.size();
+  }
+  tm.place = std::chrono::duration<double>(t1 - t0).count();
+  tm.thorough = std::chrono::duration<double>(t2 - t1).count();
+  tm.post = std::chrono::duration<double>(clk::now() - t2).count();
+  return blo_sample;
+}
+}  // namespace
+
 Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std::string& outdir,
                      const Options& options, const std::string& invocation, int device) {
+  return simple_mpi(tree, query_file, outdir, options, invocation, std::vector<int>{device});
+}
+
+// Chunks are read and encoded by one staging thread (the reference prefetches its next chunk the
+// same way, src/core/place.cpp:190-215) and handed, in file order, to one worker per GPU: every
+// (query, branch) pair is independent, the reference shards the query file across MPI ranks the
+// same way (src/net/epa_mpi_util.cpp:10-30).  Results are written in chunk order, so the jplace
+// does not depend on the number of devices.
+Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std::string& outdir,
+                     const Options& options, const std::string& invocation, const std::vector<int>& devices) {
   using clk = std::chrono::steady_clock;
+  if (devices.empty()) throw std::runtime_error{"no device given"};
   Run_Stats st;
   configure_host_threads();
-  const size_t B = tree.num_branches();
   auto ts = clk::now();
-  Device_Evaluator dev(tree, options, device);
-  st.ref_tree_logl = dev.ref_tree_logl(0);
+  std::vector<std::unique_ptr<Device_Evaluator>> devs;
+  for (int d : devices) devs.emplace_back(new Device_Evaluator(tree, options, d));
+  st.ref_tree_logl = devs[0]->ref_tree_logl(0);
   st.seconds_setup = std::chrono::duration<double>(clk::now() - ts).count();
-  Fasta_Stream reader(query_file);
+
+  struct Staged { size_t index = 0, offset = 0; MSA chunk; Encoded_Chunk enc; };
+  std::mutex mu;
+  std::condition_variable cv_put, cv_get;
+  std::deque<Staged> queue;
+  bool eof = false;
+  std::exception_ptr failure;
+  const size_t depth = devices.size() + 1;  // staged chunks in flight
   std::vector<Sample> results;
-  std::vector<double> lnl;
-  size_t done = 0;
-  // The next chunk is read and encoded on a host thread while the device works on the current
-  // one (the reference prefetches its next chunk the same way, src/core/place.cpp:190-215).
-  struct Staged { MSA chunk; Encoded_Chunk enc; double seconds_read = 0; };
-  auto stage = [&]() {
-    Staged s;
-    const auto r0 = clk::now();
-    reader.read_next(s.chunk, options.chunk_size);
-    s.seconds_read = std::chrono::duration<double>(clk::now() - r0).count();
-    if (!s.chunk.empty()) s.enc = encode_chunk(s.chunk, tree, options);
-    return s;
-  };
-  std::future<Staged> next = std::async(std::launch::async, stage);
-  for (;;) {
-    auto tw = clk::now();
-    Staged cur = next.get();
-    st.seconds_stage_wait += std::chrono::duration<double>(clk::now() - tw).count();
-    st.seconds_read += cur.seconds_read;
-    if (cur.chunk.empty()) break;
-    const MSA& chunk = cur.chunk;
-    const Encoded_Chunk& enc = cur.enc;
-    const size_t n = chunk.size();
-    next = std::async(std::launch::async, stage);
-    Work blo_work;
-    Sample blo_sample;
-    auto t0 = clk::now();
-    auto t1 = t0;
-    // --no-heur: pairs, thorough placement, LWR and filter all on the device (epa_dev_place_all)
-    const bool all_on_device = !options.prescoring && options.filter_min >= 1 &&
-                               options.filter_max >= options.filter_min && options.filter_max <= 64 &&
-                               (uint64_t)n * B <= 0xffffffffull;
-    const bool fused = options.prescoring && options.device_select && !options.baseball &&
-                       !options.prescoring_by_percentage && B <= 65536;
-    size_t pairs_done = 0;
-    if (all_on_device) {
-      pairs_done = place_all(chunk, enc, tree, dev, blo_sample, options, done);
-      t1 = clk::now();
-    } else if (fused) {
-      // default configuration: the whole chunk body runs on the GPU (epa_dev_place_chunk), the
-      // Q x B table never crosses PCIe
-      place_chunk(chunk, enc, tree, dev, blo_work, blo_sample, options, done);
-      t1 = clk::now();
-    } else {
-      if (options.prescoring) {
-        place(chunk, enc, tree, dev, lnl, options);
-        blo_work = apply_heuristic(lnl, n, B, options);
-      } else {  // --no-heur: all B x Q pairs (src/core/place.cpp:189,228)
-        blo_work.reserve(n * B);
-        for (size_t b = 0; b < B; ++b)
-          for (size_t q = 0; q < n; ++q) blo_work.push_back(Work_Pair{b, q});
+
+  std::thread stager([&] {
+    try {
+      Fasta_Stream reader(query_file);
+      size_t index = 0, offset = 0;
+      for (;;) {
+        Staged s;
+        const auto r0 = clk::now();
+        reader.read_next(s.chunk, options.chunk_size);
+        const double rd = std::chrono::duration<double>(clk::now() - r0).count();
+        if (s.chunk.empty()) break;
+        s.index = index++;
+        s.offset = offset;
+        offset += s.chunk.size();
+        s.enc = encode_chunk(s.chunk, tree, options);
+        std::unique_lock<std::mutex> lk(mu);
+        st.seconds_read += rd;
+        cv_put.wait(lk, [&] { return queue.size() < depth || failure; });
+        if (failure) break;
+        queue.push_back(std::move(s));
+        cv_get.notify_one();
       }
-      t1 = clk::now();
-      place_thorough(blo_work, chunk, enc, tree, dev, blo_sample, options, done);
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!failure) failure = std::current_exception();
     }
-    auto t2 = clk::now();
-    if (!all_on_device) {
-      compute_and_set_lwr(blo_sample);
-      filter(blo_sample, options);
-      pairs_done = blo_work.size();
+    std::lock_guard<std::mutex> lk(mu);
+    eof = true;
+    cv_get.notify_all();
+  });
+
+  auto worker = [&](size_t k) {
+    try {
+      for (;;) {
+        Staged cur;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          const auto tw = clk::now();
+          cv_get.wait(lk, [&] { return !queue.empty() || eof || failure; });
+          st.seconds_stage_wait += std::chrono::duration<double>(clk::now() - tw).count() / devices.size();
+          if (failure || queue.empty()) return;
+          cur = std::move(queue.front());
+          queue.pop_front();
+          cv_put.notify_one();
+        }
+        Chunk_Timing tm;
+        Sample smp = process_chunk(cur.chunk, cur.enc, tree, *devs[k], options, cur.offset, tm);
+        std::lock_guard<std::mutex> lk(mu);
+        if (results.size() <= cur.index) results.resize(cur.index + 1);
+        results[cur.index] = std::move(smp);
+        st.queries += cur.chunk.size();
+        st.pairs += tm.pairs;
+        st.seconds_place += tm.place;
+        st.seconds_thorough += tm.thorough;
+        st.seconds_post += tm.post;
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!failure) failure = std::current_exception();
+      cv_put.notify_all();
+      cv_get.notify_all();
     }
-    results.push_back(std::move(blo_sample));
-    st.seconds_post += std::chrono::duration<double>(clk::now() - t2).count();
-    st.pairs += pairs_done;
-    st.seconds_place += std::chrono::duration<double>(t1 - t0).count();
-    st.seconds_thorough += std::chrono::duration<double>(t2 - t1).count();
-    done += n;
+  };
+  std::vector<std::thread> workers;
+  for (size_t k = 1; k < devices.size(); ++k) workers.emplace_back(worker, k);
+  worker(0);
+  for (auto& w : workers) w.join();
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    cv_put.notify_all();
   }
-  st.queries = done;
+  stager.join();
+  if (failure) std::rethrow_exception(failure);
+
   std::string dir = outdir;
   if (!dir.empty() && dir.back() != '/') dir += "/";
   ts = clk::now();

@@ -523,3 +523,36 @@ def test_no_heur_all_pairs_lwr_and_filter_on_device(states, acc):
             assert np.array_equal(l_, col[order[:k]])
             assert np.max(np.abs(w_ - lw[order[:k]])) < 1e-12
             assert np.array_equal(p_, full["pendant_length"].reshape(B, Q)[order[:k], q])
+
+
+def test_cli_several_devices_same_jplace(tmp_path):
+    """--devices a,b: one worker thread per GPU, chunks dealt in file order; the jplace must not
+    depend on the device count (two contexts on GPU 0 stand in for two GPUs)."""
+    import subprocess
+    from epa_ng_amd import synth
+    w = synth.dna_workload(30, 400, 900, 100, (121, 122, 123))
+    tre, aln, qf = tmp_path / "r.tre", tmp_path / "r.fasta", tmp_path / "q.fasta"
+    tre.write_text(w["newick"] + "\n")
+    with open(aln, "w") as f:
+        for l, s in zip(w["labels"], w["seqs"]):
+            f.write(">%s\n%s\n" % (l, s))
+    with open(qf, "w") as f:
+        for i, s in enumerate(w["reads"]):
+            f.write(">q%d\n%s\n" % (i, s))
+    exe = os.path.join(os.path.dirname(hostlib.HOST_SO), "epa-ng-amd")
+    model = "GTR{%s}+FU{%s}+G4{0.478218}" % ("/".join(map(repr, w["subst"])), "/".join(map(repr, w["freqs"])))
+    outs = []
+    for devs, extra in (("0", []), ("0,0", []), ("0,0,0", ["--no-heur"]), ("0", ["--no-heur"])):
+        od = tmp_path / ("out_" + devs.replace(",", "_") + ("_nh" if extra else ""))
+        od.mkdir()
+        r = subprocess.run([exe, "-t", str(tre), "-s", str(aln), "-q", str(qf), "-m", model, "-w", str(od),
+                            "--chunk-size", "100", "--devices", devs] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        jp = json.load(open(od / "epa_result.jplace"))
+        jp.pop("metadata", None)
+        outs.append(jp)
+        assert len(jp["placements"]) == 900
+    assert outs[0] == outs[1]
+    assert outs[2] == outs[3]
+    assert [p["n"] for p in outs[0]["placements"]] == [["q%d" % i] for i in range(900)]
