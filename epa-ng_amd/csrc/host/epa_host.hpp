@@ -235,6 +235,11 @@ private:
 };
 void write_jplace(std::ostream& os, const std::vector<Sample>& chunks, const std::string& newick,
                   const std::string& invocation, unsigned int precision);
+// the same in two steps: every chunk is turned into text as soon as it is done (by the device
+// worker that produced it), the file is assembled at the end
+std::string jplace_chunk_text(const Sample& sample, unsigned int precision);
+void write_jplace_text(std::ostream& os, const std::vector<std::string>& chunk_texts, const std::string& newick,
+                       const std::string& invocation);
 
 // ---- device-backed evaluator: one epa_ctx, RAII
 class Device_Evaluator {

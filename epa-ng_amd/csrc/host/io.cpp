@@ -1,5 +1,6 @@
 // FASTA reading and jplace writing (formats of src/io/jplace_util.cpp:20-98 and
 // src/io/jplace_writer.hpp:79-148; fixed-point doubles with `precision` digits).
+#include <algorithm>
 #include <cctype>
 #include <fstream>
 #include <ostream>
@@ -88,34 +89,64 @@ MSA read_fasta(const std::string& path) {
   return out;
 }
 
-void write_jplace(std::ostream& os, const std::vector<Sample>& chunks, const std::string& newick,
-                  const std::string& invocation, unsigned int precision) {
-  os.precision(precision);
-  os.setf(std::ios::fixed, std::ios::floatfield);
+// One chunk of the "placements" array as text (sample_to_jplace_string, src/io/jplace_util.cpp:
+// 60-98): formatted per pquery in parallel with snprintf into per-thread strings, then joined.
+// Numbers are fixed-point with `precision` digits like the reference's stream settings.
+std::string jplace_chunk_text(const Sample& sample, unsigned int precision) {
+  configure_host_threads();
+  const long n = (long)sample.size();
+  std::vector<std::string> part(n);
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < n; ++i) {
+    const auto& pq = sample[i];
+    std::string& o = part[i];
+    o.reserve(64 + pq.size() * (40 + 4 * (precision + 8)));
+    o += "    {\"p\": [\n";
+    char buf[512];
+    size_t j = 0;
+    for (const auto& p : pq) {
+      const int len = std::snprintf(buf, sizeof(buf), "      [%zu, %.*f, %.*f, %.*f, %.*f]", p.branch_id(),
+                                    (int)precision, p.likelihood(), (int)precision, p.lwr(), (int)precision,
+                                    p.distal_length(), (int)precision, p.pendant_length());
+      o.append(buf, (size_t)std::max(0, std::min(len, (int)sizeof(buf) - 1)));
+      if (++j < pq.size()) o += ",";
+      o += "\n";
+    }
+    o += "      ],\n    \"n\": [\"";
+    o += pq.header();
+    o += "\"]\n    }";
+    if (i + 1 < n) o += ",";
+    o += "\n";
+  }
+  size_t total = 0;
+  for (const auto& x : part) total += x.size();
+  std::string out;
+  out.reserve(total);
+  for (const auto& x : part) out += x;
+  return out;
+}
+
+void write_jplace_text(std::ostream& os, const std::vector<std::string>& chunk_texts, const std::string& newick,
+                       const std::string& invocation) {
   os << "{\n  \"tree\": \"" << newick << "\",\n  \"placements\": \n  [\n";
   bool first_chunk = true;
-  for (const auto& sample : chunks) {
-    if (sample.empty()) continue;
+  for (const auto& t : chunk_texts) {
+    if (t.empty()) continue;
     if (!first_chunk) os << ",\n";  // chunks separated by ",\n" (jplace_writer.hpp:141)
     first_chunk = false;
-    size_t i = 0;
-    for (const auto& pq : sample) {
-      os << "    {\"p\": [\n";
-      size_t j = 0;
-      for (const auto& p : pq) {
-        os << "      [" << p.branch_id() << ", " << p.likelihood() << ", " << p.lwr() << ", "
-           << p.distal_length() << ", " << p.pendant_length() << "]";
-        if (++j < pq.size()) os << ",";
-        os << "\n";
-      }
-      os << "      ],\n    \"n\": [\"" << pq.header() << "\"]\n    }";
-      if (++i < sample.size()) os << ",";
-      os << "\n";
-    }
+    os.write(t.data(), (std::streamsize)t.size());
   }
   os << "  ],\n  \"metadata\": {\"invocation\": \"" << invocation << "\"},\n  \"version\": 3,\n"
      << "  \"fields\": [\"edge_num\", \"likelihood\", \"like_weight_ratio\", \"distal_length\""
      << ", \"pendant_length\"]\n}\n";
+}
+
+void write_jplace(std::ostream& os, const std::vector<Sample>& chunks, const std::string& newick,
+                  const std::string& invocation, unsigned int precision) {
+  std::vector<std::string> texts;
+  texts.reserve(chunks.size());
+  for (const auto& sample : chunks) texts.push_back(jplace_chunk_text(sample, precision));
+  write_jplace_text(os, texts, newick, invocation);
 }
 
 }  // namespace epa

@@ -407,7 +407,7 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
   bool eof = false;
   std::exception_ptr failure;
   const size_t depth = devices.size() + 1;  // staged chunks in flight
-  std::vector<Sample> results;
+  std::vector<std::string> results;  // jplace text per chunk, in chunk order
 
   std::thread stager([&] {
     try {
@@ -455,9 +455,13 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
         }
         Chunk_Timing tm;
         Sample smp = process_chunk(cur.chunk, cur.enc, tree, *devs[k], options, cur.offset, tm);
+        const auto tf = clk::now();
+        std::string text = jplace_chunk_text(smp, options.precision);
+        const double secs_text = std::chrono::duration<double>(clk::now() - tf).count();
         std::lock_guard<std::mutex> lk(mu);
         if (results.size() <= cur.index) results.resize(cur.index + 1);
-        results[cur.index] = std::move(smp);
+        results[cur.index] = std::move(text);
+        st.seconds_write += secs_text;
         st.queries += cur.chunk.size();
         st.pairs += tm.pairs;
         st.seconds_place += tm.place;
@@ -487,9 +491,9 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
   ts = clk::now();
   std::ofstream os(dir + "epa_result.jplace");
   if (!os) throw std::runtime_error{"cannot open " + dir + "epa_result.jplace"};
-  write_jplace(os, results, tree.numbered_newick(options.precision), invocation, options.precision);
+  write_jplace_text(os, results, tree.numbered_newick(options.precision), invocation);
   os.flush();
-  st.seconds_write = std::chrono::duration<double>(clk::now() - ts).count();
+  st.seconds_write += std::chrono::duration<double>(clk::now() - ts).count();
   return st;
 }
 
