@@ -248,9 +248,15 @@ public:
   ~Device_Evaluator();
   Device_Evaluator(const Device_Evaluator&) = delete;
   epa_ctx* ctx() const { return ctx_; }
+  // host staging of the candidate placements of a chunk, reused from chunk to chunk (a fresh
+  // zero-filled 100 MB vector per chunk costs more than the device work)
+  std::vector<epa_pair>& pair_buffer() { return pairs_buf_; }
+  std::vector<epa_result>& result_buffer() { return res_buf_; }
   double ref_tree_logl(size_t branch = 0) const;  // Tree::ref_tree_logl evaluated on the device
 private:
   epa_ctx* ctx_ = nullptr;
+  std::vector<epa_pair> pairs_buf_;
+  std::vector<epa_result> res_buf_;
 };
 
 // encoded chunk of queries (what crosses the C-ABI)

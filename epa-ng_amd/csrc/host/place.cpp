@@ -222,14 +222,16 @@ void place_thorough(const Work& to_place, const MSA& chunk, const Encoded_Chunk&
 void place_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, Device_Evaluator& dev,
                  Work& work, Sample& sample, const Options& options, size_t seq_id_offset) {
   const size_t Q = chunk.size();
-  uint64_t cap = (uint64_t)Q * 64, n = 0;
-  std::vector<epa_pair> pairs;
-  std::vector<epa_result> res;
+  // the dynamic heuristic keeps a handful of branches per read: start with room for 8 per read,
+  // grow on overflow (the buffers live in the evaluator and are reused by the next chunk)
+  uint64_t cap = std::max<uint64_t>((uint64_t)Q * 8, dev.pair_buffer().size()), n = 0;
+  std::vector<epa_pair>& pairs = dev.pair_buffer();
+  std::vector<epa_result>& res = dev.result_buffer();
   uint32_t max_span = 0;
   for (uint32_t s : enc.win_span) max_span = std::max(max_span, s);
   for (;;) {
-    pairs.resize(cap);
-    res.resize(cap);
+    if (pairs.size() < cap) pairs.resize(cap);
+    if (res.size() < cap) res.resize(cap);
     epa_dev_set_query_layout(dev.ctx(), enc.stride);
     const int rc = epa_dev_place_chunk(dev.ctx(), enc.codes.data(), enc.win_begin.data(),
                                        enc.win_span.data(), (uint32_t)Q, max_span,
@@ -245,7 +247,6 @@ void place_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, D
   }
   work.resize(n);
   for (size_t i = 0; i < n; ++i) work[i] = Work_Pair{pairs[i].branch_id, pairs[i].seq_id};
-  res.resize(n);
   build_sample(work, res, chunk, sample, seq_id_offset);
 }
 
