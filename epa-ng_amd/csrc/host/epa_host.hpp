@@ -225,12 +225,12 @@ public:
   // appends up to max_seqs sequences to `out`; returns how many (0 = end of file)
   size_t read_next(MSA& out, size_t max_seqs);
 private:
-  bool next_line(const char*& b, const char*& e);
+  bool refill();
   std::FILE* f_ = nullptr;
   std::vector<char> buf_;
-  size_t pos_ = 0, len_ = 0;
-  bool eof_ = false, pending_header_ = false;
-  std::string header_, seq_;
+  size_t pos_ = 0, len_ = 0, scan_ = 0;  // unparsed region [pos_, len_), record index built up to scan_
+  std::vector<size_t> starts_;            // offsets of the '>' of the records found so far
+  bool eof_ = false, first_block_ = true;
   char up_[256];
 };
 void write_jplace(std::ostream& os, const std::vector<Sample>& chunks, const std::string& newick,

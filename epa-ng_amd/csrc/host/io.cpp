@@ -17,69 +17,78 @@ namespace epa {
 // (src/seq/MSA_Stream.cpp:41), whitespace inside sequence lines is dropped.
 Fasta_Stream::Fasta_Stream(const std::string& path) : f_(std::fopen(path.c_str(), "rb")) {
   if (!f_) throw std::runtime_error{"file_check failed: " + path};
-  buf_.resize(1 << 22);
+  buf_.resize(1 << 24);
   for (int c = 0; c < 256; ++c) up_[c] = std::isspace(c) ? 0 : (char)std::toupper(c);
 }
 
 Fasta_Stream::~Fasta_Stream() { if (f_) std::fclose(f_); }
 
-bool Fasta_Stream::next_line(const char*& b, const char*& e) {
-  for (;;) {
-    const char* nl = (const char*)std::memchr(buf_.data() + pos_, '\n', len_ - pos_);
-    if (nl) {
-      b = buf_.data() + pos_;
-      e = nl;
-      pos_ = (size_t)(nl - buf_.data()) + 1;
-      return true;
-    }
-    if (eof_) {
-      if (pos_ == len_) return false;
-      b = buf_.data() + pos_;
-      e = buf_.data() + len_;
-      pos_ = len_;
-      return true;
-    }
-    // refill: keep the partial line at the front, grow if a single line exceeds the buffer
+// appends more of the file behind the unparsed region [pos_, len_); false at end of file
+bool Fasta_Stream::refill() {
+  if (eof_) return false;
+  if (pos_ > 0) {
     std::memmove(buf_.data(), buf_.data() + pos_, len_ - pos_);
     len_ -= pos_;
+    scan_ -= pos_;
+    for (auto& s : starts_) s -= pos_;
     pos_ = 0;
-    if (len_ == buf_.size()) buf_.resize(buf_.size() * 2);
-    const size_t got = std::fread(buf_.data() + len_, 1, buf_.size() - len_, f_);
-    len_ += got;
-    if (got == 0) eof_ = true;
   }
+  if (buf_.size() - len_ < (buf_.size() >> 2)) buf_.resize(buf_.size() * 2);
+  const size_t got = std::fread(buf_.data() + len_, 1, buf_.size() - len_, f_);
+  len_ += got;
+  if (got == 0) eof_ = true;
+  return got != 0;
 }
 
+// Records are located first ('>' at the start of a line), then parsed in parallel: the header up
+// to the first blank, the sequence lines upper-cased with white space dropped.
 size_t Fasta_Stream::read_next(MSA& out, size_t max_seqs) {
-  size_t n = 0;
-  const char *b, *e;
-  while (n < max_seqs || !pending_header_) {
-    if (!next_line(b, e)) {
-      if (pending_header_) { out.emplace_back(std::move(header_), std::move(seq_)); ++n; }
-      pending_header_ = false;
-      header_.clear(); seq_.clear();
-      break;
+  configure_host_threads();
+  if (max_seqs == 0) return 0;
+  for (;;) {
+    // extend the index of record starts over the bytes not scanned yet
+    const char* base = buf_.data();
+    while (scan_ < len_) {
+      const char* p = (const char*)std::memchr(base + scan_, '>', len_ - scan_);
+      if (!p) { scan_ = len_; break; }
+      const size_t o = (size_t)(p - base);
+      if (o == 0 ? first_block_ : base[o - 1] == '\n') starts_.push_back(o);
+      scan_ = o + 1;
     }
-    while (e > b && (e[-1] == '\r' || e[-1] == ' ')) --e;
-    if (e == b) continue;
-    if (*b == '>') {
-      if (pending_header_) { out.emplace_back(std::move(header_), std::move(seq_)); ++n; seq_.clear(); }
-      const char* h = b + 1;
-      const char* he = h;
-      while (he < e && *he != ' ' && *he != '\t') ++he;
-      header_.assign(h, he);
-      pending_header_ = true;
-      if (n >= max_seqs) break;   // the header just read belongs to the next call
-    } else if (pending_header_) {
-      const size_t old = seq_.size();
-      seq_.resize(old + (size_t)(e - b));
-      char* d = &seq_[old];
-      size_t k = 0;
-      for (const char* p = b; p < e; ++p) { const char c = up_[(unsigned char)*p]; d[k] = c; k += c != 0; }
-      seq_.resize(old + k);
-    }
+    // a record is complete once the next one has started (or the file has ended)
+    const size_t complete = eof_ ? starts_.size() : (starts_.empty() ? 0 : starts_.size() - 1);
+    if (complete >= max_seqs || eof_) break;
+    if (starts_.empty() && len_ > 0) pos_ = len_ - 1;  // junk before the first record: keep 1 byte of context
+    first_block_ = first_block_ && len_ == 0;
+    refill();
   }
-  return n;
+  first_block_ = false;
+  const size_t complete = eof_ ? starts_.size() : (starts_.empty() ? 0 : starts_.size() - 1);
+  const size_t m = std::min(max_seqs, complete);
+  if (m == 0) { if (eof_) { pos_ = len_; starts_.clear(); } return 0; }
+  const size_t first = out.size();
+  out.resize(first + m);
+  const char* base = buf_.data();
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)m; ++i) {
+    const char* b = base + starts_[i] + 1;
+    const char* e = base + (i + 1 < (long)starts_.size() ? starts_[i + 1] : len_);
+    const char* nl = (const char*)std::memchr(b, '\n', (size_t)(e - b));
+    const char* hend = nl ? nl : e;
+    const char* h = b;
+    while (h < hend && *h != ' ' && *h != '\t' && *h != '\r') ++h;
+    std::string header(b, h), seq;
+    if (nl) {
+      seq.resize((size_t)(e - nl));
+      size_t k = 0;
+      for (const char* p = nl; p < e; ++p) { const char c = up_[(unsigned char)*p]; seq[k] = c; k += c != 0; }
+      seq.resize(k);
+    }
+    out[first + i] = Sequence(std::move(header), std::move(seq));
+  }
+  pos_ = m < starts_.size() ? starts_[m] : len_;
+  starts_.erase(starts_.begin(), starts_.begin() + m);
+  return m;
 }
 
 MSA read_fasta(const std::string& path) {
