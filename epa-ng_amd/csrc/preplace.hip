@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
                                                     const uint32_t* __restrict__ win_begin,
                                                     const uint32_t* __restrict__ win_span, uint32_t Q,
                                                     uint32_t W, uint32_t cstride, uint32_t crel,
-                                                    uint32_t Wp, uint32_t NP16,
+                                                    uint32_t span_bound, uint32_t Wp, uint32_t NP16,
                                                     uint16_t* __restrict__ packed,
                                                     uint16_t* __restrict__ tails,
                                                     uint32_t* __restrict__ keys,
@@ -394,7 +394,9 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
   if (q >= Q) return;
   const uint32_t begin = win_begin[q];
   uint32_t span = win_span[q];
-  const uint32_t cmax = crel ? cstride : 0xffffffffu;
+  // a window longer than the caller's max_span (or than a compact row) is an input error: the
+  // kernel variant and the packed rows were sized by it
+  const uint32_t cmax = min(span_bound, crel ? cstride : 0xffffffffu);
   if (lane == 0) validate_window(q, begin, span, W, cmax, status);
   if ((uint64_t)begin + span > W || span > cmax) span = 0;  // invalid window (flagged above)
   const uint8_t* c = codes + (size_t)q * cstride + (crel ? 0u : begin);
@@ -871,12 +873,12 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   while (key_bits < 32 && (1ull << key_bits) < (uint64_t)n_blocks * Wp) ++key_bits;
   if (pairs) {
     hipLaunchKernelGGL(k_pack_pairs, dim3((Q + 3) / 4), dim3(256), 0, ctx->stream, d_codes, d_begin,
-                       d_span, Q, ctx->W, cstride, crel, Wp, NP16, packed, tails, keys, status);
+                       d_span, Q, ctx->W, cstride, crel, span_bound, Wp, NP16, packed, tails, keys, status);
     EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, keys, sorted_keys, iota, perm, Q, 0,
                                            key_bits, ctx->stream));
   } else {
     hipLaunchKernelGGL(k_validate, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, d_begin, d_span, Q,
-                       ctx->W, crel ? cstride : 0xffffffffu, status);
+                       ctx->W, std::min(span_bound, crel ? cstride : 0xffffffffu), status);
     int wbits = 1;
     while (wbits < 32 && (1ull << wbits) <= (uint64_t)ctx->W) ++wbits;
     EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, d_begin, sorted_keys, iota, perm, Q, 0, wbits,

@@ -556,3 +556,23 @@ def test_cli_several_devices_same_jplace(tmp_path):
     assert outs[0] == outs[1]
     assert outs[2] == outs[3]
     assert [p["n"] for p in outs[0]["placements"]] == [["q%d" % i] for i in range(900)]
+
+
+def test_wrong_max_span_is_rejected():
+    """the caller's max_span sizes kernel variants and packed rows: a longer window is an input
+    error (EPA_ERR_QUERY_WIDTH), not a silently truncated sum -- also for device-resident inputs"""
+    import torch
+    from epa_ng_amd import synth
+    w = synth.dna_workload(16, 400, 40, 180, (131, 132, 133))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    codes, wb, ws = epa.encode_queries(4, w["reads"], compact=True)
+    dc = torch.from_numpy(codes).cuda()
+    db = torch.from_numpy(wb.view(np.int32)).cuda()
+    ds = torch.from_numpy(ws.view(np.int32)).cuda()
+    pairs, res = ev.place_chunk(dc, db, ds, Q=len(wb), max_span=int(ws.max()))
+    assert len(pairs) > 0
+    with pytest.raises(epa.EpaError) as ei:
+        ev.place_chunk(dc, db, ds, Q=len(wb), max_span=100)
+    assert ei.value.code == -4
