@@ -134,7 +134,8 @@ __device__ __forceinline__ void inner_site(const ModelDNA& m, const double (&A)[
 
 template <int NCH>
 struct SiteState {
-  double S[NCH][16];   // sumtable of the branch currently being optimised
+  double S[NCH][16];   // sumtable of the branch currently being optimised.  ZERO0: entry [0] holds
+                       // sum_k w_k S_k0 (the zero-eigenvalue terms, constant in t), [4] [8] [12] are dead
   uint32_t sc[NCH];    // proximal + distal scaler counts
   uint32_t resc[NCH];  // rescale flag of the last inner CLV toward the query
   uint32_t code[NCH];  // query column code
@@ -178,17 +179,16 @@ __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* ta
   double e[16], e1[16], e2[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    e[i] = tab[i];
-    if (!(ZERO0 && (i & 3) == 0)) { e1[i] = tab[16 + i]; e2[i] = tab[32 + i]; }
+    if (!(ZERO0 && (i & 3) == 0)) { e[i] = tab[i]; e1[i] = tab[16 + i]; e2[i] = tab[32 + i]; }
   }
   double fl = 0.0, dfl = 0.0;
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
-    double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+    double l0 = ZERO0 ? st.S[ch][0] : 0.0, l1 = 0.0, l2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      l0 = fma(st.S[ch][i], e[i], l0);
       if (!(ZERO0 && (i & 3) == 0)) {
+        l0 = fma(st.S[ch][i], e[i], l0);
         l1 = fma(st.S[ch][i], e1[i], l1);
         l2 = fma(st.S[ch][i], e2[i], l2);
       }
@@ -208,16 +208,17 @@ __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* ta
 // and exponent (v_frexp_*), mantissas multiplied, exponents and scaler counts added as integers:
 //   sum_ch log(L_ch) + sc_ch log 2^-256  =  log(prod mant) + ln2 * (sum exp - 256 sum sc)
 // -> ONE log() per lane instead of NCH.
-template <int NCH, int NW>
+template <int NCH, bool ZERO0, int NW>
 __device__ __forceinline__ double window_lnl(const SiteState<NCH>& st, const double (&ew)[16], Comb<NW>& cb,
                                              int lane) {
   double mant = 1.0;
   int ex = 0;
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
-    double l0 = 0.0;
+    double l0 = ZERO0 ? st.S[ch][0] : 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) l0 = fma(st.S[ch][i], ew[i], l0);
+    for (int i = 0; i < 16; ++i)
+      if (!(ZERO0 && (i & 3) == 0)) l0 = fma(st.S[ch][i], ew[i], l0);
     if (!st.valid[ch]) l0 = 1.0;
     const int sc = st.valid[ch] ? (int)(st.sc[ch] + st.resc[ch]) : 0;
     mant *= __builtin_amdgcn_frexp_mant(l0);
@@ -311,6 +312,13 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     const uint32_t s = st.valid[ch] ? site0 + ch * 64 + lane : 0;
     return a.cinv[begin + s] * a.inv_w0;
   };
+  // ZERO0: the four zero-eigenvalue entries of a site only ever appear as sum_k w_k S_k0 (their
+  // table entries are w_k for L_0 and 0 for L_1, L_2): keep that one number (6 fewer live VGPRs
+  // per chunk, 3 fewer FMAs per chunk and evaluation)
+  auto fold0 = [&](int ch) {
+    if constexpr (ZERO0)
+      st.S[ch][0] = fma(m.w[3], st.S[ch][12], fma(m.w[2], st.S[ch][8], fma(m.w[1], st.S[ch][4], m.w[0] * st.S[ch][0])));
+  };
   // Inner CLV toward the query at (td, tx) folded with the query, S = (U^-1 I) o qt, and the
   // window lnL at pendant length tp_.  One table pass: slot 0 -> exp(lr td), slot 1 ->
   // exp(lr tx), slot 2 -> w exp(lr tp).
@@ -336,12 +344,13 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
         st.S[ch][k * 4 + 3] = It[k * 4 + 3] * q3;
       }
       if constexpr (INV) st.S[ch][0] += cinv_of(ch);
+      fold0(ch);
       chain = zero_after(st.S[ch][15]);
     }
     double ew[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
-    return window_lnl<NCH, NW>(st, ew, cb, lane);
+    return window_lnl<NCH, ZERO0, NW>(st, ew, cb, lane);
   };
   // inner CLV toward distal: I' = (P_pend q) o (P_prox X); S = Dt o (U^-1 I')
   auto distal_sumtable = [&](double tp_, double tx_) {
@@ -364,6 +373,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 #pragma unroll
       for (int c = 0; c < 16; ++c) st.S[ch][c] = D[c] * It[c];
       if constexpr (INV) st.S[ch][0] += cinv_of(ch);
+      fold0(ch);
       chain = zero_after(st.S[ch][15]);
     }
   };
@@ -394,12 +404,13 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
         st.S[ch][k * 4 + 3] = It[k * 4 + 3] * q3;
       }
       if constexpr (INV) st.S[ch][0] += cinv_of(ch);
+      fold0(ch);
       chain = zero_after(st.S[ch][15]);
     }
     double ew[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
-    return window_lnl<NCH, NW>(st, ew, cb, lane);
+    return window_lnl<NCH, ZERO0, NW>(st, ew, cb, lane);
   };
 
   // traverse_update_partials + initial score (optimize.cpp:15-42,111-113)
