@@ -575,6 +575,193 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Single-site fast path (20 states): the machinery of k_preplace_pairs -- per-site LDS offsets
+// precomputed once per chunk of queries (16 bit each), 1024-query groups, one workgroup per CU,
+// register prefetch of the next slice, persistent grid -- over the ordinary [W][24] table.  Sums in
+// the reference's order: ((a0+a1)+(a2+a3)) per group of four sites, then the singles.
+// ---------------------------------------------------------------------------------------------
+constexpr int CHS = 128;              // sites per chunk
+constexpr int PWS = CHS / 2;          // packed words per chunk (two 16-bit offsets each)
+constexpr int TROWS_S = CHS + SPREAD; // table rows staged per (branch, chunk)
+
+template <int NCOLS>
+__global__ void __launch_bounds__(256) k_pack_sites(const uint8_t* __restrict__ codes,
+                                                    const uint32_t* __restrict__ win_begin,
+                                                    const uint32_t* __restrict__ win_span, uint32_t Q,
+                                                    uint32_t W, uint32_t cstride, uint32_t crel,
+                                                    uint32_t span_bound, uint32_t NP16,
+                                                    uint16_t* __restrict__ packed,
+                                                    uint16_t* __restrict__ tails,
+                                                    uint32_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ status) {
+  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  if (q >= Q) return;
+  const uint32_t begin = win_begin[q];
+  uint32_t span = win_span[q];
+  const uint32_t cmax = min(span_bound, crel ? cstride : 0xffffffffu);
+  if (lane == 0) validate_window(q, begin, span, W, cmax, status);
+  if ((uint64_t)begin + span > W || span > cmax) span = 0;
+  const uint8_t* c = codes + (size_t)q * cstride + (crel ? 0u : begin);
+  const uint32_t nsum = span & ~3u;  // sites summed in groups of four
+  for (uint32_t p = lane; p < NP16; p += 64) {
+    // slots past the last full group are masked by the kernel: any finite entry of the own row
+    uint32_t v = 0;
+    if (p < nsum) v = (p % CHS) * (NCOLS * 8) + min((uint32_t)c[p], (uint32_t)NCOLS - 1) * 8;
+    packed[(size_t)q * NP16 + p] = (uint16_t)v;
+  }
+  if (lane < 4) {
+    uint32_t v = 0;
+    if (lane < (span & 3))
+      v = ((nsum + lane) % CHS) * (NCOLS * 8) + min((uint32_t)c[nsum + lane], (uint32_t)NCOLS - 1) * 8;
+    tails[(size_t)q * 4 + lane] = (uint16_t)v;
+  }
+  if (lane == 0) keys[q] = begin;
+}
+
+template <int NCOLS, bool ACC>
+__global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
+    const double* __restrict__ lookup, const uint16_t* __restrict__ packed,
+    const uint16_t* __restrict__ tails, const uint32_t* __restrict__ win_begin,
+    const uint32_t* __restrict__ win_span, const uint32_t* __restrict__ perm,
+    const Group* __restrict__ groups, uint32_t W, uint32_t B, uint32_t NP16,
+    const uint32_t* __restrict__ status, double* __restrict__ lnl) {
+  constexpr uint32_t ROWB = NCOLS * 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [TROWS_S][NCOLS] doubles, then accs
+  double* accs = reinterpret_cast<double*>(smem + (size_t)TROWS_S * ROWB);  // [NB2_ACC][GQ2] (ACC only)
+  __shared__ uint32_t s_maxspan;
+  constexpr uint32_t NBP = ACC ? NB2_ACC : NB;
+  const uint32_t ng = status[5], ntiles = (B + NBP - 1) / NBP;
+  const int t = threadIdx.x;
+  auto at = [&](uint32_t off) -> double { return *reinterpret_cast<const double*>(smem + off); };
+  for (uint32_t item = blockIdx.x; item < ng * ntiles; item += gridDim.x) {
+    const Group g = groups[item % ng];
+    const uint32_t b0 = (item / ng) * NBP;
+    const uint32_t nb = min(NBP, B - b0);
+    __syncthreads();  // the previous item's readers of s_maxspan / accs / the tile are done
+    if (g.count == 0) continue;
+    const bool active = t < (int)g.count;
+    uint32_t qi = 0, begin = 0, span = 0;
+    if (active) {
+      qi = perm[g.start + t];
+      begin = win_begin[qi];
+      span = win_span[qi];
+      if ((uint64_t)begin + span > W) span = 0;
+    }
+    if (t == 0) s_maxspan = 0;
+    __syncthreads();
+    atomicMax(&s_maxspan, span);
+    if (ACC) for (uint32_t j = 0; j < nb; ++j) accs[j * GQ2 + t] = 0.0;
+    __syncthreads();
+    const uint32_t gmin = win_begin[perm[g.start]];
+    const uint32_t gspread = win_begin[perm[g.start + g.count - 1]] - gmin;  // < SPREAD
+    const uint32_t rowoff = (begin - gmin) * ROWB;
+    const uint32_t rowoff2 = rowoff | (rowoff << 16);
+    const uint32_t nchunks = ACC ? (s_maxspan + CHS - 1) / CHS : 1;
+    const uint32_t nsum = span & ~3u, ntail = span & 3;
+    uint32_t t0 = 0, t1 = 0, t2 = 0, tailchunk = 0xffffffffu;
+    if (active && ntail) {
+      const uint16_t* tq = tails + (size_t)qi * 4;
+      t0 = tq[0] + rowoff; t1 = tq[1] + rowoff; t2 = tq[2] + rowoff;
+      tailchunk = nsum / CHS;
+    }
+    for (uint32_t c = 0; c < nchunks; ++c) {
+      const uint32_t cbase = c * CHS;
+      const bool mine = active && cbase < span;
+      // full groups of four sites of this thread inside the chunk
+      const uint32_t gfull = mine ? (min(nsum, cbase + CHS) > cbase ? (min(nsum, cbase + CHS) - cbase) >> 2 : 0) : 0;
+      uint32_t cw[PWS];
+      if (mine) {
+        const uint4* p = reinterpret_cast<const uint4*>(packed + (size_t)qi * NP16 + (size_t)c * CHS);
+#pragma unroll
+        for (int i = 0; i < PWS / 4; ++i) {
+          const uint4 v = p[i];
+          cw[4 * i] = v.x + rowoff2;
+          cw[4 * i + 1] = v.y + rowoff2;
+          cw[4 * i + 2] = v.z + rowoff2;
+          cw[4 * i + 3] = v.w + rowoff2;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PWS; ++i) cw[i] = 0;
+      }
+      const uint32_t row0 = gmin + cbase;
+      const uint32_t need = min((uint32_t)TROWS_S, gspread + min((uint32_t)CHS, s_maxspan - cbase));
+      const uint32_t rows = (row0 < W) ? min(need, W - row0) : 0;
+      const uint32_t n2 = rows * (NCOLS / 2);
+      constexpr int PF = (TROWS_S * (NCOLS / 2) + GQ2 - 1) / GQ2;
+      double2 pf[PF];
+      auto request = [&](uint32_t j) {
+        const double2* src = reinterpret_cast<const double2*>(lookup + ((size_t)(b0 + j) * W + row0) * NCOLS);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+          const uint32_t i = u * GQ2 + t;
+          pf[u] = make_double2(0.0, 0.0);
+          if (i < n2) pf[u] = src[i];
+        }
+      };
+      request(0);
+      for (uint32_t j = 0; j < nb; ++j) {
+        __syncthreads();
+        {
+          double2* dst = reinterpret_cast<double2*>(smem);
+#pragma unroll
+          for (int u = 0; u < PF; ++u) {
+            const uint32_t i = u * GQ2 + t;
+            if (i < n2) dst[i] = pf[u];
+          }
+        }
+        __syncthreads();
+        if (j + 1 < nb) request(j + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (mine) {
+          double sum = ACC ? accs[j * GQ2 + t] : 0.0;
+#pragma unroll
+          for (int i = 0; i < PWS; ++i) asm volatile("" : "+v"(cw[i]));
+          constexpr int WPB = 4, NBATCH = PWS / WPB;  // 4 words = 8 sites = 2 groups per batch
+          double rb[2][WPB * 2];
+          auto issue = [&](int bt) {
+#pragma unroll
+            for (int w = 0; w < WPB; ++w) {
+              const uint32_t v = cw[bt * WPB + w];
+              rb[bt & 1][2 * w] = at(v & 0xffffu);
+              rb[bt & 1][2 * w + 1] = at(v >> 16);
+            }
+          };
+          issue(0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int bt = 0; bt < NBATCH; ++bt) {
+            if (bt + 1 < NBATCH) issue(bt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gq = 0; gq < 2; ++gq) {
+              const double* v = &rb[bt & 1][gq * 4];
+              double s1 = v[0] + v[1];
+              const double s2 = v[2] + v[3];
+              s1 += s2;
+              sum += ((uint32_t)(bt * 2 + gq) < gfull) ? s1 : 0.0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (c == tailchunk) {  // singles of the window tail, in order
+            sum += at(t0);
+            if (ntail > 1) sum += at(t1);
+            if (ntail > 2) sum += at(t2);
+          }
+          if (ACC) accs[j * GQ2 + t] = sum;
+          else lnl[(size_t)qi * B + b0 + j] = sum;
+        }
+      }
+    }
+    if (ACC && active) {
+      double* out = lnl + (size_t)qi * B + b0;
+      for (uint32_t j = 0; j < nb; ++j) out[j] = accs[j * GQ2 + t];
+    }
+  }  // work items
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_select: dynamic heuristic on device (apply_heuristic -> dynamic_heuristic,
 // src/core/heuristics.hpp:40-68; compute_and_set_lwr src/set_manipulators.cpp:43-69;
 // until_accumulated_reached :90-114).  One wave per query, the row of B log-likelihoods in
@@ -836,16 +1023,18 @@ int launch_build_lookup2(epa_ctx* ctx) {
 int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin,
                     const uint32_t* d_span, uint32_t Q, double* d_lnl, uint32_t max_span) {
   const bool pairs = ctx->s == 4 && ctx->lookup2 && !getenv("EPA_PREPLACE_GENERIC");
+  const bool sites = ctx->s == 20 && ctx->ncols == 24 && !getenv("EPA_PREPLACE_GENERIC");
   const uint32_t crel = ctx->code_stride ? 1u : 0u, cstride = crel ? ctx->code_stride : ctx->W;
   const uint32_t n_buckets = (ctx->W + SPREAD - 1) / SPREAD;
   const uint32_t Wp = n_buckets * SPREAD;  // key space of one (class, parity) block
   const uint32_t n_blocks = pairs ? 4 : 1, class_blocks = pairs ? 2 : 1;
-  const uint32_t gq0 = pairs ? GQ2 : GQ, gq1 = GQ;
+  const uint32_t gq0 = (pairs || sites) ? GQ2 : GQ, gq1 = GQ;
   const uint32_t max_runs = (Q + GQ - 1) / GQ + n_blocks;
   const uint32_t max_groups = max_runs + n_blocks * n_buckets;  // + one split per SPREAD boundary
   // pair offsets per query: whole chunks of CP, enough for the longest window
   const uint32_t span_bound = (max_span == 0 || max_span > ctx->W) ? ctx->W : max_span;
-  const uint32_t NP16 = pairs ? ((span_bound + 1) / 2 + CP - 1) / CP * CP : 0;
+  const uint32_t NP16 = pairs ? ((span_bound + 1) / 2 + CP - 1) / CP * CP
+                        : sites ? (span_bound + CHS - 1) / CHS * CHS : 0;
   // scratch 6: [status 256 B | iota Q | sorted_keys Q | perm Q | keys Q | groups | packed | tails | rocprim temp]
   size_t temp_bytes = 0;
   (void)rocprim::radix_sort_pairs(nullptr, temp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
@@ -853,7 +1042,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   const size_t qb = align256(sizeof(uint32_t) * Q);
   const size_t gb = align256(sizeof(Group) * max_groups);
   const size_t pb = align256(sizeof(uint16_t) * (size_t)Q * NP16);
-  const size_t tb = pairs ? align256(sizeof(uint16_t) * 4 * (size_t)Q) : 0;
+  const size_t tb = (pairs || sites) ? align256(sizeof(uint16_t) * 4 * (size_t)Q) : 0;
   const size_t need = 256 + 4 * qb + gb + pb + tb + temp_bytes;
   char* base = (char*)epa_scratch(ctx, 6, need);
   if (!base) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(preplace scratch)");
@@ -876,6 +1065,13 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
                        d_span, Q, ctx->W, cstride, crel, span_bound, Wp, NP16, packed, tails, keys, status);
     EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, keys, sorted_keys, iota, perm, Q, 0,
                                            key_bits, ctx->stream));
+  } else if (sites) {
+    int wbits = 1;
+    while (wbits < 32 && (1ull << wbits) <= (uint64_t)ctx->W) ++wbits;
+    hipLaunchKernelGGL(k_pack_sites<24>, dim3((Q + 3) / 4), dim3(256), 0, ctx->stream, d_codes, d_begin,
+                       d_span, Q, ctx->W, cstride, crel, span_bound, NP16, packed, tails, keys, status);
+    EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, keys, sorted_keys, iota, perm, Q, 0, wbits,
+                                           ctx->stream));
   } else {
     hipLaunchKernelGGL(k_validate, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, d_begin, d_span, Q,
                        ctx->W, std::min(span_bound, crel ? cstride : 0xffffffffu), status);
@@ -913,6 +1109,24 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   } while (0)
   if (pairs) { if (acc) PRE2(true); else PRE2(false); }
 #undef PRE2
+  if (sites) {
+    const bool acc_s = max_span == 0 || max_span > (uint32_t)CHS || getenv("EPA_PREPLACE_ACC");
+    const size_t lds_s = (size_t)TROWS_S * 24 * 8 + (acc_s ? sizeof(double) * NB2_ACC * GQ2 : 0);
+    const uint32_t ntiles_s = (ctx->B + (acc_s ? NB2_ACC : NB) - 1) / (acc_s ? NB2_ACC : NB);
+    const dim3 grid_s((uint32_t)std::min<uint64_t>((uint64_t)max_groups * ntiles_s, (uint64_t)ctx->n_cu));
+#define PRES(A)                                                                                      \
+  do {                                                                                               \
+    EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_sites<24, A>,                           \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));       \
+    hipLaunchKernelGGL((k_preplace_sites<24, A>), grid_s, dim3(GQ2), lds_s, ctx->stream, ctx->lookup, \
+                       packed, tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, NP16, status, d_lnl); \
+  } while (0)
+    if (acc_s) PRES(true); else PRES(false);
+#undef PRES
+    epa_timer_stop(ctx, ctx->t_preplace);
+    EPA_HIP(ctx, hipGetLastError());
+    return EPA_OK;
+  }
 #define PRE(NC, A)                                                                                  \
   do {                                                                                              \
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace<NC, A>,                                \

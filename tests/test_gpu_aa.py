@@ -70,3 +70,52 @@ def test_synthetic_aa_window_lengths(read_len, seeds):
     assert np.max(np.abs(res["pendant_length"] - tp) / np.maximum(1.0, tp)) < 1e-6
     assert ev.last_stats["rounds"] == o.last_stats["rounds"]
     assert ev.last_stats["reverts"] == o.last_stats["reverts"]
+
+
+def test_aa_preplace_site_path_bitwise_equals_generic(monkeypatch):
+    """20-state fast path (k_preplace_sites: precomputed LDS offsets, 1024-query groups) vs the
+    generic gather kernel vs the oracle: every window length mod 4, windows longer than one
+    128-site chunk (accumulating variant), ambiguity codes (B, Z, X, gap) inside the window; then
+    the single-chunk variant through place_chunk with a declared max_span."""
+    w = synth.aa_workload(24, 520, 8, 60, (91, 92, 93))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=20, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    o = Oracle(w["newick"], w["labels"], w["seqs"], 20, w["subst"], w["freqs"], w["rates"])
+    rng = np.random.RandomState(5)
+    W = 520
+    aa = list("ARNDCQEGHILKMFPSTWYV")
+
+    def make(spans, n):
+        reads = []
+        for i in range(n):
+            span = int(rng.choice(spans))
+            begin = int(rng.randint(0, W - span + 1))
+            body = rng.choice(aa, span)
+            if i % 3 == 0:
+                k = rng.randint(0, span, max(1, span // 10))
+                body[k] = rng.choice(list("BZX-"), len(k))
+                body[0] = "A"; body[-1] = "C"
+            reads.append("-" * begin + "".join(body) + "-" * (W - begin - span))
+        return reads
+
+    reads = make([1, 2, 3, 4, 5, 7, 37, 126, 127, 128, 129, 130, 131, 255, 257, 390, 519], 1300)
+    for compact in (False, True):
+        codes, wb, ws = epa.encode_queries(20, reads, compact=compact)
+        assert len(set(ws % 4)) == 4 and ws.max() > 384
+        fast = ev.preplace(codes, wb, ws)
+        monkeypatch.setenv("EPA_PREPLACE_GENERIC", "1")
+        generic = ev.preplace(codes, wb, ws)
+        monkeypatch.delenv("EPA_PREPLACE_GENERIC")
+        assert np.array_equal(fast, generic)  # same association order, bit for bit
+        assert np.max(np.abs(fast - o.preplace(reads))) < 1e-6
+    short = make([1, 2, 3, 5, 6, 7, 64, 99, 100, 101, 102], 1300)
+    codes, wb, ws = epa.encode_queries(20, short, compact=True)
+    pf, rf = ev.place_chunk(codes, wb, ws, max_span=int(ws.max()))
+    monkeypatch.setenv("EPA_PREPLACE_GENERIC", "1")
+    pg, rg = ev.place_chunk(codes, wb, ws, max_span=int(ws.max()))
+    monkeypatch.delenv("EPA_PREPLACE_GENERIC")
+    assert np.array_equal(pf, pg) and np.array_equal(rf, rg)
+    lnl = ev.preplace(codes, wb, ws)
+    hb, hs = hostlib.heuristic(lnl, "dynamic", 0.99999)
+    assert sorted(zip(hb.tolist(), hs.tolist())) == sorted(zip(pf["branch_id"].tolist(), pf["seq_id"].tolist()))
