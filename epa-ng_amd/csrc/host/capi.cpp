@@ -26,10 +26,10 @@ extern "C" {
 const char* epa_host_last_error() { return g_err.c_str(); }
 
 // model given either as descriptor string (model_desc != NULL) or explicit arrays
-void* epa_host_ref_create_ex(const char* newick, int n_seqs, const char* const* labels,
-                             const char* const* seqs, const char* model_desc, int states,
-                             const double* subst, const double* freqs, int cats, const double* rates,
-                             const double* weights, double pinv) {
+void* epa_host_ref_create_ex2(const char* newick, int n_seqs, const char* const* labels,
+                              const char* const* seqs, const char* model_desc, int states,
+                              const double* subst, const double* freqs, int cats, const double* rates,
+                              const double* weights, double pinv, int preserve_rooting) {
   Ref* r = nullptr;
   if (guarded([&] {
         MSA msa;
@@ -42,10 +42,19 @@ void* epa_host_ref_create_ex(const char* newick, int n_seqs, const char* const* 
                                              : std::vector<double>(),
                                      pinv);
         r = new Ref();
+        r->opt.preserve_rooting = preserve_rooting != 0;
         r->tree.reset(new Tree(newick, msa, m, r->opt));
       }))
     return nullptr;
   return r;
+}
+
+void* epa_host_ref_create_ex(const char* newick, int n_seqs, const char* const* labels,
+                             const char* const* seqs, const char* model_desc, int states,
+                             const double* subst, const double* freqs, int cats, const double* rates,
+                             const double* weights, double pinv) {
+  return epa_host_ref_create_ex2(newick, n_seqs, labels, seqs, model_desc, states, subst, freqs, cats, rates,
+                                 weights, pinv, 1);
 }
 
 void* epa_host_ref_create(const char* newick, int n_seqs, const char* const* labels,
@@ -76,6 +85,18 @@ int epa_host_ref_numbered_newick(void* h, unsigned precision, char* out, size_t 
   if (s.size() + 1 > cap) return -(int)s.size();
   std::memcpy(out, s.c_str(), s.size() + 1);
   return (int)s.size();
+}
+
+// rooted input tree: placement (edge, distal) on the unrooted working tree -> on the rooted tree
+// (rtree_mapper::in_rtree).  Returns 1 when no mapping is active (unrooted input / preserve off).
+int epa_host_ref_in_rtree(void* h, uint32_t branch, double distal, uint32_t* out_branch, double* out_distal) {
+  const auto& m = static_cast<Ref*>(h)->tree->mapper();
+  if (!m) return 1;
+  return guarded([&] {
+    const auto p = m.in_rtree(branch, distal);
+    *out_branch = p.first;
+    *out_distal = p.second;
+  });
 }
 
 void epa_host_ref_model(void* h, double* eigenvals, double* u, double* uinv, double* freqs,

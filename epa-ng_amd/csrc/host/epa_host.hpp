@@ -43,6 +43,7 @@ struct Options {  // defaults: src/util/Options.hpp:13-34
   bool aa_x_as_n = false;   // quirk D4 switch
   bool device_select = true;  // run the dynamic heuristic on the GPU (default heuristic only)
   bool device_precompute = true;  // reference CLVs computed on the GPU from the tree (no host CLVs)
+  bool preserve_rooting = true;   // rooted input: jplace on the rooted tree (Options.hpp:34)
 };
 
 class Sequence {
@@ -143,6 +144,24 @@ struct Tree_Numbers {  // src/tree/Tree_Numbers.hpp
   unsigned int tip_nodes = 0, inner_nodes = 0, nodes = 0, branches = 0;
 };
 
+// Edge-number translation from the unrooted working tree back to a rooted input tree
+// (src/core/pll/rtree_mapper.hpp:9-110; built like determine_edge_num_translation,
+// src/io/file_io.cpp:46-116).  Inactive (operator bool false) for unrooted input.
+class Rtree_Mapper {
+public:
+  explicit operator bool() const { return !map_.empty(); }
+  // (branch_id, distal_length) of a placement on the unrooted tree -> the same on the rooted tree;
+  // the former root edge splits into a distal part (kept) and a proximal part (direction flipped)
+  std::pair<unsigned int, double> in_rtree(unsigned int branch_id, double distal_length) const;
+  unsigned int map_at(size_t i) const;  // throws for the root edge
+  bool uroot_is_left() const { return left_; }
+  unsigned int utree_root_edge = 0, rtree_proximal_edge = 0, rtree_distal_edge = 0;
+  double proximal_edge_length = -1.0, distal_edge_length = -1.0;
+  bool left_ = true;
+  std::string root_label;
+  std::vector<unsigned int> map_;
+};
+
 // Reference tree with all 3(n-2) directional CLVs precomputed (Tree::Tree src/tree/Tree.cpp:16-56,
 // precompute_clvs src/core/pll/epa_pll_util.cpp:62-107).
 class Tree {
@@ -155,7 +174,10 @@ public:
   bool rooted_input() const { return rooted_input_; }  // the newick had a bifurcating root (removed)
   double ref_tree_logl(size_t branch = 0) const;  // edge lnL (Tree::ref_tree_logl :119-131)
   // numbered newick, edge ids in utree_query_branches order (pll_util.cpp:182-259)
+  // Rooted input with preserve_rooting: the rooted tree with its own edge numbering
+  // (pll_util.cpp:227-352; literals test/src/pll_util.cpp:159-186).
   std::string numbered_newick(unsigned int precision) const;
+  const Rtree_Mapper& mapper() const { return mapper_; }
 
   // the two sides of branch b after the tip-is-distal orientation of Tiny_Tree.cpp:64-74
   struct Branch {
@@ -187,7 +209,7 @@ public:
   void ensure_host_clvs() const;
 
 private:
-  struct Rec { int next = -1, back = -1, tip = -1; double length = 0.0; };
+  struct Rec { int next = -1, back = -1, tip = -1; double length = 0.0; std::string label; };
   int new_rec();
   int parse_subtree(const char*& p, double& len);
   void compute_all_clvs();
@@ -201,6 +223,8 @@ private:
   std::vector<std::string> labels_;
   int vroot_ = -1;
   bool rooted_input_ = false;
+  Rtree_Mapper mapper_;
+  std::string root_label_;
   std::vector<int> branch_rec_;
   std::vector<std::vector<uint8_t>> tipchars_;   // per tip
   std::vector<std::vector<double>> clv_;         // per record (empty for tips)
@@ -234,10 +258,12 @@ private:
   char up_[256];
 };
 void write_jplace(std::ostream& os, const std::vector<Sample>& chunks, const std::string& newick,
-                  const std::string& invocation, unsigned int precision);
+                  const std::string& invocation, unsigned int precision,
+                  const Rtree_Mapper* mapper = nullptr);
 // the same in two steps: every chunk is turned into text as soon as it is done (by the device
 // worker that produced it), the file is assembled at the end
-std::string jplace_chunk_text(const Sample& sample, unsigned int precision);
+std::string jplace_chunk_text(const Sample& sample, unsigned int precision,
+                              const Rtree_Mapper* mapper = nullptr);
 void write_jplace_text(std::ostream& os, const std::vector<std::string>& chunk_texts, const std::string& newick,
                        const std::string& invocation);
 

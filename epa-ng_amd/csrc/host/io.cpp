@@ -101,7 +101,8 @@ MSA read_fasta(const std::string& path) {
 // One chunk of the "placements" array as text (sample_to_jplace_string, src/io/jplace_util.cpp:
 // 60-98): formatted per pquery in parallel with snprintf into per-thread strings, then joined.
 // Numbers are fixed-point with `precision` digits like the reference's stream settings.
-std::string jplace_chunk_text(const Sample& sample, unsigned int precision) {
+std::string jplace_chunk_text(const Sample& sample, unsigned int precision, const Rtree_Mapper* mapper) {
+  const bool remap = mapper && (bool)*mapper;  // placement_to_jplace_string, jplace_util.cpp:20-26
   configure_host_threads();
   const long n = (long)sample.size();
   std::vector<std::string> part(n);
@@ -114,9 +115,16 @@ std::string jplace_chunk_text(const Sample& sample, unsigned int precision) {
     char buf[512];
     size_t j = 0;
     for (const auto& p : pq) {
-      const int len = std::snprintf(buf, sizeof(buf), "      [%zu, %.*f, %.*f, %.*f, %.*f]", p.branch_id(),
+      size_t edge = p.branch_id();
+      double distal = p.distal_length();
+      if (remap) {
+        const auto m = mapper->in_rtree((unsigned int)edge, distal);
+        edge = m.first;
+        distal = m.second;
+      }
+      const int len = std::snprintf(buf, sizeof(buf), "      [%zu, %.*f, %.*f, %.*f, %.*f]", edge,
                                     (int)precision, p.likelihood(), (int)precision, p.lwr(), (int)precision,
-                                    p.distal_length(), (int)precision, p.pendant_length());
+                                    distal, (int)precision, p.pendant_length());
       o.append(buf, (size_t)std::max(0, std::min(len, (int)sizeof(buf) - 1)));
       if (++j < pq.size()) o += ",";
       o += "\n";
@@ -151,10 +159,10 @@ void write_jplace_text(std::ostream& os, const std::vector<std::string>& chunk_t
 }
 
 void write_jplace(std::ostream& os, const std::vector<Sample>& chunks, const std::string& newick,
-                  const std::string& invocation, unsigned int precision) {
+                  const std::string& invocation, unsigned int precision, const Rtree_Mapper* mapper) {
   std::vector<std::string> texts;
   texts.reserve(chunks.size());
-  for (const auto& sample : chunks) texts.push_back(jplace_chunk_text(sample, precision));
+  for (const auto& sample : chunks) texts.push_back(jplace_chunk_text(sample, precision, mapper));
   write_jplace_text(os, texts, newick, invocation);
 }
 

@@ -1,6 +1,6 @@
 // epa-ng-amd: command-line front end keeping EPA-ng's flags for the placement path
 // (src/main.cpp:96-270).  Flags outside the hot path (binary dump, bfast conversion, --split,
-// rooted-tree preservation, model files) are rejected with a message, not silently ignored.
+// model files) are rejected with a message, not silently ignored.
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -15,7 +15,7 @@ using namespace epa;
 static void usage() {
   std::cout <<
       "epa-ng-amd - Evolutionary Placement Algorithm, MI355X placement evaluator\n"
-      "  -t,--tree FILE        reference tree (newick, unrooted)\n"
+      "  -t,--tree FILE        reference tree (newick, unrooted or rooted)\n"
       "  -s,--ref-msa FILE     reference MSA (fasta)\n"
       "  -q,--query FILE       query MSA (fasta, aligned to the reference)\n"
       "  -m,--model STR        model descriptor, e.g. GTR{..}+FU{..}+G4{a} (default GTR+G)\n"
@@ -28,6 +28,7 @@ static void usage() {
       "  --precision N         output digits (default 10)\n"
       "  --chunk-size N        queries per chunk (default 50000; EPA-ng's CPU default is 5000)\n"
       "  --no-pre-mask         evaluate all sites of every query\n"
+      "  --preserve-rooting on|off  rooted reference tree: report on the rooted tree (default on)\n"
       "  --device N            GPU ordinal (default 0)\n"
       "  --devices a,b,..      place on several GPUs of the node (chunks are dealt to them in turn)\n";
 }
@@ -62,6 +63,12 @@ int main(int argc, char** argv) {
     else if (a == "--precision") opt.precision = (unsigned)std::stoul(need(i));
     else if (a == "--chunk-size") opt.chunk_size = (unsigned)std::stoul(need(i));
     else if (a == "--no-pre-mask") opt.premasking = false;
+    else if (a == "--preserve-rooting") {  // src/main.cpp:196-199, 410-418
+      const std::string v = need(i);
+      if (v == "off") opt.preserve_rooting = false;
+      else if (v == "on") opt.preserve_rooting = true;
+      else { std::cerr << "--preserve-rooting: " << v << " not in {on,off}\n"; return 1; }
+    }
     else if (a == "-T" || a == "--threads") opt.num_threads = (unsigned)std::stoul(need(i));
     else if (a == "--device") device = std::stoi(need(i));
     else if (a == "--devices") {
@@ -85,8 +92,9 @@ int main(int argc, char** argv) {
     const auto t_tree = std::chrono::steady_clock::now();
     const Tree tree(ss.str(), ref, model, opt);
     if (tree.rooted_input())
-      std::cout << "WARNING: rooted reference tree: the root was removed, placements are reported on the "
-                   "unrooted tree in the jplace (no --preserve-rooting in this build)." << std::endl;
+      std::cout << "Rooted reference tree: placements are reported on the "
+                << (tree.mapper() ? "rooted tree (--preserve-rooting on)." : "unrooted tree (--preserve-rooting off).")
+                << std::endl;
     const double secs_tree = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tree).count();
     if (devices.empty()) devices.push_back(device);
     const Run_Stats st = simple_mpi(tree, query_file, outdir, opt, invocation, devices);

@@ -457,7 +457,7 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
         Chunk_Timing tm;
         Sample smp = process_chunk(cur.chunk, cur.enc, tree, *devs[k], options, cur.offset, tm);
         const auto tf = clk::now();
-        std::string text = jplace_chunk_text(smp, options.precision);
+        std::string text = jplace_chunk_text(smp, options.precision, &tree.mapper());
         const double secs_text = std::chrono::duration<double>(clk::now() - tf).count();
         std::lock_guard<std::mutex> lk(mu);
         if (results.size() <= cur.index) results.resize(cur.index + 1);

@@ -61,7 +61,7 @@ int Tree::parse_subtree(const char*& p, double& len) {
     recs_[a].next = b; recs_[b].next = c; recs_[c].next = a;
     recs_[b].back = k1; recs_[k1].back = b; recs_[b].length = recs_[k1].length = l1;
     recs_[c].back = k2; recs_[k2].back = c; recs_[c].length = recs_[k2].length = l2;
-    label_and_length(p, nullptr, len);
+    label_and_length(p, &recs_[a].label, len);  // inner label (printed by numbered_newick)
     return a;
   }
   const int a = new_rec();
@@ -73,7 +73,7 @@ int Tree::parse_subtree(const char*& p, double& len) {
   return a;
 }
 
-Tree::Tree(const std::string& newick, const MSA& ref_msa, const Model& model, const Options&)
+Tree::Tree(const std::string& newick, const MSA& ref_msa, const Model& model, const Options& options)
     : model_(model) {
   const char* p = newick.c_str();
   skip_ws(p);
@@ -91,19 +91,64 @@ Tree::Tree(const std::string& newick, const MSA& ref_msa, const Model& model, co
     if (*p == ')') { ++p; break; }
     throw std::runtime_error{"Treeparsing failed! expected ',' or ')'"};
   }
+  double top_len = 0.0;
+  {  // label (and an ignored length) after the top-level ')'
+    std::string lab;
+    label_and_length(p, &lab, top_len);
+    root_label_ = lab;
+  }
   if (nk == 2) {
-    // Rooted input: the root is removed and its two edges become one (what pll_rtree_unroot does
-    // for the reference, src/io/file_io.cpp:129-171).  Placements are reported on the unrooted
-    // tree written to the jplace; the reference's --preserve-rooting edge renumbering
-    // (rtree_mapper) depends on libpll internals and is not reproduced.
-    int top = kids[0], other = kids[1];
-    if (recs_[top].next < 0) std::swap(top, other);
+    // Rooted input (src/io/file_io.cpp:129-171): the root is removed and its two edges become
+    // one, as libpll's pll_rtree_unroot does -- the first root child that has descendants becomes
+    // the top-level trifurcation, its ring = {other root child, its left child, its right child}.
+    // When that is the LEFT root child the reference moves the virtual root one ring step on
+    // (file_io.cpp:147-153), so that the branch order is left child, right child, other subtree
+    // and the former root edge is the last branch.
+    const bool left = recs_[kids[0]].next >= 0;
+    const int top = left ? kids[0] : kids[1], other = left ? kids[1] : kids[0];
     if (recs_[top].next < 0) throw std::runtime_error{"Number of tip nodes too small"};
     recs_[top].back = other;
     recs_[other].back = top;
     recs_[top].length = recs_[other].length = kl[0] + kl[1];
     rooted_input_ = true;
-    vroot_ = top;
+    vroot_ = left ? recs_[top].next : top;
+    const std::string rtree_root_label = root_label_;
+    root_label_ = recs_[top].label;  // the utree root carries the label of the promoted child
+    if (options.preserve_rooting) {
+      // determine_edge_num_translation (file_io.cpp:60-116)
+      const unsigned n_tips = (unsigned)labels_.size();
+      const unsigned nb = 2 * n_tips - 3;
+      mapper_.left_ = left;
+      mapper_.root_label = rtree_root_label;
+      mapper_.map_.resize(nb);
+      if (left) {
+        // branches of the promoted child's two subtrees keep their numbers, the rooted edge above
+        // the promoted child takes the next number, everything in the other subtree shifts by one
+        struct Count { static unsigned edges(const std::vector<Rec>& r, int rec) {
+          // edges of the subtree hanging below `rec` including the edge above it
+          unsigned cnt = 0; std::vector<int> st{rec};
+          while (!st.empty()) { const int x = st.back(); st.pop_back(); ++cnt;
+            if (r[x].next >= 0) { st.push_back(r[r[x].next].back); st.push_back(r[r[r[x].next].next].back); } }
+          return cnt; } };
+        const unsigned below = Count::edges(recs_, recs_[vroot_].back) +
+                               Count::edges(recs_, recs_[recs_[vroot_].next].back);
+        for (unsigned i = 0; i < nb; ++i) mapper_.map_[i] = i < below ? i : i + 1;
+        mapper_.rtree_proximal_edge = below;
+        mapper_.rtree_distal_edge = mapper_.map_.back();
+        mapper_.utree_root_edge = nb - 1;
+        mapper_.proximal_edge_length = kl[0];
+        mapper_.distal_edge_length = kl[1];
+      } else {
+        // the left root child is a tip: it is branch 0 on both trees, every other branch keeps
+        // its number, the rooted edge above the promoted (right) child is the extra last one
+        for (unsigned i = 0; i < nb; ++i) mapper_.map_[i] = i;
+        mapper_.rtree_distal_edge = 0;
+        mapper_.utree_root_edge = 0;
+        mapper_.rtree_proximal_edge = nb;
+        mapper_.proximal_edge_length = kl[1];
+        mapper_.distal_edge_length = kl[0];
+      }
+    }
   } else {
   const int a = new_rec(), b = new_rec(), c = new_rec();
   recs_[a].next = b; recs_[b].next = c; recs_[c].next = a;
@@ -445,13 +490,36 @@ double Tree::ref_tree_logl(size_t b) const {
   return logl;
 }
 
+std::pair<unsigned int, double> Rtree_Mapper::in_rtree(unsigned int branch_id, double distal_length) const {
+  // rtree_mapper::in_rtree (src/core/pll/rtree_mapper.hpp:38-61; literals test/src/rtree_mapper.cpp:58-102)
+  if (branch_id >= map_.size()) throw std::out_of_range{"Rtree_Mapper: branch id out of range"};
+  if (branch_id == utree_root_edge) {
+    if (distal_length > distal_edge_length) {
+      // past the former root: the placement lands on the proximal rooted edge, whose direction
+      // towards the root is flipped
+      const double carryover = distal_length - distal_edge_length;
+      return {rtree_proximal_edge, proximal_edge_length - carryover};
+    }
+    return {rtree_distal_edge, distal_length};
+  }
+  return {map_[branch_id], distal_length};
+}
+
+unsigned int Rtree_Mapper::map_at(size_t i) const {
+  if (i == utree_root_edge)
+    throw std::invalid_argument{"Edge " + std::to_string(i) + " is the root edge! Please handle separately"};
+  return map_.at(i);
+}
+
 std::string Tree::numbered_newick(unsigned int precision) const {
-  // get_numbered_newick_string (src/core/pll/pll_util.cpp:207-259); literal expectations in the
-  // reference's test/src/pll_util.cpp:134-143.  Inner labels are not kept.
+  // get_numbered_newick_string (src/core/pll/pll_util.cpp:207-352); literal expectations in the
+  // reference's test/src/pll_util.cpp:134-186 (unrooted, inner labels, rooted x3, rooted + labels).
   std::ostringstream ss;
   ss.precision(precision);
   ss.setf(std::ios::fixed, std::ios::floatfield);
-  unsigned idx = 0;
+  unsigned idx = 0;  // edge id on the UNROOTED tree
+  const bool rooted = (bool)mapper_;
+  auto edge_id = [&](unsigned i) { return rooted ? mapper_.map_at(i) : i; };
   struct Frame { int rec; int state; };
   auto emit = [&](int start) {
     std::vector<Frame> st{{start, 0}};
@@ -459,7 +527,8 @@ std::string Tree::numbered_newick(unsigned int precision) const {
       Frame& f = st.back();
       const Rec& r = recs_[f.rec];
       if (r.next < 0) {
-        ss << labels_[r.tip] << ":" << r.length << "{" << idx++ << "}";
+        ss << labels_[r.tip] << ":" << r.length << "{" << edge_id(idx) << "}";
+        ++idx;
         st.pop_back();
       } else if (f.state == 0) {
         ss << "(";
@@ -470,18 +539,54 @@ std::string Tree::numbered_newick(unsigned int precision) const {
         f.state = 2;
         st.push_back({recs_[recs_[r.next].next].back, 0});
       } else {
-        ss << "):" << r.length << "{" << idx++ << "}";
+        ss << ")" << r.label << ":" << r.length << "{" << edge_id(idx) << "}";
+        ++idx;
         st.pop_back();
       }
     }
   };
+  const int r0 = recs_[vroot_].back, r1 = recs_[recs_[vroot_].next].back,
+            r2 = recs_[recs_[recs_[vroot_].next].next].back;
+  if (!rooted) {
+    ss << "(";
+    emit(r0);
+    ss << ",";
+    emit(r1);
+    ss << ",";
+    emit(r2);
+    ss << ")" << root_label_ << ";";
+    return ss.str();
+  }
+  // the rooted tree, simulated on the unrooted one
   ss << "(";
-  emit(recs_[vroot_].back);
-  ss << ",";
-  emit(recs_[recs_[vroot_].next].back);
-  ss << ",";
-  emit(recs_[recs_[recs_[vroot_].next].next].back);
-  ss << ");";
+  if (mapper_.uroot_is_left()) {
+    ss << "(";
+    emit(r0);
+    ss << ",";
+    emit(r1);
+    ss << ")" << root_label_ << ":" << mapper_.proximal_edge_length << "{" << mapper_.rtree_proximal_edge << "},";
+    const Rec& right = recs_[r2];
+    if (right.next < 0) {
+      ss << labels_[right.tip];
+    } else {
+      ss << "(";
+      emit(recs_[right.next].back);
+      ss << ",";
+      emit(recs_[recs_[right.next].next].back);
+      ss << ")" << right.label;
+    }
+    ss << ":" << mapper_.distal_edge_length << "{" << mapper_.rtree_distal_edge << "}";
+  } else {
+    const Rec& lf = recs_[r0];  // the left root child, a tip: branch 0 of both trees
+    ss << labels_[lf.tip] << ":" << mapper_.distal_edge_length << "{" << mapper_.rtree_distal_edge << "},";
+    idx = 1;
+    ss << "(";
+    emit(r1);
+    ss << ",";
+    emit(r2);
+    ss << ")" << root_label_ << ":" << mapper_.proximal_edge_length << "{" << mapper_.rtree_proximal_edge << "}";
+  }
+  ss << ")" << mapper_.root_label << ";";
   return ss.str();
 }
 

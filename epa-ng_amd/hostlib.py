@@ -29,6 +29,10 @@ def host_lib():
         L.epa_host_ref_create_ex.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p),
                                              C.POINTER(C.c_char_p), C.c_char_p, C.c_int, dp, dp,
                                              C.c_int, dp, dp, C.c_double]
+        L.epa_host_ref_create_ex2.restype = C.c_void_p
+        L.epa_host_ref_create_ex2.argtypes = L.epa_host_ref_create_ex.argtypes + [C.c_int]
+        L.epa_host_ref_in_rtree.argtypes = [C.c_void_p, C.c_uint32, C.c_double,
+                                            C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
         L.epa_host_ref_destroy.argtypes = [C.c_void_p]
         L.epa_host_configure_threads.restype = C.c_int
         u32p = C.POINTER(C.c_uint32)
@@ -76,22 +80,22 @@ class Reference:
     (mirror of the reference's `Tree`, src/tree/Tree.cpp:16-56)."""
 
     def __init__(self, newick, labels, seqs, model=None, states=None, subst=None, freqs=None,
-                 rates=None, weights=None, pinv=0.0):
+                 rates=None, weights=None, pinv=0.0, preserve_rooting=True):
         L = host_lib()
         self._keep = (_strs(labels), _strs(seqs))
         if model is not None:
-            self.h = L.epa_host_ref_create(newick.encode(), len(labels), self._keep[0],
-                                           self._keep[1], model.encode(), 0, None, None, 0, None,
-                                           None)
+            self.h = L.epa_host_ref_create_ex2(newick.encode(), len(labels), self._keep[0],
+                                               self._keep[1], model.encode(), 0, None, None, 0, None,
+                                               None, 0.0, int(preserve_rooting))
         else:
             subst = np.ascontiguousarray(subst, np.float64)
             freqs = np.ascontiguousarray(freqs, np.float64)
             rates = np.ascontiguousarray(rates, np.float64)
             w = None if weights is None else np.ascontiguousarray(weights, np.float64)
-            self.h = L.epa_host_ref_create_ex(newick.encode(), len(labels), self._keep[0],
-                                              self._keep[1], None, states, _dp(subst), _dp(freqs),
-                                              len(rates), _dp(rates), None if w is None else _dp(w),
-                                              float(pinv))
+            self.h = L.epa_host_ref_create_ex2(newick.encode(), len(labels), self._keep[0],
+                                               self._keep[1], None, states, _dp(subst), _dp(freqs),
+                                               len(rates), _dp(rates), None if w is None else _dp(w),
+                                               float(pinv), int(preserve_rooting))
         if not self.h:
             raise RuntimeError(L.epa_host_last_error().decode())
         s, c, w_, b = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
@@ -105,6 +109,17 @@ class Reference:
 
     def tree_lnl(self, branch=0):
         return host_lib().epa_host_ref_tree_logl(self.h, branch)
+
+    def in_rtree(self, branch, distal):
+        """(edge, distal) on the unrooted working tree -> on the rooted input tree, or None when
+        the input was unrooted / rooting is not preserved (rtree_mapper::in_rtree)."""
+        ob, od = C.c_uint32(), C.c_double()
+        rc = host_lib().epa_host_ref_in_rtree(self.h, branch, distal, C.byref(ob), C.byref(od))
+        if rc == 1:
+            return None
+        if rc:
+            raise RuntimeError(host_lib().epa_host_last_error().decode())
+        return ob.value, od.value
 
     def numbered_newick(self, precision=10):
         buf = C.create_string_buffer(256 * (self.B + 4))

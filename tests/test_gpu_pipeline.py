@@ -576,3 +576,61 @@ def test_wrong_max_span_is_rejected():
     with pytest.raises(epa.EpaError) as ei:
         ev.place_chunk(dc, db, ds, Q=len(wb), max_span=100)
     assert ei.value.code == -4
+
+
+def test_cli_rooted_tree_preserve_rooting(tmp_path):
+    """rooted reference tree through the CLI: with --preserve-rooting on (default) the jplace
+    carries the rooted tree and every placement is mapped by rtree_mapper::in_rtree
+    (src/io/jplace_util.cpp:20-26); off reports the unrooted working tree.  The two runs must agree
+    placement by placement through the mapping (the mapping itself is pinned by the reference's
+    literals in tests/test_host_cpu.py)."""
+    import subprocess
+    from epa_ng_amd import synth
+    root = synth.random_tree(14, 141)
+    rates = synth.gamma_rates(0.478218)
+    labels, seqs = synth.simulate_msa(root, 300, synth.CFG2_SUBST, synth.CFG2_FREQS, rates, 142)
+    reads, _ = synth.make_reads(seqs, 40, 120, 0.03, 143)
+    k0, k1, k2 = root.kids
+
+    def sub(node):
+        r = synth.Node()
+        r.kids = [node]
+        return synth.newick(r)[1:-2]
+    l2 = k2.length
+    k2.length = 0.6 * l2
+    rooted = "((%s,%s):%r,%s);" % (sub(k0), sub(k1), 0.4 * l2, sub(k2))
+    k2.length = l2
+    tre, aln, qf = tmp_path / "r.tre", tmp_path / "r.fasta", tmp_path / "q.fasta"
+    tre.write_text(rooted + "\n")
+    with open(aln, "w") as f:
+        for l, s in zip(labels, seqs):
+            f.write(">%s\n%s\n" % (l, s))
+    with open(qf, "w") as f:
+        for i, s in enumerate(reads):
+            f.write(">q%d\n%s\n" % (i, s))
+    exe = os.path.join(os.path.dirname(hostlib.HOST_SO), "epa-ng-amd")
+    model = "GTR{%s}+FU{%s}+G4{0.478218}" % ("/".join(map(repr, synth.CFG2_SUBST)), "/".join(map(repr, synth.CFG2_FREQS)))
+    B = 2 * 14 - 3
+    out = {}
+    for mode in ("on", "off"):
+        od = tmp_path / mode
+        od.mkdir()
+        r = subprocess.run([exe, "-t", str(tre), "-s", str(aln), "-q", str(qf), "-m", model, "-w", str(od),
+                            "--no-heur", "--filter-max", str(B), "--filter-min-lwr", "0",
+                            "--preserve-rooting", mode], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[mode] = json.load(open(od / "epa_result.jplace"))
+    assert out["on"]["tree"].count("{") == B + 1 and out["off"]["tree"].count("{") == B
+    ref = hostlib.Reference(rooted, labels, seqs, states=4, subst=synth.CFG2_SUBST, freqs=synth.CFG2_FREQS,
+                            rates=rates)
+    assert out["on"]["tree"] == ref.numbered_newick(10)
+    sides = set()
+    for pon, poff in zip(out["on"]["placements"], out["off"]["placements"]):
+        assert pon["n"] == poff["n"] and len(pon["p"]) == len(poff["p"])
+        for a, b in zip(pon["p"], poff["p"]):
+            e, d = ref.in_rtree(b[0], b[3])
+            assert a[0] == e and abs(a[3] - d) < 2e-10
+            assert a[1] == b[1] and a[2] == b[2] and a[4] == b[4]
+            if b[0] == B - 1:
+                sides.add(e)
+    assert sides == {B, ref.in_rtree(B - 1, 0.99 * l2)[0]}   # both halves of the former root edge got placements

@@ -224,8 +224,17 @@ def test_rooted_reference_tree_is_unrooted():
     la = a.tree_lnl(0)
     for e in range(b.B):
         assert abs(b.tree_lnl(e) - la) < 1e-8
-    nw = b.numbered_newick()
-    assert nw.count("{") == b.B and nw.endswith(";")
+    nw = b.numbered_newick()   # rooting preserved: the rooted tree, one edge more
+    assert nw.count("{") == b.B + 1 and nw.endswith(";")
+    # the former root edge (last branch, k2 side distal): a placement 0.5*l2 above k2 lies on
+    # the distal rooted edge, one 0.9*l2 above it on the proximal one, measured from the top child
+    e, d = b.in_rtree(b.B - 1, 0.5 * l2)
+    assert e == b.B and abs(d - 0.5 * l2) < 1e-12
+    e, d = b.in_rtree(b.B - 1, 0.9 * l2)
+    assert abs(d - (0.3 * l2 - 0.2 * l2)) < 1e-12 and e < b.B - 1
+    c = hostlib.Reference(rooted, labels, seqs, preserve_rooting=False, **kw)
+    nwc = c.numbered_newick()
+    assert nwc.count("{") == c.B and c.in_rtree(0, 0.1) is None
 
 
 def test_prop_invariant_sites_host_vs_oracle():
@@ -274,3 +283,68 @@ def test_free_rate_model_string():
     assert np.allclose(m["rates"], r, rtol=1e-12) and np.allclose(m["weights"], w, rtol=1e-12)
     assert abs(a.tree_lnl(0) - b.tree_lnl(0)) < 1e-9
     assert abs(a.tree_lnl(0) - o.tree_lnl(0)) < 1e-8
+
+
+# --- rooted reference trees: edge numbering and placement mapping, pinned by the literals of the
+# reference's own tests (test/src/pll_util.cpp:134-186, test/src/rtree_mapper.cpp:58-102); the
+# newick inputs are the reference's test/data/ref_rooted*.tre fixtures.
+ROOTED_1 = "((((G:1.01,H:1.08):0.01,A:1.34):1.0,B:1.66):1.01,(C:1.08,D:1.26):1.12);"
+ROOTED_2 = "(A:1.34,((B:1.66,(C:1.08,D:1.26):1.12):1.00,(G:1.01,H:1.08):1.90):0.01);"
+ROOTED_3 = "(((A:1.34,(B:1.66,(C:1.08,D:1.26):1.12):1.00):1.01,G:1.08):1.90,H:0.01);"
+ROOTED_1_LAB = "((((G:1.01,H:1.08)GH:0.01,A:1.34)GHA:1.00,B:1.66)GHAB:1.01,(C:1.08,D:1.26)CD:1.12)GHABCD;"
+ROOTED_2_LAB = "(A:1.34,((B:1.66,(C:1.08,D:1.26)CD:1.12)BCD:1.00,(G:1.01,H:1.08)GH:1.90)BCDGH:0.01)ABCDGH;"
+ROOTED_3_LAB = "(((A:1.34,(B:1.66,(C:1.08,D:1.26)CD:1.12)BCD:1.00)ABCD:1.01,G:1.08)ABCDG:1.90,H:0.01)ABCDGH;"
+
+
+def _tree_only(newick, **kw):
+    import re
+    labels = re.findall(r"[(,]([A-Za-z]\w*):", newick)
+    return hostlib.Reference(newick, labels, ["ACGT"] * len(labels), model="GTR+G", **kw)
+
+
+def test_numbered_newick_inner_labels():
+    """test/src/pll_util.cpp:139-142 (branch lengths set to one there)"""
+    nw = ("(A:1,(B:1,(C:1,(D:1,(E:1,(F:1,G:1)FG:1)EFG:1)DEFG:1)CDEFG:1)BCDEFG:1,H:1)ABCDEFGH;")
+    assert _tree_only(nw).numbered_newick(2) == (
+        "(A:1.00{0},(B:1.00{1},(C:1.00{2},(D:1.00{3},(E:1.00{4},(F:1.00{5},G:1.00{6})FG:1.00{7})EFG:"
+        "1.00{8})DEFG:1.00{9})CDEFG:1.00{10})BCDEFG:1.00{11},H:1.00{12})ABCDEFGH;")
+
+
+@pytest.mark.parametrize("newick,expected", [
+    (ROOTED_1, "((((G:1.01{0},H:1.08{1}):0.01{2},A:1.34{3}):1.00{4},B:1.66{5}):1.01{6},(C:"
+               "1.08{7},D:1.26{8}):1.12{9});"),
+    (ROOTED_2, "(A:1.34{0},((B:1.66{1},(C:1.08{2},D:1.26{3}):1.12{4}):1.00{5},(G:1.01{6},H:"
+               "1.08{7}):1.90{8}):0.01{9});"),
+    (ROOTED_3, "(((A:1.34{0},(B:1.66{1},(C:1.08{2},D:1.26{3}):1.12{4}):1.00{5}):1.01{6},G:"
+               "1.08{7}):1.90{8},H:0.01{9});"),
+    (ROOTED_1_LAB, "((((G:1.01{0},H:1.08{1})GH:0.01{2},A:1.34{3})GHA:1.00{4},B:1.66{5})GHAB:1."
+                   "01{6},(C:1.08{7},D:1.26{8})CD:1.12{9})GHABCD;"),
+    (ROOTED_2_LAB, "(A:1.34{0},((B:1.66{1},(C:1.08{2},D:1.26{3})CD:1.12{4})BCD:1.00{5},(G:1.01{"
+                   "6},H:1.08{7})GH:1.90{8})BCDGH:0.01{9})ABCDGH;"),
+    (ROOTED_3_LAB, "(((A:1.34{0},(B:1.66{1},(C:1.08{2},D:1.26{3})CD:1.12{4})BCD:1.00{5})ABCD:1."
+                   "01{6},G:1.08{7})ABCDG:1.90{8},H:0.01{9})ABCDGH;"),
+])
+def test_numbered_newick_rooted_preserved(newick, expected):
+    """test/src/pll_util.cpp:159-186"""
+    assert _tree_only(newick).numbered_newick(2) == expected
+
+
+@pytest.mark.parametrize("newick,utree,rtree", [
+    (ROOTED_1, [(8, 1.0), (8, 1.5), (6, 0.5), (7, 0.001)], [(9, 1.0), (6, 0.63), (7, 0.5), (8, 0.001)]),
+    (ROOTED_2, [(0, 1.34), (0, 1.345), (8, 0.5), (2, 0.001)], [(0, 1.34), (9, 0.005), (8, 0.5), (2, 0.001)]),
+    (ROOTED_3, [(8, 0.5), (8, 0.005), (0, 0.5), (2, 0.001)], [(8, 1.41), (9, 0.005), (0, 0.5), (2, 0.001)]),
+])
+def test_rtree_mapper_placement_mapping(newick, utree, rtree):
+    """test/src/rtree_mapper.cpp:58-102"""
+    r = _tree_only(newick)
+    for (ub, ud), (rb, rd) in zip(utree, rtree):
+        b, d = r.in_rtree(ub, ud)
+        assert b == rb and abs(d - rd) < 1e-10
+
+
+def test_preserve_rooting_off_reports_unrooted_tree():
+    r = _tree_only(ROOTED_1, preserve_rooting=False)
+    assert r.in_rtree(8, 1.0) is None
+    # the former root edge is the last branch, its length the sum of the two root edges
+    assert r.numbered_newick(2) == ("(((G:1.01{0},H:1.08{1}):0.01{2},A:1.34{3}):1.00{4},B:1.66{5},"
+                                    "(C:1.08{6},D:1.26{7}):2.13{8});")
