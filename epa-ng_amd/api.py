@@ -90,6 +90,7 @@ def dev_lib():
                                        C.c_void_p]
         L.epa_dev_thorough.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(_Stats)]
+        L.epa_dev_set_heuristic.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L.epa_dev_select_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double,
                                                 C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.epa_dev_place_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
@@ -270,6 +271,12 @@ class Evaluator:
         self.last_stats = {"pairs": st.pairs, "rounds": st.rounds,
                            "newton_evals": st.newton_evals, "reverts": st.reverts}
         return out
+
+    def set_heuristic(self, mode="dynamic", param=0.0):
+        """selection rule of select() / place_chunk(): "dynamic" (the call's threshold), "fixed"
+        (param = fraction of the branches) or "baseball" (epa_dev_set_heuristic)"""
+        self._check(self.L.epa_dev_set_heuristic(self.h, {"dynamic": 0, "fixed": 1, "baseball": 2}[mode],
+                                                 float(param)))
 
     def select(self, lnl, Q, threshold=0.99999, max_pairs=None, out=None):
         """dynamic heuristic -> branch-major sorted PAIR_DTYPE array"""

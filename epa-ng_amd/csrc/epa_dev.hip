@@ -356,6 +356,17 @@ extern "C" int epa_dev_set_query_layout(epa_ctx* ctx, uint32_t code_stride) {
   return EPA_OK;
 }
 
+extern "C" int epa_dev_set_heuristic(epa_ctx* ctx, int mode, double param) {
+  if (!ctx) return EPA_ERR_INVALID_ARG;
+  if (mode < EPA_HEUR_DYNAMIC || mode > EPA_HEUR_BASEBALL)
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "set_heuristic: unknown mode");
+  if (mode == EPA_HEUR_FIXED && !(param >= 0.0 && param <= 1.0))
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "set_heuristic: the fraction must lie in [0, 1]");
+  ctx->heur_mode = mode;
+  ctx->heur_param = param;
+  return EPA_OK;
+}
+
 extern "C" int epa_dev_set_stream(epa_ctx* ctx, void* s) {
   if (!ctx) return EPA_ERR_INVALID_ARG;
   ctx->stream = (hipStream_t)s;

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <condition_variable>
 #include <deque>
 #include <fstream>
@@ -225,6 +226,16 @@ void place_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, D
   // the dynamic heuristic keeps a handful of branches per read: start with room for 8 per read,
   // grow on overflow (the buffers live in the evaluator and are reused by the next chunk)
   uint64_t cap = std::max<uint64_t>((uint64_t)Q * 8, dev.pair_buffer().size()), n = 0;
+  // apply_heuristic's three rules all run on the device (src/core/heuristics.hpp:119-127)
+  const size_t nb = tree.num_branches();
+  const int mode = options.baseball ? EPA_HEUR_BASEBALL
+                                    : options.prescoring_by_percentage ? EPA_HEUR_FIXED : EPA_HEUR_DYNAMIC;
+  if (epa_dev_set_heuristic(dev.ctx(), mode, mode == EPA_HEUR_FIXED ? options.prescoring_threshold : 0.0) != EPA_OK)
+    throw std::runtime_error{epa_dev_last_error(dev.ctx())};
+  if (mode == EPA_HEUR_FIXED)
+    cap = std::max<uint64_t>(cap, (uint64_t)Q * std::min<size_t>(nb, (size_t)std::ceil(options.prescoring_threshold * (double)nb)));
+  else if (mode == EPA_HEUR_BASEBALL)
+    cap = std::max<uint64_t>(cap, (uint64_t)Q * std::min<size_t>(nb, 46));
   std::vector<epa_pair>& pairs = dev.pair_buffer();
   std::vector<epa_result>& res = dev.result_buffer();
   uint32_t max_span = 0;
@@ -343,14 +354,15 @@ Sample process_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tre
   const bool all_on_device = !options.prescoring && options.filter_min >= 1 &&
                              options.filter_max >= options.filter_min && options.filter_max <= 64 &&
                              (uint64_t)n * B <= 0xffffffffull;
-  const bool fused = options.prescoring && options.device_select && !options.baseball &&
-                     !options.prescoring_by_percentage && B <= 65536;
+  // EPA_HOST_HEURISTIC=1: keep the Q x B table round trip and the host heuristics (cross-check)
+  static const bool host_heur = std::getenv("EPA_HOST_HEURISTIC") != nullptr;
+  const bool fused = options.prescoring && options.device_select && B <= 65536 && !host_heur;
   if (all_on_device) {
     tm.pairs = place_all(chunk, enc, tree, dev, blo_sample, options, seq_id_offset);
     t1 = clk::now();
   } else if (fused) {
-    // default configuration: the whole chunk body runs on the GPU (epa_dev_place_chunk), the
-    // Q x B table never crosses PCIe
+    // the whole chunk body runs on the GPU (epa_dev_place_chunk, any of the three heuristics),
+    // the Q x B table never crosses PCIe
     place_chunk(chunk, enc, tree, dev, blo_work, blo_sample, options, seq_id_offset);
     t1 = clk::now();
   } else {

@@ -780,9 +780,41 @@ __device__ __forceinline__ double wave_add(double v) {
   return v;
 }
 
+// Stop rule of the per-query extraction loop (descending lnL == descending LWR, ties by branch id):
+//   0 dynamic   until the accumulated LWR reaches thr, the crossing element included
+//               (until_accumulated_reached, src/set_manipulators.cpp:90-114)
+//   1 fixed     the ceil(x * B) best (until_top_percent, :82-88); limit precomputed by the host
+//   2 baseball  every branch within 3.0 lnL of the best ("strike box"), plus min(40 - hits, 6)
+//               more when fewer than 40 were hit (src/core/heuristics.hpp:70-117, clamped at B)
+struct SelRule {
+  int mode;
+  double thr;
+  uint32_t limit;
+  double sum = 0.0;
+  uint32_t hits = 0;
+  bool striking = true;
+  __device__ __forceinline__ SelRule(int m, double t, uint32_t l) : mode(m), thr(t), limit(l) {}
+  __device__ __forceinline__ bool more(uint32_t taken, uint32_t B) const {
+    if (mode == 0) return taken < B && sum < thr;
+    if (mode == 1) return taken < limit;
+    return taken < B && (striking || taken < limit);
+  }
+  // the next best value: take it?  (wave / workgroup uniform)
+  __device__ __forceinline__ bool accept(double best, double mx, double tot, uint32_t taken) {
+    if (mode == 0) { sum += exp(best - mx) / tot; return true; }
+    if (mode == 1) return true;
+    if (striking) {
+      if (!(best < mx - 3.0)) { ++hits; return true; }
+      striking = false;
+      limit = hits + (hits >= 40u ? 0u : min(40u - hits, 6u));
+    }
+    return taken < limit;
+  }
+};
+
 template <int NR>
 __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, uint32_t Q, uint32_t B,
-                                                double threshold, uint32_t cap,
+                                                double threshold, int mode, uint32_t limit, uint32_t cap,
                                                 unsigned long long* __restrict__ stage,
                                                 uint32_t* __restrict__ counts,
                                                 uint32_t* __restrict__ status) {
@@ -803,10 +835,10 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
 #pragma unroll
   for (int r = 0; r < NR; ++r) tot += exp(v[r] - mx);  // exp(-inf) == 0 for the padding
   tot = wave_add(tot);
-  double sum = 0.0;
+  SelRule rule(mode, threshold, limit);
   uint32_t taken = 0;
   unsigned long long* out = stage + (size_t)q * cap;
-  while (taken < B && sum < threshold) {
+  while (rule.more(taken, B)) {
     double best = -INFINITY;
     uint32_t bi = 0xffffffffu;
 #pragma unroll
@@ -819,7 +851,7 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
       if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
     if (bi == 0xffffffffu) break;
-    sum += exp(best - mx) / tot;
+    if (!rule.accept(best, mx, tot, taken)) break;
 #pragma unroll
     for (int r = 0; r < NR; ++r)
       if ((uint32_t)(r * 64 + lane) == bi) v[r] = -INFINITY;
@@ -838,7 +870,7 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
 // through LDS.  Used for 4096 < B <= 16384.
 template <int NRT>
 __global__ void __launch_bounds__(256) k_select_wg(const double* __restrict__ lnl, uint32_t Q, uint32_t B,
-                                                   double threshold, uint32_t cap,
+                                                   double threshold, int mode, uint32_t limit, uint32_t cap,
                                                    unsigned long long* __restrict__ stage,
                                                    uint32_t* __restrict__ counts,
                                                    uint32_t* __restrict__ status) {
@@ -873,10 +905,10 @@ __global__ void __launch_bounds__(256) k_select_wg(const double* __restrict__ ln
   __syncthreads();
   tot = (s_val[ph][0] + s_val[ph][1]) + (s_val[ph][2] + s_val[ph][3]);
   ph ^= 1;
-  double sum = 0.0;
+  SelRule rule(mode, threshold, limit);
   uint32_t taken = 0;
   unsigned long long* out = stage + (size_t)q * cap;
-  while (taken < B && sum < threshold) {
+  while (rule.more(taken, B)) {
     double best = -INFINITY;
     uint32_t bi = 0xffffffffu;
 #pragma unroll
@@ -900,7 +932,7 @@ __global__ void __launch_bounds__(256) k_select_wg(const double* __restrict__ ln
     }
     ph ^= 1;
     if (bi == 0xffffffffu) break;
-    sum += exp(best - mx) / tot;
+    if (!rule.accept(best, mx, tot, taken)) break;
 #pragma unroll
     for (int r = 0; r < NRT; ++r)
       if ((uint32_t)(r * 256) + t == bi) v[r] = -INFINITY;
@@ -919,7 +951,7 @@ __global__ void __launch_bounds__(256) k_select_wg(const double* __restrict__ ln
 // (element i lives in lane i % 64, bit i / 64; up to 64 x 64 x NW branches).
 template <int NW>
 __global__ void __launch_bounds__(256) k_select_big(const double* __restrict__ lnl, uint32_t Q, uint32_t B,
-                                                    double threshold, uint32_t cap,
+                                                    double threshold, int mode, uint32_t limit, uint32_t cap,
                                                     unsigned long long* __restrict__ stage,
                                                     uint32_t* __restrict__ counts,
                                                     uint32_t* __restrict__ status) {
@@ -936,10 +968,10 @@ __global__ void __launch_bounds__(256) k_select_big(const double* __restrict__ l
   double tot = 0.0;
   for (uint32_t i = lane; i < B; i += 64) tot += exp(src[i] - mx);
   tot = wave_add(tot);
-  double sum = 0.0;
+  SelRule rule(mode, threshold, limit);
   uint32_t taken = 0;
   unsigned long long* out = stage + (size_t)q * cap;
-  while (taken < B && sum < threshold) {
+  while (rule.more(taken, B)) {
     double best = -INFINITY;
     uint32_t bi = 0xffffffffu;
     for (uint32_t i = lane, r = 0; i < B; i += 64, ++r) {
@@ -954,7 +986,7 @@ __global__ void __launch_bounds__(256) k_select_big(const double* __restrict__ l
       if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
     if (bi == 0xffffffffu) break;
-    sum += exp(best - mx) / tot;
+    if (!rule.accept(best, mx, tot, taken)) break;
     if ((bi & 63u) == lane) {
       const uint32_t r = bi >> 6;
 #pragma unroll
@@ -1161,6 +1193,16 @@ int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshol
   const uint32_t B = ctx->B;
   if (B > 64 * 64 * 16)
     return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "select_candidates: more than 65536 branches");
+  // selection rule of the context (epa_dev_set_heuristic); fixed: ceil(x * B) best, at least... none:
+  // until_top_percent keeps ceil(x * B) elements, 0 for x == 0 (src/set_manipulators.cpp:82-88)
+  const int mode = ctx->heur_mode;
+  uint32_t limit = 0;
+  if (mode == 1) {
+    limit = (uint32_t)std::min<double>((double)B, std::ceil(ctx->heur_param * (double)B));
+    ctx->select_cap = std::max(ctx->select_cap, std::max(limit, 1u));
+  } else if (mode == 2) {
+    ctx->select_cap = std::max(ctx->select_cap, std::min(B, 48u));
+  }
   for (;;) {
     const uint32_t cap = ctx->select_cap;
     size_t scan_bytes = 0, sort_bytes = 0;
@@ -1188,12 +1230,12 @@ int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshol
     epa_timer_start(ctx, ctx->t_select);
     const dim3 grid((Q + 3) / 4);
     const int nr = (int)((B + 63) / 64);
-#define SEL(N) hipLaunchKernelGGL(k_select<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, cap, stage, counts, status)
-#define SELBIG(N) hipLaunchKernelGGL(k_select_big<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, cap, stage, counts, status)
+#define SEL(N) hipLaunchKernelGGL(k_select<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, mode, limit, cap, stage, counts, status)
+#define SELBIG(N) hipLaunchKernelGGL(k_select_big<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, mode, limit, cap, stage, counts, status)
     if (nr <= 2) SEL(2); else if (nr <= 4) SEL(4); else if (nr <= 8) SEL(8); else if (nr <= 16) SEL(16);
     else if (nr <= 32) SEL(32); else if (nr <= 64) SEL(64);
-    else if (nr <= 128) hipLaunchKernelGGL(k_select_wg<32>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, cap, stage, counts, status);
-    else if (nr <= 256) hipLaunchKernelGGL(k_select_wg<64>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, cap, stage, counts, status);
+    else if (nr <= 128) hipLaunchKernelGGL(k_select_wg<32>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, mode, limit, cap, stage, counts, status);
+    else if (nr <= 256) hipLaunchKernelGGL(k_select_wg<64>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, mode, limit, cap, stage, counts, status);
     else SELBIG(16);
 #undef SELBIG
 #undef SEL

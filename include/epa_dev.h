@@ -245,6 +245,20 @@ int epa_dev_select_candidates(epa_ctx* ctx, const double* lnl, uint32_t Q, doubl
                               epa_pair* pairs, uint64_t max_pairs, uint64_t* n_pairs);
 
 /*
+ * Selection rule used by epa_dev_select_candidates() and epa_dev_place_chunk() of this context
+ * (apply_heuristic, src/core/heuristics.hpp:119-127):
+ *   EPA_HEUR_DYNAMIC   (default) accumulated LWR >= the call's `threshold`   (--dyn-heur)
+ *   EPA_HEUR_FIXED     the ceil(param * B) best branches per query           (--fix-heur,
+ *                      until_top_percent src/set_manipulators.cpp:82-88); `threshold` is ignored
+ *   EPA_HEUR_BASEBALL  every branch within 3.0 lnL of the best, plus min(40 - hits, 6) more while
+ *                      fewer than 40 were hit (--baseball-heur, heuristics.hpp:70-117, clamped at B)
+ */
+#define EPA_HEUR_DYNAMIC 0
+#define EPA_HEUR_FIXED 1
+#define EPA_HEUR_BASEBALL 2
+int epa_dev_set_heuristic(epa_ctx* ctx, int mode, double param);
+
+/*
  * The body of the reference's chunk loop for the default configuration (src/core/place.cpp:
  * 219-235): place() -> apply_heuristic() [dynamic, `threshold`] -> place_thorough(), fused so
  * that the Q x B preplacement table never leaves HBM and the host is only consulted once (the

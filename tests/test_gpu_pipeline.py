@@ -634,3 +634,71 @@ def test_cli_rooted_tree_preserve_rooting(tmp_path):
             if b[0] == B - 1:
                 sides.add(e)
     assert sides == {B, ref.in_rtree(B - 1, 0.99 * l2)[0]}   # both halves of the former root edge got placements
+
+
+@pytest.mark.parametrize("tips,width,reads,read_len", [(96, 300, 200, 90), (2200, 64, 24, 40), (8300, 24, 4, 24)])
+def test_fixed_and_baseball_heuristics_on_device(tips, width, reads, read_len):
+    """--fix-heur / --baseball-heur candidate selection on the device (epa_dev_set_heuristic) vs the
+    host restatement of until_top_percent and baseball_heuristic (src/set_manipulators.cpp:82-88,
+    src/core/heuristics.hpp:70-117) on the same table; all three selection kernels (row in one
+    wave's registers, in a workgroup's registers, streamed)."""
+    from epa_ng_amd import synth
+    w = synth.dna_workload(tips, width, reads, read_len, (151, 152, 153))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    codes, wb, ws = epa.encode_queries(4, w["reads"], compact=True)
+    lnl = ev.preplace(codes, wb, ws)
+    Q = len(w["reads"])
+
+    def as_set(b, s):
+        return sorted(zip(np.asarray(b).tolist(), np.asarray(s).tolist()))
+    for mode, param in (("fixed", 0.02), ("fixed", 0.3), ("fixed", 0.0004), ("baseball", 0.0), ("dynamic", 0.0)):
+        ev.set_heuristic(mode, param)
+        pairs = ev.select(lnl, Q, 0.99999, max_pairs=Q * ref.B)
+        hb, hs = hostlib.heuristic(lnl, mode, param if mode == "fixed" else 0.99999)
+        assert as_set(hb, hs) == as_set(pairs["branch_id"], pairs["seq_id"]), (mode, param)
+        assert np.all(np.diff(pairs["branch_id"].astype(np.int64)) >= 0)
+        if mode == "fixed":
+            assert len(pairs) == Q * min(ref.B, int(np.ceil(param * ref.B)))
+    # fused chunk with the baseball rule == select + thorough
+    ev.set_heuristic("baseball")
+    pairs = ev.select(lnl, Q, 0.99999, max_pairs=Q * ref.B)
+    p2, r2 = ev.place_chunk(codes, wb, ws, max_pairs=Q * ref.B)
+    assert np.array_equal(p2, pairs)
+    res = ev.thorough(pairs, codes, wb, ws)
+    assert np.array_equal(r2["lnl"], res["lnl"])
+    ev.set_heuristic("dynamic")
+
+
+def test_cli_fix_and_baseball_heuristics(tmp_path):
+    """-G / --baseball-heur through the CLI run fused on the device; same jplace as with the host
+    heuristic path (EPA_HOST_HEURISTIC=1 keeps the table round trip for this cross-check)."""
+    import subprocess
+    from epa_ng_amd import synth
+    w = synth.dna_workload(40, 300, 120, 100, (161, 162, 163))
+    tre, aln, qf = tmp_path / "r.tre", tmp_path / "r.fasta", tmp_path / "q.fasta"
+    tre.write_text(w["newick"] + "\n")
+    with open(aln, "w") as f:
+        for l, s in zip(w["labels"], w["seqs"]):
+            f.write(">%s\n%s\n" % (l, s))
+    with open(qf, "w") as f:
+        for i, s in enumerate(w["reads"]):
+            f.write(">q%d\n%s\n" % (i, s))
+    exe = os.path.join(os.path.dirname(hostlib.HOST_SO), "epa-ng-amd")
+    model = "GTR{%s}+FU{%s}+G4{0.478218}" % ("/".join(map(repr, w["subst"])), "/".join(map(repr, w["freqs"])))
+    for flags in (["-G", "0.1"], ["--baseball-heur"]):
+        outs = []
+        for host in (False, True):
+            od = tmp_path / ("o_%s_%d" % (flags[0].strip("-"), host))
+            od.mkdir()
+            env = dict(os.environ)
+            if host:
+                env["EPA_HOST_HEURISTIC"] = "1"
+            r = subprocess.run([exe, "-t", str(tre), "-s", str(aln), "-q", str(qf), "-m", model, "-w", str(od)] + flags,
+                               capture_output=True, text=True, timeout=300, env=env)
+            assert r.returncode == 0, r.stdout + r.stderr
+            jp = json.load(open(od / "epa_result.jplace"))
+            jp.pop("metadata", None)
+            outs.append(jp)
+        assert outs[0] == outs[1], flags
