@@ -245,3 +245,53 @@ def test_thorough_long_windows_hbm_slab():
         assert np.max(np.abs(res["distal_length"] - td)) < 1e-6
         assert e.last_stats["rounds"] == o.last_stats["rounds"]
         assert e.last_stats["reverts"] == o.last_stats["reverts"]
+
+
+@pytest.mark.parametrize("seed", [0, 4, 5, 15, 25, 28, 34, 37, 44, 53])
+def test_randomised_odd_shapes_lnl_parity(seed):
+    """Odd corners drawn at random (seeded): 4..90 tips, 12..500 columns, branch lengths from 1e-8
+    to 20, alpha 0.05..50, +I, both alphabets, 1-site to full-length reads, ambiguity codes inside
+    the reads; every (branch, read) pair placed thoroughly.  The log-likelihoods must agree with the
+    oracle to 1e-6 everywhere; branch lengths are compared only where the optimum is well
+    conditioned (on saturated branches lnL is flat in the pendant length and a last-bit
+    difference in f / f' legitimately moves the Newton iterate, likewise the revert test
+    `new - old > new * 1e-14` can flip on a rounding-level difference)."""
+    from epa_ng_amd import hostlib, synth
+    rng = np.random.RandomState(seed)
+    states = 4 if rng.rand() < 0.7 else 20
+    tips = int(rng.choice([4, 5, 9, 17, 40, 90]))
+    W = int(rng.choice([12, 64, 65, 130, 260, 500]))
+    mean_bl = float(rng.choice([1e-5, 1e-3, 0.05, 0.5, 3.0]))
+    hi = float(rng.choice([1.0, 20.0]))
+    lo = float(rng.choice([1e-8, 1e-6, 1e-4]))
+    pinv = float(rng.choice([0.0, 0.0, 0.35]))
+    alpha = float(rng.choice([0.05, 0.5, 2.0, 50.0]))
+    root = synth.random_tree(tips, seed, mean_bl=mean_bl, lo=lo, hi=hi)
+    rates = synth.gamma_rates(alpha)
+    subst, freqs = (synth.CFG2_SUBST, synth.CFG2_FREQS) if states == 4 else synth.aa_model(seed)
+    labels, seqs = synth.simulate_msa(root, W, subst, freqs, rates, seed + 1)
+    nreads = 24
+    rl = min(int(rng.choice([1, 2, 3, 7, min(W, 64), min(W, 65), min(W, 129), W])), W)
+    reads, _ = synth.make_reads(seqs, nreads, rl, float(rng.choice([0.0, 0.03, 0.5])), seed + 2, states)
+    amb = "RYKMSWBDHVN-" if states == 4 else "BZX-"
+    reads = list(reads)
+    for i in range(0, nreads, 3):
+        r = list(reads[i])
+        idx = [k for k, ch in enumerate(r) if ch != "-"]
+        if len(idx) > 2:
+            for k in rng.choice(idx[1:-1], max(1, len(idx) // 6)):
+                r[k] = amb[rng.randint(len(amb))]
+        reads[i] = "".join(r)
+    nw = synth.newick(root)
+    o = Oracle(nw, labels, seqs, states, subst, freqs, rates, pinv=pinv)
+    ref = hostlib.Reference(nw, labels, seqs, states=states, subst=subst, freqs=freqs, rates=rates, pinv=pinv)
+    ev = ref.evaluator()
+    codes, wb, ws = epa.encode_queries(states, reads, compact=True)
+    assert np.max(np.abs(ev.preplace(codes, wb, ws) - o.preplace(reads))) < LNL_TOL
+    pairs = all_pairs(ref.B, nreads)
+    res = ev.thorough(pairs, codes, wb, ws)
+    tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
+    assert np.max(np.abs(res["lnl"] - tl)) < LNL_TOL
+    assert ev.last_stats["rounds"] == o.last_stats["rounds"]
+    same = (np.abs(res["pendant_length"] - tp) <= 1e-6 * np.maximum(1.0, tp)) & (np.abs(res["distal_length"] - td) <= 1e-6)
+    assert same.mean() > 0.99
