@@ -351,6 +351,7 @@ constexpr int PW = CP / 2;              // packed words (2 x 16-bit LDS offsets)
 constexpr int TROWS2 = TROWS / 2;       // pair rows staged per (branch, chunk)
 constexpr int GQ2 = 1024;               // queries (threads) per group of the pair path: one
                                         // workgroup per CU, the staged slice is shared by 1024 queries
+constexpr int NB2 = 32;                 // branches per item of the fast paths (single-chunk variant)
 constexpr int NB2_ACC = 8;              // branches per workgroup when partial sums live in LDS
 constexpr uint32_t ZERO_OFF = (PE - 1) * 8;  // (none, none) of the thread's own first row: exact +0.0
 
@@ -437,7 +438,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [TROWS2][PE] doubles, then accs
   double* accs = reinterpret_cast<double*>(smem + (size_t)TROWS2 * PROWB);  // [NB2_ACC][GQ2] (ACC only)
   __shared__ uint32_t s_maxspan;
-  constexpr uint32_t NBP = ACC ? NB2_ACC : NB;
+  constexpr uint32_t NBP = ACC ? NB2_ACC : NB2;
   // persistent grid over (group, branch tile) items of class 0, see k_preplace
   const uint32_t ng = status[5], ntiles = (B + NBP - 1) / NBP;
   const int t = threadIdx.x;
@@ -562,8 +563,18 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
           sum += at(t1);
           sum += at(t2);
         }
-        if (ACC) accs[j * GQ2 + t] = sum;
-        else lnl[(size_t)qi * B + b0 + j] = sum;
+        if (ACC) {
+          accs[j * GQ2 + t] = sum;
+        } else {
+          // results leave in bursts of 8 consecutive branches (64 B per query, issued back to back
+          // so that L2 merges them into whole sectors): single 8-byte stores spread over the item
+          // were evicted sector by sector -- 1.76 GB written for a 0.41 GB table
+          accs[(j & 7u) * GQ2 + t] = sum;
+          if ((j & 7u) == 7u || j + 1 == nb) {
+            double* out = lnl + (size_t)qi * B + b0 + (j & ~7u);
+            for (uint32_t k = 0; k <= (j & 7u); ++k) out[k] = accs[k * GQ2 + t];
+          }
+        }
       }
     }
   }
@@ -630,7 +641,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [TROWS_S][NCOLS] doubles, then accs
   double* accs = reinterpret_cast<double*>(smem + (size_t)TROWS_S * ROWB);  // [NB2_ACC][GQ2] (ACC only)
   __shared__ uint32_t s_maxspan;
-  constexpr uint32_t NBP = ACC ? NB2_ACC : NB;
+  constexpr uint32_t NBP = ACC ? NB2_ACC : NB2;
   const uint32_t ng = status[5], ntiles = (B + NBP - 1) / NBP;
   const int t = threadIdx.x;
   auto at = [&](uint32_t off) -> double { return *reinterpret_cast<const double*>(smem + off); };
@@ -749,8 +760,18 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
             if (ntail > 1) sum += at(t1);
             if (ntail > 2) sum += at(t2);
           }
-          if (ACC) accs[j * GQ2 + t] = sum;
-          else lnl[(size_t)qi * B + b0 + j] = sum;
+          if (ACC) {
+            accs[j * GQ2 + t] = sum;
+          } else {
+            // results leave in bursts of 8 consecutive branches (64 B per query, issued back to back
+            // so that L2 merges them into whole sectors): single 8-byte stores spread over the item
+            // were evicted sector by sector -- 1.76 GB written for a 0.41 GB table
+            accs[(j & 7u) * GQ2 + t] = sum;
+            if ((j & 7u) == 7u || j + 1 == nb) {
+              double* out = lnl + (size_t)qi * B + b0 + (j & ~7u);
+              for (uint32_t k = 0; k <= (j & 7u); ++k) out[k] = accs[k * GQ2 + t];
+            }
+          }
         }
       }
     }
@@ -1121,8 +1142,8 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   // max_span: upper bound of the window spans when the caller knows it (0 = unknown)
   const bool acc = max_span == 0 || max_span > (uint32_t)CH || getenv("EPA_PREPLACE_ACC");
   const size_t lds = sizeof(double) * ((size_t)TROWS * ctx->ncols + (acc ? (size_t)NB * GQ : 0));
-  const size_t lds2 = (size_t)TROWS2 * PROWB + (acc ? sizeof(double) * NB2_ACC * GQ2 : 0);
-  const uint32_t ntiles2 = (ctx->B + (acc ? NB2_ACC : NB) - 1) / (acc ? NB2_ACC : NB);
+  const size_t lds2 = (size_t)TROWS2 * PROWB + sizeof(double) * NB2_ACC * GQ2;  // accs / result staging
+  const uint32_t ntiles2 = (ctx->B + (acc ? NB2_ACC : NB2) - 1) / (acc ? NB2_ACC : NB2);
   const dim3 grid2((uint32_t)std::min<uint64_t>((uint64_t)max_groups * ntiles2, (uint64_t)ctx->n_cu));  // 1 per CU
   // generic kernel: with the pair path on it only sees the few groups of queries with rare
   // ambiguity codes -> persistent grid; as the only kernel (20 states) one workgroup per item,
@@ -1143,8 +1164,8 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
 #undef PRE2
   if (sites) {
     const bool acc_s = max_span == 0 || max_span > (uint32_t)CHS || getenv("EPA_PREPLACE_ACC");
-    const size_t lds_s = (size_t)TROWS_S * 24 * 8 + (acc_s ? sizeof(double) * NB2_ACC * GQ2 : 0);
-    const uint32_t ntiles_s = (ctx->B + (acc_s ? NB2_ACC : NB) - 1) / (acc_s ? NB2_ACC : NB);
+    const size_t lds_s = (size_t)TROWS_S * 24 * 8 + sizeof(double) * NB2_ACC * GQ2;  // accs / result staging
+    const uint32_t ntiles_s = (ctx->B + (acc_s ? NB2_ACC : NB2) - 1) / (acc_s ? NB2_ACC : NB2);
     const dim3 grid_s((uint32_t)std::min<uint64_t>((uint64_t)max_groups * ntiles_s, (uint64_t)ctx->n_cu));
 #define PRES(A)                                                                                      \
   do {                                                                                               \
