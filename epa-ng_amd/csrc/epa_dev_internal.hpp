@@ -71,7 +71,7 @@ struct epa_ctx {
   //   scSum  [B][W]        prox + dist per-site scaler counts
   //   blen   [B]
   //   lookup [B][W][ncols]
-  //   lookup2 [B][W][36]   DNA: lookup[s][c0] + lookup[s+1][c1] over {A,C,G,T,N,none}^2
+  //   lookup2 [B][2][ceil(W/2)][36]  (start parity, site >> 1)  DNA: lookup[s][c0] + lookup[s+1][c1] over {A,C,G,T,N,none}^2
   double* refT = nullptr;
   uint32_t* scSum = nullptr;
   double* blen = nullptr;
@@ -81,7 +81,7 @@ struct epa_ctx {
   uint8_t* resc0 = nullptr;
   double* cinv = nullptr;     // +I only: [W] p * pi[invariant state of the site] (0 where not invariant)
   double inv_w0 = 0.0;        // 1 / w_0: folds cinv into the zero-eigenvalue sumtable entry (thorough)
-  double* lookup2 = nullptr;  // DNA only: [B][W][36] site-pair sums (preplace.hip, k_preplace_pairs)
+  double* lookup2 = nullptr;  // DNA only: [B][2][ceil(W/2)][36] site-pair sums (preplace.hip, k_preplace_pairs)
   bool lookup_built = false;
   std::vector<double> h_blen;
 

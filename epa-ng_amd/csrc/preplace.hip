@@ -375,7 +375,10 @@ __global__ void __launch_bounds__(256) k_build_lookup2(const double* __restrict_
   const double* T = lookup + (size_t)b * W * 16;
   const double v0 = i0 < 5 ? T[(size_t)s * 16 + code[i0]] : 0.0;
   const double v1 = (i1 < 5 && s + 1 < W) ? T[(size_t)(s + 1) * 16 + code[i1]] : 0.0;
-  lookup2[((size_t)b * W + s) * PE + e] = v0 + v1;
+  // rows of one start parity are contiguous: [b][s & 1][s >> 1][PE].  A group of queries uses the
+  // rows of ONE parity; interleaved, its slice was 288 useful bytes out of every 576
+  const uint32_t Wh = (W + 1) / 2;
+  lookup2[(((size_t)b * 2 + (s & 1u)) * Wh + (s >> 1)) * PE + e] = v0 + v1;
 }
 
 // One wave per query: per-pair LDS offsets relative to the query's first pair row, 16 bit each
@@ -503,14 +506,14 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     constexpr int PF = (TROWS2 * (PE / 2) + GQ2 - 1) / GQ2;
     double2 pf[PF];
     auto request = [&](uint32_t j) {
-      // pair row r = table row (row0 + 2r): 18 double2 each, consecutive pair rows 36 apart
-      const double2* src = reinterpret_cast<const double2*>(lookup2 + ((size_t)(b0 + j) * W + row0) * PE);
+      // pair row r = table row (row0 + 2r); the rows of one parity are contiguous in lookup2
+      const double2* src = reinterpret_cast<const double2*>(
+          lookup2 + (((size_t)(b0 + j) * 2 + (row0 & 1u)) * ((W + 1) / 2) + (row0 >> 1)) * PE);
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const uint32_t i = u * GQ2 + t;
-        const uint32_t r = i / (PE / 2);
         pf[u] = make_double2(0.0, 0.0);
-        if (i < n2) pf[u] = src[(size_t)i + (size_t)r * (PE / 2)];
+        if (i < n2) pf[u] = src[i];
       }
     };
     request(0);
@@ -1066,7 +1069,7 @@ size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 int launch_build_lookup2(epa_ctx* ctx) {
   if (!ctx->lookup2)
-    EPA_HIP(ctx, hipMalloc(&ctx->lookup2, sizeof(double) * (size_t)ctx->B * ctx->W * PE));
+    EPA_HIP(ctx, hipMalloc(&ctx->lookup2, sizeof(double) * (size_t)ctx->B * 2 * ((ctx->W + 1) / 2) * PE));
   dim3 grid((ctx->W * PE + 255) / 256, ctx->B);
   hipLaunchKernelGGL(k_build_lookup2, grid, dim3(256), 0, ctx->stream, ctx->lookup, ctx->W, ctx->lookup2);
   EPA_HIP(ctx, hipGetLastError());
