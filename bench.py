@@ -34,7 +34,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=4)
     p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--chunk", type=int, default=50000, help="reads per step (EPA-ng --chunk-size)")
+    p.add_argument("--chunk", type=int, default=100000,
+                   help="reads per step (EPA-ng --chunk-size; default = the whole cfg2 query set)")
     p.add_argument("--tips", type=int, default=512)
     p.add_argument("--width", type=int, default=1500)
     p.add_argument("--read-len", type=int, default=150)
