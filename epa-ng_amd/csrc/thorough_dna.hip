@@ -756,8 +756,9 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
   // Grid: 2048 wavefronts are resident (8 per CU, 2 per SIMD at this kernel's VGPR budget), i.e.
   // 2048 / NW workgroups.  Oversubscribing the resident set lets the hardware dispatcher do the
   // load balancing (pairs differ 10x in cost): a finished workgroup's slot is refilled at once.
-  // EPA_TH_WAVES_PER_SLOT tunes it (default 8 -> ~3 pairs per wave at 50k pairs).
-  uint32_t per_slot = 8;
+  // About four pairs per wave balance best (measured: 131k pairs 8 vs 16, 262k pairs 8 / 16 / 32
+  // / 64 -> 6.64 / 6.66 / 6.50 / 6.58 ms; one pair per wave: 10.2 ms).  EPA_TH_WAVES_PER_SLOT overrides.
+  uint32_t per_slot = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(8, n_pairs / (2048 * 4)));
   if (const char* e = getenv("EPA_TH_WAVES_PER_SLOT")) per_slot = (uint32_t)std::max(1, atoi(e));
   // class -> (wavefronts per pair NW, 64-site chunks per wavefront NCH): windows up to 192 sites
   // are one wave's job; longer ones are spread over 2 / 4 / 8 waves of a workgroup, each keeping
