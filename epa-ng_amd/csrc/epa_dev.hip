@@ -383,6 +383,7 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
   if (ctx->blen) (void)hipFree(ctx->blen);
   if (ctx->lookup) (void)hipFree(ctx->lookup);
   if (ctx->lookup2) (void)hipFree(ctx->lookup2);
+  if (ctx->th_ctr) (void)hipFree(ctx->th_ctr);
   if (ctx->refI) (void)hipFree(ctx->refI);
   if (ctx->cinv) (void)hipFree(ctx->cinv);
   if (ctx->resc0) (void)hipFree(ctx->resc0);
@@ -487,6 +488,7 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
 
   const size_t W = ctx->W, B = ctx->B, cs = (size_t)c * s;
   EPA_HIP(ctx, hipMalloc(&ctx->refT, sizeof(double) * 2 * B * cs * W));
+  EPA_HIP(ctx, hipMalloc(&ctx->th_ctr, 256));
   EPA_HIP(ctx, hipMalloc(&ctx->scSum, sizeof(uint32_t) * B * W));
   EPA_HIP(ctx, hipMemset(ctx->scSum, 0, sizeof(uint32_t) * B * W));
   EPA_HIP(ctx, hipMalloc(&ctx->blen, sizeof(double) * B));

@@ -96,6 +96,7 @@ struct epa_ctx {
   uint32_t cls_hist[16] = {};
   uint64_t cls_hist_pairs = 0;  // 0 = not valid
   uint32_t select_cap = 64;       // staging slots per query of the candidate selection
+  uint32_t* th_ctr = nullptr;  // work counters of the thorough kernel (one per XCD slice)
   int heur_mode = 0;        // EPA_HEUR_* (epa_dev_set_heuristic)
   double heur_param = 0.0;  // fixed: fraction of the branches
 

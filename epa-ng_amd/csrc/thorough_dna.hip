@@ -55,6 +55,7 @@ struct ThArgs {
   const uint32_t* win_span;
   epa_result* out;
   unsigned long long* stats;  // [0] rounds [1] newton evals [2] reverts [3] non-finite [4] first bad
+  uint32_t* qctr;          // single-wave classes: one work counter per XCD slice (dynamic pair fetch), or null
   double* sscratch;        // NCH == 0 only: [waves][16][Wpad]
   uint64_t n_pairs;
   uint32_t W;
@@ -497,8 +498,29 @@ __global__ void __launch_bounds__(64 * NW, 2) k_thorough_dna(const ThArgs a) {
   const uint64_t lo = (uint64_t)x * per;
   const uint64_t hi = lo + per < a.n_pairs ? lo + per : a.n_pairs;
   uint32_t wstat[3] = {0, 0, 0};
-  for (uint64_t p = lo + w; p < hi; p += stride)
-    process_pair<NCH, ZERO0, INV, NW>(a, p, lane, tab + cb.wv * 64, qts, lc, cb, wstat);
+  bool queued = false;
+  if constexpr (NW == 1) {
+    if (a.qctr) {
+      // resident waves fetch the next pair of their XCD slice from a counter: no relaunches, no
+      // tail of unlucky waves.  The next index is requested before the current pair is processed.
+      queued = true;
+      uint32_t* ctr = a.qctr + x;
+      const uint32_t cnt = (uint32_t)(hi > lo ? hi - lo : 0);
+      uint32_t nxt = 0;
+      if (lane == 0) nxt = atomicAdd(ctr, 1u);
+      nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+      while (nxt < cnt) {
+        const uint32_t cur = nxt;
+        uint32_t f = 0;
+        if (lane == 0) f = atomicAdd(ctr, 1u);
+        process_pair<NCH, ZERO0, INV, NW>(a, lo + cur, lane, tab + cb.wv * 64, qts, lc, cb, wstat);
+        nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+      }
+    }
+  }
+  if (!queued)
+    for (uint64_t p = lo + w; p < hi; p += stride)
+      process_pair<NCH, ZERO0, INV, NW>(a, p, lane, tab + cb.wv * 64, qts, lc, cb, wstat);
   if (threadIdx.x == 0) {
     atomicAdd(&a.stats[0], (unsigned long long)wstat[0]);
     atomicAdd(&a.stats[1], (unsigned long long)wstat[1]);
@@ -763,9 +785,18 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
   // class -> (wavefronts per pair NW, 64-site chunks per wavefront NCH): windows up to 192 sites
   // are one wave's job; longer ones are spread over 2 / 4 / 8 waves of a workgroup, each keeping
   // its part of the sumtable in registers (NCH stays <= 3: the kernel's register budget)
+  // single-wave classes: resident waves + a work counter per XCD slice (EPA_TH_QUEUE=0: the
+  // oversubscribed static grid instead; 262k pairs: 6.56 -> 6.47 ms)
+  static const bool use_queue = !(getenv("EPA_TH_QUEUE") && atoi(getenv("EPA_TH_QUEUE")) == 0);
 #define LAUNCH(N, NW_)                                                                            \
   do {                                                                                            \
     uint64_t want = (uint64_t)256 * 8 * per_slot / (NW_);                                          \
+    a.qctr = nullptr;                                                                              \
+    if ((NW_) == 1 && use_queue && ctx->th_ctr) {                                                  \
+      EPA_HIP(ctx, hipMemsetAsync(ctx->th_ctr, 0, 64, ctx->stream));                               \
+      a.qctr = ctx->th_ctr;                                                                        \
+      want = 2048;                                                                                 \
+    }                                                                                              \
     if (want > n_pairs) want = n_pairs;                                                            \
     const uint32_t nwg = (uint32_t)((want + 7) / 8 * 8);                                           \
     if (a.cinv) hipLaunchKernelGGL((k_thorough_dna<N, true, true, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
@@ -888,6 +919,7 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
     a.out = d_out;
     a.stats = d_stats;
     a.sscratch = nullptr;
+    a.qctr = nullptr;
     a.n_pairs = hist[c];
     a.W = ctx->W;
     a.Wpad = 0;
