@@ -1084,15 +1084,19 @@ extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const u
   const uint32_t* d_begin = (const uint32_t*)epa_to_device(ctx, 1, win_begin, sizeof(uint32_t) * Q);
   const uint32_t* d_span = (const uint32_t*)epa_to_device(ctx, 2, win_span, sizeof(uint32_t) * Q);
   if (!d_codes || !d_begin || !d_span) return epa_fail(ctx, EPA_ERR_HIP, "query upload failed");
-  double* d_lnl = (double*)epa_scratch(ctx, 3, sizeof(double) * (size_t)Q * ctx->B);
+  // internal table: rows padded to whole 64-byte sectors (the preplacement kernels write 8
+  // consecutive branches per burst; with rows of B doubles every burst straddled two sectors)
+  const uint32_t pitch = (ctx->B + 7u) & ~7u;
+  double* d_lnl = (double*)epa_scratch(ctx, 3, sizeof(double) * (size_t)Q * pitch);
   const bool pairs_dev = epa_is_device_ptr(pairs), res_dev = epa_is_device_ptr(results);
   epa_pair* d_pairs = pairs_dev ? pairs : (epa_pair*)epa_scratch(ctx, 4, sizeof(epa_pair) * max_pairs);
   epa_result* d_res = res_dev ? results : (epa_result*)epa_scratch(ctx, 5, sizeof(epa_result) * max_pairs);
   if (!d_lnl || !d_pairs || !d_res) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(chunk buffers)");
+  ctx->lnl_pitch = pitch;
   rc = launch_preplace(ctx, d_codes, d_begin, d_span, Q, d_lnl, max_span);
-  if (rc) return rc;
   uint64_t n = 0;
-  rc = launch_select(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, &n, d_span);  // syncs once
+  if (!rc) rc = launch_select(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, &n, d_span);  // syncs once
+  ctx->lnl_pitch = 0;
   if (rc) return rc;
   rc = preplace_check_status(ctx);
   if (rc) return rc;

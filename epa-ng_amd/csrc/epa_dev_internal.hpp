@@ -97,6 +97,7 @@ struct epa_ctx {
   uint64_t cls_hist_pairs = 0;  // 0 = not valid
   uint32_t select_cap = 64;       // staging slots per query of the candidate selection
   uint32_t* th_ctr = nullptr;  // work counters of the thorough kernel (one per XCD slice)
+  uint32_t lnl_pitch = 0;  // row pitch (doubles) of the table handed to launch_preplace / launch_select; 0 = B
   int heur_mode = 0;        // EPA_HEUR_* (epa_dev_set_heuristic)
   double heur_param = 0.0;  // fixed: fraction of the branches
 

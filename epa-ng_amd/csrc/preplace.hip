@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(GQ, ACC ? 2 : 4) k_preplace(const double* __re
                                                  const uint32_t* __restrict__ perm,
                                                  const Group* __restrict__ groups, uint32_t W,
                                                  uint32_t cstride, uint32_t crel,
-                                                 uint32_t B, size_t codes_bytes, uint32_t want_cls,
+                                                 uint32_t B, uint32_t pitch, size_t codes_bytes, uint32_t want_cls,
                                                  const uint32_t* __restrict__ status,
                                                  double* __restrict__ lnl) {
   constexpr bool SWZ = NCOLS == 16;
@@ -329,12 +329,12 @@ __global__ void __launch_bounds__(GQ, ACC ? 2 : 4) k_preplace(const double* __re
             if ((uint32_t)k < ntail) sum += at(s0 + k, (w >> (8 * k)) & 0xff);
         }
         if (ACC) accs[j * GQ + t] = sum;
-        else lnl[(size_t)qi * B + b0 + j] = sum;
+        else lnl[(size_t)qi * pitch + b0 + j] = sum;
       }
     }
   }
   if (ACC && active) {
-    double* out = lnl + (size_t)qi * B + b0;
+    double* out = lnl + (size_t)qi * pitch + b0;
     for (uint32_t j = 0; j < nb; ++j) out[j] = accs[j * GQ + t];
   }
   }  // work items
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     const double* __restrict__ lookup2, const uint16_t* __restrict__ packed,
     const uint16_t* __restrict__ tails, const uint32_t* __restrict__ win_begin,
     const uint32_t* __restrict__ win_span, const uint32_t* __restrict__ perm,
-    const Group* __restrict__ groups, uint32_t W, uint32_t B, uint32_t NP16,
+    const Group* __restrict__ groups, uint32_t W, uint32_t B, uint32_t pitch, uint32_t NP16,
     const uint32_t* __restrict__ status, double* __restrict__ lnl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [TROWS2][PE] doubles, then accs
   double* accs = reinterpret_cast<double*>(smem + (size_t)TROWS2 * PROWB);  // [NB2_ACC][GQ2] (ACC only)
@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
           // were evicted sector by sector -- 1.76 GB written for a 0.41 GB table
           accs[(j & 7u) * GQ2 + t] = sum;
           if ((j & 7u) == 7u || j + 1 == nb) {
-            double* out = lnl + (size_t)qi * B + b0 + (j & ~7u);
+            double* out = lnl + (size_t)qi * pitch + b0 + (j & ~7u);
             for (uint32_t k = 0; k <= (j & 7u); ++k) out[k] = accs[k * GQ2 + t];
           }
         }
@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     }
   }
   if (ACC && active) {
-    double* out = lnl + (size_t)qi * B + b0;
+    double* out = lnl + (size_t)qi * pitch + b0;
     for (uint32_t j = 0; j < nb; ++j) out[j] = accs[j * GQ2 + t];
   }
   }  // work items
@@ -638,7 +638,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
     const double* __restrict__ lookup, const uint16_t* __restrict__ packed,
     const uint16_t* __restrict__ tails, const uint32_t* __restrict__ win_begin,
     const uint32_t* __restrict__ win_span, const uint32_t* __restrict__ perm,
-    const Group* __restrict__ groups, uint32_t W, uint32_t B, uint32_t NP16,
+    const Group* __restrict__ groups, uint32_t W, uint32_t B, uint32_t pitch, uint32_t NP16,
     const uint32_t* __restrict__ status, double* __restrict__ lnl) {
   constexpr uint32_t ROWB = NCOLS * 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [TROWS_S][NCOLS] doubles, then accs
@@ -771,7 +771,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
             // were evicted sector by sector -- 1.76 GB written for a 0.41 GB table
             accs[(j & 7u) * GQ2 + t] = sum;
             if ((j & 7u) == 7u || j + 1 == nb) {
-              double* out = lnl + (size_t)qi * B + b0 + (j & ~7u);
+              double* out = lnl + (size_t)qi * pitch + b0 + (j & ~7u);
               for (uint32_t k = 0; k <= (j & 7u); ++k) out[k] = accs[k * GQ2 + t];
             }
           }
@@ -779,7 +779,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
       }
     }
     if (ACC && active) {
-      double* out = lnl + (size_t)qi * B + b0;
+      double* out = lnl + (size_t)qi * pitch + b0;
       for (uint32_t j = 0; j < nb; ++j) out[j] = accs[j * GQ2 + t];
     }
   }  // work items
@@ -837,7 +837,7 @@ struct SelRule {
 };
 
 template <int NR>
-__global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, uint32_t Q, uint32_t B,
+__global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, uint32_t Q, uint32_t B, uint32_t pitch,
                                                 double threshold, int mode, uint32_t limit, uint32_t cap,
                                                 unsigned long long* __restrict__ stage,
                                                 uint32_t* __restrict__ counts,
@@ -845,7 +845,7 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
   const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (q >= Q) return;
-  const double* src = lnl + (size_t)q * B;
+  const double* src = lnl + (size_t)q * pitch;
   double v[NR];
   double mx = -INFINITY;
 #pragma unroll
@@ -893,7 +893,7 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
 // read exactly once; wave-level (max, argmax, sum) results are combined across the four waves
 // through LDS.  Used for 4096 < B <= 16384.
 template <int NRT>
-__global__ void __launch_bounds__(256) k_select_wg(const double* __restrict__ lnl, uint32_t Q, uint32_t B,
+__global__ void __launch_bounds__(256) k_select_wg(const double* __restrict__ lnl, uint32_t Q, uint32_t B, uint32_t pitch,
                                                    double threshold, int mode, uint32_t limit, uint32_t cap,
                                                    unsigned long long* __restrict__ stage,
                                                    uint32_t* __restrict__ counts,
@@ -902,7 +902,7 @@ __global__ void __launch_bounds__(256) k_select_wg(const double* __restrict__ ln
   __shared__ uint32_t s_idx[2][4];
   const uint32_t q = blockIdx.x;
   const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const double* src = lnl + (size_t)q * B;
+  const double* src = lnl + (size_t)q * pitch;
   double v[NRT];
   double mx = -INFINITY;
 #pragma unroll
@@ -974,7 +974,7 @@ __global__ void __launch_bounds__(256) k_select_wg(const double* __restrict__ ln
 // branch: 3-4 on typical data); taken branches are remembered in a per-lane bitmask
 // (element i lives in lane i % 64, bit i / 64; up to 64 x 64 x NW branches).
 template <int NW>
-__global__ void __launch_bounds__(256) k_select_big(const double* __restrict__ lnl, uint32_t Q, uint32_t B,
+__global__ void __launch_bounds__(256) k_select_big(const double* __restrict__ lnl, uint32_t Q, uint32_t B, uint32_t pitch,
                                                     double threshold, int mode, uint32_t limit, uint32_t cap,
                                                     unsigned long long* __restrict__ stage,
                                                     uint32_t* __restrict__ counts,
@@ -982,7 +982,7 @@ __global__ void __launch_bounds__(256) k_select_big(const double* __restrict__ l
   const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63;
   if (q >= Q) return;
-  const double* src = lnl + (size_t)q * B;
+  const double* src = lnl + (size_t)q * pitch;
   unsigned long long takenmask[NW];
 #pragma unroll
   for (int w = 0; w < NW; ++w) takenmask[w] = 0ull;
@@ -1078,6 +1078,7 @@ int launch_build_lookup2(epa_ctx* ctx) {
 
 int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin,
                     const uint32_t* d_span, uint32_t Q, double* d_lnl, uint32_t max_span) {
+  const uint32_t pitch = ctx->lnl_pitch ? ctx->lnl_pitch : ctx->B;  // row pitch of d_lnl in doubles
   const bool pairs = ctx->s == 4 && ctx->lookup2 && !getenv("EPA_PREPLACE_GENERIC");
   const bool sites = ctx->s == 20 && ctx->ncols == 24 && !getenv("EPA_PREPLACE_GENERIC");
   const uint32_t crel = ctx->code_stride ? 1u : 0u, cstride = crel ? ctx->code_stride : ctx->W;
@@ -1161,7 +1162,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<A>,                               \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));        \
     hipLaunchKernelGGL((k_preplace_pairs<A>), grid2, dim3(GQ2), lds2, ctx->stream, ctx->lookup2, packed, \
-                       tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, NP16, status, d_lnl);           \
+                       tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl);    \
   } while (0)
   if (pairs) { if (acc) PRE2(true); else PRE2(false); }
 #undef PRE2
@@ -1175,7 +1176,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_sites<24, A>,                           \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));       \
     hipLaunchKernelGGL((k_preplace_sites<24, A>), grid_s, dim3(GQ2), lds_s, ctx->stream, ctx->lookup, \
-                       packed, tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, NP16, status, d_lnl); \
+                       packed, tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl); \
   } while (0)
     if (acc_s) PRES(true); else PRES(false);
 #undef PRES
@@ -1188,7 +1189,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace<NC, A>,                                \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
     hipLaunchKernelGGL((k_preplace<NC, A>), grid, dim3(GQ), lds, ctx->stream, ctx->lookup, d_codes, \
-                       d_begin, d_span, perm, groups, ctx->W, cstride, crel, ctx->B, codes_bytes, want_cls, status, d_lnl); \
+                       d_begin, d_span, perm, groups, ctx->W, cstride, crel, ctx->B, pitch, codes_bytes, want_cls, status, d_lnl); \
   } while (0)
   if (ctx->ncols == 16) { if (acc) PRE(16, true); else PRE(16, false); }
   else { if (acc) PRE(24, true); else PRE(24, false); }
@@ -1215,6 +1216,7 @@ int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshol
                   epa_pair* d_pairs, uint64_t max_pairs, uint64_t* n_pairs, const uint32_t* d_span) {
   ctx->cls_hist_pairs = 0;
   const uint32_t B = ctx->B;
+  const uint32_t pitch = ctx->lnl_pitch ? ctx->lnl_pitch : B;  // row pitch of d_lnl in doubles
   if (B > 64 * 64 * 16)
     return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "select_candidates: more than 65536 branches");
   // selection rule of the context (epa_dev_set_heuristic); fixed: ceil(x * B) best, at least... none:
@@ -1254,12 +1256,12 @@ int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshol
     epa_timer_start(ctx, ctx->t_select);
     const dim3 grid((Q + 3) / 4);
     const int nr = (int)((B + 63) / 64);
-#define SEL(N) hipLaunchKernelGGL(k_select<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, mode, limit, cap, stage, counts, status)
-#define SELBIG(N) hipLaunchKernelGGL(k_select_big<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, mode, limit, cap, stage, counts, status)
+#define SEL(N) hipLaunchKernelGGL(k_select<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, cap, stage, counts, status)
+#define SELBIG(N) hipLaunchKernelGGL(k_select_big<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, cap, stage, counts, status)
     if (nr <= 2) SEL(2); else if (nr <= 4) SEL(4); else if (nr <= 8) SEL(8); else if (nr <= 16) SEL(16);
     else if (nr <= 32) SEL(32); else if (nr <= 64) SEL(64);
-    else if (nr <= 128) hipLaunchKernelGGL(k_select_wg<32>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, mode, limit, cap, stage, counts, status);
-    else if (nr <= 256) hipLaunchKernelGGL(k_select_wg<64>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, threshold, mode, limit, cap, stage, counts, status);
+    else if (nr <= 128) hipLaunchKernelGGL(k_select_wg<32>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, cap, stage, counts, status);
+    else if (nr <= 256) hipLaunchKernelGGL(k_select_wg<64>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, cap, stage, counts, status);
     else SELBIG(16);
 #undef SELBIG
 #undef SEL
