@@ -87,6 +87,16 @@ int epa_host_ref_numbered_newick(void* h, unsigned precision, char* out, size_t 
   return (int)s.size();
 }
 
+// model descriptor scraped from a model file (src/util/parse_model.hpp); returns the length, or
+// -needed if `cap` is too small, or INT_MIN on error (epa_host_last_error)
+int epa_host_parse_model(const char* file, char* out, size_t cap) {
+  std::string s;
+  if (guarded([&] { s = epa::parse_model(file); })) return -2147483647 - 1;
+  if (s.size() + 1 > cap) return -(int)s.size();
+  std::memcpy(out, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+
 // rooted input tree: placement (edge, distal) on the unrooted working tree -> on the rooted tree
 // (rtree_mapper::in_rtree).  Returns 1 when no mapping is active (unrooted input / preserve off).
 int epa_host_ref_in_rtree(void* h, uint32_t branch, double distal, uint32_t* out_branch, double* out_distal) {

@@ -138,7 +138,10 @@ private:
   std::vector<double> subst_, freqs_, rates_, weights_, eigenvals_, u_, uinv_;
 };
 
-std::vector<double> compute_gamma_cats(double alpha, int k);  // mean mode (pll_compute_gamma_cats)
+std::vector<double> compute_gamma_cats(double alpha, int k, bool median = false);  // pll_compute_gamma_cats
+// model descriptor from a RAxML 8 info / RAxML-NG .bestModel / IQ-TREE report file
+// (src/util/parse_model.hpp)
+std::string parse_model(const std::string& file);
 
 struct Tree_Numbers {  // src/tree/Tree_Numbers.hpp
   unsigned int tip_nodes = 0, inner_nodes = 0, nodes = 0, branches = 0;

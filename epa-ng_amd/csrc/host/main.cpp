@@ -18,7 +18,8 @@ static void usage() {
       "  -t,--tree FILE        reference tree (newick, unrooted or rooted)\n"
       "  -s,--ref-msa FILE     reference MSA (fasta)\n"
       "  -q,--query FILE       query MSA (fasta, aligned to the reference)\n"
-      "  -m,--model STR        model descriptor, e.g. GTR{..}+FU{..}+G4{a} (default GTR+G)\n"
+      "  -m,--model STR|FILE   model descriptor, e.g. GTR{..}+FU{..}+G4{a} (default GTR+G), or a RAxML 8\n"
+      "                        info / RAxML-NG .bestModel / IQ-TREE report file\n"
       "  -w,--outdir DIR       output directory (default ./)\n"
       "  -g,--dyn-heur X       accumulated-LWR preplacement threshold (default 0.99999)\n"
       "  -G,--fix-heur X       fixed fraction of branches\n"
@@ -87,6 +88,10 @@ int main(int argc, char** argv) {
     std::stringstream ss;
     ss << tf.rdbuf();
     const MSA ref = read_fasta(ref_file);
+    {  // --model may name a RAxML 8 info / RAxML-NG .bestModel / IQ-TREE report file (src/main.cpp:433-436)
+      std::ifstream mf(model_desc);
+      if (mf.good()) model_desc = parse_model(model_desc);
+    }
     const Model model(model_desc);
     std::cout << "Using model parameters: " << model.to_string() << std::endl;
     const auto t_tree = std::chrono::steady_clock::now();

@@ -94,20 +94,28 @@ std::vector<double> parse_list(const std::string& s) {
 
 }  // namespace
 
-std::vector<double> compute_gamma_cats(double alpha, int k) {
-  // Yang 1994, category means: cut points are quantiles of Gamma(alpha, rate alpha); the mean of
-  // a slice is K * [P(alpha+1, alpha*hi) - P(alpha+1, alpha*lo)].
-  std::vector<double> cuts(k + 1, 0.0), rates(k);
-  for (int i = 1; i < k; ++i) {
-    const double p = (double)i / k;
+std::vector<double> compute_gamma_cats(double alpha, int k, bool median) {
+  // Yang 1994.  Quantiles of Gamma(alpha, rate alpha) by bisection on the regularised P.
+  auto quantile = [&](double p) {
     double lo = 0.0, hi = 1.0;
     while (gamma_p(alpha, hi * alpha) < p) hi *= 2.0;
     for (int it = 0; it < 300 && hi - lo > 1e-17 * hi; ++it) {
       const double mid = 0.5 * (lo + hi);
       (gamma_p(alpha, mid * alpha) < p ? lo : hi) = mid;
     }
-    cuts[i] = 0.5 * (lo + hi);
+    return 0.5 * (lo + hi);
+  };
+  std::vector<double> cuts(k + 1, 0.0), rates(k);
+  if (median) {
+    // PLL_GAMMA_RATES_MEDIAN ("+G4a"): the medians of the k equal-probability slices, rescaled to
+    // mean 1 (libpll's published algorithm, restated; not covered by a reference literal)
+    double sum = 0.0;
+    for (int i = 0; i < k; ++i) { rates[i] = quantile((2.0 * i + 1.0) / (2.0 * k)); sum += rates[i]; }
+    for (double& r : rates) r *= k / sum;
+    return rates;
   }
+  // category means: the mean of a slice is K * [P(alpha+1, alpha*hi) - P(alpha+1, alpha*lo)]
+  for (int i = 1; i < k; ++i) cuts[i] = quantile((double)i / k);
   double prev = 0.0;
   for (int i = 0; i < k; ++i) {
     const double cur = (i == k - 1) ? 1.0 : gamma_p(alpha + 1.0, cuts[i + 1] * alpha);
@@ -146,7 +154,7 @@ Model::Model(const std::string& descriptor) {
   freqs_.assign(states_, 1.0 / states_);
   int cats = 1;
   alpha_ = 1.0;
-  bool gamma = false, free_rates = false;
+  bool gamma = false, free_rates = false, gamma_median = false;
   std::string rest = pos == std::string::npos ? "" : descriptor.substr(pos);
   size_t i = 0;
   auto braces = [&](std::string& out) {
@@ -189,6 +197,10 @@ Model::Model(const std::string& descriptor) {
       size_t nb = i;
       while (i < rest.size() && std::isdigit((unsigned char)rest[i])) ++i;
       if (i > nb) cats = std::stoi(rest.substr(nb, i - nb));
+      // rate mode suffix of RAxML-NG descriptors (Model.cpp:390-396): m = category means
+      // (default), a = medians
+      if (i < rest.size() && (rest[i] == 'm' || rest[i] == 'M')) ++i;
+      else if (i < rest.size() && (rest[i] == 'a' || rest[i] == 'A')) { ++i; gamma_median = true; }
       if (braces(arg)) alpha_ = std::stod(arg);
     } else if (opt == "R") {
       // free rates: +R<n>{r1/../rn}{w1/../wn} (Model.cpp:405-455): weights normalised to sum 1
@@ -229,7 +241,7 @@ Model::Model(const std::string& descriptor) {
   }
   if (gamma && free_rates) throw std::runtime_error{"Model: +G and +R are mutually exclusive"};
   if (!free_rates) {
-    if (gamma) rates_ = compute_gamma_cats(alpha_, cats);
+    if (gamma) rates_ = compute_gamma_cats(alpha_, cats, gamma_median);
     else rates_.assign(1, 1.0);
     weights_.assign(rates_.size(), 1.0 / rates_.size());
   }

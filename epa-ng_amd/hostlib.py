@@ -33,6 +33,7 @@ def host_lib():
         L.epa_host_ref_create_ex2.argtypes = L.epa_host_ref_create_ex.argtypes + [C.c_int]
         L.epa_host_ref_in_rtree.argtypes = [C.c_void_p, C.c_uint32, C.c_double,
                                             C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+        L.epa_host_parse_model.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
         L.epa_host_ref_destroy.argtypes = [C.c_void_p]
         L.epa_host_configure_threads.restype = C.c_int
         u32p = C.POINTER(C.c_uint32)
@@ -191,6 +192,15 @@ def filter_lwr(lwr, thresh, acc=False, mn=1, mx=0xffffffff):
     if rc:
         raise RuntimeError(host_lib().epa_host_last_error().decode())
     return out[:n.value]
+
+
+def parse_model(path):
+    """model descriptor from a RAxML 8 info / RAxML-NG .bestModel / IQ-TREE report file"""
+    buf = C.create_string_buffer(1 << 16)
+    n = host_lib().epa_host_parse_model(str(path).encode(), buf, len(buf))
+    if n < 0:
+        raise RuntimeError(host_lib().epa_host_last_error().decode())
+    return buf.value.decode()
 
 
 def heuristic(lnl, mode="dynamic", thresh=0.99999):

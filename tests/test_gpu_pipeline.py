@@ -702,3 +702,30 @@ def test_cli_fix_and_baseball_heuristics(tmp_path):
             jp.pop("metadata", None)
             outs.append(jp)
         assert outs[0] == outs[1], flags
+
+
+def test_cli_model_file(tmp_path):
+    """-m <file>: the RAxML 8 info file of the reference's test data parses to the cfg1 descriptor
+    (test/src/parse_model.cpp:7-13), so the run must equal the one with the descriptor itself."""
+    import subprocess
+    g = load_case("dna8_gtr_fu_g4")
+    data = os.path.join(GOLDEN, "data")
+    qf = tmp_path / "q.fasta"
+    with open(qf, "w") as f:
+        for q in g["queries"]:
+            f.write(">%s\n%s\n" % (q["name"], q["seq"]))
+    exe = os.path.join(os.path.dirname(hostlib.HOST_SO), "epa-ng-amd")
+    desc = ("GTR{0.787874/1.821672/1.294006/0.698421/3.034135/1.000000}+FU{0.256465/0.222535/0.308594/"
+            "0.212406}+G4{0.478218}")
+    outs = []
+    for m in (desc, os.path.join(data, "modelfiles", "rax8_dna")):
+        od = tmp_path / ("o%d" % len(outs))
+        od.mkdir()
+        r = subprocess.run([exe, "-t", os.path.join(data, "ref.tre"), "-s", os.path.join(data, "aln.fasta"),
+                            "-q", str(qf), "-m", m, "-w", str(od)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "GTR{0.787874/1.821672/1.294006/0.698421/3.034135/1.000000}" in r.stdout
+        jp = json.load(open(od / "epa_result.jplace"))
+        jp.pop("metadata", None)
+        outs.append(jp)
+    assert outs[0] == outs[1] and len(outs[0]["placements"]) == len(g["queries"])
