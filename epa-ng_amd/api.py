@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEV_SO = os.environ.get("EPA_DEV_SO", os.path.join(HERE, "libepa_dev.so"))
 
 __all__ = ["EpaError", "dev_lib", "device_count", "encode_queries", "Evaluator", "PAIR_DTYPE",
-           "RESULT_DTYPE", "DEV_SO"]
+           "RESULT_DTYPE", "DEV_SO", "Packed4", "pack_codes_4bit", "unpack_codes_4bit"]
 
 PAIR_DTYPE = np.dtype([("branch_id", np.uint32), ("seq_id", np.uint32)])
 RESULT_DTYPE = np.dtype([("lnl", np.float64), ("pendant_length", np.float64),
@@ -91,6 +91,9 @@ def dev_lib():
         L.epa_dev_thorough.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(_Stats)]
         L.epa_dev_set_heuristic.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        L.epa_dev_set_query_packing.argtypes = [C.c_void_p, C.c_int]
+        L.epa_pack_codes_4bit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.epa_unpack_codes_4bit.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.epa_dev_select_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_double,
                                                 C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.epa_dev_place_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
@@ -111,10 +114,38 @@ def device_count():
     return dev_lib().epa_dev_device_count()
 
 
+class Packed4:
+    """code rows in the 4-bit wire format (epa_pack_codes_4bit): `data` is [Q][(stride + 1) // 2]
+    (numpy on the host or a torch cuda tensor), `stride` the row length of the unpacked layout"""
+
+    def __init__(self, data, stride):
+        self.data, self.stride = data, int(stride)
+
+
+def pack_codes_4bit(codes):
+    """[Q][stride] nucleotide codes -> Packed4 (two codes per byte, earlier site in the high nibble)"""
+    codes = np.ascontiguousarray(codes, np.uint8)
+    Q, stride = codes.shape
+    out = np.zeros((Q, (stride + 1) // 2), np.uint8)
+    rc = dev_lib().epa_pack_codes_4bit(codes.ctypes.data, Q, stride, out.ctypes.data)
+    if rc:
+        raise EpaError(rc, "pack_codes_4bit: a code does not fit four bits")
+    return Packed4(out, stride)
+
+
+def unpack_codes_4bit(p):
+    Q = p.data.shape[0]
+    out = np.zeros((Q, p.stride), np.uint8)
+    dev_lib().epa_unpack_codes_4bit(np.ascontiguousarray(p.data).ctypes.data, Q, p.stride, out.ctypes.data)
+    return out
+
+
 def _ptr(a):
     """numpy array -> host pointer; torch tensor / int -> raw (device) pointer"""
     if a is None:
         return None
+    if isinstance(a, Packed4):
+        return _ptr(a.data)
     if isinstance(a, np.ndarray):
         assert a.flags["C_CONTIGUOUS"]
         return a.ctypes.data
@@ -245,8 +276,10 @@ class Evaluator:
 
     def _layout(self, codes):
         """tells the context whether `codes` rows are aligned rows (W bytes) or compact windows"""
-        row = int(codes.shape[1]) if len(codes.shape) == 2 else self.W
+        packed = isinstance(codes, Packed4)
+        row = codes.stride if packed else (int(codes.shape[1]) if len(codes.shape) == 2 else self.W)
         self._check(self.L.epa_dev_set_query_layout(self.h, 0 if row == self.W else row))
+        self._check(self.L.epa_dev_set_query_packing(self.h, 4 if packed else 8))
 
     def preplace(self, codes, win_begin, win_span, Q=None, out=None):
         """-> lnl [Q][B].  Inputs numpy (host) or torch cuda tensors (HBM-resident)."""

@@ -45,6 +45,34 @@ const void* epa_to_device(epa_ctx* ctx, int slot, const void* p, size_t bytes) {
   return d;
 }
 
+// 4-bit wire format (the packing of the reference's FourBit, src/io/encoding.hpp:18-27,81-97: two
+// codes per byte, the earlier site in the high nibble, an odd row padded with code 0).  The DNA
+// column codes ARE the 4-bit state sets, so a row of `stride` codes travels as (stride + 1) / 2
+// bytes and is expanded on the device into the one-byte layout every kernel reads.
+__global__ void __launch_bounds__(256) k_unpack4(const uint8_t* __restrict__ packed, uint8_t* __restrict__ codes,
+                                                 uint32_t Q, uint32_t stride, uint32_t pstride) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // one packed byte each
+  if (i >= (uint64_t)Q * pstride) return;
+  const uint32_t q = (uint32_t)(i / pstride), p = (uint32_t)(i - (uint64_t)q * pstride);
+  const uint8_t b = packed[i];
+  uint8_t* row = codes + (size_t)q * stride;
+  row[2 * p] = b >> 4;
+  if (2 * p + 1 < stride) row[2 * p + 1] = b & 15u;
+}
+
+const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_t Q) {
+  const size_t stride = ctx->code_stride ? ctx->code_stride : ctx->W;
+  if (!ctx->code_packed4) return (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * stride);
+  const size_t pstride = (stride + 1) / 2;
+  const uint8_t* d_packed = (const uint8_t*)epa_to_device(ctx, 10, q_codes, (size_t)Q * pstride);
+  uint8_t* d = (uint8_t*)epa_scratch(ctx, 0, (size_t)Q * stride + 1024);
+  if (!d_packed || !d) return nullptr;
+  const uint64_t n = (uint64_t)Q * pstride;
+  hipLaunchKernelGGL(k_unpack4, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_packed, d, Q,
+                     (uint32_t)stride, (uint32_t)pstride);
+  return d;
+}
+
 void epa_timer_start(epa_ctx* ctx, EvTimer& t) {
   if (!t.a) { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
   (void)hipEventRecord(t.a, ctx->stream);
@@ -364,6 +392,41 @@ extern "C" int epa_dev_set_heuristic(epa_ctx* ctx, int mode, double param) {
     return epa_fail(ctx, EPA_ERR_INVALID_ARG, "set_heuristic: the fraction must lie in [0, 1]");
   ctx->heur_mode = mode;
   ctx->heur_param = param;
+  return EPA_OK;
+}
+
+extern "C" int epa_dev_set_query_packing(epa_ctx* ctx, int bits) {
+  if (!ctx) return EPA_ERR_INVALID_ARG;
+  if (bits != 8 && bits != 4) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "set_query_packing: 8 or 4 bits per code");
+  if (bits == 4 && ctx->s != 4)
+    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "set_query_packing: the 4-bit format holds nucleotide codes only");
+  ctx->code_packed4 = bits == 4;
+  return EPA_OK;
+}
+
+extern "C" int epa_pack_codes_4bit(const uint8_t* codes, uint32_t Q, uint32_t stride, uint8_t* packed) {
+  if (!codes || !packed) return EPA_ERR_INVALID_ARG;
+  const size_t ps = ((size_t)stride + 1) / 2;
+  for (uint32_t q = 0; q < Q; ++q) {
+    const uint8_t* r = codes + (size_t)q * stride;
+    uint8_t* o = packed + (size_t)q * ps;
+    for (uint32_t p = 0; p < ps; ++p) {
+      const uint8_t hi = r[2 * p], lo = (2 * p + 1 < stride) ? r[2 * p + 1] : 0;
+      if (hi > 15 || lo > 15) return EPA_ERR_INVALID_ARG;
+      o[p] = (uint8_t)((hi << 4) | lo);
+    }
+  }
+  return EPA_OK;
+}
+
+extern "C" int epa_unpack_codes_4bit(const uint8_t* packed, uint32_t Q, uint32_t stride, uint8_t* codes) {
+  if (!codes || !packed) return EPA_ERR_INVALID_ARG;
+  const size_t ps = ((size_t)stride + 1) / 2;
+  for (uint32_t q = 0; q < Q; ++q)
+    for (uint32_t i = 0; i < stride; ++i) {
+      const uint8_t b = packed[(size_t)q * ps + i / 2];
+      codes[(size_t)q * stride + i] = (i & 1) ? (b & 15u) : (b >> 4);
+    }
   return EPA_OK;
 }
 
@@ -959,7 +1022,7 @@ extern "C" int epa_dev_preplace(epa_ctx* ctx, const uint8_t* q_codes, const uint
   EPA_HIP(ctx, hipSetDevice(ctx->device));
   int rc = epa_dev_build_lookup(ctx);
   if (rc) return rc;
-  const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * (ctx->code_stride ? ctx->code_stride : ctx->W));
+  const uint8_t* d_codes = epa_codes_to_device(ctx, q_codes, Q);
   const uint32_t* d_begin = (const uint32_t*)epa_to_device(ctx, 1, win_begin, sizeof(uint32_t) * Q);
   const uint32_t* d_span = (const uint32_t*)epa_to_device(ctx, 2, win_span, sizeof(uint32_t) * Q);
   if (!d_codes || !d_begin || !d_span) return epa_fail(ctx, EPA_ERR_HIP, "query upload failed");
@@ -1002,7 +1065,7 @@ extern "C" int epa_dev_thorough(epa_ctx* ctx, const epa_pair* pairs, uint64_t n_
       if (pairs[i].branch_id >= ctx->B || pairs[i].seq_id >= Q)
         return epa_fail(ctx, EPA_ERR_INVALID_ARG, "pair index out of range");
   }
-  const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * (ctx->code_stride ? ctx->code_stride : ctx->W));
+  const uint8_t* d_codes = epa_codes_to_device(ctx, q_codes, Q);
   const uint32_t* d_begin = (const uint32_t*)epa_to_device(ctx, 1, win_begin, sizeof(uint32_t) * Q);
   const uint32_t* d_span = (const uint32_t*)epa_to_device(ctx, 2, win_span, sizeof(uint32_t) * Q);
   const epa_pair* d_pairs = (const epa_pair*)epa_to_device(ctx, 4, pairs, sizeof(epa_pair) * n_pairs);
@@ -1080,7 +1143,7 @@ extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const u
     for (uint32_t q = 0; q < Q; ++q) max_span = std::max(max_span, hs[q]);
   }
   if (max_span > ctx->W) max_span = ctx->W;
-  const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * (ctx->code_stride ? ctx->code_stride : ctx->W));
+  const uint8_t* d_codes = epa_codes_to_device(ctx, q_codes, Q);
   const uint32_t* d_begin = (const uint32_t*)epa_to_device(ctx, 1, win_begin, sizeof(uint32_t) * Q);
   const uint32_t* d_span = (const uint32_t*)epa_to_device(ctx, 2, win_span, sizeof(uint32_t) * Q);
   if (!d_codes || !d_begin || !d_span) return epa_fail(ctx, EPA_ERR_HIP, "query upload failed");
@@ -1258,7 +1321,7 @@ extern "C" int epa_dev_place_all(epa_ctx* ctx, const uint8_t* q_codes, const uin
   if (max_span == 0 || max_span < ms) max_span = ms;
   const uint64_t n = (uint64_t)ctx->B * Q;
   if (n > 0xffffffffull) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "place_all: more than 2^32 pairs per chunk");
-  const uint8_t* d_codes = (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * (ctx->code_stride ? ctx->code_stride : ctx->W));
+  const uint8_t* d_codes = epa_codes_to_device(ctx, q_codes, Q);
   const uint32_t* d_begin = (const uint32_t*)epa_to_device(ctx, 1, win_begin, sizeof(uint32_t) * Q);
   const uint32_t* d_span = (const uint32_t*)epa_to_device(ctx, 2, win_span, sizeof(uint32_t) * Q);
   if (!d_codes || !d_begin || !d_span) return epa_fail(ctx, EPA_ERR_HIP, "query upload failed");

@@ -86,7 +86,7 @@ struct epa_ctx {
   std::vector<double> h_blen;
 
   // per-call scratch (grown on demand)
-  static constexpr int N_SCRATCH = 10;
+  static constexpr int N_SCRATCH = 11;
   void* scratch[N_SCRATCH] = {};
   size_t scratch_sz[N_SCRATCH] = {};
 
@@ -98,6 +98,7 @@ struct epa_ctx {
   uint32_t select_cap = 64;       // staging slots per query of the candidate selection
   uint32_t* th_ctr = nullptr;  // work counters of the thorough kernel (one per XCD slice)
   uint32_t lnl_pitch = 0;  // row pitch (doubles) of the table handed to launch_preplace / launch_select; 0 = B
+  bool code_packed4 = false;  // q_codes arrive in the 4-bit wire format (epa_dev_set_query_packing)
   int heur_mode = 0;        // EPA_HEUR_* (epa_dev_set_heuristic)
   double heur_param = 0.0;  // fixed: fraction of the branches
 
@@ -111,6 +112,10 @@ void* epa_scratch(epa_ctx* ctx, int slot, size_t bytes);
 bool epa_is_device_ptr(const void* p);
 // returns a device pointer holding `bytes` of *p (copying into scratch slot if p is on the host)
 const void* epa_to_device(epa_ctx* ctx, int slot, const void* p, size_t bytes);
+// query code rows -> device in the one-byte layout the kernels read (unpacks the 4-bit wire format)
+const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_t Q);
+// query code rows -> device in the one-byte layout the kernels read (unpacks the 4-bit wire format)
+const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_t Q);
 void epa_timer_start(epa_ctx* ctx, EvTimer& t);
 void epa_timer_stop(epa_ctx* ctx, EvTimer& t);
 

@@ -290,7 +290,9 @@ private:
 
 // encoded chunk of queries (what crosses the C-ABI)
 struct Encoded_Chunk {
-  std::vector<uint8_t> codes;  // compact layout: row q = the window of query q, `stride` bytes
+  std::vector<uint8_t> codes;  // compact layout: row q = the window of query q, `stride` codes;
+                               // nucleotides travel in the 4-bit wire format (bits == 4: two codes per byte)
+  int bits = 8;
   std::vector<uint32_t> win_begin, win_span;
   uint32_t stride = 0;
 };

@@ -111,6 +111,14 @@ Encoded_Chunk encode_chunk(const MSA& chunk, const Tree& tree, const Options& op
   check(epa_encode_queries_compact((uint32_t)tree.model().num_states(), (uint32_t)W, (uint32_t)Q,
                                    rows.data(), options.premasking, options.aa_x_as_n, e.stride,
                                    e.codes.data(), e.win_begin.data(), e.win_span.data(), &bad));
+  if (tree.model().num_states() == 4) {
+    // the reference's 4-bit packing (src/io/encoding.hpp) as the H2D wire format: half the bytes
+    std::vector<uint8_t> packed(Q * (size_t)((e.stride + 1) / 2));
+    if (epa_pack_codes_4bit(e.codes.data(), (uint32_t)Q, e.stride, packed.data()) != EPA_OK)
+      throw std::runtime_error{"query packing failed"};
+    e.codes.swap(packed);
+    e.bits = 4;
+  }
   return e;
 }
 
@@ -119,6 +127,7 @@ void place(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, Device_
   const size_t Q = chunk.size(), B = tree.num_branches();
   lnl.resize(Q * B);
   epa_dev_set_query_layout(dev.ctx(), enc.stride);
+  epa_dev_set_query_packing(dev.ctx(), enc.bits);
   const int rc = epa_dev_preplace(dev.ctx(), enc.codes.data(), enc.win_begin.data(),
                                   enc.win_span.data(), (uint32_t)Q, lnl.data());
   if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
@@ -211,6 +220,7 @@ void place_thorough(const Work& to_place, const MSA& chunk, const Encoded_Chunk&
     pairs[i] = epa_pair{(uint32_t)to_place[i].branch_id, (uint32_t)to_place[i].sequence_id};
   std::vector<epa_result> res(n);
   epa_dev_set_query_layout(dev.ctx(), enc.stride);
+  epa_dev_set_query_packing(dev.ctx(), enc.bits);
   const int rc = epa_dev_thorough(dev.ctx(), pairs.data(), n, enc.codes.data(), enc.win_begin.data(),
                                   enc.win_span.data(), (uint32_t)Q, res.data(), nullptr);
   if (rc == EPA_ERR_NEG_INF)  // Tiny_Tree.cpp:209-212
@@ -244,6 +254,7 @@ void place_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, D
     if (pairs.size() < cap) pairs.resize(cap);
     if (res.size() < cap) res.resize(cap);
     epa_dev_set_query_layout(dev.ctx(), enc.stride);
+  epa_dev_set_query_packing(dev.ctx(), enc.bits);
     const int rc = epa_dev_place_chunk(dev.ctx(), enc.codes.data(), enc.win_begin.data(),
                                        enc.win_span.data(), (uint32_t)Q, max_span,
                                        options.prescoring_threshold, pairs.data(), res.data(), cap, &n,
@@ -271,6 +282,7 @@ size_t place_all(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, D
   uint32_t max_span = 0;
   for (uint32_t s : enc.win_span) max_span = std::max(max_span, s);
   epa_dev_set_query_layout(dev.ctx(), enc.stride);
+  epa_dev_set_query_packing(dev.ctx(), enc.bits);
   const int rc = epa_dev_place_all(dev.ctx(), enc.codes.data(), enc.win_begin.data(), enc.win_span.data(),
                                    (uint32_t)Q, max_span, options.support_threshold,
                                    options.acc_threshold ? 1 : 0, options.filter_min, options.filter_max,

@@ -217,6 +217,19 @@ int epa_encode_queries_compact(uint32_t states, uint32_t sites, uint32_t Q, cons
 int epa_dev_set_query_layout(epa_ctx* ctx, uint32_t code_stride);
 
 /*
+ * 4-bit wire format for nucleotide queries (the packing of the reference's FourBit,
+ * src/io/encoding.hpp:18-27,81-97): two codes per byte, the earlier site in the high nibble, an
+ * odd row padded with code 0 ('-').  The DNA column codes of epa_encode_queries*() are the 4-bit
+ * state sets of NT_MAP (src/util/maps.hpp:9-26), so a row of `stride` codes packs into
+ * (stride + 1) / 2 bytes.  epa_dev_set_query_packing(ctx, 4) tells a context that the q_codes of
+ * the following calls are packed rows (row pitch (stride + 1) / 2, stride = the query layout's
+ * row length); they are expanded on the device.  8 (default) = one byte per code.
+ */
+int epa_pack_codes_4bit(const uint8_t* codes, uint32_t Q, uint32_t stride, uint8_t* packed);
+int epa_unpack_codes_4bit(const uint8_t* packed, uint32_t Q, uint32_t stride, uint8_t* codes);
+int epa_dev_set_query_packing(epa_ctx* ctx, int bits);
+
+/*
  * Replaces place() (src/core/place.cpp:41-95): lnl[q*B + b] = sum over the query's window of
  * T[b][site][code(q,site)]  (Lookup_Store::sum_precomputed_sitelk, Lookup_Store.hpp:110-141,
  * same summation order).  pendant = pendant_default and distal = branch_length/2 are implied.

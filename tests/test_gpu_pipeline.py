@@ -729,3 +729,37 @@ def test_cli_model_file(tmp_path):
         jp.pop("metadata", None)
         outs.append(jp)
     assert outs[0] == outs[1] and len(outs[0]["placements"]) == len(g["queries"])
+
+
+def test_fourbit_wire_format_same_results():
+    """queries in the 4-bit wire format (epa_dev_set_query_packing): expanded on the device, every
+    entry point returns exactly what it returns for one-byte codes; aligned rows of odd length and
+    compact rows, host arrays and device-resident buffers; rejected for 20 states"""
+    import torch
+    from epa_ng_amd import synth
+    w = synth.dna_workload(24, 701, 300, 120, (171, 172, 173))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    reads = list(w["reads"])
+    reads[3] = reads[3].replace("A", "R", 2).replace("C", "N", 1)   # ambiguity codes survive the nibbles
+    for compact in (False, True):
+        codes, wb, ws = epa.encode_queries(4, reads, compact=compact)
+        packed = epa.pack_codes_4bit(codes)
+        assert packed.data.shape[1] == (codes.shape[1] + 1) // 2
+        lnl = ev.preplace(codes, wb, ws)
+        assert np.array_equal(ev.preplace(packed, wb, ws), lnl)
+        p1, r1 = ev.place_chunk(codes, wb, ws, max_span=int(ws.max()))
+        p2, r2 = ev.place_chunk(packed, wb, ws, max_span=int(ws.max()))
+        assert np.array_equal(p1, p2) and np.array_equal(r1, r2)
+        dev = epa.Packed4(torch.from_numpy(packed.data).cuda(), packed.stride)
+        p3, r3 = ev.place_chunk(dev, torch.from_numpy(wb.view(np.int32)).cuda(),
+                                torch.from_numpy(ws.view(np.int32)).cuda(), Q=len(reads), max_span=int(ws.max()))
+        assert np.array_equal(p1, p3) and np.array_equal(r1, r3)
+        assert np.array_equal(ev.thorough(p1, packed, wb, ws), ev.thorough(p1, codes, wb, ws))
+    wa = synth.aa_workload(8, 60, 4, 30, (174, 175, 176))
+    ra = hostlib.Reference(wa["newick"], wa["labels"], wa["seqs"], states=20, subst=wa["subst"],
+                           freqs=wa["freqs"], rates=wa["rates"])
+    ea = ra.evaluator()
+    with pytest.raises(epa.EpaError):
+        ea._check(ea.L.epa_dev_set_query_packing(ea.h, 4))

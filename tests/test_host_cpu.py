@@ -409,3 +409,22 @@ def test_gamma_median_mode():
     from scipy.stats import gamma
     q = gamma.ppf((2 * np.arange(4) + 1) / 8.0, 0.5, scale=2.0)
     assert np.max(np.abs(med - q * 4 / q.sum())) < 1e-9
+
+
+def test_fourbit_wire_format():
+    """4-bit packing == the reference's FourBit (src/io/encoding.hpp): nibble = index in NT_MAP
+    ('-TGKCYSBAWRDMHVN', src/util/maps.hpp:9-26), earlier site in the high nibble, odd rows padded
+    with '-'; round trip on the string of the reference's own test (test/src/encoding.cpp:5-19)."""
+    text = "AATGCTTCGTAA---NNNATTCBDAVMKWYR"
+    nt_map = "-TGKCYSBAWRDMHVN"
+    codes, wb, ws = epa.encode_queries(4, [text], premasking=False)
+    assert codes.shape == (1, len(text))
+    assert codes[0].tolist() == [nt_map.index(ch) for ch in text]
+    p = epa.pack_codes_4bit(codes)
+    assert p.data.shape == (1, (len(text) + 1) // 2) and p.stride == len(text)
+    idx = [nt_map.index(ch) for ch in text] + [0]
+    assert p.data[0].tolist() == [(idx[2 * i] << 4) | idx[2 * i + 1] for i in range((len(text) + 1) // 2)]
+    back = epa.unpack_codes_4bit(p)
+    assert "".join(nt_map[c] for c in back[0]) == text
+    with pytest.raises(epa.EpaError):
+        epa.pack_codes_4bit(np.full((1, 4), 16, np.uint8))
