@@ -243,7 +243,8 @@ int configure_host_threads();
 
 // ---- readers / writers
 MSA read_fasta(const std::string& path);
-// chunked FASTA reader of the query file (the reference's MSA_Stream, src/seq/MSA_Stream.hpp)
+// chunked reader of the query file: FASTA (the reference's MSA_Stream, src/seq/MSA_Stream.hpp) or
+// binary fasta (.bfast, Binary_Fasta_Reader), detected by the magic
 class Fasta_Stream {
 public:
   explicit Fasta_Stream(const std::string& path);
@@ -253,6 +254,11 @@ public:
   size_t read_next(MSA& out, size_t max_seqs);
 private:
   bool refill();
+  bool open_bfast();                                  // binary fasta (src/io/Binary_Fasta.hpp)?
+  size_t read_next_bfast(MSA& out, size_t max_seqs);
+  bool bfast_ = false;
+  std::vector<uint64_t> bfast_offsets_;
+  size_t bfast_next_ = 0;
   std::FILE* f_ = nullptr;
   std::vector<char> buf_;
   size_t pos_ = 0, len_ = 0, scan_ = 0;  // unparsed region [pos_, len_), record index built up to scan_

@@ -15,10 +15,90 @@ namespace epa {
 
 // ---- FASTA: block reads + memchr line splitting; sites are upper-cased by the reader
 // (src/seq/MSA_Stream.cpp:41), whitespace inside sequence lines is dropped.
+// ---- binary fasta (".bfast", the reference's --bfast conversion, src/io/Binary_Fasta.hpp):
+//   "BFAST\0\0" (7 bytes) | u64 n | [u64 len + that many '0'/'1' chars: the all-gap column mask;
+//   files written before the mask existed have none] | n x (u64 id, u64 offset) |
+//   per sequence at its offset: u64 len, header bytes, u64 sites, ceil(sites / 2) bytes of 4-bit
+//   codes (FourBit: index in NT_MAP, earlier site in the high nibble).  Integers little-endian.
+namespace {
+constexpr char kBfastMagic[7] = {'B', 'F', 'A', 'S', 'T', 0, 0};
+constexpr char kNtMap[] = "-TGKCYSBAWRDMHVN";  // src/util/maps.hpp:9-26
+
+uint64_t get_u64(std::FILE* f) {
+  unsigned char b[8];
+  if (std::fread(b, 1, 8, f) != 8) throw std::runtime_error{"bfast: unexpected end of file"};
+  uint64_t v = 0;
+  for (int i = 7; i >= 0; --i) v = (v << 8) | b[i];
+  return v;
+}
+}  // namespace
+
+bool Fasta_Stream::open_bfast() {
+  char magic[7];
+  if (std::fread(magic, 1, 7, f_) != 7 || std::memcmp(magic, kBfastMagic, 7) != 0) {
+    std::rewind(f_);
+    return false;
+  }
+  const uint64_t n = get_u64(f_);
+  // with or without the mask string?  The first table entry names the data section's offset.
+  const long table_plain = 7 + 8;
+  std::vector<uint64_t> offs(n);
+  auto read_table = [&](long at) {
+    if (std::fseek(f_, at, SEEK_SET) != 0) return false;
+    for (uint64_t i = 0; i < n; ++i) {
+      const uint64_t id = get_u64(f_), off = get_u64(f_);
+      if (id >= n) return false;
+      offs[id] = off;
+    }
+    return true;
+  };
+  bool ok = false;
+  if (n > 0) {
+    std::fseek(f_, table_plain, SEEK_SET);
+    const uint64_t mask_len = get_u64(f_);
+    const uint64_t data_masked = 7 + 8 + 8 + mask_len + n * 16;
+    if (mask_len < (1ull << 40) && read_table((long)(table_plain + 8 + mask_len)) && offs[0] == data_masked) ok = true;
+    if (!ok && read_table(table_plain) && offs[0] == 7 + 8 + n * 16) ok = true;
+  } else {
+    ok = true;
+  }
+  if (!ok) throw std::runtime_error{"File is not an epa::Binary_Fasta file"};
+  bfast_ = true;
+  bfast_offsets_ = std::move(offs);
+  bfast_next_ = 0;
+  return true;
+}
+
+size_t Fasta_Stream::read_next_bfast(MSA& out, size_t max_seqs) {
+  size_t got = 0;
+  std::vector<unsigned char> packed;
+  while (got < max_seqs && bfast_next_ < bfast_offsets_.size()) {
+    if (std::fseek(f_, (long)bfast_offsets_[bfast_next_], SEEK_SET) != 0)
+      throw std::runtime_error{"bfast: bad sequence offset"};
+    const uint64_t hlen = get_u64(f_);
+    std::string header(hlen, '\0');
+    if (hlen && std::fread(&header[0], 1, hlen, f_) != hlen) throw std::runtime_error{"bfast: truncated header"};
+    const uint64_t sites = get_u64(f_);
+    packed.resize((sites + 1) / 2);
+    if (!packed.empty() && std::fread(packed.data(), 1, packed.size(), f_) != packed.size())
+      throw std::runtime_error{"bfast: truncated sequence"};
+    std::string seq(sites, '-');
+    for (uint64_t i = 0; i < sites; ++i) {
+      const unsigned char b = packed[i / 2];
+      seq[i] = kNtMap[(i & 1) ? (b & 15) : (b >> 4)];
+    }
+    out.emplace_back(std::move(header), std::move(seq));
+    ++bfast_next_;
+    ++got;
+  }
+  return got;
+}
+
 Fasta_Stream::Fasta_Stream(const std::string& path) : f_(std::fopen(path.c_str(), "rb")) {
   if (!f_) throw std::runtime_error{"file_check failed: " + path};
-  buf_.resize(1 << 24);
   for (int c = 0; c < 256; ++c) up_[c] = std::isspace(c) ? 0 : (char)std::toupper(c);
+  if (open_bfast()) return;  // like the reference: try bfast first, fall back to fasta (msa_reader.hpp:15-24)
+  buf_.resize(1 << 24);
 }
 
 Fasta_Stream::~Fasta_Stream() { if (f_) std::fclose(f_); }
@@ -45,6 +125,7 @@ bool Fasta_Stream::refill() {
 size_t Fasta_Stream::read_next(MSA& out, size_t max_seqs) {
   configure_host_threads();
   if (max_seqs == 0) return 0;
+  if (bfast_) return read_next_bfast(out, max_seqs);
   for (;;) {
     // extend the index of record starts over the bytes not scanned yet
     const char* base = buf_.data();

@@ -763,3 +763,23 @@ def test_fourbit_wire_format_same_results():
     ea = ra.evaluator()
     with pytest.raises(epa.EpaError):
         ea._check(ea.L.epa_dev_set_query_packing(ea.h, 4))
+
+
+def test_cli_bfast_queries(tmp_path):
+    """-q <file>.bfast: the reference's own binary-fasta fixture (test/data/query.fasta.bin) gives
+    the same jplace as its query.fasta"""
+    import subprocess
+    data = os.path.join(GOLDEN, "data")
+    exe = os.path.join(os.path.dirname(hostlib.HOST_SO), "epa-ng-amd")
+    outs = []
+    for q in ("query.fasta", "query.fasta.bin"):
+        od = tmp_path / q.replace(".", "_")
+        od.mkdir()
+        r = subprocess.run([exe, "-t", os.path.join(data, "ref.tre"), "-s", os.path.join(data, "aln.fasta"),
+                            "-q", os.path.join(data, q), "-m", "GTR+G", "-w", str(od)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        jp = json.load(open(od / "epa_result.jplace"))
+        jp.pop("metadata", None)
+        outs.append(jp)
+    assert outs[0] == outs[1] and len(outs[0]["placements"]) == 2

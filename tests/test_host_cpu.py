@@ -428,3 +428,79 @@ def test_fourbit_wire_format():
     assert "".join(nt_map[c] for c in back[0]) == text
     with pytest.raises(epa.EpaError):
         epa.pack_codes_4bit(np.full((1, 4), 16, np.uint8))
+
+
+def _stream_dump_exe(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "dump.cpp"
+    src.write_text(r'''
+#include "epa_host.hpp"
+#include <cstdio>
+#include <cstdlib>
+int main(int argc, char** argv) {
+  epa::Fasta_Stream in(argv[1]);
+  const size_t chunk = std::strtoul(argv[2], nullptr, 10);
+  for (;;) {
+    epa::MSA m;
+    const size_t n = in.read_next(m, chunk);
+    if (!n) break;
+    for (auto& s : m) std::printf("%s %s\n", s.header().c_str(), s.sequence().c_str());
+  }
+}
+''')
+    exe = tmp_path / "dump"
+    pkg = os.path.join(root, "epa-ng_amd")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"),
+                    "-I", os.path.join(pkg, "csrc", "host"), str(src), "-o", str(exe),
+                    "-L", pkg, "-lepa_host", "-lepa_dev", "-Wl,-rpath," + pkg], check=True)
+    return exe
+
+
+def test_bfast_query_files(tmp_path):
+    """binary fasta query files (the reference's --bfast conversion, src/io/Binary_Fasta.hpp) are
+    read by the same chunked reader: (a) the reference's own fixture test/data/query.fasta.bin
+    (written before the gap mask was added to the header) decodes to its query.fasta; (b) a file
+    in the current layout (with mask string), odd lengths and ambiguity codes, chunked reads."""
+    import struct
+    import subprocess
+    exe = _stream_dump_exe(tmp_path)
+    data = os.path.join(os.path.dirname(__file__), "golden", "data")
+
+    def read_fasta(path):
+        recs, h, s = [], None, []
+        for line in open(path):
+            line = line.strip()
+            if line.startswith(">"):
+                if h is not None:
+                    recs.append((h, "".join(s).upper()))
+                h, s = line[1:].split()[0], []
+            elif line:
+                s.append(line)
+        recs.append((h, "".join(s).upper()))
+        return recs
+    want = read_fasta(os.path.join(data, "query.fasta"))
+    out = subprocess.run([str(exe), os.path.join(data, "query.fasta.bin"), "1"], check=True, capture_output=True, text=True).stdout
+    got = [tuple(l.split()) for l in out.strip().split("\n")]
+    assert got == want and len(got) == 2
+
+    nt_map = "-TGKCYSBAWRDMHVN"
+    recs = [("r%d" % i, ("ACGTRYKMSWBDHVN-" * 3)[i: i + 17 + i]) for i in range(7)]
+
+    def entry(h, s):
+        idx = [nt_map.index(c) for c in s] + [0]
+        packed = bytes((idx[2 * i] << 4) | idx[2 * i + 1] for i in range((len(s) + 1) // 2))
+        return struct.pack("<Q", len(h)) + h.encode() + struct.pack("<Q", len(s)) + packed
+    entries = [entry(h, s) for h, s in recs]
+    mask = "0" * 23
+    off = 7 + 8 + 8 + len(mask) + 16 * len(recs)
+    table = b""
+    for i, e in enumerate(entries):
+        table += struct.pack("<QQ", i, off)
+        off += len(e)
+    blob = b"BFAST\0\0" + struct.pack("<Q", len(recs)) + struct.pack("<Q", len(mask)) + mask.encode() + table + b"".join(entries)
+    bf = tmp_path / "q.bfast"
+    bf.write_bytes(blob)
+    for chunk in (1, 3, 50):
+        out = subprocess.run([str(exe), str(bf), str(chunk)], check=True, capture_output=True, text=True).stdout
+        assert [tuple(l.split()) for l in out.strip().split("\n")] == recs
