@@ -177,7 +177,7 @@ int main(int argc, char** argv) {
 }
 ''')
     exe = tmp_path / "t"
-    pkg = os.path.join(root, "epa-ng_amd")
+    pkg = os.path.join(root, "epa_ng_amd")
     subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"),
                     "-I", os.path.join(pkg, "csrc", "host"), str(src), "-o", str(exe),
                     "-L", pkg, "-lepa_host", "-lepa_dev", "-Wl,-rpath," + pkg], check=True)
@@ -450,7 +450,7 @@ int main(int argc, char** argv) {
 }
 ''')
     exe = tmp_path / "dump"
-    pkg = os.path.join(root, "epa-ng_amd")
+    pkg = os.path.join(root, "epa_ng_amd")
     subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"),
                     "-I", os.path.join(pkg, "csrc", "host"), str(src), "-o", str(exe),
                     "-L", pkg, "-lepa_host", "-lepa_dev", "-Wl,-rpath," + pkg], check=True)
