@@ -3,12 +3,21 @@
 
 Metric (BASELINE.json): query placements/sec, 512-tip GTR+G4 DNA reference, preplace + thorough.
 Workload = cfg2 of SURVEY.md section 8d: 512-tip random-join tree (seed 1), 1500-column MSA
-simulated on that tree (seed 2), 150 bp reads with 3 % substitutions (seed 3 + 1000*rank),
-dynamic heuristic 0.99999.  A "step" is one chunk of --chunk reads through
-    preplace (Q x B lookup sums) -> candidate selection -> thorough NR placement
-with the encoded reads already resident in HBM (default 50 000 reads per step: the GPU wants
-larger chunks than the reference's CPU default of 5000, it is the same --chunk-size knob); every rank works on its own reads (weak
-scaling, no data-path collective) and rank 0 gathers the per-pair results over RCCL.
+simulated on that tree (seed 2), 150 bp reads with 3 % substitutions (seed 3; chunk g of the read
+stream uses seed 3 + 1000003 g), dynamic heuristic 0.99999.  A "step" is one chunk of --chunk
+reads through the reference's chunk body
+    place() (Q x B lookup sums) -> apply_heuristic() -> place_thorough() (NR placement).
+
+Two timed loops over the SAME chunks, both in the JSON line:
+  value            inputs resident in HBM when the clock starts, results left in HBM (the bench
+                   contract's definition of `value`): epa_dev_place_chunk on device buffers;
+  pcie_inclusive   SURVEY 8d's definition (H2D of the queries + D2H of the results inside the
+                   step): the double-buffered epa_dev_chunk_stage / _launch / _finish pipeline,
+                   4-bit wire format up, pairs + results down, copies on the copy stream.
+N > 1: one process per GPU; --scaling weak (default): every rank its own --chunk reads per step;
+--scaling strong: a step is --chunk reads GLOBALLY, sharded with the reference's
+local_seq_package formula (--reads R sets steps = ceil(R / chunk), e.g. cfg4: --reads 10000000).
+The only exchange is the RCCL gather of the per-pair results to rank 0, overlapped.
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps 5 --warmup 1
@@ -16,7 +25,10 @@ scaling, no data-path collective) and rank 0 gathers the per-pair results over R
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -25,8 +37,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == matrix peak (spec); the kernel is fp64 VALU
-HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
+FP64_PEAK_TFLOPS = 78.6       # AMD MI355X spec sheet: fp64 vector = fp64 matrix = 78.6 TFLOP/s
+FP64_MEASURED_CEILING = 63.3  # dependency-free v_fma_f64 stream on this chip (profiles/r1_mfma_overlap.txt)
+HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md (spec; 6290 GB/s measured copy)
 
 
 def parse():
@@ -36,15 +49,61 @@ def parse():
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--chunk", type=int, default=100000,
                    help="reads per step (EPA-ng --chunk-size; default = the whole cfg2 query set)")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    p.add_argument("--reads", type=int, default=0,
+                   help="strong scaling: total reads of the job (steps = ceil(reads / chunk))")
     p.add_argument("--tips", type=int, default=512)
     p.add_argument("--width", type=int, default=1500)
     p.add_argument("--read-len", type=int, default=150)
     p.add_argument("--cpu-sample", type=int, default=20000, help="reads timed on the CPU baseline")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-extras", action="store_true",
+                   help="skip the secondary measurements (chunk-5000 rate, reference-binary hook)")
     p.add_argument("--workload", choices=["dna", "aa"], default="dna",
                    help="dna = cfg2 (the metric's config); aa = cfg3 shape (use --tips 2000 --width 500 "
                         "--read-len 100), a parity/measurement case, not the headline")
     return p.parse_args()
+
+
+def reference_binary_check(newick, labels, seqs, sample_codes, wb, ws, W, states, model, ours):
+    """SURVEY 8d / BASELINE.md:33: if an `epa-ng` executable is on PATH, run it on the same files
+    and diff the placements; otherwise say so.  `ours`: {read index: (best edge, its lnL)}."""
+    exe = shutil.which("epa-ng")
+    if not exe:
+        return {"status": "reference binary unavailable (no epa-ng on PATH)"}
+    from epa_ng_amd import synth
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            with open(os.path.join(d, "ref.tre"), "w") as f:
+                f.write(newick + "\n")
+            with open(os.path.join(d, "ref.fasta"), "w") as f:
+                for l, s in zip(labels, seqs):
+                    f.write(">%s\n%s\n" % (l, s))
+            reads = synth.compact_to_ascii(sample_codes, wb, ws, W, states)
+            with open(os.path.join(d, "q.fasta"), "w") as f:
+                for i, s in enumerate(reads):
+                    f.write(">q%d\n%s\n" % (i, s))
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "--tree", os.path.join(d, "ref.tre"), "--ref-msa", os.path.join(d, "ref.fasta"),
+                                "--query", os.path.join(d, "q.fasta"), "--model", model, "--outdir", d,
+                                "--redo"], capture_output=True, text=True, timeout=1800)
+            secs = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"status": "epa-ng failed", "stderr": r.stderr[-400:]}
+            jp = json.load(open(os.path.join(d, "epa_result.jplace")))
+        same_edge, dl = 0, []
+        for pq in jp["placements"]:
+            q = int(pq["n"][0][1:])
+            best = max(pq["p"], key=lambda p: p[2])
+            if q in ours:
+                same_edge += int(best[0] == ours[q][0])
+                if best[0] == ours[q][0]:
+                    dl.append(abs(best[1] - ours[q][1]))
+        return {"status": "ran", "reads": len(reads), "wall_s": round(secs, 2),
+                "placements_per_s_incl_setup": round(len(reads) / secs, 1),
+                "best_edge_agree": same_edge, "max_abs_dlnl_on_agreeing": float(max(dl)) if dl else None}
+    except Exception as e:  # noqa: BLE001  (a diagnostic hook must never take the bench line down)
+        return {"status": "hook error: %r" % (e,)}
 
 
 def main():
@@ -73,7 +132,9 @@ def main():
     dev = torch.device("cuda", local)
     cdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")  # collective buffers
 
-    # ---------------- workload (identical reference on every rank, rank-private reads)
+    # ---------------- workload (identical reference on every rank)
+    if a.scaling == "strong" and a.reads:
+        a.steps = -(-a.reads // a.chunk)
     n_chunks = a.steps + a.warmup
     states = 4 if a.workload == "dna" else 20
     if a.workload == "dna":
@@ -85,71 +146,133 @@ def main():
     rates = synth.gamma_rates(alpha)
     labels, seqs = synth.simulate_msa(root, a.width, subst, freqs, rates, seeds[1])
     newick = synth.newick(root)
-    reads, _ = synth.make_reads(seqs, n_chunks * a.chunk, a.read_len, 0.03, seeds[2] + 1000 * rank,
-                                states=states)
     ref = hostlib.Reference(newick, labels, seqs, states=states, subst=subst, freqs=freqs, rates=rates)
     ev = ref.evaluator(device=local)
-    t0 = time.time()
     ev.build_lookup()
     torch.cuda.synchronize()
     lookup_ms = ev.kernel_ms("lookup")
-    B, W, Q = ref.B, ref.W, a.chunk
+    B, W = ref.B, ref.W
 
-    chunks = []
+    # reads of step c on this rank, generated straight in the compact wire layout.  weak: the rank's
+    # own chunk of the stream (global chunk index rank * n_chunks + c); strong: this rank's
+    # local_seq_package slice of the global chunk c (src/net/epa_mpi_util.cpp:10-30)
+    host_chunks = []
     for c in range(n_chunks):
-        # compact wire format: one row per read holding only its window (152 B instead of 1500 B)
-        codes, wb, ws = epa.encode_queries(states, reads[c * Q:(c + 1) * Q], compact=True)
-        chunks.append((torch.from_numpy(codes).to(dev), torch.from_numpy(wb.view(np.int32)).to(dev),
-                       torch.from_numpy(ws.view(np.int32)).to(dev), codes, wb, ws))
-    cap = Q * 64   # pair capacity per step (dynamic heuristic selects a handful per read)
+        if a.scaling == "weak":
+            g = rank * n_chunks + c
+            codes, wb, ws = synth.make_reads_compact(seqs, a.chunk, a.read_len, 0.03, seeds[2] + 1000003 * g, states)
+        else:
+            codes, wb, ws = synth.make_reads_compact(seqs, a.chunk, a.read_len, 0.03, seeds[2] + 1000003 * c, states)
+            off, cnt = parallel.local_seq_package(a.chunk, rank, world)
+            codes, wb, ws = codes[off:off + cnt].copy(), wb[off:off + cnt].copy(), ws[off:off + cnt].copy()
+        wire = epa.pack_codes_4bit(codes) if states == 4 else codes   # what crosses PCIe
+        host_chunks.append((codes, wb, ws, wire))
+    Q = len(host_chunks[0][1])                    # reads per step on this rank
+    step_reads = a.chunk * world if a.scaling == "weak" else a.chunk   # reads per step, whole job
+    dev_chunks = [(torch.from_numpy(c).to(dev), torch.from_numpy(b.view(np.int32)).to(dev),
+                   torch.from_numpy(s.view(np.int32)).to(dev)) for c, b, s, _ in host_chunks]
+    cap = max(Q, 1) * 64   # pair capacity per step (dynamic heuristic selects a handful per read)
     d_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
     d_res = torch.zeros((cap, 3), dtype=torch.float64, device=dev)
-    exch = parallel.AsyncResultGather(dist, min(cap, 8 * Q), dev) if world > 1 else None
 
     th_ms, th_pairs, th_rounds, th_evals, pre_ms, sel_ms = [], [], [], [], [], []
 
-    def step(i, record):
-        dc, dwb, dws = chunks[i][0], chunks[i][1], chunks[i][2]
+    def timed(loop_body, finish):
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks"""
+        for i in range(a.warmup):
+            loop_body(i, False)
+        finish()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.warmup, n_chunks):
+            loop_body(i, True)
+        finish()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    # ---------------- loop 1: inputs resident in HBM (the contract's `value`)
+    exch = parallel.AsyncResultGather(dist, min(cap, 8 * max(Q, 1)), dev) if world > 1 else None
+
+    def step_resident(i, record):
+        dc, dwb, dws = dev_chunks[i]
         # one fused call = the reference's chunk body: place() -> apply_heuristic() -> place_thorough()
         n = ev.place_chunk(dc, dwb, dws, Q=Q, threshold=0.99999, max_span=a.read_len, max_pairs=cap,
-                           pairs_out=d_pairs, results_out=d_res)
+                           pairs_out=d_pairs, results_out=d_res) if Q else 0
         if world > 1:
             # the path's only exchange: every rank's candidate placements -> rank 0 (RCCL over
             # xGMI; the reference gathers jplace byte ranges, src/io/jplace_writer.hpp:117-129).
             # Posted asynchronously: it overlaps the next chunk's kernels (parallel.py).
             exch.post(d_pairs, d_res, n)
-        if record:
+        if record and Q:
             th_ms.append(ev.kernel_ms("thorough")); pre_ms.append(ev.kernel_ms("preplace"))
             sel_ms.append(ev.kernel_ms("select"))
             th_pairs.append(n); th_rounds.append(ev.last_stats["rounds"])
             th_evals.append(ev.last_stats["newton_evals"])
         return n
 
-    for i in range(a.warmup):
-        step(i, False)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.warmup, n_chunks):
-        step(i, True)
-    if world > 1:
-        exch.finish()   # the last chunks' gathers are part of the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(step_resident, (lambda: exch.finish()) if world > 1 else (lambda: None))
+
+    # ---------------- loop 2: PCIe inside the step, overlapped on the copy stream (SURVEY 8d)
+    exch2 = parallel.AsyncResultGather(dist, min(cap, 8 * max(Q, 1)), dev, host_copy=True) if world > 1 else None
+    state = {"staged": None, "inflight": None, "bytes_up": 0, "bytes_down": 0}
+    bufs = [(d_pairs, d_res), (torch.empty_like(d_pairs), torch.empty_like(d_res))]
+
+    def stage(i):
+        _, hb, hs, wire = host_chunks[i]
+        ev.chunk_stage(i & 1, wire, hb, hs)                  # host -> pinned -> async H2D (copy stream)
+        state["staged"] = i
+        state["bytes_up"] += (wire.data if isinstance(wire, epa.Packed4) else wire).nbytes + 8 * Q
+
+    def retire(slot):
+        if world > 1:
+            n = ev.chunk_finish_device(slot)
+            exch2.post(bufs[slot][0], bufs[slot][1], n)     # gather to rank 0, which copies it to the host
+        else:
+            p, r = ev.chunk_finish(slot, copy=False)        # views of the slot's pinned host buffer
+            n = len(p)
+        state["bytes_down"] += n * 32
+        state["inflight"] = None
+
+    def step_pcie(i, record):
+        if not Q:
+            if world > 1:
+                exch2.post(d_pairs, d_res, 0)
+            return
+        slot = i & 1
+        if state["staged"] != i:                             # first step of a loop: nothing prefetched
+            stage(i)
+        kw = dict(pairs_out=bufs[slot][0], results_out=bufs[slot][1], keep_on_device=True) if world > 1 else {}
+        # returns once the candidate count is known; thorough kernels + result D2H are queued
+        ev.chunk_launch(slot, threshold=0.99999, max_span=a.read_len, max_pairs=cap, **kw)
+        if state["inflight"] is not None:                    # previous chunk: its D2H ran under this preplace
+            retire(state["inflight"])
+        state["inflight"] = slot
+        if i + 1 < n_chunks and i + 1 != a.warmup:           # upload of the next chunk under this one's kernels
+            stage(i + 1)                                     # (never across the warmup / timed boundary)
+
+    def finish_pcie():
+        if state["inflight"] is not None:
+            retire(state["inflight"])
+        if world > 1:
+            exch2.finish()
+
+    elapsed_pcie = timed(step_pcie, finish_pcie)
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    total_reads = world * a.steps * Q
+    total_reads = a.steps * step_reads
     value = total_reads / elapsed
     # ---------------- roofline of the dominant kernel (thorough NR), per launch
     pairs = float(np.mean(th_pairs))
@@ -164,30 +287,49 @@ def main():
     else:  # same accounting with s = 20: P = c(4s^2+s), E = c(2s^2+2s), D = 6cs
         P_, E_, D_ = 4 * (4 * 400 + 20), 4 * (2 * 400 + 40), 6 * 4 * 20
         flops_pair = nq * ((2 * P_ + E_) + R * (4 * P_ + E_ + 2 * kbar * D_))
-        # initial inner CLV from the per-branch precompute: only the fold with the query and the
-        # lnL contraction (3cs flop per site) are executed of the 2P + E
         flops_exec = nq * (3 * 4 * 20 + R * (4 * P_ + E_ + 2 * kbar * D_))
     cs = 4 * states
     bytes_pair = 2 * nq * cs * 8 + 2 * nq * 4 + nq + 24
     t_th = float(np.mean(th_ms)) * 1e-3
-    ach_tflops = pairs * flops_pair / t_th / 1e12
+    exec_tflops = pairs * flops_exec / t_th / 1e12
+    alg_tflops = pairs * flops_pair / t_th / 1e12
     traffic = None   # HBM bytes per launch from the committed PMC passes, same workload only
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))["k_thorough_dna"]
-        if states == 4 and tj["reads_per_step"] == Q and abs(tj["pairs_per_launch"] - pairs) < 0.02 * pairs:
-            traffic = (tj["fetch_kb"] + tj["write_kb"]) * 1024.0
-    except (OSError, KeyError, ValueError):
-        pass
-    roof = {"bound": "mfma", "kernel": "k_thorough_dna" if states == 4 else "k_thorough_aa", "achieved": round(ach_tflops, 3),
-            "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach_tflops / FP64_PEAK_TFLOPS, 4),
+    kname = "k_thorough_dna" if states == 4 else "k_thorough_aa"
+    for tf in ("r2_traffic.json", "r1_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", tf)))[kname]
+            if tj["reads_per_step"] == Q and abs(tj["pairs_per_launch"] - pairs) < 0.02 * pairs:
+                traffic = (tj["fetch_kb"] + tj["write_kb"]) * 1024.0
+                break
+        except (OSError, KeyError, ValueError):
+            pass
+    roof = {"bound": "fp64-valu", "kernel": kname,
+            "achieved": round(exec_tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(exec_tflops / FP64_PEAK_TFLOPS, 4),
             "traffic": traffic,
-            "note": "fp64 VALU kernel priced against the fp64 vector=matrix peak (78.6 TF spec)",
+            "note": "achieved / frac price the fp64 flop the kernel EXECUTES (zero MFMA instructions: "
+                    "fp64 vector FMA kernel); *_algorithmic price SURVEY 8d's per-pair figure",
+            "peak_source": "AMD MI355X spec sheet, fp64 vector = fp64 matrix = 78.6 TFLOP/s (the microarch "
+                           "guide lists no fp64 row); measured ceiling of a dependency-free v_fma_f64 "
+                           "stream on this chip: %.1f TFLOP/s (profiles/r1_mfma_overlap.txt)" % FP64_MEASURED_CEILING,
+            "frac_of_measured_fma_ceiling": round(exec_tflops / FP64_MEASURED_CEILING, 4),
+            "achieved_algorithmic": round(alg_tflops, 3), "frac_algorithmic": round(alg_tflops / FP64_PEAK_TFLOPS, 4),
             "pairs_per_launch": pairs, "rounds_per_pair": round(R, 3), "newton_iters_per_solve": round(kbar, 3),
             "flops_per_pair": round(flops_pair), "flops_executed_per_pair": round(flops_exec),
-            "frac_executed": round(pairs * flops_exec / t_th / 1e12 / FP64_PEAK_TFLOPS, 4), "ms_per_launch": round(t_th * 1e3, 4),
+            "ms_per_launch": round(t_th * 1e3, 4),
             "hbm_algorithmic_GBs": round(pairs * bytes_pair / t_th / 1e9, 1),
             "hbm_frac": round(pairs * bytes_pair / t_th / 1e9 / HBM_PEAK_GBS, 4)}
+    # preplacement kernel against the HBM roofline, SURVEY 8d's algorithmic bytes for ONE launch:
+    # query windows + the Q x B result table + one read of the lookup table
+    ncol = 16 if states == 4 else 24
+    pre_bytes = Q * nq + 8.0 * Q * B + 8.0 * ncol * W * B
+    t_pre = float(np.mean(pre_ms)) * 1e-3
+    roof_pre = {"bound": "hbm", "kernel": "k_preplace_pairs" if states == 4 else "k_preplace_sites",
+                "achieved": round(pre_bytes / t_pre / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(pre_bytes / t_pre / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": pre_bytes,
+                "ms_per_launch": round(t_pre * 1e3, 4)}
 
+    extras = {}
     # ---------------- CPU baseline: the oracle's OpenMP restatement on a bounded sample
     cpu = None
     parity = None
@@ -197,7 +339,8 @@ def main():
         eff = hostlib.configure_threads()
         from oracle_lib import Oracle, lib as orc_lib
         ns = min(a.cpu_sample, Q)
-        sample = reads[a.warmup * Q: a.warmup * Q + ns]
+        hc, hb, hs, _ = host_chunks[a.warmup]
+        sample = synth.compact_to_ascii(hc[:ns], hb[:ns], hs[:ns], W, states)
         o = Oracle(newick, labels, seqs, states, subst, freqs, rates)
         o.preplace(sample[:8])                      # builds the per-branch lookups (one-off)
         codes, wb, ws = epa.encode_queries(states, sample)
@@ -215,24 +358,77 @@ def main():
         parity = {"preplace_max_abs_dlnl": float(np.max(np.abs(lnl_gpu - lnl_cpu))),
                   "thorough_max_abs_dlnl": float(np.max(np.abs(res_gpu["lnl"] - tl))),
                   "pairs_checked": int(len(prs))}
+        if not a.no_extras:
+            # the reference's own executable, if the box happens to have one (it never did so far)
+            nref = min(ns, 2000)
+            best = {}
+            row_best = np.argmax(lnl_gpu[:nref], axis=1)
+            for q in range(nref):
+                m = prs["seq_id"] == q
+                k = int(np.argmax(res_gpu["lnl"][m]))
+                best[q] = (int(prs["branch_id"][m][k]), float(res_gpu["lnl"][m][k]))
+            del row_best
+            model = ("GTR{%s}+FU{%s}+G4{%r}" % ("/".join(map(repr, subst)), "/".join(map(repr, freqs)), alpha)
+                     if states == 4 else "PROTGTR{%s}+FU{%s}+G4{%r}" % ("/".join(map(repr, subst)),
+                                                                         "/".join(map(repr, freqs)), alpha))
+            extras["reference_binary"] = reference_binary_check(newick, labels, seqs, hc[:nref], hb[:nref], hs[:nref],
+                                                                W, states, model, best)
+    if world == 1 and not a.no_extras and Q >= 5000:
+        # the reference's default chunk size (--chunk-size 5000, src/util/Options.hpp) through the
+        # same double-buffered pipeline: 40 chunks cut from step 0's reads, PCIe inside the clock
+        hc, hb, hs, wire = host_chunks[a.warmup]
+        nsm = min(40, Q // 5000)
+        small = []
+        for k in range(nsm):
+            sl = slice(k * 5000, (k + 1) * 5000)
+            c5 = np.ascontiguousarray(hc[sl])
+            small.append((epa.pack_codes_4bit(c5) if states == 4 else c5, hb[sl].copy(), hs[sl].copy()))
+        for rep in range(2):                                     # first pass warms the buffers
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev.chunk_stage(0, *small[0])
+            for k in range(nsm):
+                ev.chunk_launch(k & 1, threshold=0.99999, max_span=a.read_len, max_pairs=5000 * 64)
+                if k + 1 < nsm:
+                    ev.chunk_stage((k + 1) & 1, *small[k + 1])
+                if k:
+                    ev.chunk_finish((k - 1) & 1, copy=False)
+            ev.chunk_finish((nsm - 1) & 1, copy=False)
+            t5 = time.perf_counter() - t0
+        extras["chunk5000"] = {"value": round(nsm * 5000 / t5, 1), "unit": "placements/s", "chunks": nsm,
+                               "ms_per_chunk": round(t5 / nsm * 1e3, 3),
+                               "note": "reference default --chunk-size 5000, H2D/D2H inside the clock"}
 
     metric = ("query placements/sec (whole node), 512-tip GTR+G4 DNA ref, preplace+thorough" if states == 4
               else "query placements/sec (whole node), AA PROTGTR+G4 ref (cfg3 shape), preplace+thorough")
+    pcie = {"value": round(total_reads / elapsed_pcie, 2), "unit": "placements/s",
+            "ms_per_step": round(elapsed_pcie / a.steps * 1e3, 3),
+            "h2d_bytes_per_step": state["bytes_up"] // max(1, n_chunks),
+            "d2h_bytes_per_step": state["bytes_down"] // max(1, n_chunks),
+            "how": "epa_dev_chunk_stage/_launch/_finish: %s codes + windows up, pairs + results down, copies on "
+                   "the copy stream under the previous / next chunk's kernels%s"
+                   % ("4-bit" if states == 4 else "1-byte",
+                      "; N > 1: results gathered over RCCL to rank 0, which copies them to the host" if world > 1 else "")}
     out = {"metric": metric,
            "value": round(value, 2), "unit": "placements/s", "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+           "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
            "config": {"workload": ("cfg2: %d-tip DNA GTR+G4 ref, W=%d, %d bp reads, dyn-heur 0.99999, "
                                    "preplace+thorough" if states == 4 else
                                    "cfg3-shape: %d-tip AA PROTGTR+G4 ref, W=%d, %d aa queries, dyn-heur "
                                    "0.99999, preplace+thorough") % (a.tips, a.width, a.read_len),
-                      "reads_per_step_per_gpu": Q, "branches": B, "parallelism": "query-shard x%d" % world,
+                      "reads_per_step_whole_job": step_reads, "reads_per_step_per_gpu": Q, "branches": B,
+                      "parallelism": "query-shard x%d (%s)" % (world, a.scaling),
+                      "value_definition": "inputs resident in HBM when the clock starts (bench contract); "
+                                          "see pcie_inclusive for SURVEY 8d's H2D/D2H-inclusive rate",
                       "lookup_build_ms_once": round(lookup_ms, 3),
                       "kernel_ms_per_step": {"preplace": round(float(np.mean(pre_ms)), 3),
                                              "select": round(float(np.mean(sel_ms)), 3),
                                              "thorough": round(float(np.mean(th_ms)), 3)}},
-           "roofline": roof, "cpu_baseline": cpu, "parity": parity}
+           "pcie_inclusive": pcie,
+           "roofline": roof, "roofline_preplace": roof_pre, "cpu_baseline": cpu, "parity": parity}
+    out.update(extras)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -99,6 +99,11 @@ def dev_lib():
         L.epa_dev_place_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                           C.c_uint32, C.c_double, C.c_void_p, C.c_void_p,
                                           C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(_Stats)]
+        L.epa_dev_chunk_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.epa_dev_chunk_launch.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_double, C.c_void_p,
+                                           C.c_void_p, C.c_uint64, C.c_uint32]
+        L.epa_dev_chunk_finish.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(_Stats)]
         L.epa_dev_tree_logl.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
         L.epa_dev_place_all.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                         C.c_uint32, C.c_double, C.c_int, C.c_uint32, C.c_uint32,
@@ -345,6 +350,51 @@ class Evaluator:
                            "newton_evals": st.newton_evals, "reverts": st.reverts}
         if host:
             return pairs_out[:n.value], results_out[:n.value]
+        return n.value
+
+    # ---- double-buffered chunk pipeline (epa_dev_chunk_stage / _launch / _finish): the upload of
+    # chunk k+1 and the download of chunk k-1 overlap the kernels of chunk k
+    def chunk_stage(self, slot, codes, win_begin, win_span):
+        """HOST arrays (numpy; codes may be Packed4) -> pinned buffer -> async H2D; returns at once"""
+        self._layout(codes)
+        data = codes.data if isinstance(codes, Packed4) else codes
+        assert isinstance(data, np.ndarray) and isinstance(win_begin, np.ndarray)
+        self._check(self.L.epa_dev_chunk_stage(self.h, slot, _ptr(codes), _ptr(win_begin), _ptr(win_span),
+                                               len(win_begin)))
+
+    def chunk_launch(self, slot, threshold=0.99999, max_span=0, max_pairs=None, pairs_out=None,
+                     results_out=None, keep_on_device=False):
+        """preplace -> heuristic -> thorough of the staged chunk; blocks only until the candidate
+        count is known.  pairs_out / results_out: optional device buffers (torch) of max_pairs rows"""
+        assert max_pairs is not None
+        self._check(self.L.epa_dev_chunk_launch(self.h, slot, max_span, threshold, _ptr(pairs_out),
+                                                _ptr(results_out), max_pairs, 1 if keep_on_device else 0))
+
+    def chunk_finish(self, slot, copy=True):
+        """waits for the slot's results -> (pairs, results) numpy views of the slot's pinned buffer
+        (copy=False: valid until the slot is staged again), or n_pairs when the launch kept the
+        results on the device"""
+        pp, pr, n, st = C.c_void_p(), C.c_void_p(), C.c_uint64(0), _Stats()
+        rc = self.L.epa_dev_chunk_finish(self.h, slot, C.byref(pp), C.byref(pr), C.byref(n), C.byref(st))
+        self.last_stats = {"pairs": st.pairs, "rounds": st.rounds,
+                           "newton_evals": st.newton_evals, "reverts": st.reverts}
+        self._check(rc)
+        n = n.value
+        import ctypes
+        if n == 0:
+            return np.zeros(0, PAIR_DTYPE), np.zeros(0, RESULT_DTYPE)
+        pairs = np.ctypeslib.as_array(ctypes.cast(pp, C.POINTER(C.c_uint32)), (2 * n,)).view(PAIR_DTYPE)
+        res = np.ctypeslib.as_array(ctypes.cast(pr, C.POINTER(C.c_double)), (3 * n,)).view(RESULT_DTYPE)
+        return (pairs.copy(), res.copy()) if copy else (pairs, res)
+
+    def chunk_finish_device(self, slot):
+        """finish() of a launch with keep_on_device=True -> n_pairs (results are in the buffers
+        handed to chunk_launch)"""
+        n, st = C.c_uint64(0), _Stats()
+        rc = self.L.epa_dev_chunk_finish(self.h, slot, None, None, C.byref(n), C.byref(st))
+        self.last_stats = {"pairs": st.pairs, "rounds": st.rounds,
+                           "newton_evals": st.newton_evals, "reverts": st.reverts}
+        self._check(rc)
         return n.value
 
     def place_all(self, codes, win_begin, win_span, Q=None, min_lwr=0.01, acc=False, filter_min=1,

@@ -43,8 +43,9 @@ def build_dev(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)
     if force or procs or _newer(out, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp"] + objs
         subprocess.check_call(cmd)
+        os.replace(out + ".tmp", out)   # atomic: a process that has the old file mapped keeps it
     return out
 
 
@@ -62,15 +63,17 @@ def build_host(force=False, verbose=False):
     deps = srcs + [os.path.join(hdir, "epa_host.hpp"), os.path.join(ROOT, "include", "epa_dev.h")]
     link = ["-L", HERE, "-lepa_dev", "-Wl,-rpath,$ORIGIN"]
     if force or _newer(out, deps):
-        cmd = ["g++"] + HOST_FLAGS + ["-shared", "-o", out] + srcs + link
+        cmd = ["g++"] + HOST_FLAGS + ["-shared", "-o", out + ".tmp"] + srcs + link
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        os.replace(out + ".tmp", out)
     main = os.path.join(hdir, "main.cpp")
     if force or _newer(exe, deps + [main, out]):
-        cmd = ["g++"] + HOST_FLAGS + ["-o", exe, main, "-L", HERE, "-lepa_host", "-lepa_dev",
+        cmd = ["g++"] + HOST_FLAGS + ["-o", exe + ".tmp", main, "-L", HERE, "-lepa_host", "-lepa_dev",
                                       "-Wl,-rpath,$ORIGIN"]
         subprocess.check_call(cmd)
+        os.replace(exe + ".tmp", exe)
     return out
 
 

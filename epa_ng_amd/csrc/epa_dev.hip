@@ -451,6 +451,18 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
   if (ctx->cinv) (void)hipFree(ctx->cinv);
   if (ctx->resc0) (void)hipFree(ctx->resc0);
   if (ctx->dmodel) (void)hipFree(ctx->dmodel);
+  for (ChunkSlot& sl : ctx->slots) {
+    if (sl.h_in) (void)hipHostFree(sl.h_in);
+    if (sl.h_out) (void)hipHostFree(sl.h_out);
+    if (sl.h_stats) (void)hipHostFree(sl.h_stats);
+    if (sl.d_in) (void)hipFree(sl.d_in);
+    if (sl.d_unpacked) (void)hipFree(sl.d_unpacked);
+    if (sl.d_pairs) (void)hipFree(sl.d_pairs);
+    if (sl.d_res) (void)hipFree(sl.d_res);
+    if (sl.d_stats) (void)hipFree(sl.d_stats);
+    for (hipEvent_t e : {sl.ev_up, sl.ev_done, sl.ev_down}) if (e) (void)hipEventDestroy(e);
+  }
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   EvTimer* ts[4] = {&ctx->t_lookup, &ctx->t_preplace, &ctx->t_thorough, &ctx->t_select};
   for (auto* t : ts) { if (t->a) (void)hipEventDestroy(t->a); if (t->b) (void)hipEventDestroy(t->b); }
   delete ctx;
@@ -1118,10 +1130,51 @@ extern "C" int epa_dev_select_candidates(epa_ctx* ctx, const double* lnl, uint32
   return EPA_OK;
 }
 
-// The body of the reference's chunk loop (src/core/place.cpp:219-235) for the default dynamic
-// heuristic, entirely on device: place() -> apply_heuristic() -> place_thorough().  The Q x B
-// table never leaves HBM; one host sync in the middle (the candidate count sizes the thorough
-// launch) and one at the end.
+// The body of the reference's chunk loop (src/core/place.cpp:219-235) on device buffers:
+// place() -> apply_heuristic() -> place_thorough().  The Q x B table never leaves HBM; ONE host
+// sync in the middle (the candidate count sizes the thorough launch); the thorough kernels are
+// queued on return, nothing is waited for after them.
+static int chunk_body(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span,
+                      uint32_t Q, uint32_t max_span, double threshold, epa_pair* d_pairs, epa_result* d_res,
+                      uint64_t max_pairs, unsigned long long* d_stats, uint64_t* n_out) {
+  // internal table: rows padded to whole 64-byte sectors (the preplacement kernels write 8
+  // consecutive branches per burst; with rows of B doubles every burst straddled two sectors)
+  const uint32_t pitch = (ctx->B + 7u) & ~7u;
+  double* d_lnl = (double*)epa_scratch(ctx, 3, sizeof(double) * (size_t)Q * pitch);
+  if (!d_lnl) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(chunk table)");
+  ctx->lnl_pitch = pitch;
+  int rc = launch_preplace(ctx, d_codes, d_begin, d_span, Q, d_lnl, max_span);
+  uint64_t n = 0;
+  if (!rc) rc = launch_select(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, &n, d_span);  // syncs once
+  ctx->lnl_pitch = 0;
+  if (rc) return rc;
+  rc = preplace_check_status(ctx);
+  if (rc) return rc;
+  *n_out = n;
+  EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, ctx->stream));
+  if (n == 0) return EPA_OK;
+  return launch_thorough(ctx, d_pairs, n, d_codes, d_begin, d_span, max_span, d_res, d_stats);
+}
+
+static int chunk_stats(epa_ctx* ctx, uint64_t n, const unsigned long long* hst, epa_thorough_stats* stats) {
+  ctx->last_stats.pairs = n;
+  ctx->last_stats.rounds = hst[0];
+  ctx->last_stats.newton_evals = hst[1];
+  ctx->last_stats.reverts = hst[2];
+  if (stats) *stats = ctx->last_stats;
+  if (hst[3])
+    return epa_fail(ctx, EPA_ERR_NEG_INF,
+                    "-INF logl at branch " + std::to_string((uint32_t)(hst[4] >> 32)) +
+                        " with sequence " + std::to_string((uint32_t)(hst[4] & 0xffffffffu)));
+  return EPA_OK;
+}
+
+static int thorough_supported(epa_ctx* ctx) {
+  if (!(ctx->s == 4 && ctx->c == 4) && !(ctx->s == 20))
+    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "thorough: DNA needs 4 rate categories");
+  return EPA_OK;
+}
+
 extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_begin,
                                    const uint32_t* win_span, uint32_t Q, uint32_t max_span,
                                    double threshold, epa_pair* pairs, epa_result* results,
@@ -1132,9 +1185,9 @@ extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const u
   if (stats) memset(stats, 0, sizeof(*stats));
   if (Q == 0) return EPA_OK;
   EPA_HIP(ctx, hipSetDevice(ctx->device));
-  if (!(ctx->s == 4 && ctx->c == 4) && !(ctx->s == 20))
-    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "thorough: DNA needs 4 rate categories");
-  int rc = epa_dev_build_lookup(ctx);
+  int rc = thorough_supported(ctx);
+  if (rc) return rc;
+  rc = epa_dev_build_lookup(ctx);
   if (rc) return rc;
   if (max_span == 0) {  // not supplied: look at the spans (host array, or one small D2H copy)
     std::vector<uint32_t> buf;
@@ -1147,30 +1200,17 @@ extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const u
   const uint32_t* d_begin = (const uint32_t*)epa_to_device(ctx, 1, win_begin, sizeof(uint32_t) * Q);
   const uint32_t* d_span = (const uint32_t*)epa_to_device(ctx, 2, win_span, sizeof(uint32_t) * Q);
   if (!d_codes || !d_begin || !d_span) return epa_fail(ctx, EPA_ERR_HIP, "query upload failed");
-  // internal table: rows padded to whole 64-byte sectors (the preplacement kernels write 8
-  // consecutive branches per burst; with rows of B doubles every burst straddled two sectors)
-  const uint32_t pitch = (ctx->B + 7u) & ~7u;
-  double* d_lnl = (double*)epa_scratch(ctx, 3, sizeof(double) * (size_t)Q * pitch);
   const bool pairs_dev = epa_is_device_ptr(pairs), res_dev = epa_is_device_ptr(results);
   epa_pair* d_pairs = pairs_dev ? pairs : (epa_pair*)epa_scratch(ctx, 4, sizeof(epa_pair) * max_pairs);
   epa_result* d_res = res_dev ? results : (epa_result*)epa_scratch(ctx, 5, sizeof(epa_result) * max_pairs);
-  if (!d_lnl || !d_pairs || !d_res) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(chunk buffers)");
-  ctx->lnl_pitch = pitch;
-  rc = launch_preplace(ctx, d_codes, d_begin, d_span, Q, d_lnl, max_span);
+  if (!d_pairs || !d_res) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(chunk buffers)");
+  // thorough counters: second half of the context's 256-byte counter block
+  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->th_ctr) + 128);
   uint64_t n = 0;
-  if (!rc) rc = launch_select(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, &n, d_span);  // syncs once
-  ctx->lnl_pitch = 0;
-  if (rc) return rc;
-  rc = preplace_check_status(ctx);
+  rc = chunk_body(ctx, d_codes, d_begin, d_span, Q, max_span, threshold, d_pairs, d_res, max_pairs, d_stats, &n);
   if (rc) return rc;
   *n_pairs = n;
   if (n == 0) return EPA_OK;
-  // thorough counters: second half of the 256-byte status block at the head of scratch 6
-  unsigned long long* d_stats =
-      reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->d_status) + 128);
-  EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, ctx->stream));
-  rc = launch_thorough(ctx, d_pairs, n, d_codes, d_begin, d_span, max_span, d_res, d_stats);
-  if (rc) return rc;
   unsigned long long hst[8];
   if (!pairs_dev)
     EPA_HIP(ctx, hipMemcpyAsync(pairs, d_pairs, sizeof(epa_pair) * n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1178,16 +1218,168 @@ extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const u
     EPA_HIP(ctx, hipMemcpyAsync(results, d_res, sizeof(epa_result) * n, hipMemcpyDeviceToHost, ctx->stream));
   EPA_HIP(ctx, hipMemcpyAsync(hst, d_stats, 64, hipMemcpyDeviceToHost, ctx->stream));
   EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->last_stats.pairs = n;
-  ctx->last_stats.rounds = hst[0];
-  ctx->last_stats.newton_evals = hst[1];
-  ctx->last_stats.reverts = hst[2];
-  if (stats) *stats = ctx->last_stats;
-  if (hst[3])
-    return epa_fail(ctx, EPA_ERR_NEG_INF,
-                    "-INF logl at branch " + std::to_string((uint32_t)(hst[4] >> 32)) +
-                        " with sequence " + std::to_string((uint32_t)(hst[4] & 0xffffffffu)));
+  return chunk_stats(ctx, n, hst, stats);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Double-buffered chunk pipeline (see include/epa_dev.h): stage -> launch -> finish per slot.
+// ---------------------------------------------------------------------------------------------
+static int slot_of(epa_ctx* ctx, int slot, ChunkSlot** out) {
+  if (!ctx) return EPA_ERR_INVALID_ARG;
+  if (slot < 0 || slot > 1) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk pipeline: slot must be 0 or 1");
+  ChunkSlot& s = ctx->slots[slot];
+  if (!ctx->copy_stream) EPA_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  if (!s.ev_up) {
+    EPA_HIP(ctx, hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
+    EPA_HIP(ctx, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+    EPA_HIP(ctx, hipEventCreateWithFlags(&s.ev_down, hipEventDisableTiming));
+    EPA_HIP(ctx, hipHostMalloc((void**)&s.h_stats, 64, hipHostMallocDefault));
+    EPA_HIP(ctx, hipMalloc((void**)&s.d_stats, 128));
+  }
+  *out = &s;
   return EPA_OK;
+}
+
+template <class T>
+static int grow_dev(epa_ctx* ctx, T** p, size_t* have, size_t want_bytes) {
+  if (want_bytes <= *have) return EPA_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr; *have = 0;
+  const size_t sz = want_bytes + want_bytes / 4 + 1024;
+  EPA_HIP(ctx, hipMalloc((void**)p, sz));
+  *have = sz;
+  return EPA_OK;
+}
+static int grow_pinned(epa_ctx* ctx, void** p, size_t* have, size_t want_bytes) {
+  if (want_bytes <= *have) return EPA_OK;
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr; *have = 0;
+  const size_t sz = want_bytes + want_bytes / 4 + 1024;
+  EPA_HIP(ctx, hipHostMalloc(p, sz, hipHostMallocDefault));
+  *have = sz;
+  return EPA_OK;
+}
+
+extern "C" int epa_dev_chunk_stage(epa_ctx* ctx, int slot, const uint8_t* q_codes, const uint32_t* win_begin,
+                                   const uint32_t* win_span, uint32_t Q) {
+  ChunkSlot* s;
+  int rc = slot_of(ctx, slot, &s);
+  if (rc) return rc;
+  if (!q_codes || !win_begin || !win_span || Q == 0) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_stage: null / empty chunk");
+  if (s->state == 2) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_stage: the slot has an unfinished launch");
+  EPA_HIP(ctx, hipSetDevice(ctx->device));
+  s->stride = ctx->code_stride ? ctx->code_stride : ctx->W;
+  s->packed4 = ctx->code_packed4;
+  const size_t row = s->packed4 ? ((size_t)s->stride + 1) / 2 : s->stride;
+  s->codes_bytes = ((size_t)Q * row + 255) & ~(size_t)255;
+  const size_t total = s->codes_bytes + 2 * sizeof(uint32_t) * (size_t)Q;
+  rc = grow_pinned(ctx, &s->h_in, &s->h_in_sz, total);
+  if (!rc) rc = grow_dev(ctx, (char**)&s->d_in, &s->d_in_sz, total + 1024);
+  if (rc) return rc;
+  char* h = (char*)s->h_in;
+  memcpy(h, q_codes, (size_t)Q * row);
+  memcpy(h + s->codes_bytes, win_begin, sizeof(uint32_t) * (size_t)Q);
+  memcpy(h + s->codes_bytes + sizeof(uint32_t) * (size_t)Q, win_span, sizeof(uint32_t) * (size_t)Q);
+  EPA_HIP(ctx, hipMemcpyAsync(s->d_in, s->h_in, total, hipMemcpyHostToDevice, ctx->copy_stream));
+  EPA_HIP(ctx, hipEventRecord(s->ev_up, ctx->copy_stream));
+  s->Q = Q;
+  s->state = 1;
+  return EPA_OK;
+}
+
+extern "C" int epa_dev_chunk_launch(epa_ctx* ctx, int slot, uint32_t max_span, double threshold,
+                                    epa_pair* d_pairs, epa_result* d_results, uint64_t max_pairs,
+                                    uint32_t flags) {
+  ChunkSlot* s;
+  int rc = slot_of(ctx, slot, &s);
+  if (rc) return rc;
+  if (s->state != 1) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_launch: the slot holds no staged chunk");
+  if ((d_pairs == nullptr) != (d_results == nullptr))
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_launch: pass both result buffers or neither");
+  if (d_pairs && (!epa_is_device_ptr(d_pairs) || !epa_is_device_ptr(d_results)))
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_launch: result buffers must be device memory");
+  EPA_HIP(ctx, hipSetDevice(ctx->device));
+  rc = thorough_supported(ctx);
+  if (!rc) rc = epa_dev_build_lookup(ctx);
+  if (rc) return rc;
+  const uint32_t Q = s->Q;
+  if (max_span == 0 || max_span > ctx->W) max_span = ctx->W;
+  if (!d_pairs) {
+    if (s->cap < max_pairs) {
+      if (s->d_pairs) (void)hipFree(s->d_pairs);
+      if (s->d_res) (void)hipFree(s->d_res);
+      s->d_pairs = nullptr; s->d_res = nullptr; s->cap = 0;
+      EPA_HIP(ctx, hipMalloc((void**)&s->d_pairs, sizeof(epa_pair) * max_pairs));
+      EPA_HIP(ctx, hipMalloc((void**)&s->d_res, sizeof(epa_result) * max_pairs));
+      s->cap = max_pairs;
+    }
+    d_pairs = s->d_pairs;
+    d_results = s->d_res;
+  }
+  EPA_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_up, 0));
+  const char* d = (const char*)s->d_in;
+  const uint8_t* d_codes = (const uint8_t*)d;
+  const uint32_t* d_begin = (const uint32_t*)(d + s->codes_bytes);
+  const uint32_t* d_span = d_begin + Q;
+  // the kernels read the layout the chunk was staged with
+  const uint32_t keep_stride = ctx->code_stride;
+  const bool keep_packed = ctx->code_packed4;
+  ctx->code_stride = s->stride == ctx->W ? 0 : s->stride;
+  ctx->code_packed4 = false;
+  if (s->packed4) {
+    size_t have = s->d_unpacked_sz;
+    rc = grow_dev(ctx, &s->d_unpacked, &have, (size_t)Q * s->stride + 1024);
+    s->d_unpacked_sz = have;
+    if (!rc) {
+      const size_t pstride = ((size_t)s->stride + 1) / 2;
+      const uint64_t nb = (uint64_t)Q * pstride;
+      hipLaunchKernelGGL(k_unpack4, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, ctx->stream, d_codes,
+                         s->d_unpacked, Q, s->stride, (uint32_t)pstride);
+      d_codes = s->d_unpacked;
+    }
+  }
+  uint64_t n = 0;
+  if (!rc) rc = chunk_body(ctx, d_codes, d_begin, d_span, Q, max_span, threshold, d_pairs, d_results, max_pairs,
+                           s->d_stats, &n);
+  ctx->code_stride = keep_stride;
+  ctx->code_packed4 = keep_packed;
+  if (rc) return rc;  // candidate overflow etc.: the slot stays staged
+  s->n = n;
+  EPA_HIP(ctx, hipEventRecord(s->ev_done, ctx->stream));
+  EPA_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, s->ev_done, 0));
+  if (flags & EPA_CHUNK_NO_D2H) {
+    s->out_pairs = d_pairs;
+    s->out_res = d_results;
+  } else {
+    const size_t off_r = (sizeof(epa_pair) * n + 255) & ~(size_t)255;
+    rc = grow_pinned(ctx, &s->h_out, &s->h_out_sz, off_r + sizeof(epa_result) * n);
+    if (rc) return rc;
+    if (n) {
+      EPA_HIP(ctx, hipMemcpyAsync(s->h_out, d_pairs, sizeof(epa_pair) * n, hipMemcpyDeviceToHost, ctx->copy_stream));
+      EPA_HIP(ctx, hipMemcpyAsync((char*)s->h_out + off_r, d_results, sizeof(epa_result) * n, hipMemcpyDeviceToHost,
+                                  ctx->copy_stream));
+    }
+    s->out_pairs = (const epa_pair*)s->h_out;
+    s->out_res = (const epa_result*)((char*)s->h_out + off_r);
+  }
+  EPA_HIP(ctx, hipMemcpyAsync(s->h_stats, s->d_stats, 64, hipMemcpyDeviceToHost, ctx->copy_stream));
+  EPA_HIP(ctx, hipEventRecord(s->ev_down, ctx->copy_stream));
+  s->state = 2;
+  return EPA_OK;
+}
+
+extern "C" int epa_dev_chunk_finish(epa_ctx* ctx, int slot, const epa_pair** pairs, const epa_result** results,
+                                    uint64_t* n_pairs, epa_thorough_stats* stats) {
+  ChunkSlot* s;
+  int rc = slot_of(ctx, slot, &s);
+  if (rc) return rc;
+  if (s->state != 2) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_finish: the slot has no launch in flight");
+  EPA_HIP(ctx, hipEventSynchronize(s->ev_down));
+  s->state = 0;
+  if (pairs) *pairs = s->out_pairs;
+  if (results) *results = s->out_res;
+  if (n_pairs) *n_pairs = s->n;
+  return chunk_stats(ctx, s->n, s->h_stats, stats);
 }
 
 // =============================================================================================

@@ -49,6 +49,33 @@ struct EvTimer {
   bool valid = false;
 };
 
+// One slot of the double-buffered chunk pipeline (epa_dev_chunk_stage / _launch / _finish): the
+// query upload of chunk k+1 and the result download of chunk k-1 run on the context's copy stream
+// while the kernels of chunk k run on its compute stream.
+struct ChunkSlot {
+  void* h_in = nullptr;       // pinned bounce buffer: codes | win_begin | win_span
+  size_t h_in_sz = 0;
+  void* d_in = nullptr;       // the same three arrays in HBM
+  size_t d_in_sz = 0;
+  uint8_t* d_unpacked = nullptr;  // one-byte codes when the chunk arrived in the 4-bit wire format
+  size_t d_unpacked_sz = 0;
+  size_t codes_bytes = 0;
+  uint32_t Q = 0, stride = 0;
+  bool packed4 = false;
+  epa_pair* d_pairs = nullptr;    // slot-owned result buffers (used when the caller passes none)
+  epa_result* d_res = nullptr;
+  size_t cap = 0;
+  void* h_out = nullptr;      // pinned: pairs | results
+  size_t h_out_sz = 0;
+  unsigned long long* h_stats = nullptr;  // pinned, 8 words
+  unsigned long long* d_stats = nullptr;  // 16 words in HBM
+  hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_down = nullptr;
+  const epa_pair* out_pairs = nullptr;    // what finish() hands out
+  const epa_result* out_res = nullptr;
+  uint64_t n = 0;
+  int state = 0;              // 0 free, 1 staged, 2 launched
+};
+
 struct epa_ctx {
   int device = 0;
   int n_cu = 256;  // compute units of the device (persistent-grid sizing)
@@ -101,6 +128,9 @@ struct epa_ctx {
   bool code_packed4 = false;  // q_codes arrive in the 4-bit wire format (epa_dev_set_query_packing)
   int heur_mode = 0;        // EPA_HEUR_* (epa_dev_set_heuristic)
   double heur_param = 0.0;  // fixed: fraction of the branches
+
+  hipStream_t copy_stream = nullptr;  // H2D of staged chunks, D2H of their results (non-blocking stream)
+  ChunkSlot slots[2];
 
   EvTimer t_lookup, t_preplace, t_thorough, t_select;
   epa_thorough_stats last_stats{};

@@ -287,11 +287,13 @@ public:
   // zero-filled 100 MB vector per chunk costs more than the device work)
   std::vector<epa_pair>& pair_buffer() { return pairs_buf_; }
   std::vector<epa_result>& result_buffer() { return res_buf_; }
+  uint64_t& pair_capacity() { return pair_cap_; }  // candidate capacity the chunk pipeline last needed
   double ref_tree_logl(size_t branch = 0) const;  // Tree::ref_tree_logl evaluated on the device
 private:
   epa_ctx* ctx_ = nullptr;
   std::vector<epa_pair> pairs_buf_;
   std::vector<epa_result> res_buf_;
+  uint64_t pair_cap_ = 0;
 };
 
 // encoded chunk of queries (what crosses the C-ABI)

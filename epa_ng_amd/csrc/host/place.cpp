@@ -193,7 +193,7 @@ Work apply_heuristic(const std::vector<double>& lnl, size_t Q, size_t B, const O
 }
 
 // one PQuery per query, in query order (quirk D8: the reference's order is thread-dependent)
-static void build_sample(const Work& to_place, const std::vector<epa_result>& res, const MSA& chunk,
+static void build_sample(const Work& to_place, const epa_result* res, const MSA& chunk,
                          Sample& sample, size_t seq_id_offset) {
   const size_t n = to_place.size(), Q = chunk.size();
   std::vector<long> slot(Q, -1);
@@ -226,7 +226,7 @@ void place_thorough(const Work& to_place, const MSA& chunk, const Encoded_Chunk&
   if (rc == EPA_ERR_NEG_INF)  // Tiny_Tree.cpp:209-212
     throw std::runtime_error{epa_dev_last_error(dev.ctx())};
   if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
-  build_sample(to_place, res, chunk, sample, seq_id_offset);
+  build_sample(to_place, res.data(), chunk, sample, seq_id_offset);
   (void)tree;
 }
 
@@ -269,7 +269,54 @@ void place_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, D
   }
   work.resize(n);
   for (size_t i = 0; i < n; ++i) work[i] = Work_Pair{pairs[i].branch_id, pairs[i].seq_id};
+  build_sample(work, res.data(), chunk, sample, seq_id_offset);
+}
+
+// ---- the fused chunk body as a two-slot pipeline (epa_dev_chunk_stage / _launch / _finish): the
+// H2D of this chunk and the D2H + host post-processing of the previous one overlap the kernels
+// (the device-side counterpart of the read-ahead in src/seq/MSA_Stream.cpp:79-82)
+void chunk_launch(const Encoded_Chunk& enc, size_t Q, const Tree& tree, Device_Evaluator& dev, int slot,
+                  const Options& options) {
+  const size_t nb = tree.num_branches();
+  const int mode = options.baseball ? EPA_HEUR_BASEBALL
+                                    : options.prescoring_by_percentage ? EPA_HEUR_FIXED : EPA_HEUR_DYNAMIC;
+  if (epa_dev_set_heuristic(dev.ctx(), mode, mode == EPA_HEUR_FIXED ? options.prescoring_threshold : 0.0) != EPA_OK)
+    throw std::runtime_error{epa_dev_last_error(dev.ctx())};
+  uint64_t cap = std::max<uint64_t>((uint64_t)Q * 8, dev.pair_capacity());
+  if (mode == EPA_HEUR_FIXED)
+    cap = std::max<uint64_t>(cap, (uint64_t)Q * std::min<size_t>(nb, (size_t)std::ceil(options.prescoring_threshold * (double)nb)));
+  else if (mode == EPA_HEUR_BASEBALL)
+    cap = std::max<uint64_t>(cap, (uint64_t)Q * std::min<size_t>(nb, 46));
+  uint32_t max_span = 0;
+  for (uint32_t s : enc.win_span) max_span = std::max(max_span, s);
+  epa_dev_set_query_layout(dev.ctx(), enc.stride);
+  epa_dev_set_query_packing(dev.ctx(), enc.bits);
+  int rc = epa_dev_chunk_stage(dev.ctx(), slot, enc.codes.data(), enc.win_begin.data(), enc.win_span.data(),
+                               (uint32_t)Q);
+  if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
+  for (;;) {
+    rc = epa_dev_chunk_launch(dev.ctx(), slot, max_span, options.prescoring_threshold, nullptr, nullptr, cap, 0);
+    if (rc == EPA_ERR_INVALID_ARG && cap < (uint64_t)Q * nb) {
+      cap = std::min<uint64_t>(cap * 8, (uint64_t)Q * nb);  // candidate overflow: the slot stays staged
+      continue;
+    }
+    if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
+    break;
+  }
+  dev.pair_capacity() = cap;
+}
+
+size_t chunk_finish(const MSA& chunk, Device_Evaluator& dev, int slot, Sample& sample, size_t seq_id_offset) {
+  const epa_pair* pairs = nullptr;
+  const epa_result* res = nullptr;
+  uint64_t n = 0;
+  const int rc = epa_dev_chunk_finish(dev.ctx(), slot, &pairs, &res, &n, nullptr);
+  if (rc == EPA_ERR_NEG_INF) throw std::runtime_error{epa_dev_last_error(dev.ctx())};  // Tiny_Tree.cpp:209-212
+  if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
+  Work work(n);
+  for (size_t i = 0; i < n; ++i) work[i] = Work_Pair{pairs[i].branch_id, pairs[i].seq_id};
   build_sample(work, res, chunk, sample, seq_id_offset);
+  return n;
 }
 
 size_t place_all(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, Device_Evaluator& dev,
@@ -464,34 +511,78 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
     cv_get.notify_all();
   });
 
+  // EPA_HOST_HEURISTIC=1: keep the Q x B table round trip and the host heuristics (cross-check)
+  const bool pipelined = options.prescoring && options.device_select && tree.num_branches() <= 65536 &&
+                         std::getenv("EPA_HOST_HEURISTIC") == nullptr && std::getenv("EPA_NO_PIPELINE") == nullptr;
   auto worker = [&](size_t k) {
     try {
-      for (;;) {
-        Staged cur;
-        {
-          std::unique_lock<std::mutex> lk(mu);
-          const auto tw = clk::now();
-          cv_get.wait(lk, [&] { return !queue.empty() || eof || failure; });
-          st.seconds_stage_wait += std::chrono::duration<double>(clk::now() - tw).count() / devices.size();
-          if (failure || queue.empty()) return;
-          cur = std::move(queue.front());
-          queue.pop_front();
-          cv_put.notify_one();
-        }
-        Chunk_Timing tm;
-        Sample smp = process_chunk(cur.chunk, cur.enc, tree, *devs[k], options, cur.offset, tm);
+      auto take = [&](Staged& cur) -> bool {
+        std::unique_lock<std::mutex> lk(mu);
+        const auto tw = clk::now();
+        cv_get.wait(lk, [&] { return !queue.empty() || eof || failure; });
+        st.seconds_stage_wait += std::chrono::duration<double>(clk::now() - tw).count() / devices.size();
+        if (failure || queue.empty()) return false;
+        cur = std::move(queue.front());
+        queue.pop_front();
+        cv_put.notify_one();
+        return true;
+      };
+      auto publish = [&](const Staged& done, Sample& smp, const Chunk_Timing& tm) {
         const auto tf = clk::now();
         std::string text = jplace_chunk_text(smp, options.precision, &tree.mapper());
         const double secs_text = std::chrono::duration<double>(clk::now() - tf).count();
         std::lock_guard<std::mutex> lk(mu);
-        if (results.size() <= cur.index) results.resize(cur.index + 1);
-        results[cur.index] = std::move(text);
+        if (results.size() <= done.index) results.resize(done.index + 1);
+        results[done.index] = std::move(text);
         st.seconds_write += secs_text;
-        st.queries += cur.chunk.size();
+        st.queries += done.chunk.size();
         st.pairs += tm.pairs;
         st.seconds_place += tm.place;
         st.seconds_thorough += tm.thorough;
         st.seconds_post += tm.post;
+      };
+      if (!pipelined) {
+        for (;;) {
+          Staged cur;
+          if (!take(cur)) return;
+          Chunk_Timing tm;
+          Sample smp = process_chunk(cur.chunk, cur.enc, tree, *devs[k], options, cur.offset, tm);
+          publish(cur, smp, tm);
+        }
+      }
+      // two-slot pipeline: launch chunk i (its upload and kernels are queued, the call returns once
+      // the candidate count is known), then finish chunk i-1: its D2H, LWR, filter and jplace text
+      // run while the GPU works on chunk i
+      Staged prev;
+      bool have_prev = false;
+      int slot = 0;
+      for (;;) {
+        Staged cur;
+        const bool have_cur = take(cur);
+        Chunk_Timing tm;
+        if (have_cur) {
+          const auto t0 = clk::now();
+          chunk_launch(cur.enc, cur.chunk.size(), tree, *devs[k], slot, options);
+          tm.place = std::chrono::duration<double>(clk::now() - t0).count();
+        }
+        if (have_prev) {
+          const auto t1 = clk::now();
+          Sample smp;
+          tm.pairs = chunk_finish(prev.chunk, *devs[k], slot ^ 1, smp, prev.offset);
+          const auto t2 = clk::now();
+          compute_and_set_lwr(smp);
+          filter(smp, options);
+          tm.thorough = std::chrono::duration<double>(t2 - t1).count();
+          tm.post = std::chrono::duration<double>(clk::now() - t2).count();
+          publish(prev, smp, tm);
+        } else if (have_cur) {
+          std::lock_guard<std::mutex> lk(mu);
+          st.seconds_place += tm.place;
+        }
+        if (!have_cur) break;
+        prev = std::move(cur);
+        have_prev = true;
+        slot ^= 1;
       }
     } catch (...) {
       std::lock_guard<std::mutex> lk(mu);

@@ -60,6 +60,22 @@ def host_lib():
     return _LIB
 
 
+def cli_exe():
+    """path of the epa-ng-amd executable; (re)built from source first when the host toolchain is
+    present, so a stale binary is never what gets tested"""
+    import importlib.util
+    import shutil
+    if shutil.which("g++"):
+        spec = importlib.util.spec_from_file_location("epa_build", os.path.join(HERE, "build.py"))
+        b = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(b)
+        b.build_host()
+    exe = os.path.join(HERE, "epa-ng-amd")
+    if not os.path.exists(exe):
+        raise ImportError("epa-ng-amd is missing: run build() of __graft_entry__.py")
+    return exe
+
+
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 

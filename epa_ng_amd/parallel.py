@@ -53,7 +53,9 @@ class AsyncResultGather:
 
     post() is collective: every rank calls it once per chunk, in the same order."""
 
-    def __init__(self, dist, max_rows, device, dst=0, depth=2):
+    def __init__(self, dist, max_rows, device, dst=0, depth=2, host_copy=False):
+        """host_copy: rank dst also copies every gathered slot into pinned host memory when it
+        retires it (the results' way to the host pipeline; puts the D2H inside a timed loop)"""
         import torch
         self.dist, self.dst, self.depth = dist, dst, depth
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
@@ -67,6 +69,10 @@ class AsyncResultGather:
         self.nmax = torch.zeros(1, dtype=torch.int64, device=self.cdev)
         self.step = 0
         self.collected = []   # dst only: list of (step, [per-rank (n, 4) arrays]) when keep=True
+        self.host = None
+        if host_copy and self.rank == dst and self.cdev.type == "cuda":
+            self.host = [torch.empty((self.world, self.max_rows + 1, 4), dtype=torch.float64).pin_memory()
+                         for _ in range(depth)]
 
     def post(self, pairs_i32, results_f64, n, keep=False):
         """pairs_i32: (cap, 2) int32 tensor, results_f64: (cap, 3) float64 tensor, n valid rows."""
@@ -94,6 +100,10 @@ class AsyncResultGather:
             return
         w.wait()
         self.work[slot] = None
+        if self.host is not None:
+            m = self.rows[slot]
+            for rk, r in enumerate(self.recv[slot]):
+                self.host[slot][rk, :m + 1].copy_(r[:m + 1], non_blocking=True)
         if keep and self.rank == self.dst:
             m = self.rows[slot]
             parts = []
@@ -106,6 +116,9 @@ class AsyncResultGather:
         """waits for every outstanding gather (oldest first)"""
         for i in range(self.depth):
             self._retire((self.step + i) % self.depth, keep)
+        if self.host is not None:
+            import torch
+            torch.cuda.current_stream().synchronize()
 
 
 def unpack_rows(rows):

@@ -176,3 +176,48 @@ def aa_workload(n_tips=2000, W=500, n_reads=50000, read_len=100, seeds=(11, 12, 
     reads, _ = make_reads(seqs, n_reads, read_len, 0.03, seeds[2], states=20)
     return {"newick": newick(root), "labels": labels, "seqs": seqs, "reads": reads, "states": 20,
             "subst": subst, "freqs": freqs, "rates": rates, "weights": np.full(4, 0.25)}
+
+
+# lookup-column order of the query codes (NT_MAP / AA_MAP of the reference's src/util/maps.hpp)
+NT_COLS = "-TGKCYSBAWRDMHVN"
+AA_COLS = "ACDEFGHIKLMNPQRSTVWY-XBZ"
+
+
+def make_reads_compact(seqs, n_reads, read_len, sub_rate, seed, states=4):
+    """The reads of make_reads(seqs, n_reads, read_len, sub_rate, seed) -- same random draws --
+    straight in the compact wire layout of epa_encode_queries_compact: (codes uint8 [n][stride]
+    holding only each read's window, win_begin uint32 [n], win_span uint32 [n]); no n x W ASCII
+    rows are ever built (10^7 reads of a 1500-column alignment would be 15 GB of text)."""
+    rng = np.random.RandomState(seed)
+    alphabet = DNA if states == 4 else AA
+    cols_of = NT_COLS if states == 4 else AA_COLS
+    W = len(seqs[0])
+    tips = rng.randint(0, len(seqs), n_reads)
+    starts = rng.randint(0, W - read_len + 1, n_reads)
+    arr = np.frombuffer("".join(seqs).encode(), dtype=np.uint8).reshape(len(seqs), W)
+    alpha = np.frombuffer(alphabet.encode(), dtype=np.uint8)
+    cols = starts[:, None] + np.arange(read_len)[None, :]
+    frag = arr[tips[:, None], cols]
+    mut = rng.random_sample(frag.shape) < sub_rate
+    frag = np.where(mut, alpha[rng.randint(0, len(alpha), frag.shape)], frag)
+    lut = np.full(256, 255, np.uint8)
+    for i, ch in enumerate(cols_of):
+        lut[ord(ch)] = i
+    stride = (read_len + 15) // 16 * 16
+    if stride == W:
+        stride += 16
+    codes = np.zeros((n_reads, stride), np.uint8)
+    codes[:, :read_len] = lut[frag]
+    assert codes.max() < 255
+    # get_valid_range trims literal '-' only; the simulated tips hold none
+    return codes, starts.astype(np.uint32), np.full(n_reads, read_len, np.uint32)
+
+
+def compact_to_ascii(codes, win_begin, win_span, W, states=4):
+    """compact code rows -> full-width ASCII query rows (for the CPU oracle, which reads text)"""
+    cols_of = np.frombuffer((NT_COLS if states == 4 else AA_COLS).encode(), dtype=np.uint8)
+    out = np.full((len(codes), W), ord("-"), np.uint8)
+    for q in range(len(codes)):
+        b, n = int(win_begin[q]), int(win_span[q])
+        out[q, b:b + n] = cols_of[codes[q, :n]]
+    return [row.tobytes().decode() for row in out]

@@ -285,6 +285,35 @@ int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* wi
                         uint64_t* n_pairs, epa_thorough_stats* stats);
 
 /*
+ * The same chunk body as a double-buffered pipeline, the device-side counterpart of the
+ * reference's read-ahead of the next chunk (src/seq/MSA_Stream.cpp:79-82, the prefetch in
+ * src/core/place.cpp:190-215): the query upload of chunk k+1 and the result download of chunk k-1
+ * run on a copy stream while the kernels of chunk k run.  Two slots (0, 1), each walks
+ *     stage -> launch -> finish -> stage -> ...
+ *   stage   copies the caller's HOST arrays (layout / packing as set for the context) into the
+ *           slot's pinned buffer and starts the H2D transfer; returns at once.
+ *   launch  preplace -> heuristic -> thorough on the compute stream as soon as the upload has
+ *           landed; blocks only until the candidate count is known (it sizes the thorough launch),
+ *           then queues the thorough kernels and the D2H of pairs / results and returns.
+ *           d_pairs / d_results: optional DEVICE buffers of max_pairs entries that receive the
+ *           results (e.g. the send buffers of a collective); NULL = buffers owned by the slot.
+ *           EPA_CHUNK_NO_D2H: results stay in HBM (finish() hands out the device pointers).
+ *   finish  waits for the slot's download; *pairs / *results point into the slot's pinned host
+ *           buffer (or HBM with EPA_CHUNK_NO_D2H), valid until the slot is staged again.
+ * A typical loop:  stage(0, c0); for k: launch(k&1); stage((k+1)&1, c[k+1]); finish((k-1)&1) ...
+ * Candidate overflow (EPA_ERR_INVALID_ARG from launch, as epa_dev_place_chunk) leaves the slot
+ * staged: launch again with a larger max_pairs.
+ */
+#define EPA_CHUNK_NO_D2H 0x1u
+int epa_dev_chunk_stage(epa_ctx* ctx, int slot, const uint8_t* q_codes, const uint32_t* win_begin,
+                        const uint32_t* win_span, uint32_t Q);
+int epa_dev_chunk_launch(epa_ctx* ctx, int slot, uint32_t max_span, double threshold,
+                         epa_pair* d_pairs, epa_result* d_results, uint64_t max_pairs,
+                         uint32_t flags);
+int epa_dev_chunk_finish(epa_ctx* ctx, int slot, const epa_pair** pairs, const epa_result** results,
+                         uint64_t* n_pairs, epa_thorough_stats* stats);
+
+/*
  * --no-heur (src/core/place.cpp:189,228: every branch gets a thorough placement) with the
  * post-processing of the chunk loop fused in: thorough optimisation of all B x Q pairs (pairs are
  * generated on the device), then per query compute_and_set_lwr over all B placements and filter()

@@ -11,7 +11,7 @@ for grp in "$@"; do
   out=$R/gpurun_out/${tag}_pmc_$name
   mkdir -p "$out"
   timeout 600 rocprofv3 --pmc $grp --output-format csv -d "$out" -o pmc -- \
-    python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} > "$out.log" 2>&1
+    python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras ${BENCH_ARGS} > "$out.log" 2>&1
   f=$(find "$out" -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && [ "$f" != "$out/pmc_counter_collection.csv" ] && cp "$f" "$out/pmc_counter_collection.csv"
 done

@@ -9,7 +9,7 @@ tail -1 gpurun_out/${tag}_bench.json | cut -c1-400
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${tag}_stats
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_stats -o st -- \
-  python $R/bench.py --no-cpu-baseline > $R/gpurun_out/${tag}_stats.log 2>&1
+  python $R/bench.py --no-cpu-baseline --no-extras > $R/gpurun_out/${tag}_stats.log 2>&1
 cd $R
 python profiles/db_to_txt.py gpurun_out/${tag}_stats/st_results.db > gpurun_out/${tag}_kernel_trace_stats.txt
 head -12 gpurun_out/${tag}_kernel_trace_stats.txt

@@ -111,6 +111,10 @@ class Oracle:
     def tree_lnl(self, b):
         return lib().orc_tree_lnl(self.h, b)
 
+    def set_aa_x_quirk(self, on=True):
+        """quirk D4: AA 'X' preplaced in the 'N' (asparagine) column (Lookup_Store.hpp:63-66)"""
+        lib().orc_set_aa_x_quirk(self.h, int(on))
+
     def numbered_newick(self, prec=10):
         buf = C.create_string_buffer(256 * (self.B + 4))
         n = lib().orc_numbered_newick(self.h, prec, buf, len(buf))

@@ -128,7 +128,7 @@ def test_cli_binary_matches_golden(tmp_path):
     with open(qf, "w") as f:
         for q in g["queries"]:
             f.write(">%s\n%s\n" % (q["name"], q["seq"]))
-    exe = os.path.join(os.path.dirname(hostlib.HOST_SO), "epa-ng-amd")
+    exe = hostlib.cli_exe()
     model = ("GTR{0.787874/1.821672/1.294006/0.698421/3.034135/1.0}+FU{0.256465/0.222535/0.308594/"
              "0.212406}+G4{0.478218}")
     r = subprocess.run([exe, "-t", os.path.join(data, "ref.tre"), "-s", os.path.join(data, "aln.fasta"),
@@ -539,7 +539,7 @@ def test_cli_several_devices_same_jplace(tmp_path):
     with open(qf, "w") as f:
         for i, s in enumerate(w["reads"]):
             f.write(">q%d\n%s\n" % (i, s))
-    exe = os.path.join(os.path.dirname(hostlib.HOST_SO), "epa-ng-amd")
+    exe = hostlib.cli_exe()
     model = "GTR{%s}+FU{%s}+G4{0.478218}" % ("/".join(map(repr, w["subst"])), "/".join(map(repr, w["freqs"])))
     outs = []
     for devs, extra in (("0", []), ("0,0", []), ("0,0,0", ["--no-heur"]), ("0", ["--no-heur"])):
@@ -608,7 +608,7 @@ def test_cli_rooted_tree_preserve_rooting(tmp_path):
     with open(qf, "w") as f:
         for i, s in enumerate(reads):
             f.write(">q%d\n%s\n" % (i, s))
-    exe = os.path.join(os.path.dirname(hostlib.HOST_SO), "epa-ng-amd")
+    exe = hostlib.cli_exe()
     model = "GTR{%s}+FU{%s}+G4{0.478218}" % ("/".join(map(repr, synth.CFG2_SUBST)), "/".join(map(repr, synth.CFG2_FREQS)))
     B = 2 * 14 - 3
     out = {}
@@ -685,7 +685,7 @@ def test_cli_fix_and_baseball_heuristics(tmp_path):
     with open(qf, "w") as f:
         for i, s in enumerate(w["reads"]):
             f.write(">q%d\n%s\n" % (i, s))
-    exe = os.path.join(os.path.dirname(hostlib.HOST_SO), "epa-ng-amd")
+    exe = hostlib.cli_exe()
     model = "GTR{%s}+FU{%s}+G4{0.478218}" % ("/".join(map(repr, w["subst"])), "/".join(map(repr, w["freqs"])))
     for flags in (["-G", "0.1"], ["--baseball-heur"]):
         outs = []
@@ -714,7 +714,7 @@ def test_cli_model_file(tmp_path):
     with open(qf, "w") as f:
         for q in g["queries"]:
             f.write(">%s\n%s\n" % (q["name"], q["seq"]))
-    exe = os.path.join(os.path.dirname(hostlib.HOST_SO), "epa-ng-amd")
+    exe = hostlib.cli_exe()
     desc = ("GTR{0.787874/1.821672/1.294006/0.698421/3.034135/1.000000}+FU{0.256465/0.222535/0.308594/"
             "0.212406}+G4{0.478218}")
     outs = []
@@ -770,7 +770,7 @@ def test_cli_bfast_queries(tmp_path):
     the same jplace as its query.fasta"""
     import subprocess
     data = os.path.join(GOLDEN, "data")
-    exe = os.path.join(os.path.dirname(hostlib.HOST_SO), "epa-ng-amd")
+    exe = hostlib.cli_exe()
     outs = []
     for q in ("query.fasta", "query.fasta.bin"):
         od = tmp_path / q.replace(".", "_")
@@ -783,3 +783,53 @@ def test_cli_bfast_queries(tmp_path):
         jp.pop("metadata", None)
         outs.append(jp)
     assert outs[0] == outs[1] and len(outs[0]["placements"]) == 2
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_staged_chunk_pipeline_equals_place_chunk(packed):
+    """epa_dev_chunk_stage / _launch / _finish (H2D of chunk k+1 and D2H of chunk k-1 on the copy
+    stream while chunk k computes) must return, chunk for chunk, the bits of epa_dev_place_chunk;
+    also: candidate overflow leaves the slot staged, state errors are loud, results can stay on
+    the device."""
+    import torch
+    w = synth.dna_workload(64, 700, 2400, 150, (61, 62, 63))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    Q = 400
+    chunks = []
+    for c in range(6):
+        codes, wb, ws = epa.encode_queries(4, w["reads"][c * Q:(c + 1) * Q], compact=True)
+        chunks.append((epa.pack_codes_4bit(codes) if packed else codes, wb, ws))
+    expect = [ev.place_chunk(*ch, max_span=150) for ch in chunks]
+    cap = Q * 64
+    with pytest.raises(epa.EpaError):
+        ev.chunk_launch(0, max_span=150, max_pairs=cap)          # nothing staged
+    ev.chunk_stage(0, *chunks[0])
+    with pytest.raises(epa.EpaError):
+        ev.chunk_launch(0, max_span=150, max_pairs=Q)            # candidate overflow: stays staged
+    got = []
+    for k in range(len(chunks)):
+        ev.chunk_launch(k & 1, max_span=150, max_pairs=cap)
+        if k + 1 < len(chunks):
+            ev.chunk_stage((k + 1) & 1, *chunks[k + 1])
+        if k:
+            got.append(ev.chunk_finish((k - 1) & 1))
+    got.append(ev.chunk_finish((len(chunks) - 1) & 1))
+    with pytest.raises(epa.EpaError):
+        ev.chunk_finish(0)                                       # nothing in flight
+    for (p, r), (ep, er) in zip(got, expect):
+        assert np.array_equal(p, ep)
+        assert np.array_equal(r["lnl"], er["lnl"]) and np.array_equal(r["pendant_length"], er["pendant_length"])
+        assert np.array_equal(r["distal_length"], er["distal_length"])
+    # results kept on the device in caller buffers (the send buffers of the N > 1 gather)
+    dev = torch.device("cuda", 0)
+    d_pairs = torch.zeros((cap, 2), dtype=torch.int32, device=dev)
+    d_res = torch.zeros((cap, 3), dtype=torch.float64, device=dev)
+    ev.chunk_stage(1, *chunks[2])
+    ev.chunk_launch(1, max_span=150, max_pairs=cap, pairs_out=d_pairs, results_out=d_res, keep_on_device=True)
+    n = ev.chunk_finish_device(1)
+    torch.cuda.synchronize()
+    assert n == len(expect[2][0])
+    assert np.array_equal(d_pairs[:n, 0].cpu().numpy().view(np.uint32), expect[2][0]["branch_id"])
+    assert np.array_equal(d_res[:n, 0].cpu().numpy(), expect[2][1]["lnl"])

@@ -353,29 +353,7 @@ def test_preserve_rooting_off_reports_unrooted_tree():
 # --- model files: the five expected descriptors of the reference's own tests
 # (test/src/parse_model.cpp:7-63) on its own fixture files (tests/golden/data/modelfiles)
 MODELFILES = os.path.join(os.path.dirname(__file__), "golden", "data", "modelfiles")
-RAX8_PROT = (
-    "PROTGTR{1.003440/0.000100/2.196009/5.059275/4.560130/5.912979/5.272299/0.699779/0.020243/"
-    "0.457291/2.383670/3.120039/0.000100/5.403822/22.495228/10.091005/0.000100/0.854092/7.486708/"
-    "2.797232/0.000100/3.336754/14.440424/0.699469/2.876841/6.187008/0.146659/1.306731/40.784484/"
-    "2.932864/0.000100/0.546610/4.283376/1.721473/7.351827/0.000100/0.242215/19.432567/2.883241/"
-    "4.941582/0.000100/10.033898/16.079424/0.091909/0.223185/8.114498/0.000100/0.000100/0.019247/"
-    "13.487358/4.159476/0.965976/0.907212/0.159272/0.000100/0.519077/19.701531/3.251195/1.851635/"
-    "0.000100/0.000100/0.019268/0.609953/0.022740/0.773217/1.163731/1.169671/0.000100/0.396903/"
-    "0.096786/0.785888/0.349871/2.773764/1.856643/0.000100/0.605999/0.000100/0.000100/4.159594/"
-    "0.000100/11.101237/2.167720/3.372110/6.818292/2.550358/12.631121/1.065164/22.029064/"
-    "0.057514/1.610956/15.065560/4.472040/0.339767/4.488237/2.790060/2.836442/0.000100/0.000100/"
-    "0.356764/1.686983/0.000100/0.000100/0.000100/2.102531/0.000100/0.000100/1.573639/1.971493/"
-    "1.619030/0.000100/0.000100/1.136575/1.577318/0.000100/0.000100/0.346037/1.243377/0.000100/"
-    "0.593558/5.343049/0.040971/0.000100/0.794127/0.325353/0.594141/0.481006/0.875320/4.863509/"
-    "1.002356/1.150123/5.988620/0.463365/5.112361/26.224851/1.003883/19.731303/1.177304/"
-    "17.282051/2.032055/0.000100/0.090724/4.148174/0.000100/0.000100/46.061900/0.088576/"
-    "34.484594/9.718744/1.963249/0.441787/0.376570/3.032150/1.205978/4.791255/4.618257/0.000100/"
-    "0.902389/0.765214/3.363404/0.000100/0.000100/0.339229/0.085804/0.000100/0.901420/4.051803/"
-    "0.000100/2.292349/5.894876/0.252951/0.069199/0.141572/4.900860/33.781619/1.583086/4.310457/"
-    "2.531992/1.573469/0.000100/0.510724/16.587826/2.264213/0.442391/0.311316/1.683277/0.672040/"
-    "5.904625/10.245562/1.330998/1.000000}+FU{0.065149/0.054231/0.041608/0.058452/0.023965/"
-    "0.036826/0.069410/0.052618/0.030732/0.067906/0.092164/0.051878/0.022917/0.045111/0.040413/"
-    "0.069908/0.072135/0.004367/0.029144/0.071068}+G4{0.563473}")
+from golden_util import RAX8_PROT  # noqa: E402  (the literal of test/src/parse_model.cpp:26-47)
 
 
 @pytest.mark.parametrize("name,expected", [
@@ -504,3 +482,18 @@ def test_bfast_query_files(tmp_path):
     for chunk in (1, 3, 50):
         out = subprocess.run([str(exe), str(bf), str(chunk)], check=True, capture_output=True, text=True).stdout
         assert [tuple(l.split()) for l in out.strip().split("\n")] == recs
+
+
+def test_compact_read_generator_equals_ascii_reads_encoded():
+    """bench.py generates its reads straight in the compact wire layout; they must be the reads
+    synth.make_reads would have produced, encoded by the library's own encoder"""
+    from epa_ng_amd import synth
+    for states, (n_tips, W, rl) in ((4, (12, 300, 150)), (20, (9, 160, 100)), (4, (5, 160, 160))):
+        subst, freqs = (synth.CFG2_SUBST, synth.CFG2_FREQS) if states == 4 else synth.aa_model()
+        root = synth.random_tree(n_tips, 3)
+        _, seqs = synth.simulate_msa(root, W, subst, freqs, synth.gamma_rates(0.5), 4)
+        reads, starts = synth.make_reads(seqs, 500, rl, 0.03, 17, states=states)
+        codes, wb, ws = epa.encode_queries(states, reads, compact=True)
+        c2, b2, s2 = synth.make_reads_compact(seqs, 500, rl, 0.03, 17, states=states)
+        assert np.array_equal(wb, b2) and np.array_equal(ws, s2) and np.array_equal(codes, c2)
+        assert synth.compact_to_ascii(c2, b2, s2, W, states) == list(reads)

@@ -110,16 +110,40 @@ def test_derivatives_match_finite_differences():
 
 
 def test_windowed_equals_full_when_outside_is_gap():
-    # reference property test/src/pll_util.cpp:325-335
+    """The reference's shift_partition_focus_logtest (test/src/pll_util.cpp:270-335) restated on
+    its own numbers: tips "--AAAA----" / "--TTTT----" / "--GGGG----", freqs {.17,.19,.25,.39},
+    all exchangeabilities 1, Gamma(1.0) x 4, branch lengths 0.123.  Every column outside [2, 6) is
+    all-gap at every tip, so it contributes log(sum_i pi_i) = 0 and the lnL over the window must
+    EQUAL the lnL over the full width (EXPECT_DOUBLE_EQ = 4 ulps), for the edge lnL of the tree and
+    for a query scored on every branch (lookup sums and direct evaluation)."""
+    from oracle_lib import Oracle, gamma_rates
+    freqs = [0.17, 0.19, 0.25, 0.39]
+    labels = ["a", "t", "g"]
+    seqs = ["--AAAA----", "--TTTT----", "--GGGG----"]
+    inner = [s_[2:6] for s_ in seqs]
+    nw = "(a:0.123,t:0.123,g:0.123);"
+    rates = gamma_rates(1.0)
+    full = Oracle(nw, labels, seqs, 4, [1.0] * 6, freqs, rates)
+    win = Oracle(nw, labels, inner, 4, [1.0] * 6, freqs, rates)
+
+    def double_eq(x, y):     # gtest's EXPECT_DOUBLE_EQ: within 4 ulps
+        return abs(x - y) <= 4 * np.spacing(max(abs(x), abs(y)))
+    for b in range(full.B):
+        assert double_eq(full.tree_lnl(b), win.tree_lnl(b))
+    q = "--ACGT----"
+    ranged = full.preplace([q], premask=True)
+    whole = full.preplace([q], premask=False)
+    cut = win.preplace([q[2:6]], premask=False)
+    for b in range(full.B):
+        assert double_eq(ranged[0, b], whole[0, b]) and double_eq(ranged[0, b], cut[0, b])
+        assert double_eq(full.direct_default_lnl(b, q, True), full.direct_default_lnl(b, q, False))
+        assert abs(full.direct_default_lnl(b, q, True) - ranged[0, b]) < 1e-10   # lookup == direct
+    # and on the bundled data: a windowed query scored over the full width differs from its
+    # windowed score exactly by the reference-only columns, which are not all-gap there
     g = load_case("dna8_gtr_g_default")
     o = make_oracle(g)
-    q = g["queries"][2]["seq"]           # window 100..250
-    a = o.preplace([q], premask=True)
-    full = o.preplace([q], premask=False)
-    # outside the window the query is all-gap: those sites add the reference-only site lnL
-    ref_only = o.preplace(["-" * (o.W - 1) + "A"], premask=False)  # not used for equality
-    assert a.shape == full.shape and np.all(full < a)
-    assert ref_only.shape == a.shape
+    qq = g["queries"][2]["seq"]           # window 100..250
+    assert np.all(o.preplace([qq], premask=False) < o.preplace([qq], premask=True))
 
 
 def test_error_codes():
