@@ -223,22 +223,27 @@ def main():
 
     # ---------------- loop 2: PCIe inside the step, overlapped on the copy stream
     exch2 = parallel.AsyncResultGather(dist, min(cap, 8 * max(Q, 1)), dev, host_copy=True) if world > 1 else None
-    state = {"staged": None, "inflight": None, "bytes_up": 0, "bytes_down": 0}
+    state = {"staged": None, "inflight": None, "bytes_up": 0, "bytes_down": 0,
+             "t_stage": 0.0, "t_launch": 0.0, "t_finish": 0.0, "timed": False}
     bufs = [(d_pairs, d_res), (torch.empty_like(d_pairs), torch.empty_like(d_res))]
 
     def stage(i):
         _, hb, hs, wire = host_chunks[i]
+        t = time.perf_counter()
         ev.chunk_stage(i & 1, wire, hb, hs)                  # host -> pinned -> async H2D (copy stream)
+        state["t_stage"] += (time.perf_counter() - t) if i > a.warmup else 0.0   # timed steps only
         state["staged"] = i
         state["bytes_up"] += (wire.data if isinstance(wire, epa.Packed4) else wire).nbytes + 8 * Q
 
     def retire(slot):
+        t = time.perf_counter()
         if world > 1:
             n = ev.chunk_finish_device(slot)
             exch2.post(bufs[slot][0], bufs[slot][1], n)     # gather to rank 0, which copies it to the host
         else:
             p, r = ev.chunk_finish(slot, copy=False)        # views of the slot's pinned host buffer
             n = len(p)
+        state["t_finish"] += (time.perf_counter() - t) if state["timed"] else 0.0
         state["bytes_down"] += n * 32
         state["inflight"] = None
 
@@ -252,7 +257,10 @@ def main():
             stage(i)
         kw = dict(pairs_out=bufs[slot][0], results_out=bufs[slot][1], keep_on_device=True) if world > 1 else {}
         # returns once the candidate count is known; thorough kernels + result D2H are queued
+        t = time.perf_counter()
         ev.chunk_launch(slot, threshold=0.99999, max_span=a.read_len, max_pairs=cap, **kw)
+        state["timed"] = i > a.warmup
+        state["t_launch"] += (time.perf_counter() - t) if i >= a.warmup else 0.0
         if state["inflight"] is not None:                    # previous chunk: its D2H ran under this preplace
             retire(state["inflight"])
         state["inflight"] = slot
@@ -389,10 +397,10 @@ def main():
             ev.chunk_stage(0, *small[0])
             for k in range(nsm):
                 ev.chunk_launch(k & 1, threshold=0.99999, max_span=a.read_len, max_pairs=5000 * 64)
-                if k + 1 < nsm:
-                    ev.chunk_stage((k + 1) & 1, *small[k + 1])
                 if k:
                     ev.chunk_finish((k - 1) & 1, copy=False)
+                if k + 1 < nsm:
+                    ev.chunk_stage((k + 1) & 1, *small[k + 1])
             ev.chunk_finish((nsm - 1) & 1, copy=False)
             t5 = time.perf_counter() - t0
         extras["chunk5000"] = {"value": round(nsm * 5000 / t5, 1), "unit": "placements/s", "chunks": nsm,
@@ -405,6 +413,9 @@ def main():
             "ms_per_step": round(elapsed_pcie / a.steps * 1e3, 3),
             "h2d_bytes_per_step": state["bytes_up"] // max(1, n_chunks),
             "d2h_bytes_per_step": state["bytes_down"] // max(1, n_chunks),
+            "host_ms_per_step": {"stage (memcpy to pinned + H2D enqueue)": round(state["t_stage"] / max(1, a.steps - 1) * 1e3, 3),
+                                 "launch (returns when the candidate count is known)": round(state["t_launch"] / a.steps * 1e3, 3),
+                                 "finish (wait for the previous chunk's D2H)": round(state["t_finish"] / max(1, a.steps - 1) * 1e3, 3)},
             "how": "epa_dev_chunk_stage/_launch/_finish: %s codes + windows up, pairs + results down, copies on "
                    "the copy stream under the previous / next chunk's kernels%s"
                    % ("4-bit" if states == 4 else "1-byte",

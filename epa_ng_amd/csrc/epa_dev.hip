@@ -301,9 +301,12 @@ static int encode_impl(uint32_t states, uint32_t sites, uint32_t Q, const char* 
   if (dna) {
     map['U'] = map['u'] = map['T'];
     map['X'] = map['x'] = map['O'] = map['o'] = map['.'] = map['-'];
-  } else if (aa_x_as_n) {
-    map['X'] = map['x'] = map['N'];
   }
+  // aa_x_as_n (quirk D4) is NOT applied here: the reference remaps 'X' to the 'N' column only in
+  // Lookup_Store's index map (preplacement), the thorough placement reads 'X' as "any" through
+  // pll_map_aa.  A context created with epa_ref_desc.aa_x_as_n builds its 'X' lookup column as a
+  // copy of the 'N' column instead, so the same code rows serve both steps.
+  (void)aa_x_as_n;
   map['?'] = map['-'];
   // queries are independent: a few host threads (the first offender in query order is reported)
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -463,6 +466,7 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
     for (hipEvent_t e : {sl.ev_up, sl.ev_done, sl.ev_down}) if (e) (void)hipEventDestroy(e);
   }
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
   EvTimer* ts[4] = {&ctx->t_lookup, &ctx->t_preplace, &ctx->t_thorough, &ctx->t_select};
   for (auto* t : ts) { if (t->a) (void)hipEventDestroy(t->a); if (t->b) (void)hipEventDestroy(t->b); }
   delete ctx;
@@ -539,6 +543,8 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
       m.qt[col * s + x] = acc;
     }
   }
+  if (s == 20 && ctx->aa_x_as_n)  // quirk D4: the lookup (preplacement) column of 'X' holds asparagine's numbers
+    m.colmask[21] = m.colmask[11];  // AA_COLS[21] == 'X', AA_COLS[11] == 'N'
   if (s == 4 && c == 4) {
     for (int i = 0; i < 16; ++i) { ctx->dna.U[i] = m.U[i]; ctx->dna.Ui[i] = m.Ui[i]; }
     for (int i = 0; i < 4; ++i) {
@@ -1229,6 +1235,7 @@ static int slot_of(epa_ctx* ctx, int slot, ChunkSlot** out) {
   if (slot < 0 || slot > 1) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk pipeline: slot must be 0 or 1");
   ChunkSlot& s = ctx->slots[slot];
   if (!ctx->copy_stream) EPA_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  if (!ctx->down_stream) EPA_HIP(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
   if (!s.ev_up) {
     EPA_HIP(ctx, hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
     EPA_HIP(ctx, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
@@ -1346,7 +1353,7 @@ extern "C" int epa_dev_chunk_launch(epa_ctx* ctx, int slot, uint32_t max_span, d
   if (rc) return rc;  // candidate overflow etc.: the slot stays staged
   s->n = n;
   EPA_HIP(ctx, hipEventRecord(s->ev_done, ctx->stream));
-  EPA_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, s->ev_done, 0));
+  EPA_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, s->ev_done, 0));
   if (flags & EPA_CHUNK_NO_D2H) {
     s->out_pairs = d_pairs;
     s->out_res = d_results;
@@ -1355,15 +1362,15 @@ extern "C" int epa_dev_chunk_launch(epa_ctx* ctx, int slot, uint32_t max_span, d
     rc = grow_pinned(ctx, &s->h_out, &s->h_out_sz, off_r + sizeof(epa_result) * n);
     if (rc) return rc;
     if (n) {
-      EPA_HIP(ctx, hipMemcpyAsync(s->h_out, d_pairs, sizeof(epa_pair) * n, hipMemcpyDeviceToHost, ctx->copy_stream));
+      EPA_HIP(ctx, hipMemcpyAsync(s->h_out, d_pairs, sizeof(epa_pair) * n, hipMemcpyDeviceToHost, ctx->down_stream));
       EPA_HIP(ctx, hipMemcpyAsync((char*)s->h_out + off_r, d_results, sizeof(epa_result) * n, hipMemcpyDeviceToHost,
-                                  ctx->copy_stream));
+                                  ctx->down_stream));
     }
     s->out_pairs = (const epa_pair*)s->h_out;
     s->out_res = (const epa_result*)((char*)s->h_out + off_r);
   }
-  EPA_HIP(ctx, hipMemcpyAsync(s->h_stats, s->d_stats, 64, hipMemcpyDeviceToHost, ctx->copy_stream));
-  EPA_HIP(ctx, hipEventRecord(s->ev_down, ctx->copy_stream));
+  EPA_HIP(ctx, hipMemcpyAsync(s->h_stats, s->d_stats, 64, hipMemcpyDeviceToHost, ctx->down_stream));
+  EPA_HIP(ctx, hipEventRecord(s->ev_down, ctx->down_stream));
   s->state = 2;
   return EPA_OK;
 }

@@ -129,7 +129,9 @@ struct epa_ctx {
   int heur_mode = 0;        // EPA_HEUR_* (epa_dev_set_heuristic)
   double heur_param = 0.0;  // fixed: fraction of the branches
 
-  hipStream_t copy_stream = nullptr;  // H2D of staged chunks, D2H of their results (non-blocking stream)
+  // non-blocking copy streams of the chunk pipeline: uploads and downloads each have their own, so
+  // the H2D of chunk k+1 is not queued behind the D2H of chunk k (which waits for k's kernels)
+  hipStream_t copy_stream = nullptr, down_stream = nullptr;
   ChunkSlot slots[2];
 
   EvTimer t_lookup, t_preplace, t_thorough, t_select;

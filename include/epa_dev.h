@@ -196,6 +196,9 @@ int epa_dev_build_lookup(epa_ctx* ctx);
  */
 
 /* ASCII -> column codes + windows on the host.  seqs: Q pointers to W characters each.
+ * aa_x_as_n is accepted for ABI stability and ignored: quirk D4 lives in the lookup table of a
+ * context created with epa_ref_desc.aa_x_as_n (preplacement only, as in the reference), the
+ * code of 'X' is the same either way and the thorough placement always reads it as "any".
  * Returns EPA_OK, EPA_ERR_INVALID_CHAR or EPA_ERR_QUERY_ALL_GAP (first offender in *bad_query). */
 int epa_encode_queries(uint32_t states, uint32_t sites, uint32_t Q, const char* const* seqs,
                        int premasking, int aa_x_as_n, uint8_t* codes, uint32_t* win_begin,
@@ -300,7 +303,7 @@ int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* wi
  *           EPA_CHUNK_NO_D2H: results stay in HBM (finish() hands out the device pointers).
  *   finish  waits for the slot's download; *pairs / *results point into the slot's pinned host
  *           buffer (or HBM with EPA_CHUNK_NO_D2H), valid until the slot is staged again.
- * A typical loop:  stage(0, c0); for k: launch(k&1); stage((k+1)&1, c[k+1]); finish((k-1)&1) ...
+ * A typical loop:  stage(0, c0); for k: { launch(k&1); finish((k-1)&1); stage((k+1)&1, c[k+1]); }
  * Candidate overflow (EPA_ERR_INVALID_ARG from launch, as epa_dev_place_chunk) leaves the slot
  * staged: launch again with a larger max_pairs.
  */

@@ -811,10 +811,13 @@ def test_staged_chunk_pipeline_equals_place_chunk(packed):
     got = []
     for k in range(len(chunks)):
         ev.chunk_launch(k & 1, max_span=150, max_pairs=cap)
-        if k + 1 < len(chunks):
-            ev.chunk_stage((k + 1) & 1, *chunks[k + 1])
         if k:
             got.append(ev.chunk_finish((k - 1) & 1))
+        if k + 1 < len(chunks):
+            if k:
+                with pytest.raises(epa.EpaError):
+                    ev.chunk_stage(k & 1, *chunks[k + 1])        # that slot's launch is in flight
+            ev.chunk_stage((k + 1) & 1, *chunks[k + 1])
     got.append(ev.chunk_finish((len(chunks) - 1) & 1))
     with pytest.raises(epa.EpaError):
         ev.chunk_finish(0)                                       # nothing in flight
