@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
                                                       double* __restrict__ lookup,
                                                       double* __restrict__ refI,
                                                       uint8_t* __restrict__ resc0,
-                                                      const double* __restrict__ cinv) {
+                                                      const double* __restrict__ cinv, int rate_scalers) {
   __shared__ double U[S * S], Ui[S * S];
   __shared__ double Eh[EPA_MAX_CATS * S], Ep[EPA_MAX_CATS * S];  // exp tables: half branch, pendant
   const int c = m->c, ncols = m->ncols;
@@ -166,7 +166,10 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
   const double* Xt = refT + (size_t)(2 * b) * c * S * W + site;
   const double* Dt = refT + (size_t)(2 * b + 1) * c * S * W + site;
   double I[EPA_MAX_CATS][S];
+  double cmult[EPA_MAX_CATS];   // per-rate scalers: rescale + alignment factor of every category
+  uint32_t ccnt[EPA_MAX_CATS];
   double mx = 0.0;
+  uint32_t sc = 0xffffffffu;
   for (int k = 0; k < c; ++k) {
     double dv[S], xv[S];
 #pragma unroll
@@ -174,6 +177,7 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
       dv[x] = Dt[(size_t)(k * S + x) * W] * Eh[k * S + x];
       xv[x] = Xt[(size_t)(k * S + x) * W] * Eh[k * S + x];
     }
+    double mxk = 0.0;
 #pragma unroll
     for (int i = 0; i < S; ++i) {
       double a = 0.0, bb = 0.0;
@@ -184,13 +188,29 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
       }
       const double v = a * bb;
       I[k][i] = v;
-      mx = fmax(mx, v);
+      mxk = fmax(mxk, v);
+    }
+    mx = fmax(mx, mxk);
+    if (rate_scalers) {   // count of this category: both sides + its own rescale
+      const bool small = mxk < 0x1p-256;
+      ccnt[k] = scSum[((size_t)b * c + k) * W + site] + (small ? 1u : 0u);
+      cmult[k] = small ? 0x1p+256 : 1.0;
+      sc = min(sc, ccnt[k]);
     }
   }
-  uint32_t sc = scSum[(size_t)b * W + site];
   // per-site scaling of pll_update_partials: every entry below 2^-256 -> multiply by 2^256
-  const bool resc = mx < 0x1p-256;
-  if (resc) sc += 1;
+  const bool resc = !rate_scalers && mx < 0x1p-256;
+  if (!rate_scalers) {
+    sc = scSum[(size_t)b * W + site];
+    if (resc) sc += 1;
+  } else {
+    // align every category to the site's minimum count: 2^(-256 min(cnt - min, 4)) (libpll
+    // rate_scalings / scale_minlh; oracle rate_alignment)
+    for (int k = 0; k < c; ++k) {
+      const uint32_t d = min(ccnt[k] - sc, 4u);
+      cmult[k] *= d == 0 ? 1.0 : d == 1 ? 0x1p-256 : d == 2 ? 0x1p-512 : d == 3 ? 0x1p-768 : 0x1p-1024;
+    }
+  }
   if (resc0) resc0[(size_t)b * W + site] = resc ? 1 : 0;
   const double mult = resc ? 0x1p+256 : 1.0;
   // g[k][i] = pi_i * (P_pendant I)_i  via the eigenbasis: P I = U (e o (Ui I))
@@ -201,7 +221,7 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
     for (int x = 0; x < S; ++x) {
       double acc = 0.0;
 #pragma unroll
-      for (int i = 0; i < S; ++i) acc = fma(Ui[x * S + i], I[k][i] * mult, acc);
+      for (int i = 0; i < S; ++i) acc = fma(Ui[x * S + i], I[k][i] * (rate_scalers ? cmult[k] : mult), acc);
       // the thorough kernel starts every pair from exactly this vector (same lengths): keep it
       if (refI) refI[((size_t)b * c * S + (size_t)(k * S + x)) * W + site] = acc;
       it[x] = acc * Ep[k * S + x];
@@ -239,11 +259,11 @@ int launch_build_lookup(epa_ctx* ctx) {
   if (ctx->s == 4)
     hipLaunchKernelGGL(k_build_lookup<4>, grid, dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT,
                        ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup, ctx->refI,
-                       ctx->resc0, ctx->cinv);
+                       ctx->resc0, ctx->cinv, ctx->rate_scalers ? 1 : 0);
   else
     hipLaunchKernelGGL(k_build_lookup<20>, grid, dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT,
                        ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup, ctx->refI,
-                       ctx->resc0, ctx->cinv);
+                       ctx->resc0, ctx->cinv, ctx->rate_scalers ? 1 : 0);
   EPA_HIP(ctx, hipGetLastError());
   if (ctx->s == 4) {
     int rc = launch_build_lookup2(ctx);
@@ -253,10 +273,13 @@ int launch_build_lookup(epa_ctx* ctx) {
   return EPA_OK;
 }
 
+// src: the caller's scaler row, [W] or (per-rate scalers) libpll's [W][cdim]; dst: [cdim][W]
 __global__ void k_add_scaler(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
-                             uint32_t W) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < W) dst[i] += src[i];
+                             uint32_t W, uint32_t cdim) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // i = k * W + site
+  if (i >= W * cdim) return;
+  const uint32_t k = i / W, w = i - k * W;
+  dst[i] += src[(size_t)w * cdim + k];
 }
 
 // =============================================================================================
@@ -481,6 +504,9 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   // The thorough kernels are built for 4 rate categories.  1 or 2 categories (no +G, +G2) are
   // replicated to 4 with the weights divided accordingly: sum_k w_k L_k is unchanged.
   const int c = (c_in == 1 || c_in == 2) ? 4 : c_in;
+  if (c_in != c && (d->flags & EPA_FLAG_RATE_SCALERS) && !tree)
+    return epa_fail(ctx, EPA_ERR_UNSUPPORTED,
+                    "per-rate scaler arrays of a 1- or 2-category model: use epa_dev_create_from_tree");
   ctx->c_in = c_in;
   if (!d->sites || !d->branches) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "empty reference");
   const double pinv = d->prop_invar;
@@ -559,22 +585,25 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   ctx->blo.pendant_default = d->pendant_default > 0 ? d->pendant_default : -log(0.9);
   ctx->blo.max_rounds = d->blo_max_rounds ? d->blo_max_rounds : 32;
   ctx->blo.max_newton = d->blo_max_newton ? d->blo_max_newton : 30;
-  const uint32_t flags = d->flags ? d->flags : EPA_FLAG_SLIDING_BLO;
-  ctx->blo.sliding = (flags & EPA_FLAG_SLIDING_BLO) ? 1 : 0;
-  if (!ctx->blo.sliding)
-    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "--raxml-blo (non-sliding BLO) is not implemented");
+  if ((d->flags & EPA_FLAG_SLIDING_BLO) && (d->flags & EPA_FLAG_RAXML_BLO))
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "flags: sliding and raxml BLO are mutually exclusive");
+  ctx->blo.sliding = (d->flags & EPA_FLAG_RAXML_BLO) ? 0 : 1;
+  ctx->rate_scalers = (d->flags & EPA_FLAG_RATE_SCALERS) != 0;
+  // the tuned thorough kernels are built for 4 categories, per-site scalers and the sliding rule
+  ctx->generic_thorough = c != 4 || ctx->rate_scalers || !ctx->blo.sliding;
 
   EPA_HIP(ctx, hipMalloc(&ctx->dmodel, sizeof(ModelDev)));
   EPA_HIP(ctx, hipMemcpy(ctx->dmodel, &m, sizeof(ModelDev), hipMemcpyHostToDevice));
 
   const size_t W = ctx->W, B = ctx->B, cs = (size_t)c * s;
+  const size_t cdim = ctx->rate_scalers ? (size_t)c : 1;   // scaler counts per site
   EPA_HIP(ctx, hipMalloc(&ctx->refT, sizeof(double) * 2 * B * cs * W));
   EPA_HIP(ctx, hipMalloc(&ctx->th_ctr, 256));
-  EPA_HIP(ctx, hipMalloc(&ctx->scSum, sizeof(uint32_t) * B * W));
-  EPA_HIP(ctx, hipMemset(ctx->scSum, 0, sizeof(uint32_t) * B * W));
+  EPA_HIP(ctx, hipMalloc(&ctx->scSum, sizeof(uint32_t) * B * cdim * W));
+  EPA_HIP(ctx, hipMemset(ctx->scSum, 0, sizeof(uint32_t) * B * cdim * W));
   EPA_HIP(ctx, hipMalloc(&ctx->blen, sizeof(double) * B));
   EPA_HIP(ctx, hipMalloc(&ctx->lookup, sizeof(double) * B * W * ctx->ncols));
-  if (c == 4) {  // starting vectors of the thorough kernels (both are built for 4 categories)
+  if (!ctx->generic_thorough) {  // starting vectors of the tuned thorough kernels
     EPA_HIP(ctx, hipMalloc(&ctx->refI, sizeof(double) * B * cs * W));
     EPA_HIP(ctx, hipMalloc(&ctx->resc0, B * W));
   }
@@ -645,10 +674,10 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
         if (rc) return rc;
       }
       if (sc) {
-        const uint32_t* dsc = (const uint32_t*)epa_to_device(ctx, 3 + side, sc, sizeof(uint32_t) * W);
+        const uint32_t* dsc = (const uint32_t*)epa_to_device(ctx, 3 + side, sc, sizeof(uint32_t) * W * cdim);
         if (!dsc) return epa_fail(ctx, EPA_ERR_HIP, "staging copy of scaler failed");
-        hipLaunchKernelGGL(k_add_scaler, dim3((W + 255) / 256), dim3(256), 0, ctx->stream, dsc,
-                           ctx->scSum + b * W, (uint32_t)W);
+        hipLaunchKernelGGL(k_add_scaler, dim3((uint32_t)((W * cdim + 255) / 256)), dim3(256), 0, ctx->stream, dsc,
+                           ctx->scSum + b * cdim * W, (uint32_t)W, (uint32_t)cdim);
       }
       // staging buffers are reused by the next branch: pageable H2D copies are synchronous
       // with respect to the host buffer but the kernel must finish before the slot is reused
@@ -681,7 +710,7 @@ __global__ void __launch_bounds__(256) k_clv_level(const ModelDev* __restrict__ 
                                                    const uint8_t* __restrict__ tipchars,
                                                    const uint32_t* __restrict__ tipmap, uint32_t W,
                                                    double* __restrict__ refT,
-                                                   uint32_t* __restrict__ sc_side) {
+                                                   uint32_t* __restrict__ sc_side, int rate_scalers) {
   __shared__ double U[S * S], Ui[S * S];
   __shared__ double Ea[EPA_MAX_CATS * S], Eb[EPA_MAX_CATS * S];
   const int c = m->c;
@@ -717,6 +746,7 @@ __global__ void __launch_bounds__(256) k_clv_level(const ModelDev* __restrict__ 
     }
   }
   double I[EPA_MAX_CATS][S];
+  bool ksmall[EPA_MAX_CATS];
   double mx = 0.0;
   for (int k = 0; k < c; ++k) {
     double av[S], bv[S];
@@ -725,6 +755,7 @@ __global__ void __launch_bounds__(256) k_clv_level(const ModelDev* __restrict__ 
       av[x] = (tip_a ? ta[x] : A[(size_t)(k * S + x) * W]) * Ea[k * S + x];
       bv[x] = (tip_b ? tb[x] : Bv[(size_t)(k * S + x) * W]) * Eb[k * S + x];
     }
+    double mxk = 0.0;
 #pragma unroll
     for (int i = 0; i < S; ++i) {
       double a = 0.0, b = 0.0;
@@ -735,13 +766,16 @@ __global__ void __launch_bounds__(256) k_clv_level(const ModelDev* __restrict__ 
       }
       const double v = a * b;
       I[k][i] = v;
-      mx = fmax(mx, v);
+      mxk = fmax(mxk, v);
     }
+    ksmall[k] = mxk < 0x1p-256;
+    mx = fmax(mx, mxk);
   }
+  // per-site scaling: all c * s entries below 2^-256; per-rate: every category on its own
   const bool resc = mx < 0x1p-256;
-  const double mult = resc ? 0x1p+256 : 1.0;
   double* out = refT + (size_t)r.side * cs * W + site;
-  for (int k = 0; k < c; ++k)
+  for (int k = 0; k < c; ++k) {
+    const double mult = (rate_scalers ? ksmall[k] : resc) ? 0x1p+256 : 1.0;
 #pragma unroll
     for (int x = 0; x < S; ++x) {
       double acc = 0.0;
@@ -749,6 +783,15 @@ __global__ void __launch_bounds__(256) k_clv_level(const ModelDev* __restrict__ 
       for (int i = 0; i < S; ++i) acc = fma(Ui[x * S + i], I[k][i] * mult, acc);
       out[(size_t)(k * S + x) * W] = acc;
     }
+  }
+  if (rate_scalers) {   // sc_side [2B][c][W]
+    for (int k = 0; k < c; ++k) {
+      const uint32_t sa = tip_a ? 0u : sc_side[((size_t)r.ca * c + k) * W + site];
+      const uint32_t sb = tip_b ? 0u : sc_side[((size_t)r.cb * c + k) * W + site];
+      sc_side[((size_t)r.side * c + k) * W + site] = sa + sb + (ksmall[k] ? 1u : 0u);
+    }
+    return;
+  }
   const uint32_t sa = tip_a ? 0u : sc_side[(size_t)r.ca * W + site];
   const uint32_t sb = tip_b ? 0u : sc_side[(size_t)r.cb * W + site];
   sc_side[(size_t)r.side * W + site] = sa + sb + (resc ? 1u : 0u);
@@ -775,12 +818,13 @@ __global__ void __launch_bounds__(256) k_tip_sides(const ModelDev* __restrict__ 
   }
 }
 
+// row = cdim * W entries per branch side (cdim = rate categories with per-rate scalers, else 1)
 __global__ void k_scaler_sum(const uint32_t* __restrict__ sc_side, uint32_t* __restrict__ scSum, size_t n,
-                             uint32_t W) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // i = b * W + site
+                             size_t row) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // i = b * row + (k * W + site)
   if (i >= n) return;
-  const size_t b = i / W, w = i % W;
-  scSum[i] = sc_side[(2 * b) * W + w] + sc_side[(2 * b + 1) * W + w];
+  const size_t b = i / row, w = i % row;
+  scSum[i] = sc_side[(2 * b) * row + w] + sc_side[(2 * b + 1) * row + w];
 }
 
 static int precompute_from_tree(epa_ctx* ctx, const epa_tree_desc* t, const uint32_t* d_tipmap) {
@@ -861,8 +905,9 @@ static int precompute_from_tree(epa_ctx* ctx, const epa_tree_desc* t, const uint
   TREE_HIP(hipMemcpy(d_tips, t->tipchars, (size_t)n * W, hipMemcpyHostToDevice));
   TREE_HIP(hipMalloc(&d_recs, sizeof(RecDev) * recs.size()));
   TREE_HIP(hipMemcpy(d_recs, recs.data(), sizeof(RecDev) * recs.size(), hipMemcpyHostToDevice));
-  TREE_HIP(hipMalloc(&d_sc, sizeof(uint32_t) * 2 * (size_t)B * W));
-  TREE_HIP(hipMemset(d_sc, 0, sizeof(uint32_t) * 2 * (size_t)B * W));
+  const size_t cdim = ctx->rate_scalers ? (size_t)ctx->c : 1;
+  TREE_HIP(hipMalloc(&d_sc, sizeof(uint32_t) * 2 * (size_t)B * cdim * W));
+  TREE_HIP(hipMemset(d_sc, 0, sizeof(uint32_t) * 2 * (size_t)B * cdim * W));
   TREE_HIP(hipMalloc(&d_tob, sizeof(uint32_t) * B));
   TREE_HIP(hipMemcpy(d_tob, tip_of_branch.data(), sizeof(uint32_t) * B, hipMemcpyHostToDevice));
   const dim3 blk(256);
@@ -875,14 +920,15 @@ static int precompute_from_tree(epa_ctx* ctx, const epa_tree_desc* t, const uint
       const dim3 grid((W + 255) / 256, std::min<uint32_t>(65535, cnt - off));
       if (ctx->s == 4)
         hipLaunchKernelGGL(k_clv_level<4>, grid, blk, 0, ctx->stream, ctx->dmodel, d_recs + lev_begin[l] + off,
-                           d_tips, d_tipmap, W, ctx->refT, d_sc);
+                           d_tips, d_tipmap, W, ctx->refT, d_sc, ctx->rate_scalers ? 1 : 0);
       else
         hipLaunchKernelGGL(k_clv_level<20>, grid, blk, 0, ctx->stream, ctx->dmodel, d_recs + lev_begin[l] + off,
-                           d_tips, d_tipmap, W, ctx->refT, d_sc);
+                           d_tips, d_tipmap, W, ctx->refT, d_sc, ctx->rate_scalers ? 1 : 0);
     }
   }
-  const size_t nbw = (size_t)B * W;
-  hipLaunchKernelGGL(k_scaler_sum, dim3((uint32_t)((nbw + 255) / 256)), blk, 0, ctx->stream, d_sc, ctx->scSum, nbw, W);
+  const size_t nbw = (size_t)B * cdim * W;
+  hipLaunchKernelGGL(k_scaler_sum, dim3((uint32_t)((nbw + 255) / 256)), blk, 0, ctx->stream, d_sc, ctx->scSum, nbw,
+                     cdim * (size_t)W);
   TREE_HIP(hipStreamSynchronize(ctx->stream));
   TREE_HIP(hipGetLastError());
 #undef TREE_HIP
@@ -896,7 +942,7 @@ __global__ void __launch_bounds__(256) k_tree_logl(const ModelDev* __restrict__ 
                                                   const double* __restrict__ refT,
                                                   const uint32_t* __restrict__ scSum, uint32_t b, double len,
                                                   uint32_t W, const double* __restrict__ cinv,
-                                                  double* __restrict__ partial) {
+                                                  int rate_scalers, double* __restrict__ partial) {
   __shared__ double U[S * S];
   __shared__ double E[EPA_MAX_CATS * S];
   __shared__ double red[256];
@@ -911,6 +957,11 @@ __global__ void __launch_bounds__(256) k_tree_logl(const ModelDev* __restrict__ 
     const double* X = refT + (size_t)(2 * b) * cs * W + site;
     const double* D = refT + (size_t)(2 * b + 1) * cs * W + site;
     double L = 0.0;
+    uint32_t smin = 0xffffffffu;
+    if (rate_scalers)
+      for (int k = 0; k < c; ++k) smin = min(smin, scSum[((size_t)b * c + k) * W + site]);
+    else
+      smin = scSum[(size_t)b * W + site];
     for (int k = 0; k < c; ++k) {
       double xv[S], dv[S];
 #pragma unroll
@@ -923,10 +974,14 @@ __global__ void __launch_bounds__(256) k_tree_logl(const ModelDev* __restrict__ 
         for (int x = 0; x < S; ++x) { a = fma(U[i * S + x], xv[x], a); d = fma(U[i * S + x], dv[x], d); }
         t = fma(m->pi[i] * a, d, t);
       }
+      if (rate_scalers) {   // align the category to the site's minimum count
+        const uint32_t dd = min(scSum[((size_t)b * c + k) * W + site] - smin, 4u);
+        t *= dd == 0 ? 1.0 : dd == 1 ? 0x1p-256 : dd == 2 ? 0x1p-512 : dd == 3 ? 0x1p-768 : 0x1p-1024;
+      }
       L = fma(m->w[k], t, L);
     }
     if (cinv) L += cinv[site];
-    v = log(L) + (double)scSum[(size_t)b * W + site] * (-256.0 * 0.6931471805599453094);
+    v = log(L) + (double)smin * (-256.0 * 0.6931471805599453094);
   }
   red[threadIdx.x] = v;
   __syncthreads();
@@ -946,10 +1001,10 @@ extern "C" int epa_dev_tree_logl(epa_ctx* ctx, uint32_t branch, double* lnl) {
   const double len = ctx->h_blen[branch];
   if (ctx->s == 4)
     hipLaunchKernelGGL(k_tree_logl<4>, dim3(nblk), dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT, ctx->scSum,
-                       branch, len, ctx->W, ctx->cinv, d_part);
+                       branch, len, ctx->W, ctx->cinv, ctx->rate_scalers ? 1 : 0, d_part);
   else
     hipLaunchKernelGGL(k_tree_logl<20>, dim3(nblk), dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT, ctx->scSum,
-                       branch, len, ctx->W, ctx->cinv, d_part);
+                       branch, len, ctx->W, ctx->cinv, ctx->rate_scalers ? 1 : 0, d_part);
   std::vector<double> part(nblk);
   EPA_HIP(ctx, hipMemcpyAsync(part.data(), d_part, sizeof(double) * nblk, hipMemcpyDeviceToHost, ctx->stream));
   EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1065,8 +1120,6 @@ extern "C" int epa_dev_thorough(epa_ctx* ctx, const epa_pair* pairs, uint64_t n_
   if (stats) memset(stats, 0, sizeof(*stats));
   if (n_pairs == 0) return EPA_OK;
   EPA_HIP(ctx, hipSetDevice(ctx->device));
-  if (!(ctx->s == 4 && ctx->c == 4) && !(ctx->s == 20))
-    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "thorough: DNA needs 4 rate categories");
   if (ctx->refI) {  // per-branch starting vectors of the DNA kernel come with the lookup build
     int brc = epa_dev_build_lookup(ctx);
     if (brc) return brc;
@@ -1175,11 +1228,7 @@ static int chunk_stats(epa_ctx* ctx, uint64_t n, const unsigned long long* hst, 
   return EPA_OK;
 }
 
-static int thorough_supported(epa_ctx* ctx) {
-  if (!(ctx->s == 4 && ctx->c == 4) && !(ctx->s == 20))
-    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "thorough: DNA needs 4 rate categories");
-  return EPA_OK;
-}
+static int thorough_supported(epa_ctx*) { return EPA_OK; }  // every model has a thorough kernel
 
 extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_begin,
                                    const uint32_t* win_span, uint32_t Q, uint32_t max_span,
@@ -1506,8 +1555,6 @@ extern "C" int epa_dev_place_all(epa_ctx* ctx, const uint8_t* q_codes, const uin
   if (stats) memset(stats, 0, sizeof(*stats));
   if (Q == 0) return EPA_OK;
   EPA_HIP(ctx, hipSetDevice(ctx->device));
-  if (!(ctx->s == 4 && ctx->c == 4) && !(ctx->s == 20))
-    return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "thorough: DNA needs 4 rate categories");
   int rc = epa_dev_build_lookup(ctx);  // starting vectors of the thorough kernels
   if (rc) return rc;
   std::vector<uint32_t> hb_buf, hs_buf;

@@ -11,7 +11,7 @@
 #include "epa_dev.h"
 
 #define EPA_MAX_STATES 20
-#define EPA_MAX_CATS 8
+#define EPA_MAX_CATS 16
 #define EPA_MAX_COLS 24
 
 // Model constants handed to kernels by value (kernarg -> SGPRs via s_load).
@@ -89,13 +89,17 @@ struct epa_ctx {
   ModelDev* dmodel = nullptr;
   ModelDNA dna;             // valid when s == 4 && c == 4
   bool dna_zero0 = false;   // eigenvalue 0 is the (exactly) zero one after the create-time reorder
+  bool rate_scalers = false;  // per-rate scalers (EPA_FLAG_RATE_SCALERS): scSum is [B][c][W]
+  // the tuned thorough kernels serve 4 categories + per-site scalers + sliding BLO; everything
+  // else runs on k_thorough_generic (thorough_generic.hip)
+  bool generic_thorough = false;
   BloConsts blo;
   int aa_x_as_n = 0;
   uint32_t code_stride = 0;  // 0: query codes are Q x W rows; S: compact rows of S bytes (window only)
 
   // HBM-resident reference data
   //   refT   [2B][c*s][W]  eigen-transformed CLVs, component-major (side 0 proximal, 1 distal)
-  //   scSum  [B][W]        prox + dist per-site scaler counts
+  //   scSum  [B][W]        prox + dist per-site scaler counts ([B][c][W] with per-rate scalers)
   //   blen   [B]
   //   lookup [B][W][ncols]
   //   lookup2 [B][2][ceil(W/2)][36]  (start parity, site >> 1)  DNA: lookup[s][c0] + lookup[s+1][c1] over {A,C,G,T,N,none}^2
@@ -184,6 +188,9 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
 int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_order, uint64_t n_pairs,
                        const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span,
                        uint32_t max_span, bool want_lds, epa_result* d_out, unsigned long long* d_stats);
+int launch_thorough_generic(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
+                            const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
+                            epa_result* d_out, unsigned long long* d_stats);
 int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshold,
                   epa_pair* d_pairs, uint64_t max_pairs, uint64_t* n_pairs,
                   const uint32_t* d_span = nullptr);  // d_span: also histogram the span classes

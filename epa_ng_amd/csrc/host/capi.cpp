@@ -138,7 +138,14 @@ uint32_t epa_host_ref_tipmap(void* h, uint32_t* out, uint32_t cap) {
 
 // creates the device context straight from the host tree (what simple_mpi does internally).
 // device_precompute != 0: reference CLVs computed on the GPU from the tree; 0: host CLVs uploaded.
+// flags: EPA_FLAG_* of include/epa_dev.h (per-rate scalers, --raxml-blo); 0 = defaults
+int epa_host_dev_create_flags(void* h, int device, int aa_x_as_n, int device_precompute, uint32_t flags,
+                              epa_ctx** out);
 int epa_host_dev_create_ex(void* h, int device, int aa_x_as_n, int device_precompute, epa_ctx** out) {
+  return epa_host_dev_create_flags(h, device, aa_x_as_n, device_precompute, 0, out);
+}
+int epa_host_dev_create_flags(void* h, int device, int aa_x_as_n, int device_precompute, uint32_t flags,
+                              epa_ctx** out) {
   const Tree& t = *static_cast<Ref*>(h)->tree;
   int rc;
   if (device_precompute) {
@@ -146,6 +153,7 @@ int epa_host_dev_create_ex(void* h, int device, int aa_x_as_n, int device_precom
     Tree::Tree_Desc_Storage store;
     t.fill_tree_desc(d, store);
     d.ref.aa_x_as_n = aa_x_as_n;
+    d.ref.flags = flags;
     rc = epa_dev_create_from_tree(&d, device, out);
   } else {
     epa_ref_desc d;
@@ -155,6 +163,7 @@ int epa_host_dev_create_ex(void* h, int device, int aa_x_as_n, int device_precom
     std::vector<double> bl;
     t.fill_desc(d, pc, ps, dc, dt, ds, bl);
     d.aa_x_as_n = aa_x_as_n;
+    d.flags = flags;
     rc = epa_dev_create(&d, device, out);
   }
   if (rc) g_err = epa_dev_last_error(nullptr);

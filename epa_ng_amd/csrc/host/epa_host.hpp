@@ -44,6 +44,13 @@ struct Options {  // defaults: src/util/Options.hpp:13-34
   bool device_select = true;  // run the dynamic heuristic on the GPU (default heuristic only)
   bool device_precompute = true;  // reference CLVs computed on the GPU from the tree (no host CLVs)
   bool preserve_rooting = true;   // rooted input: jplace on the rooted tree (Options.hpp:34)
+  // per-rate scalers (Options.hpp:33, src/main.cpp:248-250,399-407): auto = on above 2000 tips
+  // (Tree_Numbers::large_tree, src/io/file_io.cpp:211-214)
+  enum class NumericalScaling { kOn, kOff, kAuto };
+  NumericalScaling scaling = NumericalScaling::kAuto;
+  bool rate_scalers(size_t tips) const {
+    return scaling == NumericalScaling::kOn || (scaling == NumericalScaling::kAuto && tips > 2000);
+  }
 };
 
 class Sequence {

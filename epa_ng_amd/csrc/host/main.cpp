@@ -1,6 +1,6 @@
 // epa-ng-amd: command-line front end keeping EPA-ng's flags for the placement path
-// (src/main.cpp:96-270).  Flags outside the hot path (binary dump, bfast conversion, --split,
-// model files) are rejected with a message, not silently ignored.
+// (src/main.cpp:96-270).  Flags outside the hot path (binary dump, bfast conversion, --split)
+// are rejected with a message, not silently ignored.
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -29,6 +29,8 @@ static void usage() {
       "  --precision N         output digits (default 10)\n"
       "  --chunk-size N        queries per chunk (default 50000; EPA-ng's CPU default is 5000)\n"
       "  --no-pre-mask         evaluate all sites of every query\n"
+      "  --raxml-blo           radius-1 local branch-length optimisation instead of the sliding rule\n"
+      "  --rate-scalers auto|on|off  per-rate-category numerical scaling (auto: on above 2000 tips)\n"
       "  --preserve-rooting on|off  rooted reference tree: report on the rooted tree (default on)\n"
       "  --device N            GPU ordinal (default 0)\n"
       "  --devices a,b,..      place on several GPUs of the node (chunks are dealt to them in turn)\n";
@@ -64,13 +66,25 @@ int main(int argc, char** argv) {
     else if (a == "--precision") opt.precision = (unsigned)std::stoul(need(i));
     else if (a == "--chunk-size") opt.chunk_size = (unsigned)std::stoul(need(i));
     else if (a == "--no-pre-mask") opt.premasking = false;
+    else if (a == "--raxml-blo") opt.sliding_blo = false;   // src/main.cpp:239-242
+    else if (a == "--rate-scalers") {                       // src/main.cpp:248-250,399-407
+      const std::string v = need(i);
+      if (v == "auto") opt.scaling = Options::NumericalScaling::kAuto;
+      else if (v == "on") opt.scaling = Options::NumericalScaling::kOn;
+      else if (v == "off") opt.scaling = Options::NumericalScaling::kOff;
+      else { std::cerr << "--rate-scalers: " << v << " not in {auto,on,off}\n"; return 1; }
+    }
     else if (a == "--preserve-rooting") {  // src/main.cpp:196-199, 410-418
       const std::string v = need(i);
       if (v == "off") opt.preserve_rooting = false;
       else if (v == "on") opt.preserve_rooting = true;
       else { std::cerr << "--preserve-rooting: " << v << " not in {on,off}\n"; return 1; }
     }
-    else if (a == "-T" || a == "--threads") opt.num_threads = (unsigned)std::stoul(need(i));
+    else if (a == "-T" || a == "--threads") {
+      opt.num_threads = (unsigned)std::stoul(need(i));
+      std::cerr << "note: -T/--threads is accepted for command-line compatibility; the placement runs on the "
+                   "GPU and the host stages use the CPUs the process is allowed to use\n";
+    }
     else if (a == "--device") device = std::stoi(need(i));
     else if (a == "--devices") {
       std::stringstream ls(need(i));

@@ -47,7 +47,12 @@ const double kDefaultBranchLength = -std::log(0.9);
 }  // namespace
 
 Device_Evaluator::Device_Evaluator(const Tree& tree, const Options& options, int device) {
-  const uint32_t flags = options.sliding_blo ? EPA_FLAG_SLIDING_BLO : 0x80000000u;  // non-sliding: rejected
+  const bool rs = options.rate_scalers(tree.nums().tip_nodes);
+  const uint32_t flags = (options.sliding_blo ? EPA_FLAG_SLIDING_BLO : EPA_FLAG_RAXML_BLO) |
+                         (rs ? EPA_FLAG_RATE_SCALERS : 0u);
+  if (rs && !options.device_precompute)
+    throw std::runtime_error{"per-rate scalers need the device-side reference precompute (the host CLV "
+                             "path keeps per-site scalers): drop --host-precompute or pass --rate-scalers off"};
   int rc;
   if (options.device_precompute) {
     // tree + tip sequences go to the device, all directional CLVs are computed there

@@ -831,6 +831,10 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
                     const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
                     epa_result* d_out, unsigned long long* d_stats) {
   if (n_pairs > 0xffffffffull) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "thorough: more than 2^32 pairs per call");
+  if (ctx->generic_thorough) {  // any category count, per-rate scalers, --raxml-blo
+    ctx->cls_hist_pairs = 0;
+    return launch_thorough_generic(ctx, d_pairs, n_pairs, d_codes, d_begin, d_span, max_span, d_out, d_stats);
+  }
   // ---- span classes present in this call
   uint32_t hist[EPA_N_CLS] = {};
   const int cmax = epa_span_class(ctx->s, max_span);

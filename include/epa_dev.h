@@ -49,13 +49,20 @@ typedef enum {
 
 /* flags of epa_ref_desc.flags */
 #define EPA_FLAG_SLIDING_BLO 0x1u  /* Options::sliding_blo (default on, src/util/Options.hpp:16) */
+#define EPA_FLAG_RAXML_BLO 0x4u    /* --raxml-blo: pllmod_opt_optimize_branch_lengths_local, radius 1 *
+                                    * (src/core/pll/optimize.cpp:274-279) instead of the sliding rule */
+#define EPA_FLAG_RATE_SCALERS 0x2u /* PLL_ATTRIB_RATE_SCALERS: every rate category is rescaled on its *
+                                    * own (src/tree/tiny_util.cpp:37-44; the reference turns it on    *
+                                    * above 2000 tips, src/io/file_io.cpp:211-214, or with            *
+                                    * --rate-scalers).  prox_scaler / dist_scaler rows are then      *
+                                    * [W][rate_cats] (libpll layout)                                  */
 
 /*
  * Reference-side inputs: what Tiny_Tree's constructor pulls out of `Tree` per branch
  * (Tree::get_clv for the proximal and distal node, their scalers, the branch length:
  * src/tree/tiny_util.cpp:72-199) plus the model arrays the tiny partition shares by pointer
  * (:109-163).  Arrays use libpll's layouts: CLV [site][rate_cat][state] fp64, scaler
- * uint32[site] (per-site scaling; per-rate scalers = PLL_ATTRIB_RATE_SCALERS are "next").
+ * uint32[site] (or uint32[site][rate_cat] with EPA_FLAG_RATE_SCALERS).
  * Branch b is EPA-ng's branch_id == jplace edge_num (utree_query_branches order,
  * src/core/pll/pll_util.cpp:182-205).  Orientation is the caller's job exactly as in
  * Tiny_Tree.cpp:64-74: when one end of the branch is a tip it is passed as the DISTAL side.
@@ -98,7 +105,7 @@ typedef struct {
   double pendant_default;    /* DEFAULT_BRANCH_LENGTH          [-ln 0.9] util/constants.hpp:12  */
   uint32_t blo_max_rounds;   /* smoothings                     [32]    optimize.cpp:269         */
   uint32_t blo_max_newton;   /* max_iters                      [30]    optimize.cpp:62          */
-  uint32_t flags;            /* EPA_FLAG_*; 0 selects EPA_FLAG_SLIDING_BLO                     */
+  uint32_t flags;            /* EPA_FLAG_*; neither BLO bit set selects EPA_FLAG_SLIDING_BLO     */
   uint32_t aa_x_as_n;        /* 1: reproduce quirk D4 (AA 'X' preplaced in the 'N' column,      *
                               *    Lookup_Store.hpp:63-66); 0 (default): 'X' = any             */
   /* +I: state of every site that is invariant over the REFERENCE tips (libpll

@@ -61,7 +61,21 @@ typedef struct {
   double rates[ORC_MAX_C];
   double weights[ORC_MAX_C];
   double pinv;
+  int rate_scalers; /* PLL_ATTRIB_RATE_SCALERS: scaler arrays are [site][cat] (src/tree/tiny_util.cpp:37-44,
+                     * auto-on for > 2000 tips, src/io/file_io.cpp:211-214) */
 } orc_model;
+
+/* libpll PLL_SCALE_RATE_MAXDIFF and the scale_minlh table (recollection, like the other pll
+ * constants): with per-rate scalers a category whose count exceeds the site minimum by d is
+ * multiplied by 2^(-256 min(d, 4)) when the categories are combined */
+#define ORC_SCALE_RATE_MAXDIFF 4
+static double orc_rate_scale_factor(uint32_t diff) {
+  if (diff == 0) return 1.0;
+  if (diff > ORC_SCALE_RATE_MAXDIFF) diff = ORC_SCALE_RATE_MAXDIFF;
+  return ldexp(1.0, -256 * (int)diff);
+}
+/* scaler count of (site, cat) of one side: per-site array or per-rate array */
+#define ORC_SC(sd, m, site, k) ((sd)->scaler ? ((m)->rate_scalers ? (sd)->scaler[(site) * (m)->c + (k)] : (sd)->scaler[(site)]) : 0u)
 
 /* cyclic Jacobi for a symmetric n x n matrix; v columns = eigenvectors */
 static void jacobi_sym(int n, double* a, double* w, double* v) {
@@ -106,6 +120,7 @@ int orc_model_init(orc_model* m, int s, const double* subst, const double* freqs
   m->s = s;
   m->c = c;
   m->pinv = pinv;
+  m->rate_scalers = 0;
   double q[ORC_MAX_S * ORC_MAX_S];
   int k = 0;
   for (int i = 0; i < s; ++i) {
@@ -500,14 +515,26 @@ static void update_partial(const orc_model* m, const orc_side* l, const double* 
   for (size_t site = b; site < b + n; ++site) {
     int scaling = 1;
     double* p = parent + site * c * s;
-    for (int k = 0; k < c; ++k)
+    for (int k = 0; k < c; ++k) {
+      int rate_scaling = 1;
       for (int i = 0; i < s; ++i) {
         double ta = side_term(l, Pl + ((size_t)k * s + i) * s, s, site, k, c);
         double tb = side_term(r, Pr + ((size_t)k * s + i) * s, s, site, k, c);
         double v = ta * tb;
         p[k * s + i] = v;
-        scaling = scaling && (v < thr);
+        rate_scaling = rate_scaling && (v < thr);
       }
+      scaling = scaling && rate_scaling;
+      if (m->rate_scalers) { /* per-rate scaling: every category on its own */
+        uint32_t sc = ORC_SC(l, m, site, k) + ORC_SC(r, m, site, k);
+        if (rate_scaling) {
+          for (int i = 0; i < s; ++i) p[k * s + i] *= fac;
+          sc += 1;
+        }
+        parent_sc[site * c + k] = sc;
+      }
+    }
+    if (m->rate_scalers) continue;
     uint32_t sc = (l->scaler ? l->scaler[site] : 0) + (r->scaler ? r->scaler[site] : 0);
     if (scaling) {
       for (int x = 0; x < c * s; ++x) p[x] *= fac;
@@ -515,6 +542,20 @@ static void update_partial(const orc_model* m, const orc_side* l, const double* 
     }
     parent_sc[site] = sc;
   }
+}
+
+/* per-rate scalers: the site's minimum count over the categories and the alignment factor of
+ * every category (restates the rate_scalings logic of libpll's core_edge_loglikelihood /
+ * core_update_sumtable) */
+static uint32_t rate_alignment(const orc_model* m, const orc_side* a, const orc_side* b2, size_t site,
+                               double* factor) {
+  uint32_t mn = 0xffffffffu, cnt[ORC_MAX_C];
+  for (int k = 0; k < m->c; ++k) {
+    cnt[k] = ORC_SC(a, m, site, k) + ORC_SC(b2, m, site, k);
+    if (cnt[k] < mn) mn = cnt[k];
+  }
+  for (int k = 0; k < m->c; ++k) factor[k] = orc_rate_scale_factor(cnt[k] - mn);
+  return mn;
 }
 
 /* restates pll_compute_edge_loglikelihood over sites [b, b+n) (call sites
@@ -528,6 +569,9 @@ static double edge_lnl(const orc_model* m, const orc_side* par, const orc_side* 
   double logl = 0.0;
   for (size_t site = b; site < b + n; ++site) {
     double terma = 0.0;
+    double rfac[ORC_MAX_C];
+    uint32_t rmin = 0;
+    if (m->rate_scalers) rmin = rate_alignment(m, par, ch, site, rfac);
     for (int k = 0; k < c; ++k) {
       double terma_r = 0.0;
       for (int i = 0; i < s; ++i) {
@@ -538,6 +582,7 @@ static double edge_lnl(const orc_model* m, const orc_side* par, const orc_side* 
         double termb = side_term(ch, P + ((size_t)k * s + i) * s, s, site, k, c);
         terma_r += pv * m->freqs[i] * termb;
       }
+      if (m->rate_scalers) terma_r *= rfac[k];
       if (m->pinv > 0.0) {
         double inv = (invariant && invariant[site] >= 0) ? m->freqs[invariant[site]] : 0.0;
         terma += m->weights[k] * (terma_r * (1.0 - m->pinv) + inv * m->pinv);
@@ -545,7 +590,8 @@ static double edge_lnl(const orc_model* m, const orc_side* par, const orc_side* 
         terma += terma_r * m->weights[k];
       }
     }
-    uint32_t sc = (par->scaler ? par->scaler[site] : 0) + (ch->scaler ? ch->scaler[site] : 0);
+    uint32_t sc = m->rate_scalers ? rmin
+                                  : (par->scaler ? par->scaler[site] : 0) + (ch->scaler ? ch->scaler[site] : 0);
     double site_lk = log(terma);
     if (sc) site_lk += sc * log_thr;
     if (persite) persite[site] = site_lk;
@@ -559,7 +605,9 @@ static double edge_lnl(const orc_model* m, const orc_side* par, const orc_side* 
 static void update_sumtable(const orc_model* m, const orc_side* A, const orc_side* Bs, double* S,
                             size_t b, size_t n) {
   const int s = m->s, c = m->c;
-  for (size_t site = b; site < b + n; ++site)
+  for (size_t site = b; site < b + n; ++site) {
+    double rfac[ORC_MAX_C];
+    if (m->rate_scalers) (void)rate_alignment(m, A, Bs, site, rfac);
     for (int k = 0; k < c; ++k)
       for (int j = 0; j < s; ++j) {
         double lt = 0.0, rt = 0.0;
@@ -571,8 +619,9 @@ static void update_sumtable(const orc_model* m, const orc_side* A, const orc_sid
           lt += av * m->freqs[i] * m->u[i * s + j];
           rt += m->uinv[j * s + i] * bv;
         }
-        S[((site - b) * c + k) * s + j] = lt * rt;
+        S[((site - b) * c + k) * s + j] = m->rate_scalers ? lt * rt * rfac[k] : lt * rt;
       }
+  }
 }
 
 /* restates pll_compute_likelihood_derivatives (via utree_derivative_func,
@@ -626,20 +675,23 @@ static void lk_derivatives(const orc_model* m, const double* S, size_t n, double
 typedef struct {
   const orc_model* m; const double* S; size_t n; const int8_t* inv; size_t b;
   long n_evals;
+  int variant;
 } nr_ctx;
 
 static double minimize_newton(double x1, double xguess, double x2, double tol, int max_iters,
                               nr_ctx* cx) {
-  double rts = xguess, f, df, xl, xh, dx;
+  double rts = xguess, f, df, xl, xh, dx, dxold;
   if (rts < x1) rts = x1;
   if (rts > x2) rts = x2;
   lk_derivatives(cx->m, cx->S, cx->n, rts, cx->inv, cx->b, &f, &df); cx->n_evals++;
   if (!isfinite(f) || !isfinite(df)) return NAN;
-  if (df >= 0.0 && fabs(f) < tol) return rts;
+  if (((cx->variant & 2) ? df > 0.0 : df >= 0.0) && fabs(f) < tol) return rts;
   if (f < 0.0) { xl = rts; xh = x2; } else { xh = rts; xl = x1; }
-  dx = fabs(xh - xl);
+  dx = dxold = fabs(xh - xl);
   for (int i = 1; i <= max_iters; ++i) {
-    if (df <= 0.0 || (((rts - xh) * df - f) * ((rts - xl) * df - f) >= 0.0)) {
+    const int slow = (cx->variant & 1) && fabs(2.0 * f) > fabs(dxold * df); /* Numerical Recipes rtsafe */
+    dxold = dx;
+    if (df <= 0.0 || (((rts - xh) * df - f) * ((rts - xl) * df - f) >= 0.0) || slow) {
       dx = 0.5 * (xh - xl);
       rts = xl + dx;
       if (xl == rts) return rts;
@@ -672,6 +724,12 @@ typedef struct {
   uint32_t** scaler;  /* per record (NULL for tips) */
   int8_t* invariant;  /* [W] or NULL */
   int aa_x_quirk;
+  /* constants of the branch-length optimiser: recollected pll-modules values by default, runtime
+   * parameters so that their blast radius can be measured (orc_set_blo, tests/sensitivity.py) */
+  double blo_min, blo_max, blo_default, blo_eps;
+  int raxml_blo;      /* 1: --raxml-blo (optimize.cpp:274-279) instead of the sliding rule */
+  int newton_variant; /* bit 0: rtsafe's "slow convergence -> bisect" clause; bit 1: strict df > 0
+                       * in the first convergence test (0 = the recollected routine) */
   double** store; /* Lookup_Store: per-branch [W][C], lazily filled */
 #ifdef _OPENMP
   omp_lock_t* locks;
@@ -696,7 +754,7 @@ static void compute_clv(orc_ctx* x, int rec) {
   orc_pmatrix(&x->m, x->t->r[c1].length, P1);
   orc_pmatrix(&x->m, x->t->r[c2].length, P2);
   x->clv[rec] = (double*)malloc(sizeof(double) * x->W * c * s);
-  x->scaler[rec] = (uint32_t*)malloc(sizeof(uint32_t) * x->W);
+  x->scaler[rec] = (uint32_t*)malloc(sizeof(uint32_t) * x->W * (x->m.rate_scalers ? c : 1));
   orc_side a, b;
   side_of(x, c1, &a);
   side_of(x, c2, &b);
@@ -720,6 +778,11 @@ void orc_destroy(orc_ctx* x) {
   free(x);
 }
 
+/* per-rate scalers (PLL_ATTRIB_RATE_SCALERS) for the NEXT orc_create: the reference turns them on
+ * for trees with more than 2000 tips (src/io/file_io.cpp:211-214) or with --rate-scalers */
+static int g_next_rate_scalers = 0;
+void orc_next_create_rate_scalers(int on) { g_next_rate_scalers = on; }
+
 /* labels/seqs: the reference MSA (n_seqs rows of width W, ASCII).  Returns NULL on error. */
 orc_ctx* orc_create(const char* newick, int n_seqs, const char** labels, const char** seqs,
                     size_t W, int s, const double* subst, const double* freqs, int c,
@@ -729,6 +792,11 @@ orc_ctx* orc_create(const char* newick, int n_seqs, const char** labels, const c
   x->t = orc_tree_parse(newick);
   if (!x->t) { free(x); return NULL; }
   x->W = W;
+  x->blo_min = ORC_OPT_MIN_BRANCH_LEN;
+  x->blo_max = ORC_OPT_MAX_BRANCH_LEN;
+  x->blo_default = ORC_OPT_DEFAULT_BRANCH_LEN;
+  x->blo_eps = ORC_OPT_BRANCH_EPSILON;
+  x->m.rate_scalers = g_next_rate_scalers;
   x->tipmask = (uint32_t**)calloc(x->t->n_tips, sizeof(uint32_t*));
   x->clv = (double**)calloc(x->t->n_recs, sizeof(double*));
   x->scaler = (uint32_t**)calloc(x->t->n_recs, sizeof(uint32_t*));
@@ -763,6 +831,16 @@ int orc_num_branches(const orc_ctx* x) { return x->t->B; }
 int orc_num_tips(const orc_ctx* x) { return x->t->n_tips; }
 size_t orc_width(const orc_ctx* x) { return x->W; }
 void orc_set_aa_x_quirk(orc_ctx* x, int on) { x->aa_x_quirk = on; }
+int orc_rate_scalers(const orc_ctx* x) { return x->m.rate_scalers; }
+void orc_set_raxml_blo(orc_ctx* x, int on) { x->raxml_blo = on; }
+/* optimiser constants / Newton variant (0 keeps a value); see the fields of orc_ctx */
+void orc_set_blo(orc_ctx* x, double mn, double mx, double def, double eps, int newton_variant) {
+  if (mn > 0) x->blo_min = mn;
+  if (mx > 0) x->blo_max = mx;
+  if (def > 0) x->blo_default = def;
+  if (eps > 0) x->blo_eps = eps;
+  if (newton_variant >= 0) x->newton_variant = newton_variant;
+}
 const double* orc_model_evals(const orc_ctx* x) { return x->m.evals; }
 const double* orc_model_u(const orc_ctx* x) { return x->m.u; }
 const double* orc_model_uinv(const orc_ctx* x) { return x->m.uinv; }
@@ -833,7 +911,7 @@ static orc_tiny* tiny_create(const orc_ctx* x, int b) {
   tt->P_dist = tt->P_prox + psz;
   tt->P_pend = tt->P_dist + psz;
   tt->inner = (double*)malloc(sizeof(double) * x->W * c * s);
-  tt->inner_sc = (uint32_t*)malloc(sizeof(uint32_t) * x->W);
+  tt->inner_sc = (uint32_t*)malloc(sizeof(uint32_t) * x->W * (x->m.rate_scalers ? c : 1));
   tt->sumtable = (double*)malloc(sizeof(double) * x->W * c * s);
   tiny_reset_lengths(tt);
   /* inner <- distal (x) proximal (src/tree/Tiny_Tree.cpp:88-112) */
@@ -894,13 +972,13 @@ static double opt_pplacer(orc_tiny* tt, const orc_side* tip, size_t b, size_t n,
   orc_side in = {tt->inner, NULL, tt->inner_sc};
   const double original_length = tt->len_dist * 2;
   double loglikelihood = -edge_lnl(m, tip, &in, tt->P_pend, x->invariant, NULL, b, n);
-  nr_ctx cx = {m, tt->sumtable, n, x->invariant, b, 0};
+  nr_ctx cx = {m, tt->sumtable, n, x->invariant, b, 0, x->newton_variant};
   while (smoothings) {
     const double old_dist = tt->len_dist, old_pend = tt->len_pend;
     /* ---- NR for pendant (:135-166) ---- */
-    double xmin = ORC_OPT_MIN_BRANCH_LEN, xmax = ORC_OPT_MAX_BRANCH_LEN, xtol = xmin / 10.0;
+    double xmin = x->blo_min, xmax = x->blo_max, xtol = xmin / 10.0;
     double xguess = tt->len_pend;
-    if (xguess < xmin || xguess > xmax) xguess = ORC_OPT_DEFAULT_BRANCH_LEN;
+    if (xguess < xmin || xguess > xmax) xguess = x->blo_default;
     update_sumtable(m, &in, tip, tt->sumtable, b, n);
     double xres = minimize_newton(xmin, xguess, xmax, xtol, max_iters, &cx);
     if (xres > 0.0) {
@@ -910,7 +988,7 @@ static double opt_pplacer(orc_tiny* tt, const orc_side* tip, size_t b, size_t n,
     /* ---- NR for distal, proximal := orig - distal (:170-211) ---- */
     update_partial(m, tip, tt->P_pend, &tt->prox, tt->P_prox, tt->inner, tt->inner_sc, b, n);
     xguess = tt->len_dist;
-    xmin = fmin(ORC_OPT_MIN_BRANCH_LEN / 2.0, original_length / 2.0);
+    xmin = fmin(x->blo_min / 2.0, original_length / 2.0);
     xtol = xmin / 10.0;
     xmax = original_length - xtol;
     if (xguess < xmin || xguess > xmax) xguess = original_length / 2.0;
@@ -941,6 +1019,55 @@ static double opt_pplacer(orc_tiny* tt, const orc_side* tip, size_t b, size_t n,
   return loglikelihood;
 }
 
+/* restates pll-modules pllmod_opt_optimize_branch_lengths_local(radius 1, keep_update 1) on the
+ * triplet (call site src/core/pll/optimize.cpp:274-279, `--raxml-blo`).  The source is not in the
+ * tree; recollected structure (recomp_iterative): per smoothing round
+ *   NR on the edge inner--query; CLV of the inner node re-aimed at the distal node, NR on that edge;
+ *   re-aimed at the proximal node (with the new distal length), NR on that edge; CLV re-aimed at
+ *   the query; NR on the query's edge once more (from the tip's side); edge lnL; stop when the lnL
+ *   moved by less than the tolerance.  A length is replaced when the solver moved it by more than
+ *   1e-10 (keep_update).  Bounds [MIN, MAX], tolerance MIN / 10, guess reset to DEFAULT when out
+ *   of bounds; the three lengths are independent (Tiny_Tree::place rescales distal afterwards,
+ *   src/tree/Tiny_Tree.cpp:183-185).  Returns the NEGATIVE log-likelihood. */
+static double opt_local(orc_tiny* tt, const orc_side* tip, size_t b, size_t n, int smoothings,
+                        double tolerance, long* stat) {
+  const orc_ctx* x = tt->x;
+  const orc_model* m = &x->m;
+  const int max_iters = 30;
+  orc_side in = {tt->inner, NULL, tt->inner_sc};
+  nr_ctx cx = {m, tt->sumtable, n, x->invariant, b, 0, x->newton_variant};
+  const double xmin = x->blo_min, xmax = x->blo_max, xtol = xmin / 10.0;
+  double loglikelihood = -edge_lnl(m, tip, &in, tt->P_pend, x->invariant, NULL, b, n);
+#define ORC_SOLVE(len, P)                                                            \
+  do {                                                                               \
+    double g_ = (len);                                                               \
+    if (g_ < xmin || g_ > xmax) g_ = x->blo_default;                                 \
+    const double r_ = minimize_newton(xmin, g_, xmax, xtol, max_iters, &cx);         \
+    if (isfinite(r_) && fabs((len) - r_) > 1e-10) { (len) = r_; orc_pmatrix(m, r_, (P)); } \
+  } while (0)
+  while (smoothings) {
+    update_sumtable(m, &in, tip, tt->sumtable, b, n);
+    ORC_SOLVE(tt->len_pend, tt->P_pend);
+    update_partial(m, tip, tt->P_pend, &tt->prox, tt->P_prox, tt->inner, tt->inner_sc, b, n);
+    update_sumtable(m, &tt->dist, &in, tt->sumtable, b, n);
+    ORC_SOLVE(tt->len_dist, tt->P_dist);
+    update_partial(m, tip, tt->P_pend, &tt->dist, tt->P_dist, tt->inner, tt->inner_sc, b, n);
+    update_sumtable(m, &tt->prox, &in, tt->sumtable, b, n);
+    ORC_SOLVE(tt->len_prox, tt->P_prox);
+    update_partial(m, &tt->dist, tt->P_dist, &tt->prox, tt->P_prox, tt->inner, tt->inner_sc, b, n);
+    update_sumtable(m, tip, &in, tt->sumtable, b, n);
+    ORC_SOLVE(tt->len_pend, tt->P_pend);
+    const double new_ll = -edge_lnl(m, tip, &in, tt->P_pend, x->invariant, NULL, b, n);
+    if (stat) stat[0]++;
+    --smoothings;
+    if (fabs(new_ll - loglikelihood) < tolerance) smoothings = 0;
+    loglikelihood = new_ll;
+  }
+#undef ORC_SOLVE
+  if (stat) stat[1] += cx.n_evals;
+  return loglikelihood;
+}
+
 /* restates Tiny_Tree::place, opt_branches_ == true (src/tree/Tiny_Tree.cpp:159-204) with
  * call_focused / shift_partition_focus expressed as the window [begin, begin+span)
  * (src/core/pll/pll_util.cpp:388-418) and optimize_branch_triplet (optimize.cpp:253-286).
@@ -966,7 +1093,8 @@ static int tiny_place_thorough(orc_tiny* tt, const char* q, int premask, double*
   orc_pmatrix(&x->m, tt->len_pend, tt->P_pend);
   update_partial(&x->m, &tt->dist, tt->P_dist, &tt->prox, tt->P_prox, tt->inner, tt->inner_sc,
                  begin, span);
-  double ll = -opt_pplacer(tt, &tip, begin, span, 32, ORC_OPT_BRANCH_EPSILON, stat);
+  double ll = x->raxml_blo ? -opt_local(tt, &tip, begin, span, 32, x->blo_eps, stat)
+                           : -opt_pplacer(tt, &tip, begin, span, 32, x->blo_eps, stat);
   free(mk);
   const double total = tt->len_dist + tt->len_prox;
   *distal = (tt->orig / total) * tt->len_dist;
@@ -998,7 +1126,10 @@ void orc_branch_sides(const orc_ctx* x, int b, double* clv_prox, uint32_t* sc_pr
   uint32_t* os[2] = {sc_prox, sc_dist};
   for (int z = 0; z < 2; ++z)
     for (size_t w = 0; w < x->W; ++w) {
-      os[z][w] = sd[z]->scaler ? sd[z]->scaler[w] : 0;
+      if (x->m.rate_scalers)
+        for (int k = 0; k < c; ++k) os[z][w * c + k] = sd[z]->scaler ? sd[z]->scaler[w * c + k] : 0;
+      else
+        os[z][w] = sd[z]->scaler ? sd[z]->scaler[w] : 0;
       for (int k = 0; k < c; ++k)
         for (int i = 0; i < s; ++i)
           oc[z][(w * c + k) * s + i] =

@@ -56,6 +56,10 @@ def lib():
         L.orc_model_uinv.restype = dp
         L.orc_model_uinv.argtypes = [C.c_void_p]
         L.orc_set_aa_x_quirk.argtypes = [C.c_void_p, C.c_int]
+        L.orc_next_create_rate_scalers.argtypes = [C.c_int]
+        L.orc_rate_scalers.argtypes = [C.c_void_p]
+        L.orc_set_raxml_blo.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_blo.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
         L.orc_max_threads.restype = C.c_int
         L.orc_char_column.argtypes = [C.c_int, C.c_char, C.c_int]
         L.orc_char_mask.restype = C.c_uint32
@@ -83,8 +87,13 @@ def gamma_rates(alpha, k=4):
 class Oracle:
     """The CPU restatement of the reference tree + placement evaluator."""
 
-    def __init__(self, newick, labels, seqs, states, subst, freqs, rates, weights=None, pinv=0.0):
+    def __init__(self, newick, labels, seqs, states, subst, freqs, rates, weights=None, pinv=0.0,
+                 rate_scalers=False):
+        """rate_scalers: per-rate scaling (PLL_ATTRIB_RATE_SCALERS; the reference turns it on for
+        trees with more than 2000 tips, src/io/file_io.cpp:211-214)"""
         L = lib()
+        self.rate_scalers = bool(rate_scalers)
+        L.orc_next_create_rate_scalers(int(self.rate_scalers))
         self.W = len(seqs[0])
         self.s = states
         self.c = len(rates)
@@ -98,6 +107,7 @@ class Oracle:
         self.h = L.orc_create(newick.encode(), len(labels), self._keep[0], self._keep[1], self.W,
                               states, _dp(subst), _dp(freqs), self.c, _dp(rates), _dp(weights),
                               pinv)
+        L.orc_next_create_rate_scalers(0)
         if not self.h:
             raise RuntimeError("oracle: orc_create failed (tree / MSA / model)")
         self.B = L.orc_num_branches(self.h)
@@ -110,6 +120,14 @@ class Oracle:
 
     def tree_lnl(self, b):
         return lib().orc_tree_lnl(self.h, b)
+
+    def set_blo(self, min_branch=0.0, max_branch=0.0, default_branch=0.0, epsilon=0.0, newton_variant=-1):
+        """optimiser constants / Newton variant (see orc_set_blo); 0 / -1 keep the current value"""
+        lib().orc_set_blo(self.h, min_branch, max_branch, default_branch, epsilon, newton_variant)
+
+    def set_raxml_blo(self, on=True):
+        """--raxml-blo: radius-1 local BLO (optimize.cpp:274-279) instead of the sliding rule"""
+        lib().orc_set_raxml_blo(self.h, int(on))
 
     def set_aa_x_quirk(self, on=True):
         """quirk D4: AA 'X' preplaced in the 'N' (asparagine) column (Lookup_Store.hpp:63-66)"""
@@ -129,7 +147,8 @@ class Oracle:
     def branch_sides(self, b):
         n = self.W * self.c * self.s
         cp, cd = np.zeros(n), np.zeros(n)
-        sp, sd = np.zeros(self.W, np.uint32), np.zeros(self.W, np.uint32)
+        nsc = self.W * (self.c if self.rate_scalers else 1)
+        sp, sd = np.zeros(nsc, np.uint32), np.zeros(nsc, np.uint32)
         u32 = C.POINTER(C.c_uint32)
         lib().orc_branch_sides(self.h, b, _dp(cp), sp.ctypes.data_as(u32), _dp(cd),
                                sd.ctypes.data_as(u32))

@@ -116,6 +116,20 @@ def test_cfg5_shape_4000_tips_default_heuristic_and_no_heur_vs_oracle():
     tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
     _assert_thorough_parity(res, tl, tp, td)
     assert ev.last_stats["rounds"] == o.last_stats["rounds"]
+    # ---- per-rate scalers: what the reference (and epa-ng-amd) turn on above 2000 tips
+    # (src/io/file_io.cpp:211-214); on ordinary data the numbers equal the per-site ones
+    o_rs = Oracle(w["newick"], w["labels"], w["seqs"], 4, w["subst"], w["freqs"], w["rates"], rate_scalers=True)
+    ev_rs = ref.evaluator(rate_scalers=True)
+    nrs = 300
+    c3, b3, s3 = epa.encode_queries(4, reads[:nrs], compact=True)
+    lnl_rs = ev_rs.preplace(c3, b3, s3)
+    assert np.max(np.abs(lnl_rs - o_rs.preplace(reads[:nrs]))) < LNL_TOL
+    assert np.max(np.abs(lnl_rs - lnl[:nrs])) < 1e-7
+    p_rs, r_rs = ev_rs.place_chunk(c3, b3, s3, max_span=150)
+    tl_rs, tp_rs, td_rs = o_rs.thorough(p_rs["branch_id"], p_rs["seq_id"], reads[:nrs])
+    _assert_thorough_parity(r_rs, tl_rs, tp_rs, td_rs)
+    assert ev_rs.last_stats["rounds"] == o_rs.last_stats["rounds"]
+    del o_rs, ev_rs
     # ---- --no-heur on a handful of reads
     nq = 6
     sub = reads[:nq]

@@ -1,0 +1,134 @@
+"""GPU parity of the general thorough kernel (k_thorough_generic) and of the setup kernels in the
+modes the tuned kernels do not serve: any number of rate categories (+G8, +R5, ...), per-rate
+scalers (PLL_ATTRIB_RATE_SCALERS) and --raxml-blo.  Checker: the oracle in the same mode.
+Tolerances: per-branch lnL |delta| <= 1e-6; lengths 1e-6."""
+import numpy as np
+import pytest
+
+import epa_ng_amd as epa
+from epa_ng_amd import hostlib, synth
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+
+LNL_TOL = 1e-6
+
+
+def all_pairs(B, Q):
+    p = np.zeros(B * Q, epa.PAIR_DTYPE)
+    p["branch_id"] = np.repeat(np.arange(B), Q)
+    p["seq_id"] = np.tile(np.arange(Q), B)
+    return p
+
+
+def check_against_oracle(ev, o, reads, states, pairs=None, compact=True):
+    codes, wb, ws = epa.encode_queries(states, reads, compact=compact)
+    lnl = ev.preplace(codes, wb, ws)
+    assert np.max(np.abs(lnl - o.preplace(reads))) < LNL_TOL
+    if pairs is None:
+        pairs = ev.select(lnl, len(reads), 0.99999)
+    res = ev.thorough(pairs, codes, wb, ws)
+    tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
+    assert np.max(np.abs(res["lnl"] - tl)) < LNL_TOL
+    assert np.max(np.abs(res["pendant_length"] - tp) / np.maximum(1.0, tp)) < 1e-6
+    assert np.max(np.abs(res["distal_length"] - td)) < 1e-6
+    assert ev.last_stats["rounds"] == o.last_stats["rounds"]
+    assert ev.last_stats["newton_evals"] == o.last_stats["newton_evals"]
+    return lnl, pairs, res
+
+
+@pytest.mark.parametrize("states,cats,pinv", [(4, 3, 0.0), (4, 5, 0.0), (4, 8, 0.2), (4, 16, 0.0), (20, 6, 0.0),
+                                              (20, 3, 0.15)])
+def test_any_number_of_rate_categories(states, cats, pinv):
+    """+G8 / +R5-style models: `cats` categories with unequal weights (free rates), optional +I"""
+    rng = np.random.RandomState(100 + cats)
+    rates = np.sort(rng.gamma(0.7, 1.5, cats)) + 1e-3
+    weights = rng.dirichlet(np.full(cats, 4.0))
+    rates = rates / np.sum(rates * weights)            # mean rate 1 (Model.cpp:405-455)
+    subst, freqs = (synth.CFG2_SUBST, synth.CFG2_FREQS) if states == 4 else synth.aa_model(3)
+    root = synth.random_tree(40, 7 + cats)
+    labels, seqs = synth.simulate_msa(root, 260, subst, freqs, synth.gamma_rates(0.7), 8)
+    nw = synth.newick(root)
+    reads, _ = synth.make_reads(seqs, 48, 150 if states == 4 else 90, 0.05, 9, states=states)
+    ref = hostlib.Reference(nw, labels, seqs, states=states, subst=subst, freqs=freqs, rates=rates,
+                            weights=weights, pinv=pinv)
+    o = Oracle(nw, labels, seqs, states, subst, freqs, rates, weights=weights, pinv=pinv)
+    for device_precompute in (True, False):
+        ev = ref.evaluator(device_precompute=device_precompute)
+        assert abs(ev.tree_logl(2) - o.tree_lnl(2)) < 1e-7
+        check_against_oracle(ev, o, reads, states)
+    # the fused chunk body and --no-heur run on the same kernel
+    codes, wb, ws = epa.encode_queries(states, reads, compact=True)
+    p, r = ev.place_chunk(codes, wb, ws)
+    tl, _, _ = o.thorough(p["branch_id"], p["seq_id"], reads)
+    assert np.max(np.abs(r["lnl"] - tl)) < LNL_TOL
+
+
+@pytest.mark.parametrize("states", [4, 20])
+def test_per_rate_scalers_equal_per_site_scalers_on_ordinary_data(states):
+    """where nothing underflows the two scaling schemes give the same numbers (the device in
+    either mode, the oracle in either mode); a deep tree makes sure scalers are non-zero"""
+    subst, freqs = (synth.CFG2_SUBST, synth.CFG2_FREQS) if states == 4 else synth.aa_model(5)
+    root = synth.random_tree(300, 41, mean_bl=0.4, lo=0.05, hi=2.0)
+    rates = synth.gamma_rates(0.4)
+    labels, seqs = synth.simulate_msa(root, 96, subst, freqs, rates, 42)
+    nw = synth.newick(root)
+    reads, _ = synth.make_reads(seqs, 20, 60, 0.05, 43, states=states)
+    ref = hostlib.Reference(nw, labels, seqs, states=states, subst=subst, freqs=freqs, rates=rates)
+    out = {}
+    for rs in (False, True):
+        o = Oracle(nw, labels, seqs, states, subst, freqs, rates, rate_scalers=rs)
+        ev = ref.evaluator(rate_scalers=rs)
+        assert abs(ev.tree_logl(0) - o.tree_lnl(0)) < 1e-6
+        out[rs] = check_against_oracle(ev, o, reads, states)
+    assert np.max(np.abs(out[True][0] - out[False][0])) < 1e-7
+    assert np.array_equal(out[True][1], out[False][1])
+    assert np.max(np.abs(out[True][2]["lnl"] - out[False][2]["lnl"])) < 1e-7
+
+
+def test_per_rate_scalers_where_per_site_scaling_underflows():
+    """the designed case of tests/test_rate_scalers_cpu.py (one column on which per-site scaling
+    provably loses the dominant rate category) on the device: per-rate mode == the oracle's
+    per-rate mode, which that file pins against log-space pruning; the per-site device context
+    reproduces the oracle's per-site failure (tree lnL no longer equal on every edge)"""
+    import test_rate_scalers_cpu as T
+    root, labels, seqs = T.designed_case()
+    nw = synth.newick(root)
+    ref = hostlib.Reference(nw, labels, seqs, states=4, subst=T.SUBST, freqs=T.FREQS, rates=T.RATES)
+    o = Oracle(nw, labels, seqs, 4, T.SUBST, T.FREQS, T.RATES, rate_scalers=True)
+    ev = ref.evaluator(rate_scalers=True)
+    for b in (0, 9, ref.B - 1):
+        assert abs(ev.tree_logl(b) - o.tree_lnl(b)) < 1e-7 * abs(o.tree_lnl(b))
+    qs = ["C" + seqs[T.N_CLADE + 3][1:], "A" + seqs[5][1:], "G" + seqs[T.N_CLADE + 20][1:]]
+    check_against_oracle(ev, o, qs, 4, pairs=all_pairs(ref.B, len(qs))[::7].copy())
+    ps = Oracle(nw, labels, seqs, 4, T.SUBST, T.FREQS, T.RATES)
+    evs = ref.evaluator(rate_scalers=False)
+    assert abs(evs.tree_logl(ref.B - 1) - ps.tree_lnl(ref.B - 1)) < 1e-7 * abs(ps.tree_lnl(ref.B - 1))
+    assert abs(evs.tree_logl(ref.B - 1) - ev.tree_logl(ref.B - 1)) > 10.0
+
+
+@pytest.mark.parametrize("states,rs", [(4, False), (20, False), (4, True)])
+def test_raxml_blo_local_optimisation(states, rs):
+    """--raxml-blo (src/core/pll/optimize.cpp:274-279): radius-1 local optimisation of the three
+    branches of the triplet instead of the sliding rule"""
+    subst, freqs = (synth.CFG2_SUBST, synth.CFG2_FREQS) if states == 4 else synth.aa_model(11)
+    root = synth.random_tree(48, 51)
+    rates = synth.gamma_rates(0.6)
+    labels, seqs = synth.simulate_msa(root, 300, subst, freqs, rates, 52)
+    nw = synth.newick(root)
+    reads, _ = synth.make_reads(seqs, 40, 120 if states == 4 else 80, 0.04, 53, states=states)
+    ref = hostlib.Reference(nw, labels, seqs, states=states, subst=subst, freqs=freqs, rates=rates)
+    o = Oracle(nw, labels, seqs, states, subst, freqs, rates, rate_scalers=rs)
+    o.set_raxml_blo(True)
+    ev = ref.evaluator(raxml_blo=True, rate_scalers=rs)
+    _, pairs, res = check_against_oracle(ev, o, reads, states)
+    bl = np.array([ref.branch(int(b))["length"] for b in range(ref.B)])
+    assert np.all(res["distal_length"] >= 0) and np.all(res["distal_length"] <= bl[pairs["branch_id"]] + 1e-12)
+    ev2 = ref.evaluator()
+    codes, wb, ws = epa.encode_queries(states, reads, compact=True)
+    sliding = ev2.thorough(pairs, codes, wb, ws)
+    # three free lengths instead of one sliding split: better on average; both optimisers stop
+    # once a round moves lnL by less than OPT_BRANCH_EPSILON = 0.1, so "never worse" only holds
+    # up to a few stopping tolerances
+    assert np.mean(res["lnl"] - sliding["lnl"]) > 0.0
+    assert np.all(res["lnl"] >= sliding["lnl"] - 0.5)

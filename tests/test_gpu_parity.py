@@ -260,7 +260,7 @@ def test_thorough_long_windows_hbm_slab():
 #     FLAT_MAX_FRACTION of a configuration's pairs;
 #   * round counters are compared for equality whenever a configuration has no flat-optimum pair.
 # Full run of this round (profiles/r2_sweep.log): 10 of the 180 configurations hold flat-optimum
-# pairs (seeds 0, 5, 25, 37, 154, 159, 161, 166, 169, 178; 33 of 44 016 pairs), their largest
+# pairs (seeds 0, 5, 25, 37, 154, 159, 161, 166, 169, 178; 33 of 225 216 pairs), their largest
 # |dlnL| is 4.4e-6 (seed 159: 20 states, +I, alpha 50, 7-site reads); over all other pairs the
 # largest |dlnL| is 2.5e-10 and every round counter equals the oracle's.
 FLAT_LNL_TOL = 1e-5
