@@ -49,7 +49,7 @@ def build_dev(force=False, verbose=False):
     return out
 
 
-HOST_SOURCES = ["model.cpp", "parse_model.cpp", "tree.cpp", "place.cpp", "io.cpp", "capi.cpp"]
+HOST_SOURCES = ["model.cpp", "aa_models.cpp", "parse_model.cpp", "tree.cpp", "place.cpp", "io.cpp", "capi.cpp"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-fopenmp", "-Wall", "-Wextra", "-Wno-unused-parameter",
               "-I", os.path.join(ROOT, "include")]
 

@@ -121,6 +121,18 @@ void epa_host_ref_model(void* h, double* eigenvals, double* u, double* uinv, dou
   std::memcpy(weights, m.ratecat_weights().data(), sizeof(double) * c);
 }
 
+// exchangeabilities (upper triangle, row-major) and the model string the tree really uses
+void epa_host_ref_subst(void* h, double* subst) {
+  const Model& m = static_cast<Ref*>(h)->tree->model();
+  std::memcpy(subst, m.subst_rates().data(), sizeof(double) * m.subst_rates().size());
+}
+int epa_host_ref_model_string(void* h, char* out, size_t cap) {
+  const std::string s = static_cast<Ref*>(h)->tree->model().to_string();
+  if (s.size() + 1 > cap) return -1;
+  std::memcpy(out, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+
 // borrowed pointers into the tree for branch b (for parity tests against the oracle)
 void epa_host_ref_branch(void* h, uint32_t b, const double** prox_clv, const uint32_t** prox_sc,
                          const double** dist_clv, const uint8_t** dist_tip, const uint32_t** dist_sc,

@@ -112,12 +112,24 @@ struct Work_Pair {  // src/core/Work.hpp:31-34
 };
 using Work = std::vector<Work_Pair>;  // kept branch-major sorted (the reference's map order)
 
+// named empirical amino-acid matrix (aa_models.cpp): 190 exchangeabilities (upper triangle,
+// row-major, libpll state order) + 20 equilibrium frequencies
+struct Named_AA_Model {
+  const char* name;
+  const double* rates;
+  const double* freqs;
+};
+const Named_AA_Model* named_aa_model(const std::string& upper_name);
+
 class Model {
 public:
   Model() = default;
-  // raxml-ng style descriptor, subset (src/core/raxml/Model.cpp:123-538):
-  //   GTR | PROTGTR  [{r1/r2/...}]  [+FU{f1/..} | +FE | +FO(->equal)]  [+I{p}]
-  //                  [+G[n][{alpha}] | +R[n]{rates}{weights}]
+  // raxml-ng style descriptor (src/core/raxml/Model.cpp:123-538):
+  //   NAME  [{r1/r2/...}]  [+FU{f1/..} | +FE | +FO(->equal) | +F | +FC (empirical, from the
+  //         reference MSA)]  [+I{p}]  [+G[n][{alpha}] | +R[n]{rates}{weights}]
+  //   NAME: GTR, the named nucleotide models with their rate symmetries (JC K80 F81 HKY TN93[ef]
+  //         K81[uf] TPM2[uf] TPM3[uf] TIM1[uf] TIM2[uf] TIM3[uf] TVM[ef] SYM), PROTGTR, or a named
+  //         empirical amino-acid matrix (LG WAG JTT DAYHOFF: rates + frequencies from the table)
   explicit Model(const std::string& descriptor);
   Model(int states, std::vector<double> subst, std::vector<double> freqs, std::vector<double> rates,
         std::vector<double> weights, double pinv = 0.0);
@@ -129,6 +141,10 @@ public:
   const std::vector<double>& ratecat_weights() const { return weights_; }
   double alpha() const { return alpha_; }
   double pinv() const { return pinv_; }  // +I: proportion of invariant sites
+  // +F / +FC: the frequencies are counted on the reference MSA (link_tree_msa,
+  // src/core/pll/epa_pll_util.cpp:55-57); Tree's constructor does that and calls set_base_freqs
+  bool empirical_base_freqs() const { return empirical_freqs_; }
+  void set_base_freqs(std::vector<double> freqs);
   const std::vector<double>& eigenvals() const { return eigenvals_; }
   const std::vector<double>& eigenvecs_u() const { return u_; }       // libpll inv_eigenvecs
   const std::vector<double>& eigenvecs_uinv() const { return uinv_; }  // libpll eigenvecs
@@ -141,7 +157,8 @@ private:
   void update_eigen();
   int states_ = 4;
   double alpha_ = 1.0, pinv_ = 0.0;
-  bool free_rates_ = false;
+  bool free_rates_ = false, empirical_freqs_ = false;
+  std::string name_ = "GTR";
   std::vector<double> subst_, freqs_, rates_, weights_, eigenvals_, u_, uinv_;
 };
 

@@ -120,8 +120,8 @@ bool Fasta_Stream::refill() {
   return got != 0;
 }
 
-// Records are located first ('>' at the start of a line), then parsed in parallel: the header up
-// to the first blank, the sequence lines upper-cased with white space dropped.
+// Records are located first ('>' at the start of a line), then parsed in parallel: the header
+// line is the label, the sequence lines are upper-cased with white space dropped.
 size_t Fasta_Stream::read_next(MSA& out, size_t max_seqs) {
   configure_host_threads();
   if (max_seqs == 0) return 0;
@@ -156,8 +156,10 @@ size_t Fasta_Stream::read_next(MSA& out, size_t max_seqs) {
     const char* e = base + (i + 1 < (long)starts_.size() ? starts_[i + 1] : len_);
     const char* nl = (const char*)std::memchr(b, '\n', (size_t)(e - b));
     const char* hend = nl ? nl : e;
-    const char* h = b;
-    while (h < hend && *h != ' ' && *h != '\t' && *h != '\r') ++h;
+    // the label is the whole header line, as the reference's reader (genesis FastaReader via
+    // src/seq/MSA_Stream.cpp:39-41) keeps it; only the line end and trailing blanks are dropped
+    const char* h = hend;
+    while (h > b && (h[-1] == '\r' || h[-1] == ' ' || h[-1] == '\t')) --h;
     std::string header(b, h), seq;
     if (nl) {
       seq.resize((size_t)(e - nl));

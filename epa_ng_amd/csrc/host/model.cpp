@@ -136,22 +136,62 @@ Model::Model(int states, std::vector<double> subst, std::vector<double> freqs,
   update_eigen();
 }
 
-Model::Model(const std::string& descriptor) {
+namespace {
+// named nucleotide models: rate symmetries over AC AG AT CG CT GT and whether the model fixes equal
+// base frequencies (the pll-modules model list the reference queries at Model.cpp:148-183)
+struct Named_DNA { const char* name; const char* sym; bool equal_freqs; bool fixed_rates; };
+const Named_DNA DNA_MODELS[] = {
+    {"JC", "000000", true, true},     {"K80", "010010", true, false},    {"F81", "000000", false, true},
+    {"HKY", "010010", false, false},  {"TN93EF", "010020", true, false}, {"TN93", "010020", false, false},
+    {"K81", "012210", true, false},   {"K81UF", "012210", false, false}, {"TPM2", "010212", true, false},
+    {"TPM2UF", "010212", false, false}, {"TPM3", "012012", true, false}, {"TPM3UF", "012012", false, false},
+    {"TIM1", "012230", true, false},  {"TIM1UF", "012230", false, false}, {"TIM2", "010232", true, false},
+    {"TIM2UF", "010232", false, false}, {"TIM3", "012032", true, false}, {"TIM3UF", "012032", false, false},
+    {"TVMEF", "012314", true, false}, {"TVM", "012314", false, false},   {"SYM", "012345", true, false},
+    {"GTR", "012345", false, false},  {"DNA", "012345", false, false},
+};
+}  // namespace
+
+void Model::set_base_freqs(std::vector<double> freqs) {
+  if ((int)freqs.size() != states_) throw std::runtime_error{"Model: wrong number of frequencies"};
+  double sum = 0;
+  for (double f : freqs) sum += f;
+  for (double& f : freqs) f /= sum;
+  freqs_ = std::move(freqs);
+  update_eigen();
+}
+
+Model::Model(const std::string& descriptor_in) {
+  // RAxML compatibility alias of the reference (Model.cpp:113-116)
+  const std::string descriptor = descriptor_in == "DNA" ? "GTR+G+F" : descriptor_in;
   // name up to the first of "+{["
   size_t pos = descriptor.find_first_of("+{[");
   std::string name = descriptor.substr(0, pos);
   std::transform(name.begin(), name.end(), name.begin(), ::toupper);
-  if (name == "GTR" || name == "DNA") states_ = 4;
-  else if (name == "PROTGTR") states_ = 20;
+  const Named_DNA* dna = nullptr;
+  for (const auto& d : DNA_MODELS)
+    if (name == d.name) dna = &d;
+  const Named_AA_Model* aa = dna ? nullptr : named_aa_model(name);
+  if (dna) states_ = 4;
+  else if (aa || name == "PROTGTR") states_ = 20;
   else
-    throw std::runtime_error{"Invalid model name: " + name +
-                             " (this build knows GTR and PROTGTR with explicit parameters; named "
-                             "empirical AA matrices need the pll-modules model database)"};
+    throw std::runtime_error{"Invalid model name: " + name};
+  name_ = name;
   const int nr = states_ * (states_ - 1) / 2;
-  // defaults of raxml::Model (Model.cpp:190-193,470,487-488): rates 0.5.. / 1.0, equal freqs
+  // defaults of raxml::Model (Model.cpp:190-193,470,487-488): parameters a model does not fix
+  // start at rates 0.5.. / 1.0 and equal frequencies (the optimiser's starting values; EPA-ng
+  // never optimises them in the placement flow)
   subst_.assign(nr, 0.5);
   subst_.back() = 1.0;
   freqs_.assign(states_, 1.0 / states_);
+  if (dna && dna->fixed_rates) subst_.assign(nr, 1.0);
+  if (aa) {
+    subst_.assign(aa->rates, aa->rates + 190);
+    freqs_.assign(aa->freqs, aa->freqs + 20);
+    double sum = 0;
+    for (double f : freqs_) sum += f;
+    for (double& f : freqs_) f /= sum;
+  }
   int cats = 1;
   alpha_ = 1.0;
   bool gamma = false, free_rates = false, gamma_median = false;
@@ -170,8 +210,21 @@ Model::Model(const std::string& descriptor) {
   };
   std::string arg;
   if (braces(arg)) {
-    subst_ = parse_list(arg);
-    if ((int)subst_.size() != nr) throw std::runtime_error{"Model: wrong number of rates"};
+    // user rates: one value per class of the model's rate symmetry (Model.cpp:218-241)
+    const std::vector<double> user = parse_list(arg);
+    if (dna) {
+      int nuniq = 0;
+      for (const char* c = dna->sym; *c; ++c) nuniq = std::max(nuniq, *c - '0' + 1);
+      if ((int)user.size() != nuniq)
+        throw std::runtime_error{"Invalid number of substitution rates specified: " + std::to_string(user.size()) +
+                                 " (expected: " + std::to_string(nuniq) + ")"};
+      for (int r = 0; r < nr; ++r) subst_[r] = user[dna->sym[r] - '0'];
+    } else {
+      if ((int)user.size() != nr)
+        throw std::runtime_error{"Invalid number of substitution rates specified: " + std::to_string(user.size()) +
+                                 " (expected: " + std::to_string(nr) + ")"};
+      subst_ = user;
+    }
   }
   while (i < rest.size()) {
     if (rest[i] != '+') throw std::runtime_error{"Model: cannot parse '" + rest.substr(i) + "'"};
@@ -180,17 +233,24 @@ Model::Model(const std::string& descriptor) {
     while (i < rest.size() && std::isalpha((unsigned char)rest[i])) ++i;
     std::string opt = rest.substr(b, i - b);
     std::transform(opt.begin(), opt.end(), opt.begin(), ::toupper);
-    if (opt == "FU" || opt == "F") {
-      if (braces(arg)) {
-        freqs_ = parse_list(arg);
-        if ((int)freqs_.size() != states_) throw std::runtime_error{"Model: wrong number of freqs"};
-        double sum = 0;
-        for (double f : freqs_) sum += f;
-        for (double& f : freqs_) f /= sum;
-      }
-    } else if (opt == "FE" || opt == "FO" || opt == "FC") {
-      // FE: equal; FO/FC need optimisation / counting, which EPA-ng never runs in the shipped
-      // flow -- treated as equal here like the starting value in Model.cpp:470
+    if (opt == "FU" || (opt == "F" && i < rest.size() && rest[i] == '{')) {
+      if (!braces(arg)) throw std::runtime_error{"Model: +FU needs explicit frequencies, e.g. +FU{0.25/0.25/0.25/0.25}"};
+      freqs_ = parse_list(arg);
+      if ((int)freqs_.size() != states_)
+        throw std::runtime_error{"Invalid number of user frequencies specified: " + std::to_string(freqs_.size())};
+      double sum = 0;
+      for (double f : freqs_) sum += f;
+      for (double& f : freqs_) f /= sum;
+      empirical_freqs_ = false;
+    } else if (opt == "F" || opt == "FC") {
+      // empirical (Model.cpp:302-306): counted on the reference MSA when the tree is linked to it
+      // (link_tree_msa, src/core/pll/epa_pll_util.cpp:55-57); until then the current values stand
+      empirical_freqs_ = true;
+    } else if (opt == "FE" || opt == "FO") {
+      // FE: equal; FO = ML estimate, whose starting value (all EPA-ng ever uses in the placement
+      // flow) is equal frequencies as well (Model.cpp:466-471)
+      freqs_.assign(states_, 1.0 / states_);
+      empirical_freqs_ = false;
     } else if (opt == "G") {
       gamma = true;
       cats = 4;
@@ -324,8 +384,18 @@ uint32_t Model::char_mask(char ch) const {
 std::string Model::to_string() const {
   std::ostringstream s;
   s.precision(6);
-  s << std::fixed << (states_ == 4 ? "GTR{" : "PROTGTR{");
-  for (size_t i = 0; i < subst_.size(); ++i) s << (i ? "/" : "") << subst_[i];
+  const bool generic = name_ == "GTR" || name_ == "DNA" || name_ == "PROTGTR";
+  s << std::fixed << (generic ? (states_ == 4 ? "GTR" : "PROTGTR") : name_) << "{";
+  if (generic || states_ == 20) {
+    for (size_t i = 0; i < subst_.size(); ++i) s << (i ? "/" : "") << subst_[i];
+  } else {  // named nucleotide model: one value per class of its rate symmetry
+    for (const auto& d : DNA_MODELS)
+      if (name_ == d.name) {
+        int seen = 0;
+        for (int r = 0; r < 6; ++r)
+          if (d.sym[r] - '0' == seen) { s << (seen ? "/" : "") << subst_[r]; ++seen; }
+      }
+  }
   s << "}+FU{";
   for (size_t i = 0; i < freqs_.size(); ++i) s << (i ? "/" : "") << freqs_[i];
   s << "}";

@@ -167,7 +167,8 @@ Work apply_heuristic(const std::vector<double>& lnl, size_t Q, size_t B, const O
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return row[a] > row[b]; });
         size_t hits = 0;
         while (hits < B && !(row[order[hits]] < best - strike_box)) ++hits;
-        const size_t to_add = hits >= max_pitches ? 0 : std::min(max_pitches - hits, max_strikes);
+        // size_t arithmetic of heuristics.hpp:107: the difference wraps when hits > max_pitches
+        const size_t to_add = hits > max_pitches ? max_strikes : std::min(max_pitches - hits, max_strikes);
         n_keep = std::min(B, hits + to_add);
       } else {
         row_lwr(row, B, lwr);

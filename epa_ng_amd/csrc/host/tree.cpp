@@ -202,6 +202,13 @@ Tree::Tree(const std::string& newick, const MSA& ref_msa, const Model& model, co
   sites_ = ref_msa[0].sequence().size();
   std::unordered_map<std::string, size_t> by_label;
   for (size_t i = 0; i < ref_msa.size(); ++i) by_label.emplace(ref_msa[i].header(), i);
+  // convenience beyond the reference: a reference sequence whose header carries a description
+  // ("taxon1 len=1500") is also found under its first word
+  for (size_t i = 0; i < ref_msa.size(); ++i) {
+    const std::string& h = ref_msa[i].header();
+    const size_t sp = h.find_first_of(" \t");
+    if (sp != std::string::npos) by_label.emplace(h.substr(0, sp), i);
+  }
   const int s = model_.num_states();
   std::unordered_map<uint32_t, uint8_t> code_of;
   if (s == 4) {
@@ -227,6 +234,21 @@ Tree::Tree(const std::string& newick, const MSA& ref_msa, const Model& model, co
       }
       tipchars_[t][w] = c->second;
     }
+  }
+  if (model_.empirical_base_freqs()) {
+    // +F / +FC: compute_and_set_empirical_frequencies (src/core/pll/epa_pll_util.cpp:55-57 ->
+    // pllmod_msa_empirical_frequencies, pll-modules, restated): every tip character adds
+    // 1 / |state set| to each state it allows (gaps and fully ambiguous characters spread
+    // uniformly), normalised to sum 1
+    std::vector<double> f(s, 0.0);
+    for (unsigned t = 0; t < n; ++t)
+      for (size_t w = 0; w < sites_; ++w) {
+        const uint32_t m = tipmap_[tipchars_[t][w]];
+        const double share = 1.0 / (double)__builtin_popcount(m);
+        for (int i = 0; i < s; ++i)
+          if ((m >> i) & 1u) f[i] += share;
+      }
+    model_.set_base_freqs(f);
   }
   // pll_update_invariant_sites over the reference tips (the array the tiny partition borrows,
   // src/tree/tiny_util.cpp:153-156): AND of the tips' state sets is a single state -> that state

@@ -809,7 +809,8 @@ __device__ __forceinline__ double wave_add(double v) {
 //               (until_accumulated_reached, src/set_manipulators.cpp:90-114)
 //   1 fixed     the ceil(x * B) best (until_top_percent, :82-88); limit precomputed by the host
 //   2 baseball  every branch within 3.0 lnL of the best ("strike box"), plus min(40 - hits, 6)
-//               more when fewer than 40 were hit (src/core/heuristics.hpp:70-117, clamped at B)
+//               more -- 6 when more than 40 were hit: the reference's unsigned wrap-around
+//               (src/core/heuristics.hpp:70-117; quirk D7: clamped at B)
 struct SelRule {
   int mode;
   double thr;
@@ -830,7 +831,9 @@ struct SelRule {
     if (striking) {
       if (!(best < mx - 3.0)) { ++hits; return true; }
       striking = false;
-      limit = hits + (hits >= 40u ? 0u : min(40u - hits, 6u));
+      // std::min(max_pitches - hits, max_strikes) in size_t arithmetic (heuristics.hpp:107): with
+      // more than 40 hits the difference wraps around and 6 more are added, with exactly 40 none
+      limit = hits + (hits > 40u ? 6u : min(40u - hits, 6u));
     }
     return taken < limit;
   }

@@ -42,6 +42,8 @@ def host_lib():
         L.epa_host_ref_tree_logl.argtypes = [C.c_void_p, C.c_uint32]
         L.epa_host_ref_numbered_newick.argtypes = [C.c_void_p, C.c_uint, C.c_char_p, C.c_size_t]
         L.epa_host_ref_model.argtypes = [C.c_void_p, dp, dp, dp, dp, dp, dp]
+        L.epa_host_ref_subst.argtypes = [C.c_void_p, dp]
+        L.epa_host_ref_model_string.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.epa_host_ref_branch.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), dp]
@@ -153,6 +155,18 @@ class Reference:
         host_lib().epa_host_ref_model(self.h, _dp(ev), _dp(u), _dp(ui), _dp(f), _dp(r), _dp(w))
         return {"eigenvals": ev, "u": u.reshape(s, s), "uinv": ui.reshape(s, s), "freqs": f,
                 "rates": r, "weights": w}
+
+    def subst(self):
+        """exchangeabilities of the model in use (upper triangle, row-major)"""
+        out = np.zeros(self.s * (self.s - 1) // 2)
+        host_lib().epa_host_ref_subst(self.h, _dp(out))
+        return out
+
+    def model_string(self):
+        buf = C.create_string_buffer(1 << 14)
+        n = host_lib().epa_host_ref_model_string(self.h, buf, len(buf))
+        assert n > 0
+        return buf.value.decode()
 
     def tipmap(self):
         buf = np.zeros(256, np.uint32)

@@ -273,8 +273,9 @@ int epa_dev_select_candidates(epa_ctx* ctx, const double* lnl, uint32_t Q, doubl
  *   EPA_HEUR_DYNAMIC   (default) accumulated LWR >= the call's `threshold`   (--dyn-heur)
  *   EPA_HEUR_FIXED     the ceil(param * B) best branches per query           (--fix-heur,
  *                      until_top_percent src/set_manipulators.cpp:82-88); `threshold` is ignored
- *   EPA_HEUR_BASEBALL  every branch within 3.0 lnL of the best, plus min(40 - hits, 6) more while
- *                      fewer than 40 were hit (--baseball-heur, heuristics.hpp:70-117, clamped at B)
+ *   EPA_HEUR_BASEBALL  every branch within 3.0 lnL of the best, plus min(40 - hits, 6) more (6 more
+ *                      when over 40 were hit: the reference's size_t wrap-around, heuristics.hpp:107)
+ *                      (--baseball-heur, heuristics.hpp:70-117, clamped at B)
  */
 #define EPA_HEUR_DYNAMIC 0
 #define EPA_HEUR_FIXED 1

@@ -836,3 +836,91 @@ def test_staged_chunk_pipeline_equals_place_chunk(packed):
     assert n == len(expect[2][0])
     assert np.array_equal(d_pairs[:n, 0].cpu().numpy().view(np.uint32), expect[2][0]["branch_id"])
     assert np.array_equal(d_res[:n, 0].cpu().numpy(), expect[2][1]["lnl"])
+
+
+def test_baseball_heuristic_counts_follow_the_reference_arithmetic():
+    """baseball_heuristic (src/core/heuristics.hpp:74-117): hits = branches within 3.0 lnL of the
+    best, then std::min(max_pitches - hits, max_strikes) more in size_t arithmetic -- 6 more when
+    hits > 40 (the difference wraps), none at exactly 40, clamped at B (quirk D7)"""
+    w = synth.dna_workload(40, 64, 4, 40, (71, 72, 73))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    B = ref.B
+    assert B == 77
+    rng = np.random.RandomState(2)
+    hits = [1, 12, 34, 38, 40, 41, 50, 74, 77]
+    lnl = np.empty((len(hits), B))
+    for q, h in enumerate(hits):
+        row = -1000.0 - 10.0 - rng.rand(B) * 50.0          # far outside the strike box
+        idx = rng.permutation(B)[:h]
+        row[idx] = -1000.0 - rng.rand(h) * 2.9              # inside it
+        row[idx[0]] = -1000.0                               # the best
+        lnl[q] = row
+    ev.set_heuristic("baseball")
+    pairs = ev.select(lnl, len(hits))
+    hb, hs = hostlib.heuristic(lnl, "baseball")
+    assert sorted(zip(hb.tolist(), hs.tolist())) == sorted(zip(pairs["branch_id"].tolist(), pairs["seq_id"].tolist()))
+    got = np.bincount(pairs["seq_id"], minlength=len(hits))
+    expect = [min(B, h + (6 if h > 40 else min(40 - h, 6))) for h in hits]
+    assert got.tolist() == expect
+    for q, h in enumerate(hits):                            # and they are the best ones
+        chosen = set(pairs["branch_id"][pairs["seq_id"] == q].tolist())
+        assert chosen == set(np.argsort(-lnl[q], kind="stable")[:expect[q]].tolist())
+
+
+@pytest.mark.parametrize("states,model,flags,kw", [
+    (20, "LG+G4{0.563473}", [], {}),                                 # BASELINE configs[2]'s model family
+    (20, "WAG+F+G4{0.8}", ["--rate-scalers", "on"], {"rate_scalers": True}),
+    (4, "GTR{0.7/1.8/1.2/0.6/3.0/1.0}+FU{0.25/0.23/0.30/0.22}+G8{0.5}", ["--raxml-blo"], {"raxml_blo": True}),
+    (4, "HKY{1.0/3.5}+F+R3{0.2/1.0/3.0}{0.5/0.3/0.2}", ["--rate-scalers", "on", "--raxml-blo"],
+     {"rate_scalers": True, "raxml_blo": True}),
+])
+def test_cli_named_models_rate_scalers_raxml_blo(tmp_path, states, model, flags, kw):
+    """the model-string front end and the switches that used to be refused, end to end through the
+    executable: named empirical AA matrices, named nucleotide models with symmetric rates, +F
+    (frequencies counted on the reference MSA), +G8 / +R3, --rate-scalers, --raxml-blo.  The jplace
+    must hold, per query, the placements the API gives for the same model and switches."""
+    import subprocess
+    subst, freqs = (synth.CFG2_SUBST, synth.CFG2_FREQS) if states == 4 else synth.aa_model(21)
+    root = synth.random_tree(30, 91)
+    labels, seqs = synth.simulate_msa(root, 200, subst, freqs, synth.gamma_rates(0.6), 92)
+    reads, _ = synth.make_reads(seqs, 60, 100 if states == 4 else 70, 0.04, 93, states=states)
+    nw = synth.newick(root)
+    tre, aln, qf = tmp_path / "ref.tre", tmp_path / "ref.fasta", tmp_path / "q.fasta"
+    tre.write_text(nw + "\n")
+    with open(aln, "w") as f:
+        for l, s in zip(labels, seqs):
+            f.write(">%s\n%s\n" % (l, s))
+    with open(qf, "w") as f:
+        for i, s in enumerate(reads):
+            f.write(">q%d\n%s\n" % (i, s))
+    r = subprocess.run([hostlib.cli_exe(), "-t", str(tre), "-s", str(aln), "-q", str(qf), "-m", model,
+                        "-w", str(tmp_path), "--filter-max", "30", "--filter-min-lwr", "1e-9"] + flags,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    jp = json.load(open(tmp_path / "epa_result.jplace"))
+    assert len(jp["placements"]) == len(reads)
+    ref = hostlib.Reference(nw, labels, seqs, model=model)
+    assert ref.s == states
+    ev = ref.evaluator(**kw)
+    codes, wb, ws = epa.encode_queries(states, reads, compact=True)
+    pairs, res = ev.place_chunk(codes, wb, ws)
+    for pq in jp["placements"]:
+        q = int(pq["n"][0][1:])
+        m = pairs["seq_id"] == q
+        want = {int(b): (l, pl, dl) for b, l, pl, dl in zip(pairs["branch_id"][m], res["lnl"][m],
+                                                            res["pendant_length"][m], res["distal_length"][m])}
+        assert 1 <= len(pq["p"]) <= len(want)
+        for edge, lnl, lwr, distal, pendant in pq["p"]:
+            wl, wp, wd = want[edge]
+            assert abs(lnl - wl) < 1e-6 * max(1.0, abs(wl)) and abs(pendant - wp) < 1e-8 and abs(distal - wd) < 1e-8
+        assert abs(sum(p[2] for p in pq["p"]) - 1.0) < 1e-6 or len(pq["p"]) < len(want)
+    # the same model through the oracle: parity of what the CLI computed
+    from oracle_lib import Oracle
+    mdl = ref.model()
+    o = Oracle(nw, labels, seqs, states, ref.subst(), mdl["freqs"], mdl["rates"], weights=mdl["weights"],
+               rate_scalers=kw.get("rate_scalers", False))
+    o.set_raxml_blo(kw.get("raxml_blo", False))
+    tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
+    assert np.max(np.abs(res["lnl"] - tl)) < 1e-6

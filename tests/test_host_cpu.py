@@ -11,7 +11,7 @@ import pytest
 import epa_ng_amd as epa
 from epa_ng_amd import hostlib
 from golden_util import CASES, load_case
-from oracle_lib import Oracle
+from oracle_lib import Oracle, gamma_rates
 
 
 def refs(g):
@@ -88,7 +88,80 @@ def test_model_descriptor_parsing_and_gamma():
     assert np.allclose(m["freqs"][:, None] * q, (m["freqs"][:, None] * q).T, atol=1e-12)
     assert np.allclose(m["u"] @ m["uinv"], np.eye(4), atol=1e-12)
     with pytest.raises(RuntimeError):
-        hostlib.Reference(g["newick"], labels, seqs, model="LG+G")
+        hostlib.Reference(g["newick"], labels, seqs, model="NOSUCHMODEL+G")
+
+
+def test_named_nucleotide_models_and_empirical_frequencies():
+    """the named models of the model-string front end (src/core/raxml/Model.cpp:123-538): rate
+    symmetries, user rates per symmetry class, and +F / +FC = frequencies counted on the reference
+    MSA (link_tree_msa, src/core/pll/epa_pll_util.cpp:55-57)"""
+    g = load_case("dna8_gtr_fu_g4")
+    labels = [a for a, _ in g["msa"]]
+    seqs = [b for _, b in g["msa"]]
+    mk = lambda m: hostlib.Reference(g["newick"], labels, seqs, model=m)   # noqa: E731
+    assert np.allclose(mk("JC").subst(), 1.0) and np.allclose(mk("JC").model()["freqs"], 0.25)
+    assert np.allclose(mk("HKY{1.0/4.0}+G4").subst(), [1, 4, 1, 1, 4, 1])
+    assert np.allclose(mk("TN93{1/2/3}").subst(), [1, 2, 1, 1, 3, 1])
+    assert np.allclose(mk("K81{1/2/3}").subst(), [1, 2, 3, 3, 2, 1])
+    assert np.allclose(mk("TVM{1/2/3/4/5}").subst(), [1, 2, 3, 4, 2, 5])
+    assert np.allclose(mk("GTR").subst(), [0.5, 0.5, 0.5, 0.5, 0.5, 1.0])
+    with pytest.raises(RuntimeError):
+        mk("HKY{1/2/3}")
+    # counted frequencies: A C G T, ambiguity codes and gaps spread over the states they allow
+    cnt = np.zeros(4)
+    sets = {"A": [0], "C": [1], "G": [2], "T": [3], "U": [3], "R": [0, 2], "Y": [1, 3], "S": [1, 2], "W": [0, 3],
+            "K": [2, 3], "M": [0, 1], "B": [1, 2, 3], "D": [0, 2, 3], "H": [0, 1, 3], "V": [0, 1, 2]}
+    for sq in seqs:
+        for ch in sq.upper():
+            st = sets.get(ch, [0, 1, 2, 3])
+            cnt[st] += 1.0 / len(st)
+    emp = cnt / cnt.sum()
+    for desc in ("GTR+F+G4", "GTR+FC+G4", "DNA"):
+        r = mk(desc)
+        assert np.allclose(r.model()["freqs"], emp, atol=1e-12), desc
+    o = Oracle(g["newick"], labels, seqs, 4, [0.5, 0.5, 0.5, 0.5, 0.5, 1.0], emp, gamma_rates(1.0))
+    assert abs(mk("GTR+F+G4").tree_lnl() - o.tree_lnl(0)) < 1e-7
+    # +FO keeps the optimiser's starting value (equal), +FE is equal, +FU{..} are the user's
+    assert np.allclose(mk("GTR+FO+G4").model()["freqs"], 0.25)
+    assert np.allclose(mk("GTR+FU{0.1/0.2/0.3/0.4}").model()["freqs"], [0.1, 0.2, 0.3, 0.4])
+
+
+def test_named_amino_acid_matrices_are_consistent():
+    """LG / WAG / JTT / DAYHOFF (epa_ng_amd/csrc/host/aa_models.cpp, typed in from the published
+    tables; no pll-modules copy to diff against): internal consistency only -- frequencies sum to 1,
+    the dominant exchanges are the well-known ones, the matrices rank pairs alike, the model string
+    round-trips, and BASELINE configs[2]'s `LG+G4` builds a reversible Q with the table's
+    stationary distribution"""
+    g = load_case("aa8_protgtr_g4")
+    labels = [a for a, _ in g["msa"]]
+    seqs = [b for _, b in g["msa"]]
+    AA = "ARNDCQEGHILKMFPSTWYV"
+    iu = np.triu_indices(20, 1)
+    rates = {}
+    for name in ("LG", "WAG", "JTT", "DAYHOFF"):
+        r = hostlib.Reference(g["newick"], labels, seqs, model=name + "+G4{0.7}")
+        assert r.s == 20 and r.c == 4
+        m = r.model()
+        assert abs(m["freqs"].sum() - 1.0) < 1e-12 and m["freqs"].min() > 0.009
+        assert AA[int(np.argmax(m["freqs"]))] in "LAG" and AA[int(np.argmin(m["freqs"]))] == "W"
+        sub = r.subst()
+        rates[name] = sub
+        assert sub.min() >= 0.0 and len(sub) == 190
+        top = {AA[iu[0][k]] + AA[iu[1][k]] for k in np.argsort(-sub)[:8]}
+        assert {"IV", "DE"} <= top and ("FY" in top or "RK" in top)
+        q = m["u"] @ np.diag(m["eigenvals"]) @ m["uinv"]
+        assert np.allclose(q.sum(1), 0, atol=1e-10)
+        assert np.allclose(m["freqs"][:, None] * q, (m["freqs"][:, None] * q).T, atol=1e-10)
+        assert abs(-(m["freqs"] * np.diag(q)).sum() - 1.0) < 1e-10        # mean rate 1
+        assert r.model_string().startswith(name + "{") and np.isfinite(r.tree_lnl())
+        r2 = hostlib.Reference(g["newick"], labels, seqs, model=r.model_string())
+        assert abs(r2.tree_lnl() - r.tree_lnl()) < 1e-2                    # 6-digit round trip of 210 parameters
+    rank = lambda v: np.argsort(np.argsort(v))     # noqa: E731
+    for a, b in (("LG", "WAG"), ("LG", "JTT"), ("WAG", "JTT"), ("JTT", "DAYHOFF")):
+        assert np.corrcoef(rank(rates[a]), rank(rates[b]))[0, 1] > 0.75
+    # +F replaces the table's frequencies by the counted ones
+    r = hostlib.Reference(g["newick"], labels, seqs, model="LG+F+G4")
+    assert not np.allclose(r.model()["freqs"], hostlib.Reference(g["newick"], labels, seqs, model="LG").model()["freqs"])
 
 
 def test_filters_reference_literals():
@@ -172,7 +245,7 @@ int main(int argc, char** argv) {
     const size_t n = in.read_next(m, chunk);
     if (!n) break;
     std::printf("CHUNK %zu\n", n);
-    for (auto& s : m) std::printf("%s %s\n", s.header().c_str(), s.sequence().c_str());
+    for (auto& s : m) std::printf("%s|%s\n", s.header().c_str(), s.sequence().c_str());
   }
 }
 ''')
@@ -193,9 +266,10 @@ int main(int argc, char** argv) {
         out = subprocess.run([str(exe), str(fa), str(chunk)], check=True, capture_output=True, text=True).stdout
         lines = out.strip().split("\n")
         sizes = [int(l.split()[1]) for l in lines if l.startswith("CHUNK")]
-        got = [tuple(l.split()) for l in lines if not l.startswith("CHUNK")]
+        got = [tuple(l.split("|")) for l in lines if not l.startswith("CHUNK")]
         assert sizes == [min(chunk, len(recs) - k) for k in range(0, len(recs), chunk)]
-        assert got == [(h, s.upper()) for h, s in recs]
+        # the label is the whole header line (the reference's genesis FastaReader keeps it)
+        assert got == [(h + " some comment", s.upper()) for h, s in recs]
 
 
 def test_rooted_reference_tree_is_unrooted():
@@ -423,7 +497,7 @@ int main(int argc, char** argv) {
     epa::MSA m;
     const size_t n = in.read_next(m, chunk);
     if (!n) break;
-    for (auto& s : m) std::printf("%s %s\n", s.header().c_str(), s.sequence().c_str());
+    for (auto& s : m) std::printf("%s|%s\n", s.header().c_str(), s.sequence().c_str());
   }
 }
 ''')
@@ -459,7 +533,7 @@ def test_bfast_query_files(tmp_path):
         return recs
     want = read_fasta(os.path.join(data, "query.fasta"))
     out = subprocess.run([str(exe), os.path.join(data, "query.fasta.bin"), "1"], check=True, capture_output=True, text=True).stdout
-    got = [tuple(l.split()) for l in out.strip().split("\n")]
+    got = [tuple(l.split("|")) for l in out.strip().split("\n")]
     assert got == want and len(got) == 2
 
     nt_map = "-TGKCYSBAWRDMHVN"
@@ -481,7 +555,7 @@ def test_bfast_query_files(tmp_path):
     bf.write_bytes(blob)
     for chunk in (1, 3, 50):
         out = subprocess.run([str(exe), str(bf), str(chunk)], check=True, capture_output=True, text=True).stdout
-        assert [tuple(l.split()) for l in out.strip().split("\n")] == recs
+        assert [tuple(l.split("|")) for l in out.strip().split("\n")] == recs
 
 
 def test_compact_read_generator_equals_ascii_reads_encoded():
