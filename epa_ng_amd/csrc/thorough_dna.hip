@@ -199,8 +199,7 @@ __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* ta
     const double d2 = fma(d1, d1, -l2 * inv);
     if (st.valid[ch]) { fl += d1; dfl += d2; }
   }
-  f = wave_sum(fl);
-  df = wave_sum(dfl);
+  wave_sum2(fl, dfl, f, df);
   cb.sum2(f, df, lane);
 }
 
