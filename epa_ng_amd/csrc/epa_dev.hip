@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
                                                       double* __restrict__ lookup,
                                                       double* __restrict__ refI,
                                                       uint8_t* __restrict__ resc0,
-                                                      const double* __restrict__ cinv, int rate_scalers) {
+                                                      const double* __restrict__ cinv) {
   __shared__ double U[S * S], Ui[S * S];
   __shared__ double Eh[EPA_MAX_CATS * S], Ep[EPA_MAX_CATS * S];  // exp tables: half branch, pendant
   const int c = m->c, ncols = m->ncols;
@@ -166,10 +166,7 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
   const double* Xt = refT + (size_t)(2 * b) * c * S * W + site;
   const double* Dt = refT + (size_t)(2 * b + 1) * c * S * W + site;
   double I[EPA_MAX_CATS][S];
-  double cmult[EPA_MAX_CATS];   // per-rate scalers: rescale + alignment factor of every category
-  uint32_t ccnt[EPA_MAX_CATS];
   double mx = 0.0;
-  uint32_t sc = 0xffffffffu;
   for (int k = 0; k < c; ++k) {
     double dv[S], xv[S];
 #pragma unroll
@@ -177,7 +174,6 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
       dv[x] = Dt[(size_t)(k * S + x) * W] * Eh[k * S + x];
       xv[x] = Xt[(size_t)(k * S + x) * W] * Eh[k * S + x];
     }
-    double mxk = 0.0;
 #pragma unroll
     for (int i = 0; i < S; ++i) {
       double a = 0.0, bb = 0.0;
@@ -188,29 +184,13 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
       }
       const double v = a * bb;
       I[k][i] = v;
-      mxk = fmax(mxk, v);
-    }
-    mx = fmax(mx, mxk);
-    if (rate_scalers) {   // count of this category: both sides + its own rescale
-      const bool small = mxk < 0x1p-256;
-      ccnt[k] = scSum[((size_t)b * c + k) * W + site] + (small ? 1u : 0u);
-      cmult[k] = small ? 0x1p+256 : 1.0;
-      sc = min(sc, ccnt[k]);
+      mx = fmax(mx, v);
     }
   }
+  uint32_t sc = scSum[(size_t)b * W + site];
   // per-site scaling of pll_update_partials: every entry below 2^-256 -> multiply by 2^256
-  const bool resc = !rate_scalers && mx < 0x1p-256;
-  if (!rate_scalers) {
-    sc = scSum[(size_t)b * W + site];
-    if (resc) sc += 1;
-  } else {
-    // align every category to the site's minimum count: 2^(-256 min(cnt - min, 4)) (libpll
-    // rate_scalings / scale_minlh; oracle rate_alignment)
-    for (int k = 0; k < c; ++k) {
-      const uint32_t d = min(ccnt[k] - sc, 4u);
-      cmult[k] *= d == 0 ? 1.0 : d == 1 ? 0x1p-256 : d == 2 ? 0x1p-512 : d == 3 ? 0x1p-768 : 0x1p-1024;
-    }
-  }
+  const bool resc = mx < 0x1p-256;
+  if (resc) sc += 1;
   if (resc0) resc0[(size_t)b * W + site] = resc ? 1 : 0;
   const double mult = resc ? 0x1p+256 : 1.0;
   // g[k][i] = pi_i * (P_pendant I)_i  via the eigenbasis: P I = U (e o (Ui I))
@@ -221,7 +201,7 @@ __global__ void __launch_bounds__(256) k_build_lookup(const ModelDev* __restrict
     for (int x = 0; x < S; ++x) {
       double acc = 0.0;
 #pragma unroll
-      for (int i = 0; i < S; ++i) acc = fma(Ui[x * S + i], I[k][i] * (rate_scalers ? cmult[k] : mult), acc);
+      for (int i = 0; i < S; ++i) acc = fma(Ui[x * S + i], I[k][i] * mult, acc);
       // the thorough kernel starts every pair from exactly this vector (same lengths): keep it
       if (refI) refI[((size_t)b * c * S + (size_t)(k * S + x)) * W + site] = acc;
       it[x] = acc * Ep[k * S + x];
@@ -259,11 +239,11 @@ int launch_build_lookup(epa_ctx* ctx) {
   if (ctx->s == 4)
     hipLaunchKernelGGL(k_build_lookup<4>, grid, dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT,
                        ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup, ctx->refI,
-                       ctx->resc0, ctx->cinv, ctx->rate_scalers ? 1 : 0);
+                       ctx->resc0, ctx->cinv);
   else
     hipLaunchKernelGGL(k_build_lookup<20>, grid, dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT,
                        ctx->scSum, ctx->blen, ctx->blo.pendant_default, ctx->W, ctx->lookup, ctx->refI,
-                       ctx->resc0, ctx->cinv, ctx->rate_scalers ? 1 : 0);
+                       ctx->resc0, ctx->cinv);
   EPA_HIP(ctx, hipGetLastError());
   if (ctx->s == 4) {
     int rc = launch_build_lookup2(ctx);
@@ -496,6 +476,8 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
 }
 
 static int precompute_from_tree(epa_ctx* ctx, const epa_tree_desc* t, const uint32_t* d_tipmap);
+__global__ void k_align_rates(const ModelDev* __restrict__ m, double* __restrict__ refT,
+                              const uint32_t* __restrict__ sc_side, uint32_t* __restrict__ scSum, uint32_t W);
 
 static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const epa_tree_desc* tree = nullptr) {
   const int s = (int)d->states, c_in = (int)d->rate_cats;
@@ -590,17 +572,17 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   ctx->blo.sliding = (d->flags & EPA_FLAG_RAXML_BLO) ? 0 : 1;
   ctx->rate_scalers = (d->flags & EPA_FLAG_RATE_SCALERS) != 0;
   // the tuned thorough kernels are built for 4 categories, per-site scalers and the sliding rule
-  ctx->generic_thorough = c != 4 || ctx->rate_scalers || !ctx->blo.sliding;
+  ctx->generic_thorough = c != 4 || !ctx->blo.sliding ||
+                          getenv("EPA_TH_GENERIC") != nullptr;   // (diagnostic switch: measure the general kernel)
 
   EPA_HIP(ctx, hipMalloc(&ctx->dmodel, sizeof(ModelDev)));
   EPA_HIP(ctx, hipMemcpy(ctx->dmodel, &m, sizeof(ModelDev), hipMemcpyHostToDevice));
 
   const size_t W = ctx->W, B = ctx->B, cs = (size_t)c * s;
-  const size_t cdim = ctx->rate_scalers ? (size_t)c : 1;   // scaler counts per site
   EPA_HIP(ctx, hipMalloc(&ctx->refT, sizeof(double) * 2 * B * cs * W));
   EPA_HIP(ctx, hipMalloc(&ctx->th_ctr, 256));
-  EPA_HIP(ctx, hipMalloc(&ctx->scSum, sizeof(uint32_t) * B * cdim * W));
-  EPA_HIP(ctx, hipMemset(ctx->scSum, 0, sizeof(uint32_t) * B * cdim * W));
+  EPA_HIP(ctx, hipMalloc(&ctx->scSum, sizeof(uint32_t) * B * W));
+  EPA_HIP(ctx, hipMemset(ctx->scSum, 0, sizeof(uint32_t) * B * W));
   EPA_HIP(ctx, hipMalloc(&ctx->blen, sizeof(double) * B));
   EPA_HIP(ctx, hipMalloc(&ctx->lookup, sizeof(double) * B * W * ctx->ncols));
   if (!ctx->generic_thorough) {  // starting vectors of the tuned thorough kernels
@@ -648,6 +630,14 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
     ctx->inv_w0 = 1.0 / m.w[0];
   }
   if (tree) return precompute_from_tree(ctx, tree, d_tipmap);
+  // per-rate scaler rows of the caller ([W][c], libpll layout): collected per side, aligned at the end
+  const size_t cdim = ctx->rate_scalers ? (size_t)c : 1;
+  uint32_t* d_sc_side = nullptr;
+  if (ctx->rate_scalers) {
+    if (hipMalloc(&d_sc_side, sizeof(uint32_t) * 2 * B * cdim * W) != hipSuccess)
+      return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(per-rate scaler staging)");
+    (void)hipMemset(d_sc_side, 0, sizeof(uint32_t) * 2 * B * cdim * W);
+  }
   // upload + transform, one CLV at a time through two alternating staging buffers
   for (size_t b = 0; b < B; ++b) {
     for (int side = 0; side < 2; ++side) {
@@ -677,12 +667,19 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
         const uint32_t* dsc = (const uint32_t*)epa_to_device(ctx, 3 + side, sc, sizeof(uint32_t) * W * cdim);
         if (!dsc) return epa_fail(ctx, EPA_ERR_HIP, "staging copy of scaler failed");
         hipLaunchKernelGGL(k_add_scaler, dim3((uint32_t)((W * cdim + 255) / 256)), dim3(256), 0, ctx->stream, dsc,
-                           ctx->scSum + b * cdim * W, (uint32_t)W, (uint32_t)cdim);
+                           d_sc_side ? d_sc_side + (2 * b + side) * cdim * W : ctx->scSum + b * W, (uint32_t)W,
+                           (uint32_t)cdim);
       }
       // staging buffers are reused by the next branch: pageable H2D copies are synchronous
       // with respect to the host buffer but the kernel must finish before the slot is reused
       EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+  }
+  if (d_sc_side) {
+    hipLaunchKernelGGL(k_align_rates, dim3((uint32_t)((W + 255) / 256), (uint32_t)B), dim3(256), 0, ctx->stream,
+                       ctx->dmodel, ctx->refT, d_sc_side, ctx->scSum, (uint32_t)W);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_sc_side);
   }
   EPA_HIP(ctx, hipGetLastError());
   return EPA_OK;
@@ -818,13 +815,43 @@ __global__ void __launch_bounds__(256) k_tip_sides(const ModelDev* __restrict__ 
   }
 }
 
-// row = cdim * W entries per branch side (cdim = rate categories with per-rate scalers, else 1)
 __global__ void k_scaler_sum(const uint32_t* __restrict__ sc_side, uint32_t* __restrict__ scSum, size_t n,
-                             size_t row) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // i = b * row + (k * W + site)
+                             uint32_t W) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // i = b * W + site
   if (i >= n) return;
-  const size_t b = i / row, w = i % row;
-  scSum[i] = sc_side[(2 * b) * row + w] + sc_side[(2 * b + 1) * row + w];
+  const size_t b = i / W, w = i % W;
+  scSum[i] = sc_side[(2 * b) * W + w] + sc_side[(2 * b + 1) * W + w];
+}
+
+// Per-rate scalers -> the per-site form every other kernel reads.  The two sides of a branch only
+// ever meet category by category (inner CLV, edge lnL and sumtables are bilinear in (X_k, D_k)), so
+// libpll's alignment of the categories at evaluation time -- category k, whose total count
+// t_k = prox_k + dist_k exceeds the site's minimum by d, is multiplied by 2^(-256 min(d, 4))
+// (rate_scalings / scale_minlh, restated in oracle/epa_oracle.c rate_alignment) -- can be applied
+// ONCE to the stored proximal vector; the site then carries the minimum count alone.  What per-rate
+// scaling protects against (a category that underflows while another keeps the site from being
+// rescaled) happens during the level-by-level precompute, which keeps one count per category
+// (k_clv_level); from here on the tuned per-site kernels run unchanged.
+// sc_side [2B][c][W] per-rate counts of the branch sides; thread per (branch, site).
+__global__ void __launch_bounds__(256) k_align_rates(const ModelDev* __restrict__ m, double* __restrict__ refT,
+                                                     const uint32_t* __restrict__ sc_side,
+                                                     uint32_t* __restrict__ scSum, uint32_t W) {
+  const uint32_t b = blockIdx.y;
+  const uint32_t site = blockIdx.x * blockDim.x + threadIdx.x;
+  if (site >= W) return;
+  const int c = m->c, s = m->s;
+  const uint32_t* sp = sc_side + (size_t)(2 * b) * c * W + site;
+  const uint32_t* sd = sc_side + (size_t)(2 * b + 1) * c * W + site;
+  uint32_t mn = 0xffffffffu;
+  for (int k = 0; k < c; ++k) mn = min(mn, sp[(size_t)k * W] + sd[(size_t)k * W]);
+  double* X = refT + (size_t)(2 * b) * c * s * W + site;
+  for (int k = 0; k < c; ++k) {
+    const uint32_t d = min(sp[(size_t)k * W] + sd[(size_t)k * W] - mn, 4u);
+    if (!d) continue;
+    const double f = d == 1 ? 0x1p-256 : d == 2 ? 0x1p-512 : d == 3 ? 0x1p-768 : 0x1p-1024;
+    for (int x = 0; x < s; ++x) X[(size_t)(k * s + x) * W] *= f;
+  }
+  scSum[(size_t)b * W + site] = mn;
 }
 
 static int precompute_from_tree(epa_ctx* ctx, const epa_tree_desc* t, const uint32_t* d_tipmap) {
@@ -926,9 +953,13 @@ static int precompute_from_tree(epa_ctx* ctx, const epa_tree_desc* t, const uint
                            d_tips, d_tipmap, W, ctx->refT, d_sc, ctx->rate_scalers ? 1 : 0);
     }
   }
-  const size_t nbw = (size_t)B * cdim * W;
-  hipLaunchKernelGGL(k_scaler_sum, dim3((uint32_t)((nbw + 255) / 256)), blk, 0, ctx->stream, d_sc, ctx->scSum, nbw,
-                     cdim * (size_t)W);
+  if (ctx->rate_scalers) {
+    hipLaunchKernelGGL(k_align_rates, dim3((W + 255) / 256, B), blk, 0, ctx->stream, ctx->dmodel, ctx->refT, d_sc,
+                       ctx->scSum, W);
+  } else {
+    const size_t nbw = (size_t)B * W;
+    hipLaunchKernelGGL(k_scaler_sum, dim3((uint32_t)((nbw + 255) / 256)), blk, 0, ctx->stream, d_sc, ctx->scSum, nbw, W);
+  }
   TREE_HIP(hipStreamSynchronize(ctx->stream));
   TREE_HIP(hipGetLastError());
 #undef TREE_HIP
@@ -942,7 +973,7 @@ __global__ void __launch_bounds__(256) k_tree_logl(const ModelDev* __restrict__ 
                                                   const double* __restrict__ refT,
                                                   const uint32_t* __restrict__ scSum, uint32_t b, double len,
                                                   uint32_t W, const double* __restrict__ cinv,
-                                                  int rate_scalers, double* __restrict__ partial) {
+                                                  double* __restrict__ partial) {
   __shared__ double U[S * S];
   __shared__ double E[EPA_MAX_CATS * S];
   __shared__ double red[256];
@@ -957,11 +988,6 @@ __global__ void __launch_bounds__(256) k_tree_logl(const ModelDev* __restrict__ 
     const double* X = refT + (size_t)(2 * b) * cs * W + site;
     const double* D = refT + (size_t)(2 * b + 1) * cs * W + site;
     double L = 0.0;
-    uint32_t smin = 0xffffffffu;
-    if (rate_scalers)
-      for (int k = 0; k < c; ++k) smin = min(smin, scSum[((size_t)b * c + k) * W + site]);
-    else
-      smin = scSum[(size_t)b * W + site];
     for (int k = 0; k < c; ++k) {
       double xv[S], dv[S];
 #pragma unroll
@@ -974,14 +1000,10 @@ __global__ void __launch_bounds__(256) k_tree_logl(const ModelDev* __restrict__ 
         for (int x = 0; x < S; ++x) { a = fma(U[i * S + x], xv[x], a); d = fma(U[i * S + x], dv[x], d); }
         t = fma(m->pi[i] * a, d, t);
       }
-      if (rate_scalers) {   // align the category to the site's minimum count
-        const uint32_t dd = min(scSum[((size_t)b * c + k) * W + site] - smin, 4u);
-        t *= dd == 0 ? 1.0 : dd == 1 ? 0x1p-256 : dd == 2 ? 0x1p-512 : dd == 3 ? 0x1p-768 : 0x1p-1024;
-      }
       L = fma(m->w[k], t, L);
     }
     if (cinv) L += cinv[site];
-    v = log(L) + (double)smin * (-256.0 * 0.6931471805599453094);
+    v = log(L) + (double)scSum[(size_t)b * W + site] * (-256.0 * 0.6931471805599453094);
   }
   red[threadIdx.x] = v;
   __syncthreads();
@@ -1001,10 +1023,10 @@ extern "C" int epa_dev_tree_logl(epa_ctx* ctx, uint32_t branch, double* lnl) {
   const double len = ctx->h_blen[branch];
   if (ctx->s == 4)
     hipLaunchKernelGGL(k_tree_logl<4>, dim3(nblk), dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT, ctx->scSum,
-                       branch, len, ctx->W, ctx->cinv, ctx->rate_scalers ? 1 : 0, d_part);
+                       branch, len, ctx->W, ctx->cinv, d_part);
   else
     hipLaunchKernelGGL(k_tree_logl<20>, dim3(nblk), dim3(256), 0, ctx->stream, ctx->dmodel, ctx->refT, ctx->scSum,
-                       branch, len, ctx->W, ctx->cinv, ctx->rate_scalers ? 1 : 0, d_part);
+                       branch, len, ctx->W, ctx->cinv, d_part);
   std::vector<double> part(nblk);
   EPA_HIP(ctx, hipMemcpyAsync(part.data(), d_part, sizeof(double) * nblk, hipMemcpyDeviceToHost, ctx->stream));
   EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1209,6 +1231,7 @@ static int chunk_body(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_be
   if (rc) return rc;
   rc = preplace_check_status(ctx);
   if (rc) return rc;
+
   *n_out = n;
   EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, ctx->stream));
   if (n == 0) return EPA_OK;

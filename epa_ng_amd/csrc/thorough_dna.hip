@@ -34,7 +34,6 @@
 
 namespace {
 
-constexpr double LOG_THR = -256.0 * 0.6931471805599453094;  // log(2^-256)
 
 struct ThArgs {
   ModelDNA m;

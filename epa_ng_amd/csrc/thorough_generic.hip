@@ -1,6 +1,5 @@
 // Hot loop 2 on device, general form: any number of rate categories (1 .. EPA_MAX_CATS), 4 or 20
-// states, per-site or per-rate scalers, sliding ("pplacer") or radius-1 local ("--raxml-blo")
-// branch-length optimisation.
+// states, sliding ("pplacer") or radius-1 local ("--raxml-blo") branch-length optimisation.
 //
 // Same mapping to the reference as k_thorough_dna (thorough_dna.hip): Tiny_Tree::place with
 // opt_branches (src/tree/Tiny_Tree.cpp:159-204) -> optimize_branch_triplet
@@ -13,15 +12,9 @@
 // default shape (4 categories, per-site scalers, sliding); every other valid model lands here, so
 // no model string the parser accepts is refused by the thorough step.
 //
-// Per-rate scalers (PLL_ATTRIB_RATE_SCALERS: src/tree/tiny_util.cpp:37-44, on by default above
-// 2000 tips, src/io/file_io.cpp:211-214): every category of a CLV is rescaled on its own and
-// carries its own count; where categories are combined (site likelihood, sumtable) a category
-// whose count exceeds the site's minimum by d is multiplied by 2^(-256 min(d, 4)) (libpll's
-// rate_scalings / scale_minlh, restated in oracle/epa_oracle.c rate_alignment).  Here that factor
-// is folded into the sumtable entries of the category, so the Newton contraction is unchanged.
-// Windows index the scaler arrays correctly for every category (the
-// reference shifts per-rate scaler pointers by `offset` elements instead of `offset * rate_cats`;
-// deliberately not reproduced).
+// Per-rate scalers (PLL_ATTRIB_RATE_SCALERS) never reach the thorough kernels: the reference
+// precompute keeps one count per category and k_align_rates (epa_dev.hip) folds libpll's
+// evaluation-time alignment of the categories into the stored vectors, so scSum is per site here.
 #include "epa_dev_internal.hpp"
 #include "wave_util.hpp"
 
@@ -35,8 +28,7 @@ struct ThArgsG {
   const ModelDev* m;
   BloConsts blo;
   const double* refT;      // [2B][c*s][W]
-  const uint32_t* scSum;   // per-site: [B][W]; per-rate: [B][c][W]   (proximal + distal counts)
-  int rate_scalers;
+  const uint32_t* scSum;   // [B][W] proximal + distal scaler counts
   const double* cinv;      // +I: [W] p * pi_inv per site, or null
   double inv_w0;
   const double* blen;
@@ -59,11 +51,6 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// 2^(-256 min(d, 4)): libpll scale_minlh[d - 1], PLL_SCALE_RATE_MAXDIFF = 4
-__device__ __forceinline__ double rate_align(uint32_t d) {
-  return d == 0 ? 1.0 : d == 1 ? 0x1p-256 : d == 2 ? 0x1p-512 : d == 3 ? 0x1p-768 : 0x1p-1024;
 }
 
 // pllmod_opt_minimize_newton (rtsafe-style safeguarded Newton), wave-uniform; see newton() in
@@ -112,7 +99,6 @@ __global__ void __launch_bounds__(64) k_thorough_generic(const ThArgsG a) {
   __syncthreads();
   double* slab = a.slab + (size_t)blockIdx.x * (size_t)(cs + 1) * a.Wpad;
   const size_t cW = a.W, Wp = a.Wpad;
-  const bool rs = a.rate_scalers != 0;
   uint32_t wrounds = 0, wevals = 0, wreverts = 0;
 
   for (uint64_t pidx = blockIdx.x; pidx < a.n_pairs; pidx += gridDim.x) {
@@ -123,7 +109,7 @@ __global__ void __launch_bounds__(64) k_thorough_generic(const ThArgsG a) {
     const uint32_t nch = (n + 63) / 64;
     const double* Xt = a.refT + (size_t)(2 * b) * cs * cW + begin;       // proximal side
     const double* Dt = a.refT + (size_t)(2 * b + 1) * cs * cW + begin;   // distal side
-    const uint32_t* scp = a.scSum + (size_t)b * (rs ? c : 1) * cW + begin;
+    const uint32_t* scp = a.scSum + (size_t)b * cW + begin;
     const uint8_t* qc = a.codes + (size_t)q * a.cstride + (a.crel ? 0u : begin);
     const double orig = a.blen[b];
 
@@ -160,8 +146,6 @@ __global__ void __launch_bounds__(64) k_thorough_generic(const ThArgsG a) {
         return op == 0 ? qv[x] : (op == 1 ? Dt : Xt)[(size_t)(k * S + x) * cW + s];
       };
       double lk[EPA_MAX_CATS];
-      double mult[EPA_MAX_CATS];
-      uint32_t cnt[EPA_MAX_CATS];
       bool all_small = true;
       for (int k = 0; k < c; ++k) {
         double av[S], bv[S], I[S];
@@ -182,8 +166,7 @@ __global__ void __launch_bounds__(64) k_thorough_generic(const ThArgsG a) {
           I[i] = p * r;
           mx = fmax(mx, I[i]);
         }
-        const bool small = mx < 0x1p-256;   // pll_update_partials: every entry below 2^-256
-        all_small = all_small && small;
+        all_small = all_small && mx < 0x1p-256;   // pll_update_partials: every entry below 2^-256
         double l = 0.0;
 #pragma unroll
         for (int x = 0; x < S; ++x) {
@@ -195,29 +178,14 @@ __global__ void __launch_bounds__(64) k_thorough_generic(const ThArgsG a) {
           l = fma(sv, tab[2][k * S + x], l);
         }
         lk[k] = l;
-        mult[k] = small ? 0x1p+256 : 1.0;
-        cnt[k] = (rs ? scp[(size_t)k * cW + s] : scp[s]) + (small ? 1u : 0u);
       }
-      bool fix = false;
-      if (rs) {   // every category on its own, aligned to the site's minimum count
-        uint32_t mn = cnt[0];
-        for (int k = 1; k < c; ++k) mn = min(mn, cnt[k]);
-        for (int k = 0; k < c; ++k) {
-          mult[k] *= rate_align(cnt[k] - mn);
-          fix = fix || mult[k] != 1.0;
-        }
-        count = mn;
-      } else {    // per-site scaling: all c * s entries below the threshold
-        for (int k = 0; k < c; ++k) mult[k] = all_small ? 0x1p+256 : 1.0;
-        fix = all_small;
-        count = scp[s] + (all_small ? 1u : 0u);
-      }
+      // per-site scaling: all c * s entries below the threshold -> * 2^256, count + 1
+      const double mult = all_small ? 0x1p+256 : 1.0;
+      count = scp[s] + (all_small ? 1u : 0u);
       double l0 = 0.0;
-      for (int k = 0; k < c; ++k) l0 = fma(mult[k], lk[k], l0);
-      if (fix && valid)
-        for (int k = 0; k < c; ++k)
-          if (mult[k] != 1.0)
-            for (int x = 0; x < S; ++x) slab[(size_t)(k * S + x) * Wp + site] *= mult[k];
+      for (int k = 0; k < c; ++k) l0 = fma(mult, lk[k], l0);
+      if (all_small && valid)
+        for (int i = 0; i < cs; ++i) slab[(size_t)i * Wp + site] *= mult;
       if (a.cinv) {   // +I: p * pi_inv enters L_0 only (eigenvalue 0 is exactly 0, see thorough_dna.hip)
         const double add = a.cinv[begin + s] * a.inv_w0;
         if (valid) slab[site] += add;
@@ -392,7 +360,6 @@ int launch_thorough_generic(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pa
   a.blo = ctx->blo;
   a.refT = ctx->refT;
   a.scSum = ctx->scSum;
-  a.rate_scalers = ctx->rate_scalers ? 1 : 0;
   a.cinv = ctx->cinv;
   a.inv_w0 = ctx->inv_w0;
   a.blen = ctx->blen;
