@@ -924,3 +924,34 @@ def test_cli_named_models_rate_scalers_raxml_blo(tmp_path, states, model, flags,
     o.set_raxml_blo(kw.get("raxml_blo", False))
     tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
     assert np.max(np.abs(res["lnl"] - tl)) < 1e-6
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_on_one_gpu(scaling):
+    """bench.py's N > 1 branch end to end on the 1-GPU box: two ranks (both on device 0, gloo for the
+    collectives; RCCL needs one GPU per rank), query sharding with local_seq_package, both timed
+    loops incl. the asynchronous result gather to rank 0, MAX-over-ranks timing, one JSON line from
+    rank 0 whose aggregate value counts the reads of both ranks."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, EPA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               WORLD_SIZE="2", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--chunk", "6000", "--tips", "64", "--width", "600", "--scaling", scaling, "--no-extras"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in (1, 0)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert not [l for l in outs[0][0].splitlines() if l.startswith("{")]     # rank 1 prints no result line
+    line = json.loads([l for l in outs[1][0].splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["steps"] == 3
+    per_step = 12000 if scaling == "weak" else 6000
+    assert line["config"]["reads_per_step_whole_job"] == per_step
+    assert line["config"]["reads_per_step_per_gpu"] == (6000 if scaling == "weak" else 3000)
+    assert abs(line["value"] - 3 * per_step / (line["ms_per_step"] * 3e-3)) < 1e-3 * line["value"]
+    assert line["pcie_inclusive"]["value"] > 0 and line["roofline"]["frac"] > 0
