@@ -570,9 +570,13 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   if ((d->flags & EPA_FLAG_SLIDING_BLO) && (d->flags & EPA_FLAG_RAXML_BLO))
     return epa_fail(ctx, EPA_ERR_INVALID_ARG, "flags: sliding and raxml BLO are mutually exclusive");
   ctx->blo.sliding = (d->flags & EPA_FLAG_RAXML_BLO) ? 0 : 1;
+  ctx->blo.newton_variant = ((d->flags & EPA_FLAG_NEWTON_SLOW_BISECT) ? 1u : 0u) |
+                            ((d->flags & EPA_FLAG_NEWTON_STRICT_DF) ? 2u : 0u);
   ctx->rate_scalers = (d->flags & EPA_FLAG_RATE_SCALERS) != 0;
   // the tuned thorough kernels are built for 4 categories, per-site scalers and the sliding rule
-  ctx->generic_thorough = c != 4 || !ctx->blo.sliding ||
+  // (the Newton-variant switches exist to pin parity once a reference build is at hand, not for
+  // production runs: they are served by the general kernel too, the tuned kernels cost 1.7 % with them)
+  ctx->generic_thorough = c != 4 || !ctx->blo.sliding || ctx->blo.newton_variant != 0 ||
                           getenv("EPA_TH_GENERIC") != nullptr;   // (diagnostic switch: measure the general kernel)
 
   EPA_HIP(ctx, hipMalloc(&ctx->dmodel, sizeof(ModelDev)));

@@ -28,6 +28,7 @@ struct BloConsts {
   double min_branch, max_branch, default_branch, epsilon, pendant_default;
   uint32_t max_rounds, max_newton;
   uint32_t sliding;
+  uint32_t newton_variant;  // EPA_FLAG_NEWTON_* bits: which pllmod_opt_minimize_newton is replicated
 };
 
 // Generic model block in HBM (used by the setup kernels and the 20-state path)

@@ -156,8 +156,15 @@ int epa_host_dev_create_flags(void* h, int device, int aa_x_as_n, int device_pre
 int epa_host_dev_create_ex(void* h, int device, int aa_x_as_n, int device_precompute, epa_ctx** out) {
   return epa_host_dev_create_flags(h, device, aa_x_as_n, device_precompute, 0, out);
 }
+int epa_host_dev_create_opts(void* h, int device, int aa_x_as_n, int device_precompute, uint32_t flags,
+                             double blo_min_branch, epa_ctx** out);
 int epa_host_dev_create_flags(void* h, int device, int aa_x_as_n, int device_precompute, uint32_t flags,
                               epa_ctx** out) {
+  return epa_host_dev_create_opts(h, device, aa_x_as_n, device_precompute, flags, 0.0, out);
+}
+// blo_min_branch: PLLMOD_OPT_MIN_BRANCH_LEN (0 = the library default)
+int epa_host_dev_create_opts(void* h, int device, int aa_x_as_n, int device_precompute, uint32_t flags,
+                             double blo_min_branch, epa_ctx** out) {
   const Tree& t = *static_cast<Ref*>(h)->tree;
   int rc;
   if (device_precompute) {
@@ -166,6 +173,7 @@ int epa_host_dev_create_flags(void* h, int device, int aa_x_as_n, int device_pre
     t.fill_tree_desc(d, store);
     d.ref.aa_x_as_n = aa_x_as_n;
     d.ref.flags = flags;
+    d.ref.blo_min_branch = blo_min_branch;
     rc = epa_dev_create_from_tree(&d, device, out);
   } else {
     epa_ref_desc d;
@@ -176,6 +184,7 @@ int epa_host_dev_create_flags(void* h, int device, int aa_x_as_n, int device_pre
     t.fill_desc(d, pc, ps, dc, dt, ds, bl);
     d.aa_x_as_n = aa_x_as_n;
     d.flags = flags;
+    d.blo_min_branch = blo_min_branch;
     rc = epa_dev_create(&d, device, out);
   }
   if (rc) g_err = epa_dev_last_error(nullptr);

@@ -57,17 +57,21 @@ __device__ __forceinline__ void wave_sync() {
 // thorough_dna.hip and minimize_newton() in oracle/epa_oracle.c
 template <class Deriv>
 __device__ __forceinline__ double newton_g(Deriv&& deriv, double x1, double xguess, double x2, double tol,
-                                           int max_iters, uint32_t& evals) {
+                                           int max_iters, int nv, uint32_t& evals) {
   double rts = xguess, f, df, xl, xh, dx;
   if (rts < x1) rts = x1;
   if (rts > x2) rts = x2;
   deriv(rts, f, df);
   ++evals;
   if (!isfinite(f) || !isfinite(df)) return NAN;
-  if (df >= 0.0 && fabs(f) < tol) return rts;
+  if (((nv & 2) ? df > 0.0 : df >= 0.0) && fabs(f) < tol) return rts;
   if (f < 0.0) { xl = rts; xh = x2; } else { xh = rts; xl = x1; }
+  double dxold = fabs(xh - xl);
+  dx = dxold;
   for (int i = 1; i <= max_iters; ++i) {
-    if (df <= 0.0 || (((rts - xh) * df - f) * ((rts - xl) * df - f) >= 0.0)) {
+    const bool slow = (nv & 1) && fabs(2.0 * f) > fabs(dxold * df);   // Numerical Recipes rtsafe clause
+    dxold = dx;
+    if (df <= 0.0 || (((rts - xh) * df - f) * ((rts - xl) * df - f) >= 0.0) || slow) {
       dx = 0.5 * (xh - xl);
       rts = xl + dx;
       if (xl == rts) return rts;
@@ -284,7 +288,7 @@ __global__ void __launch_bounds__(64) k_thorough_generic(const ThArgsG a) {
       auto solve = [&](double cur) -> double {
         double g = cur;
         if (g < xmin || g > xmax) g = a.blo.default_branch;
-        const double r = newton_g(deriv, xmin, g, xmax, xtol, (int)a.blo.max_newton, evals);
+        const double r = newton_g(deriv, xmin, g, xmax, xtol, (int)a.blo.max_newton, (int)a.blo.newton_variant, evals);
         // keep_update: the length is replaced when the solver moved it (recomp_iterative)
         return (isfinite(r) && fabs(cur - r) > 1e-10) ? r : cur;
       };
@@ -307,7 +311,7 @@ __global__ void __launch_bounds__(64) k_thorough_generic(const ThArgsG a) {
       double xmin = a.blo.min_branch, xmax = a.blo.max_branch, xtol = xmin / 10.0;
       double xguess = tp;
       if (xguess < xmin || xguess > xmax) xguess = a.blo.default_branch;
-      double xres = newton_g(deriv, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
+      double xres = newton_g(deriv, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, (int)a.blo.newton_variant, evals);
       if (xres > 0.0) tp = xres;
       // ---- NR for the distal length with the proximal P-matrix held fixed (:170-211)
       side_sumtable(tp, tx, false);
@@ -316,7 +320,7 @@ __global__ void __launch_bounds__(64) k_thorough_generic(const ThArgsG a) {
       xtol = xmin / 10.0;
       xmax = orig - xtol;
       if (xguess < xmin || xguess > xmax) xguess = orig / 2.0;
-      xres = newton_g(deriv, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
+      xres = newton_g(deriv, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, (int)a.blo.newton_variant, evals);
       if (xres > 0.0) { td = xres; tx = orig - xres; }
       // ---- score (:217-222)
       const double new_ll = -score(td, tx, tp);

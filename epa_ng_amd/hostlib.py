@@ -53,6 +53,8 @@ def host_lib():
         L.epa_host_dev_create_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.epa_host_dev_create_flags.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32,
                                                 C.POINTER(C.c_void_p)]
+        L.epa_host_dev_create_opts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_double,
+                                               C.POINTER(C.c_void_p)]
         L.epa_host_place_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_int,
                                           C.c_double, C.c_int, C.c_int, C.c_char_p,
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -191,15 +193,18 @@ class Reference:
                 "dist_scaler": view(p[4], C.c_uint32, (self.W,)), "length": ln.value}
 
     def evaluator(self, device=0, aa_x_as_n=False, device_precompute=True, rate_scalers=False,
-                  raxml_blo=False):
+                  raxml_blo=False, newton_variant=0, blo_min_branch=0.0):
         """reference -> GPU -> api.Evaluator (epa_ctx created by the C++ host).  By default the
         tree and the tip sequences are sent and all directional CLVs are computed on the device;
         device_precompute=False uploads the host-computed CLVs instead.  rate_scalers: per-rate
-        numerical scaling (EPA_FLAG_RATE_SCALERS); raxml_blo: --raxml-blo (EPA_FLAG_RAXML_BLO)."""
+        numerical scaling (EPA_FLAG_RATE_SCALERS); raxml_blo: --raxml-blo (EPA_FLAG_RAXML_BLO);
+        newton_variant: bit 0 EPA_FLAG_NEWTON_SLOW_BISECT, bit 1 EPA_FLAG_NEWTON_STRICT_DF;
+        blo_min_branch: PLLMOD_OPT_MIN_BRANCH_LEN (0 = default 1e-4)."""
         h = C.c_void_p()
-        flags = (0x2 if rate_scalers else 0) | (0x4 if raxml_blo else 0)
-        rc = host_lib().epa_host_dev_create_flags(self.h, device, int(aa_x_as_n), int(device_precompute),
-                                                  flags, C.byref(h))
+        flags = ((0x2 if rate_scalers else 0) | (0x4 if raxml_blo else 0) | (0x8 if newton_variant & 1 else 0) |
+                 (0x10 if newton_variant & 2 else 0))
+        rc = host_lib().epa_host_dev_create_opts(self.h, device, int(aa_x_as_n), int(device_precompute),
+                                                 flags, float(blo_min_branch), C.byref(h))
         if rc:
             raise api.EpaError(rc, host_lib().epa_host_last_error().decode())
         ev = api.Evaluator.__new__(api.Evaluator)

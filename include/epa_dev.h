@@ -51,6 +51,12 @@ typedef enum {
 #define EPA_FLAG_SLIDING_BLO 0x1u  /* Options::sliding_blo (default on, src/util/Options.hpp:16) */
 #define EPA_FLAG_RAXML_BLO 0x4u    /* --raxml-blo: pllmod_opt_optimize_branch_lengths_local, radius 1 *
                                     * (src/core/pll/optimize.cpp:274-279) instead of the sliding rule */
+/* pllmod_opt_minimize_newton is not in the reference's tree; the routine this library replicates
+ * by default is a recollection (see oracle/epa_oracle.c minimize_newton).  Two details differ
+ * between published variants of it and are switchable (profiles/r2_sensitivity.md measures what
+ * they change): */
+#define EPA_FLAG_NEWTON_SLOW_BISECT 0x8u  /* also bisect when |2 f| > |dx_old f'| (Numerical Recipes rtsafe) */
+#define EPA_FLAG_NEWTON_STRICT_DF 0x10u   /* first convergence test needs f' > 0 instead of f' >= 0          */
 #define EPA_FLAG_RATE_SCALERS 0x2u /* PLL_ATTRIB_RATE_SCALERS: every rate category is rescaled on its *
                                     * own (src/tree/tiny_util.cpp:37-44; the reference turns it on    *
                                     * above 2000 tips, src/io/file_io.cpp:211-214, or with            *

@@ -132,3 +132,31 @@ def test_raxml_blo_local_optimisation(states, rs):
     # up to a few stopping tolerances
     assert np.mean(res["lnl"] - sliding["lnl"]) > 0.0
     assert np.all(res["lnl"] >= sliding["lnl"] - 0.5)
+
+
+@pytest.mark.parametrize("states,cats", [(4, 4), (20, 4), (4, 5)])
+def test_recollected_optimiser_constants_are_runtime_parameters(states, cats):
+    """PLLMOD_OPT_MIN_BRANCH_LEN and the two variable details of pllmod_opt_minimize_newton are
+    recollections (the pll-modules source is not in the reference's tree): they are parameters of
+    the C-ABI (epa_ref_desc.blo_min_branch, EPA_FLAG_NEWTON_*), and under every setting the device
+    follows the oracle configured the same way -- so pinning parity later is a matter of flags.
+    profiles/r2_sensitivity.md holds what each of them changes."""
+    subst, freqs = (synth.CFG2_SUBST, synth.CFG2_FREQS) if states == 4 else synth.aa_model(13)
+    root = synth.random_tree(40, 61)
+    rates = synth.gamma_rates(0.5, cats) if cats != 4 else synth.gamma_rates(0.5)
+    labels, seqs = synth.simulate_msa(root, 300, subst, freqs, synth.gamma_rates(0.5), 62)
+    nw = synth.newick(root)
+    reads, _ = synth.make_reads(seqs, 60, 150 if states == 4 else 90, 0.04, 63, states=states)
+    ref = hostlib.Reference(nw, labels, seqs, states=states, subst=subst, freqs=freqs, rates=rates)
+    o = Oracle(nw, labels, seqs, states, subst, freqs, rates)
+    base = None
+    moved = 0
+    for nv, mn in ((0, 1e-4), (1, 1e-4), (2, 1e-4), (3, 1e-6), (0, 1e-6)):
+        o.set_blo(min_branch=mn, newton_variant=nv)
+        ev = ref.evaluator(newton_variant=nv, blo_min_branch=mn)
+        _, pairs, res = check_against_oracle(ev, o, reads, states)
+        if base is None:
+            base = res
+        else:
+            moved += int((np.abs(res["lnl"] - base["lnl"]) > 1e-6).sum())
+    assert moved > 0      # the switches are not no-ops
