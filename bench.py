@@ -301,13 +301,18 @@ def main():
     t_th = float(np.mean(th_ms)) * 1e-3
     exec_tflops = pairs * flops_exec / t_th / 1e12
     alg_tflops = pairs * flops_pair / t_th / 1e12
-    traffic = None   # HBM bytes per launch from the committed PMC passes, same workload only
+    traffic = traffic_pre = None   # HBM bytes per launch from the committed PMC passes, same workload only
     kname = "k_thorough_dna" if states == 4 else "k_thorough_aa"
     for tf in ("r2_traffic.json", "r1_traffic.json"):
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", tf)))[kname]
+            tall = json.load(open(os.path.join(ROOT, "profiles", tf)))
+            tj = tall[kname]
             if tj["reads_per_step"] == Q and abs(tj["pairs_per_launch"] - pairs) < 0.02 * pairs:
-                traffic = (tj["fetch_kb"] + tj["write_kb"]) * 1024.0
+                # FETCH_SIZE x its calibrated correction (2.0 on gfx950, profiles/r2_traffic_calibration.txt)
+                traffic = (tall.get("fetch_correction", 1.0) * tj["fetch_kb"] + tj["write_kb"]) * 1024.0
+                traffic_pre = tall.get("k_preplace_pairs")
+                if traffic_pre:
+                    traffic_pre = (tall.get("fetch_correction", 1.0) * traffic_pre["fetch_kb"] + traffic_pre["write_kb"]) * 1024.0
                 break
         except (OSError, KeyError, ValueError):
             pass
@@ -334,7 +339,8 @@ def main():
     t_pre = float(np.mean(pre_ms)) * 1e-3
     roof_pre = {"bound": "hbm", "kernel": "k_preplace_pairs" if states == 4 else "k_preplace_sites",
                 "achieved": round(pre_bytes / t_pre / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(pre_bytes / t_pre / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": pre_bytes,
+                "frac": round(pre_bytes / t_pre / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic_pre,
+                "algorithmic_bytes_per_launch": pre_bytes,
                 "ms_per_launch": round(t_pre * 1e3, 4)}
 
     extras = {}
