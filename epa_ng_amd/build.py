@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-DEV_SOURCES = ["epa_dev.hip", "preplace.hip", "thorough_dna.hip", "thorough_aa.hip", "thorough_generic.hip"]
+DEV_SOURCES = ["epa_dev.hip", "preplace.hip", "thorough_dna.hip", "thorough_aa.hip", "thorough_aa_mfma.hip", "thorough_generic.hip"]
 DEV_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
              "-I", CSRC, "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 

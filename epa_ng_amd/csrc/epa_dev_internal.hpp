@@ -166,11 +166,12 @@ void epa_timer_stop(epa_ctx* ctx, EvTimer& t);
 // ---- span classes of the thorough kernels: a launch covers pairs whose window needs the same
 // kernel instantiation, so one long window does not drag a whole chunk onto the big-register
 // variant.  DNA: sites per lane NCH in {1,2,3,4,6,8,12,16,24} (class 0..8), 9 = HBM-slab kernel;
-// 20 states: 0 = LDS-resident slab (window <= EPA_AA_LDS_MAX_SPAN), 1 = HBM slab.
+// 20 states: 0 / 1 / 2 = windows up to 64 / 128 / 192 sites (k_thorough_aa_mfma<1/2/3>: sumtable
+// in registers), 3 = longer (k_thorough_aa with the HBM slab).
 constexpr int EPA_N_CLS = 10;
 constexpr uint32_t EPA_AA_LDS_MAX_SPAN = 102;
 __host__ __device__ inline int epa_span_class(int states, uint32_t span) {
-  if (states != 4) return span <= EPA_AA_LDS_MAX_SPAN ? 0 : 1;
+  if (states != 4) return span <= 64 ? 0 : span <= 128 ? 1 : span <= 192 ? 2 : 3;
   const uint32_t nch = (span + 63) / 64;
   return nch <= 4 ? (nch ? (int)nch - 1 : 0) : nch <= 6 ? 4 : nch <= 8 ? 5 : nch <= 12 ? 6 : nch <= 16 ? 7 : nch <= 24 ? 8 : 9;
 }
@@ -192,6 +193,9 @@ int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_
 int launch_thorough_generic(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
                             const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
                             epa_result* d_out, unsigned long long* d_stats);
+int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_order, uint64_t n_pairs,
+                            const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span,
+                            uint32_t max_span, epa_result* d_out, unsigned long long* d_stats);
 int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshold,
                   epa_pair* d_pairs, uint64_t max_pairs, uint64_t* n_pairs,
                   const uint32_t* d_span = nullptr);  // d_span: also histogram the span classes

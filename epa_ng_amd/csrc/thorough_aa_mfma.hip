@@ -1,0 +1,435 @@
+// Hot loop 2 on device, 20-state models with 4 rate categories, windows up to 192 sites: the
+// states x states contractions on the matrix cores.
+//
+// Same algorithm and control flow as k_thorough_aa / k_thorough_dna (Tiny_Tree::place ->
+// optimize_branch_triplet -> opt_branch_lengths_pplacer, src/core/pll/optimize.cpp:60-286, in the
+// eigenbasis of Q); what changes is the geometry.  Per (site, category) a phase needs three
+// 20 x 20 matrix-vector products (U (e o A), U (e o B), U^-1 I: 83 % of the pair's flops) and a
+// Newton evaluation is a 3 x 80 contraction of the site's sumtable with the tables
+// w lr^i exp(lr t).  Both map onto v_mfma_f64_4x4x4_4b_f64 WITHOUT padding (20 = 5 x 4): measured
+// on this chip (profiles/aa_contraction_ab.hip) the 20 x 20 . 20 x 64 contraction runs at 68.8
+// TFLOP/s in that form, 45.8 useful TFLOP/s with v_mfma_f64_16x16x4_f64 (20 rows padded to 32) and
+// 26.7 TFLOP/s in the lane = site VALU form with the matrix behind the scalar cache.
+//
+// Layout (found by an impulse-response probe of the instruction, exp/mfma_layout.hip): a lane of
+// v_mfma_f64_4x4x4_4b_f64 is (k = lane / 16, block = lane / 4 % 4, r = lane % 4); A holds
+// A_block[i = r][k], B holds B_block[k][j = r], D returns D_block[i = lane / 16][j = r].  With the
+// four blocks = four groups of four sites and the same matrix tile in every block:
+//     vector registers:  reg t, lane (q = lane / 16, s = lane % 16) = v[4 t + q] of site s
+//     D of a product  :  reg rt, lane (q, s)                        = y[4 rt + q] of site s
+// i.e. a product's output IS the next product's input, element-wise operations are lane-wise, and
+// nothing is ever transposed.  A tile of 16 sites x 4 categories is 20 vector registers.
+//
+//   workgroup = one (branch, query) pair, wave w owns the 16-site tiles w, w + 4, w + 8 (NT <= 3),
+//   all four categories of a tile live in one wave: the per-site sums over the categories and the
+//   "all 80 entries < 2^-256" rescale test need no workgroup barrier;
+//   U / U^-1 sit in LDS as 25 A-operand tiles each (a read per MFMA, shared by the a and b products);
+//   the sumtable of the wave's tiles stays in REGISTERS (NT x 20 doubles), the Newton evaluation is
+//   20 MFMAs per tile whose D rows are l0, l1, l2 of the 16 sites.
+//   Only f, f', lnL cross the waves (LDS + one barrier), and the exp tables are published per phase.
+#include "epa_dev_internal.hpp"
+#include "wave_util.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+using namespace epa_wave;
+
+constexpr int S = 20;
+constexpr int NTS = 5;   // tiles of 4 along the state axis
+constexpr double LOG_2 = 0.6931471805599453094;
+
+struct ThArgsAM {
+  const ModelDev* m;
+  BloConsts blo;
+  const double* refT;      // [2B][80][W]
+  const double* refI;      // [B][80][W] U^-1 inner CLV at the starting lengths (k_build_lookup), or null
+  const uint8_t* resc0;    // [B][W]     its per-site rescale flag
+  const double* cinv;      // +I: [W] p * pi_inv per site, or null
+  double inv_w0;
+  const uint32_t* scSum;   // [B][W]
+  const double* blen;
+  const epa_pair* pairs;
+  const uint32_t* order;
+  const uint8_t* codes;
+  uint32_t cstride, crel;
+  const uint32_t* win_begin;
+  const uint32_t* win_span;
+  epa_result* out;
+  unsigned long long* stats;
+  uint64_t n_pairs;
+  uint32_t W;
+};
+
+struct SharedM {
+  double Ua[25 * 16];    // A-operand tiles of U:   [rt * 5 + t][k * 4 + i] = U[4 rt + i][4 t + k]
+  double Uia[25 * 16];   // the same of U^-1
+  double tab[3][80];     // wave-uniform exp tables, [slot][k * 20 + x]
+  double qt[24 * S];     // eigen image of the query column codes
+  double bc[12];         // cross-wave sums
+};
+
+// 0 that the optimiser cannot see through, ordered after `v`: added to an LDS index it keeps the
+// (loop-invariant) matrix-tile and table reads where they are written -- hoisted out of the
+// category / tile loops they would pin 150 VGPRs and the kernel would live in scratch
+__device__ __forceinline__ int zero_after(double v) {
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(__double2loint(v)));
+  return z;
+}
+__device__ __forceinline__ double mfma4(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+// combine the four component rows (lanes l, l ^ 16, l ^ 32, l ^ 48) of a site
+__device__ __forceinline__ double rows_sum(double v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ double rows_max(double v) {
+  v = fmax(v, __shfl_xor(v, 16));
+  v = fmax(v, __shfl_xor(v, 32));
+  return v;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
+  __shared__ SharedM sh;
+  const ModelDev* __restrict__ m = a.m;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int kq = lane >> 4;            // component residue of this lane (state 4 t + kq of vector register t)
+  const int sl = lane & 15;            // site inside a 16-site tile
+  const int aoff = kq * 4 + (lane & 3);  // this lane's element of an A-operand tile
+  for (int idx = tid; idx < 400; idx += 256) {
+    const int tile = idx >> 4, e = idx & 15, rt = tile / NTS, t = tile % NTS, kk = e >> 2, i = e & 3;
+    sh.Ua[idx] = m->U[(4 * rt + i) * S + 4 * t + kk];
+    sh.Uia[idx] = m->Ui[(4 * rt + i) * S + 4 * t + kk];
+  }
+  for (int idx = tid; idx < 24 * S; idx += 256) sh.qt[idx] = m->qt[idx];
+  // per-thread table constants: thread t < 240 owns (slot = t / 80, kx = t % 80)
+  const int tslot = tid / 80, tkx = tid % 80;
+  double t_lr = 0.0, t_w = 0.0, t_c = 0.0;
+  if (tid < 240) {
+    t_lr = m->lam[tkx % S] * m->rate[tkx / S];
+    t_w = m->w[tkx / S];
+    t_c = tslot == 0 ? t_w : (tslot == 1 ? t_w * t_lr : t_w * t_lr * t_lr);
+  }
+  __syncthreads();
+
+  uint32_t wrounds = 0, wevals = 0, wreverts = 0;
+  for (uint64_t pidx = blockIdx.x; pidx < a.n_pairs; pidx += gridDim.x) {
+    const uint64_t pid = a.order ? a.order[pidx] : pidx;
+    const epa_pair pr = a.pairs[pid];
+    const uint32_t b = pr.branch_id, q = pr.seq_id;
+    const uint32_t begin = a.win_begin[q], n = a.win_span[q];
+    const size_t cW = a.W;
+    const double* Xt = a.refT + (size_t)(2 * b) * 80 * cW + begin;       // proximal
+    const double* Dt = a.refT + (size_t)(2 * b + 1) * 80 * cW + begin;   // distal
+    const uint32_t* scp = a.scSum + (size_t)b * cW + begin;
+    const uint8_t* qc = a.codes + (size_t)q * a.cstride + (a.crel ? 0u : begin);
+    const double orig = a.blen[b];
+
+    // this wave's tiles: tile g = wv + 4 j covers sites 16 g .. 16 g + 15 of the window
+    uint32_t ssite[NT], sscl[NT];   // site of this lane in tile j, clamped for the loads
+    bool valid[NT], tile_on[NT];
+    double qv[NT][NTS];             // query tip vector in the eigenbasis, vector layout
+    double Sm[NT][4][NTS];          // sumtable of the branch being optimised: [tile][category][reg]
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      ssite[j] = 16u * (uint32_t)(wv + 4 * j) + (uint32_t)sl;
+      valid[j] = ssite[j] < n;
+      tile_on[j] = 16u * (uint32_t)(wv + 4 * j) < n;
+      sscl[j] = valid[j] ? ssite[j] : 0;
+      const uint32_t code = qc[sscl[j]];
+#pragma unroll
+      for (int t = 0; t < NTS; ++t) qv[j][t] = sh.qt[code * S + 4 * t + kq];
+    }
+
+    // ---- table publication: every thread < 240 computes one exp()
+    auto publish = [&](double t0, double t1, double t2) {
+      __syncthreads();  // previous readers of sh.tab are done
+      if (tid < 240) {
+        const double t = tslot == 0 ? t0 : (tslot == 1 ? t1 : t2);
+        const double e = exp(t_lr * t);
+        sh.tab[tslot][tkx] = tslot == 2 ? e * t_w : e;
+      }
+      __syncthreads();
+    };
+
+    // mode 0: inner CLV toward the query from (distal, proximal), sumtable folded with the query,
+    //         window lnL; mode 1: toward distal from (query, proximal), sumtable folded with the
+    //         distal vector; mode 2: as 0 from the per-branch precomputed inner CLV (refI).
+    auto phase = [&](int mode, double& lnl_out) {
+      double mant = 1.0;
+      int ex = 0;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (!tile_on[j]) continue;   // wave-uniform
+        const uint32_t s = sscl[j];
+        double l0 = 0.0, mx = 0.0;
+        bool resc = false;
+        int zt = zero_after(mant);   // ordering token of this tile's LDS reads
+#pragma unroll
+        for (int cat = 0; cat < 4; ++cat) {
+          __builtin_amdgcn_sched_barrier(0);
+          const int ao = aoff + zt;
+          const size_t c0 = (size_t)(cat * S + kq) * cW + s + (size_t)zt;   // component 4 t + kq: + 4 t cW
+          double It[NTS], Dv[NTS];
+          if (mode == 2) {
+            const double* I0 = a.refI + (size_t)b * 80 * cW + begin;
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) It[t] = I0[c0 + (size_t)(4 * t) * cW];
+          } else {
+            double Av[NTS], Bv[NTS];
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) {
+              Bv[t] = Xt[c0 + (size_t)(4 * t) * cW];
+              Dv[t] = Dt[c0 + (size_t)(4 * t) * cW];
+            }
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) {
+              const double e0 = sh.tab[0][cat * S + 4 * t + kq + zt], e1 = sh.tab[1][cat * S + 4 * t + kq + zt];
+              Av[t] = (mode == 0 ? Dv[t] : qv[j][t]) * e0;
+              Bv[t] *= e1;
+            }
+            // a = U (e0 o A), b = U (e1 o B): one read of every U tile feeds both products
+            double ya[NTS], yb[NTS];
+#pragma unroll
+            for (int rt = 0; rt < NTS; ++rt) { ya[rt] = 0.0; yb[rt] = 0.0; }
+#pragma unroll
+            for (int t = 0; t < NTS; ++t)
+#pragma unroll
+              for (int rt = 0; rt < NTS; ++rt) {
+                const double ua = sh.Ua[(rt * NTS + t) * 16 + ao];
+                ya[rt] = mfma4(ua, Av[t], ya[rt]);
+                yb[rt] = mfma4(ua, Bv[t], yb[rt]);
+              }
+            double Iv[NTS];
+#pragma unroll
+            for (int rt = 0; rt < NTS; ++rt) {
+              Iv[rt] = ya[rt] * yb[rt];
+              mx = fmax(mx, Iv[rt]);
+            }
+#pragma unroll
+            for (int rt = 0; rt < NTS; ++rt) It[rt] = 0.0;
+#pragma unroll
+            for (int t = 0; t < NTS; ++t)
+#pragma unroll
+              for (int rt = 0; rt < NTS; ++rt) It[rt] = mfma4(sh.Uia[(rt * NTS + t) * 16 + ao], Iv[t], It[rt]);
+          }
+#pragma unroll
+          for (int t = 0; t < NTS; ++t) {
+            const double sv = It[t] * (mode == 1 ? Dv[t] : qv[j][t]);
+            Sm[j][cat][t] = sv;
+            if (mode != 1) l0 = fma(sv, sh.tab[2][cat * S + 4 * t + kq + zt], l0);
+          }
+          zt = zero_after(Sm[j][cat][NTS - 1]);   // the next category's reads come after this one's results
+        }
+        // pll_update_partials per-site scaling: ALL 80 entries of the site below 2^-256
+        if (mode == 2) {
+          resc = a.resc0[(size_t)b * cW + begin + s] != 0;   // already applied to refI
+        } else {
+          resc = rows_max(mx) < 0x1p-256;
+          if (__any(resc)) {
+            const double mult = resc ? 0x1p+256 : 1.0;
+#pragma unroll
+            for (int cat = 0; cat < 4; ++cat)
+#pragma unroll
+              for (int t = 0; t < NTS; ++t) Sm[j][cat][t] *= mult;
+            l0 *= mult;
+          }
+        }
+        // +I: p * pi_inv enters L_0 only (eigenvalue 0 is exactly 0): folded into sumtable entry
+        // (category 0, eigen index 0) = register 0 of the lanes with kq == 0
+        if (a.cinv && kq == 0) {
+          const double add = a.cinv[begin + s] * a.inv_w0;
+          Sm[j][0][0] += add;
+          if (mode != 1) l0 = fma(add, sh.tab[2][0], l0);
+        }
+        if (mode != 1) {
+          double ls = rows_sum(l0);
+          const bool mine = valid[j] && kq == 0;
+          if (!mine) ls = 1.0;
+          const int sc = mine ? (int)(scp[s] + (resc ? 1u : 0u)) : 0;
+          mant *= __builtin_amdgcn_frexp_mant(ls);
+          ex += __builtin_amdgcn_frexp_exp(ls) - 256 * sc;
+        }
+      }
+      if (mode != 1) {
+        const double tot = wave_sum(log(mant) + (double)ex * LOG_2);
+        if (lane == 0) sh.bc[8 + wv] = tot;
+        __syncthreads();
+        lnl_out = (sh.bc[8] + sh.bc[9]) + (sh.bc[10] + sh.bc[11]);
+      }
+      __syncthreads();  // sh.bc / sh.tab are free for whoever comes next
+    };
+
+    // f, f' at proposal t: per tile 20 MFMAs contract the register-resident sumtable with the
+    // Newton tables; D row i of a site is l_i (i = 0, 1, 2; row 3 is a zero row of the A operand)
+    uint32_t evals = 0;
+    auto derivatives = [&](double t, double& f, double& df) {
+      __syncthreads();
+      if (tid < 240) sh.tab[tslot][tkx] = exp(t_lr * t) * t_c;
+      __syncthreads();
+      const int row = lane & 3;
+      double fl = 0.0, dfl = 0.0;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (!tile_on[j]) continue;
+        double acc0 = 0.0, acc1 = 0.0;   // two chains: categories 0,1 and 2,3
+        const int zt = zero_after(fl);
+#pragma unroll
+        for (int cat = 0; cat < 4; ++cat)
+#pragma unroll
+          for (int t = 0; t < NTS; ++t) {
+            double av = sh.tab[row < 3 ? row : 0][cat * S + 4 * t + kq + zt];
+            if (row == 3) av = 0.0;
+            if (cat < 2) acc0 = mfma4(av, Sm[j][cat][t], acc0);
+            else acc1 = mfma4(av, Sm[j][cat][t], acc1);
+          }
+        const double l0 = acc0 + acc1;                 // lanes kq == 0: l0 of the site
+        const double l1 = __shfl_down(l0, 16), l2 = __shfl_down(l0, 32);
+        if (kq == 0 && valid[j]) {
+          const double inv = fast_rcp(l0);
+          const double d1 = -l1 * inv;
+          fl += d1;
+          dfl += fma(d1, d1, -l2 * inv);
+        }
+      }
+      double ft, dft;
+      wave_sum2(fl, dfl, ft, dft);
+      if (lane == 0) { sh.bc[wv] = ft; sh.bc[4 + wv] = dft; }
+      __syncthreads();
+      f = (sh.bc[0] + sh.bc[1]) + (sh.bc[2] + sh.bc[3]);
+      df = (sh.bc[4] + sh.bc[5]) + (sh.bc[6] + sh.bc[7]);
+      ++evals;
+    };
+
+    // pllmod_opt_minimize_newton (rtsafe-style), uniform across the workgroup
+    auto newton = [&](double x1, double xguess, double x2, double tol, int max_iters) -> double {
+      double rts = xguess, f, df, xl, xh, dx;
+      if (rts < x1) rts = x1;
+      if (rts > x2) rts = x2;
+      derivatives(rts, f, df);
+      if (!isfinite(f) || !isfinite(df)) return NAN;
+      if (df >= 0.0 && fabs(f) < tol) return rts;
+      if (f < 0.0) { xl = rts; xh = x2; } else { xh = rts; xl = x1; }
+      for (int i = 1; i <= max_iters; ++i) {
+        if (df <= 0.0 || (((rts - xh) * df - f) * ((rts - xl) * df - f) >= 0.0)) {
+          dx = 0.5 * (xh - xl);
+          rts = xl + dx;
+          if (xl == rts) return rts;
+        } else {
+          dx = f / df;
+          const double temp = rts;
+          rts -= dx;
+          if (temp == rts) return rts;
+        }
+        if (fabs(dx) < tol || i == max_iters) return rts;
+        if (rts < x1) rts = x1;
+        derivatives(rts, f, df);
+        if (!isfinite(f) || !isfinite(df)) return NAN;
+        if (df > 0.0 && fabs(f) < tol) return rts;
+        if (f < 0.0) xl = rts; else xh = rts;
+      }
+      return NAN;
+    };
+
+    double tp = a.blo.pendant_default, td = orig * 0.5, tx = orig * 0.5;
+    uint32_t rounds = 0, reverted = 0;
+    double lnl_now = 0.0;
+    publish(td, tx, tp);
+    if (a.refI) phase(2, lnl_now); else phase(0, lnl_now);
+    double loglikelihood = -lnl_now;
+    uint32_t smoothings = a.blo.max_rounds;
+    while (smoothings) {
+      const double old_td = td, old_tp = tp;
+      double xmin = a.blo.min_branch, xmax = a.blo.max_branch, xtol = xmin / 10.0;
+      double xguess = tp;
+      if (xguess < xmin || xguess > xmax) xguess = a.blo.default_branch;
+      double xres = newton(xmin, xguess, xmax, xtol, (int)a.blo.max_newton);
+      if (xres > 0.0) tp = xres;
+      publish(tp, tx, tp);
+      double dummy;
+      phase(1, dummy);
+      xguess = td;
+      xmin = fmin(a.blo.min_branch / 2.0, orig / 2.0);
+      xtol = xmin / 10.0;
+      xmax = orig - xtol;
+      if (xguess < xmin || xguess > xmax) xguess = orig / 2.0;
+      xres = newton(xmin, xguess, xmax, xtol, (int)a.blo.max_newton);
+      if (xres > 0.0) { td = xres; tx = orig - xres; }
+      publish(td, tx, tp);
+      phase(0, lnl_now);
+      const double new_ll = -lnl_now;
+      ++rounds;
+      if (new_ll - loglikelihood > new_ll * 1e-14) {
+        tp = old_tp; td = old_td; tx = orig - old_td;
+        reverted = 1;
+        break;
+      }
+      --smoothings;
+      if (fabs(new_ll - loglikelihood) < a.blo.epsilon) smoothings = 0;
+      loglikelihood = new_ll;
+    }
+    if (tid == 0) {
+      const double lnl = -loglikelihood;
+      epa_result r;
+      r.lnl = lnl;
+      r.pendant_length = tp;
+      r.distal_length = (orig / (td + tx)) * td;
+      a.out[pid] = r;
+      if (!isfinite(lnl)) {
+        if (atomicAdd(&a.stats[3], 1ull) == 0) a.stats[4] = ((unsigned long long)b << 32) | q;
+      }
+    }
+    wrounds += rounds; wevals += evals; wreverts += reverted;
+  }
+  if (tid == 0) {
+    atomicAdd(&a.stats[0], (unsigned long long)wrounds);
+    atomicAdd(&a.stats[1], (unsigned long long)wevals);
+    atomicAdd(&a.stats[2], (unsigned long long)wreverts);
+  }
+}
+
+}  // namespace
+
+// windows up to 64 * NT sites (NT = 1, 2, 3); the caller routes longer windows to k_thorough_aa
+int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_order, uint64_t n_pairs,
+                            const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span,
+                            uint32_t max_span, epa_result* d_out, unsigned long long* d_stats) {
+  ThArgsAM a;
+  a.m = ctx->dmodel;
+  a.blo = ctx->blo;
+  a.refT = ctx->refT;
+  a.refI = ctx->lookup_built ? ctx->refI : nullptr;
+  a.resc0 = ctx->resc0;
+  a.cinv = ctx->cinv;
+  a.inv_w0 = ctx->inv_w0;
+  a.scSum = ctx->scSum;
+  a.blen = ctx->blen;
+  a.pairs = d_pairs;
+  a.order = d_order;
+  a.codes = d_codes;
+  a.crel = ctx->code_stride ? 1u : 0u;
+  a.cstride = a.crel ? ctx->code_stride : ctx->W;
+  a.win_begin = d_begin;
+  a.win_span = d_span;
+  a.out = d_out;
+  a.stats = d_stats;
+  a.n_pairs = n_pairs;
+  a.W = ctx->W;
+  // 2 resident workgroups per CU, grid oversubscribed so that the dispatcher balances the cost
+  // spread of the pairs (as k_thorough_aa)
+  uint32_t per_slot = 16;
+  if (const char* e = getenv("EPA_TH_WAVES_PER_SLOT")) per_slot = (uint32_t)std::max(1, atoi(e));
+  const uint32_t nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * 2 * per_slot);
+  if (max_span <= 64) hipLaunchKernelGGL(k_thorough_aa_mfma<1>, dim3(nwg), dim3(256), 0, ctx->stream, a);
+  else if (max_span <= 128) hipLaunchKernelGGL(k_thorough_aa_mfma<2>, dim3(nwg), dim3(256), 0, ctx->stream, a);
+  else if (max_span <= 192) hipLaunchKernelGGL(k_thorough_aa_mfma<3>, dim3(nwg), dim3(256), 0, ctx->stream, a);
+  else return epa_fail(ctx, EPA_ERR_INVALID_ARG, "thorough_aa_mfma: window longer than 192 sites");
+  EPA_HIP(ctx, hipGetLastError());
+  return EPA_OK;
+}

@@ -895,8 +895,16 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
     const uint32_t* ord = order ? order + off : nullptr;
     off += hist[c];
     if (ctx->s == 20) {
-      const uint32_t bound = c == 0 ? std::min(max_span, EPA_AA_LDS_MAX_SPAN) : max_span;
-      rc = launch_thorough_aa(ctx, d_pairs, ord, hist[c], d_codes, d_begin, d_span, bound, c == 0, d_out, d_stats);
+      // windows up to 192 sites: matrix-core kernel (sumtable in registers); longer ones, or all of
+      // them with EPA_AA_VALU=1 (A/B switch), the lane = site VALU kernel
+      static const uint32_t aa_bound[4] = {64, 128, 192, 0xffffffffu};
+      static const bool aa_valu = getenv("EPA_AA_VALU") != nullptr;
+      const uint32_t bound = std::min(max_span, aa_bound[c < 4 ? c : 3]);
+      if (c < 3 && !aa_valu)
+        rc = launch_thorough_aa_mfma(ctx, d_pairs, ord, hist[c], d_codes, d_begin, d_span, bound, d_out, d_stats);
+      else
+        rc = launch_thorough_aa(ctx, d_pairs, ord, hist[c], d_codes, d_begin, d_span, bound,
+                                bound <= EPA_AA_LDS_MAX_SPAN, d_out, d_stats);
       continue;
     }
     ThArgs a;
