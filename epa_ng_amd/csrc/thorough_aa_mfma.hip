@@ -67,8 +67,7 @@ struct SharedM {
   double Ua[25 * 16];    // A-operand tiles of U:   [rt * 5 + t][k * 4 + i] = U[4 rt + i][4 t + k]
   double Uia[25 * 16];   // the same of U^-1
   double tab[3][80];     // wave-uniform exp tables, [slot][k * 20 + x]
-  double qt[24 * S];     // eigen image of the query column codes
-  double bc[12];         // cross-wave sums
+  double bc[24];         // cross-wave sums: f [0..8), f' [8..16), lnL [16..24)
 };
 
 // 0 that the optimiser cannot see through, ordered after `v`: added to an LDS index it keeps the
@@ -82,6 +81,10 @@ __device__ __forceinline__ int zero_after(double v) {
 __device__ __forceinline__ double mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
+// (wave-uniform pointer) + 32-bit byte offset: global_load with a scalar base
+__device__ __forceinline__ double ldg_off(const double* base, uint32_t byte_off) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 // combine the four component rows (lanes l, l ^ 16, l ^ 32, l ^ 48) of a site
 __device__ __forceinline__ double rows_sum(double v) {
   v += __shfl_xor(v, 16);
@@ -94,20 +97,22 @@ __device__ __forceinline__ double rows_max(double v) {
   return v;
 }
 
-template <int NT>
+template <int NT, int NBLK>
 __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
+  constexpr int NW = 4, NTHR = 64 * NW;
   __shared__ SharedM sh;
+  extern __shared__ double wcache[];   // [tile][block][reg t][lane]: see ThArgsAM::nblk
   const ModelDev* __restrict__ m = a.m;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int kq = lane >> 4;            // component residue of this lane (state 4 t + kq of vector register t)
   const int sl = lane & 15;            // site inside a 16-site tile
   const int aoff = kq * 4 + (lane & 3);  // this lane's element of an A-operand tile
-  for (int idx = tid; idx < 400; idx += 256) {
+  constexpr int nblk = NBLK;   // (side, category) blocks of a tile held in LDS: proximal 0..3, distal 4..7
+  for (int idx = tid; idx < 400; idx += NTHR) {
     const int tile = idx >> 4, e = idx & 15, rt = tile / NTS, t = tile % NTS, kk = e >> 2, i = e & 3;
     sh.Ua[idx] = m->U[(4 * rt + i) * S + 4 * t + kk];
     sh.Uia[idx] = m->Ui[(4 * rt + i) * S + 4 * t + kk];
   }
-  for (int idx = tid; idx < 24 * S; idx += 256) sh.qt[idx] = m->qt[idx];
   // per-thread table constants: thread t < 240 owns (slot = t / 80, kx = t % 80)
   const int tslot = tid / 80, tkx = tid % 80;
   double t_lr = 0.0, t_w = 0.0, t_c = 0.0;
@@ -119,6 +124,10 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
   __syncthreads();
 
   uint32_t wrounds = 0, wevals = 0, wreverts = 0;
+#ifdef AAM_PROFILE
+  long long cyc_phase = 0, cyc_newton = 0, cyc_pub = 0, cyc_total = 0, n_phase = 0, n_pairs_done = 0;
+  const long long cyc_begin = clock64();
+#endif
   for (uint64_t pidx = blockIdx.x; pidx < a.n_pairs; pidx += gridDim.x) {
     const uint64_t pid = a.order ? a.order[pidx] : pidx;
     const epa_pair pr = a.pairs[pid];
@@ -131,25 +140,44 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     const uint8_t* qc = a.codes + (size_t)q * a.cstride + (a.crel ? 0u : begin);
     const double orig = a.blen[b];
 
-    // this wave's tiles: tile g = wv + 4 j covers sites 16 g .. 16 g + 15 of the window
-    uint32_t ssite[NT], sscl[NT];   // site of this lane in tile j, clamped for the loads
+    // this wave's tiles: tile g = wv + NW j covers sites 16 g .. 16 g + 15 of the window
+    // loads are (wave-uniform row pointer)[32-bit lane offset]: scalar base + one offset VGPR per tile,
+    // instead of a 64-bit address pair per row kept live across the whole optimisation
+    uint32_t sscl[NT], lo[NT];      // site of this lane in tile j, clamped for the loads; kq W + site
     bool valid[NT], tile_on[NT];
     double qv[NT][NTS];             // query tip vector in the eigenbasis, vector layout
     double Sm[NT][4][NTS];          // sumtable of the branch being optimised: [tile][category][reg]
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      ssite[j] = 16u * (uint32_t)(wv + 4 * j) + (uint32_t)sl;
-      valid[j] = ssite[j] < n;
-      tile_on[j] = 16u * (uint32_t)(wv + 4 * j) < n;
-      sscl[j] = valid[j] ? ssite[j] : 0;
+      const uint32_t site = 16u * (uint32_t)(wv + NW * j) + (uint32_t)sl;
+      valid[j] = site < n;
+      tile_on[j] = 16u * (uint32_t)(wv + NW * j) < n;
+      sscl[j] = valid[j] ? site : 0;
+      lo[j] = ((uint32_t)kq * a.W + sscl[j]) * 8u;   // bytes
       const uint32_t code = qc[sscl[j]];
 #pragma unroll
-      for (int t = 0; t < NTS; ++t) qv[j][t] = sh.qt[code * S + 4 * t + kq];
+      for (int t = 0; t < NTS; ++t) qv[j][t] = m->qt[code * S + 4 * t + kq];
+    }
+    // The window of the two reference vectors is read by every phase of the pair (4 - 7 times):
+    // as many of its eight (side, category) blocks as fit are parked in LDS for the life of the
+    // pair -- proximal side first: the first phase (mode 2) does not touch it.  A block of a tile
+    // is read by the wave that wrote it, in the lanes that wrote it: no barrier, no bank conflict.
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (!tile_on[j]) continue;
+      double* wc = wcache + (size_t)(wv + NW * j) * nblk * (NTS * 64) + lane;
+#pragma unroll
+      for (int blk = 0; blk < nblk; ++blk) {
+        const double* src = (blk < 4 ? Xt : Dt) + (size_t)((blk & 3) * S) * cW;   // uniform
+#pragma unroll
+        for (int t = 0; t < NTS; ++t) wc[(blk * NTS + t) * 64] = ldg_off(src + (size_t)(4 * t) * cW, lo[j]);
+      }
     }
 
     // ---- table publication: every thread < 240 computes one exp()
+    // (no barrier in front: whatever ran before ended with a workgroup barrier behind its last
+    // table read -- the phases and the Newton evaluations below keep that invariant)
     auto publish = [&](double t0, double t1, double t2) {
-      __syncthreads();  // previous readers of sh.tab are done
       if (tid < 240) {
         const double t = tslot == 0 ? t0 : (tslot == 1 ? t1 : t2);
         const double e = exp(t_lr * t);
@@ -164,36 +192,63 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     auto phase = [&](int mode, double& lnl_out) {
       double mant = 1.0;
       int ex = 0;
+      const double* I0 = a.refI + (size_t)b * 80 * cW + begin;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if (!tile_on[j]) continue;   // wave-uniform
         const uint32_t s = sscl[j];
+        const double* wc = wcache + (size_t)(wv + NW * j) * nblk * (NTS * 64) + lane;
         double l0 = 0.0, mx = 0.0;
         bool resc = false;
-        int zt = zero_after(mant);   // ordering token of this tile's LDS reads
+        // the operands of category `cat + 1` are requested while category `cat` is on the matrix cores
+        double Bn[NTS], Dn[NTS];
+        auto fetch = [&](int cat, int zf) {
+          const uint32_t lof = lo[j] + (uint32_t)zf;   // the token keeps the (read-only, phase-invariant) loads in this phase
+          const size_t c0 = (size_t)(cat * S) * cW;   // uniform; component 4 t + kq: + 4 t cW + lo
+          if (mode == 2) {
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) Bn[t] = ldg_off(I0 + c0 + (size_t)(4 * t) * cW, lof);
+            return;
+          }
+          if (cat < nblk) {
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) Bn[t] = wc[(cat * NTS + t) * 64 + zf];
+          } else {
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) Bn[t] = ldg_off(Xt + c0 + (size_t)(4 * t) * cW, lof);
+          }
+          if (4 + cat < nblk) {
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) Dn[t] = wc[((4 + cat) * NTS + t) * 64 + zf];
+          } else {
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) Dn[t] = ldg_off(Dt + c0 + (size_t)(4 * t) * cW, lof);
+          }
+        };
+        fetch(0, zero_after(mant));
 #pragma unroll
         for (int cat = 0; cat < 4; ++cat) {
           __builtin_amdgcn_sched_barrier(0);
+          // ordering token of this category's matrix-tile / table reads: behind the arrival of its
+          // operands (requested a category ago).  Without it the loop-invariant tile reads are
+          // hoisted out of the category loop (150 VGPRs of them) and the kernel lives in scratch.
+          const int zt = zero_after(Bn[NTS - 1]);
           const int ao = aoff + zt;
-          const size_t c0 = (size_t)(cat * S + kq) * cW + s + (size_t)zt;   // component 4 t + kq: + 4 t cW
           double It[NTS], Dv[NTS];
           if (mode == 2) {
-            const double* I0 = a.refI + (size_t)b * 80 * cW + begin;
 #pragma unroll
-            for (int t = 0; t < NTS; ++t) It[t] = I0[c0 + (size_t)(4 * t) * cW];
+            for (int t = 0; t < NTS; ++t) It[t] = Bn[t];
+            if (cat < 3) fetch(cat + 1, zt);
           } else {
             double Av[NTS], Bv[NTS];
 #pragma unroll
             for (int t = 0; t < NTS; ++t) {
-              Bv[t] = Xt[c0 + (size_t)(4 * t) * cW];
-              Dv[t] = Dt[c0 + (size_t)(4 * t) * cW];
-            }
-#pragma unroll
-            for (int t = 0; t < NTS; ++t) {
               const double e0 = sh.tab[0][cat * S + 4 * t + kq + zt], e1 = sh.tab[1][cat * S + 4 * t + kq + zt];
-              Av[t] = (mode == 0 ? Dv[t] : qv[j][t]) * e0;
-              Bv[t] *= e1;
+              Dv[t] = Dn[t];
+              Av[t] = (mode == 0 ? Dn[t] : qv[j][t]) * e0;
+              Bv[t] = Bn[t] * e1;
             }
+            if (cat < 3) fetch(cat + 1, zt);
             // a = U (e0 o A), b = U (e1 o B): one read of every U tile feeds both products
             double ya[NTS], yb[NTS];
 #pragma unroll
@@ -211,9 +266,8 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
             for (int rt = 0; rt < NTS; ++rt) {
               Iv[rt] = ya[rt] * yb[rt];
               mx = fmax(mx, Iv[rt]);
+              It[rt] = 0.0;
             }
-#pragma unroll
-            for (int rt = 0; rt < NTS; ++rt) It[rt] = 0.0;
 #pragma unroll
             for (int t = 0; t < NTS; ++t)
 #pragma unroll
@@ -225,7 +279,6 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
             Sm[j][cat][t] = sv;
             if (mode != 1) l0 = fma(sv, sh.tab[2][cat * S + 4 * t + kq + zt], l0);
           }
-          zt = zero_after(Sm[j][cat][NTS - 1]);   // the next category's reads come after this one's results
         }
         // pll_update_partials per-site scaling: ALL 80 entries of the site below 2^-256
         if (mode == 2) {
@@ -259,18 +312,18 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
       }
       if (mode != 1) {
         const double tot = wave_sum(log(mant) + (double)ex * LOG_2);
-        if (lane == 0) sh.bc[8 + wv] = tot;
-        __syncthreads();
-        lnl_out = (sh.bc[8] + sh.bc[9]) + (sh.bc[10] + sh.bc[11]);
+        if (lane == 0) sh.bc[16 + wv] = tot;
+        __syncthreads();   // also: every wave is past its last table read
+        lnl_out = (sh.bc[16] + sh.bc[17]) + (sh.bc[18] + sh.bc[19]);
+      } else {
+        __syncthreads();   // every wave is past its last table read
       }
-      __syncthreads();  // sh.bc / sh.tab are free for whoever comes next
     };
 
     // f, f' at proposal t: per tile 20 MFMAs contract the register-resident sumtable with the
     // Newton tables; D row i of a site is l_i (i = 0, 1, 2; row 3 is a zero row of the A operand)
     uint32_t evals = 0;
     auto derivatives = [&](double t, double& f, double& df) {
-      __syncthreads();
       if (tid < 240) sh.tab[tslot][tkx] = exp(t_lr * t) * t_c;
       __syncthreads();
       const int row = lane & 3;
@@ -283,11 +336,11 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
 #pragma unroll
         for (int cat = 0; cat < 4; ++cat)
 #pragma unroll
-          for (int t = 0; t < NTS; ++t) {
-            double av = sh.tab[row < 3 ? row : 0][cat * S + 4 * t + kq + zt];
+          for (int tt = 0; tt < NTS; ++tt) {
+            double av = sh.tab[row < 3 ? row : 0][cat * S + 4 * tt + kq + zt];
             if (row == 3) av = 0.0;
-            if (cat < 2) acc0 = mfma4(av, Sm[j][cat][t], acc0);
-            else acc1 = mfma4(av, Sm[j][cat][t], acc1);
+            if (cat < 2) acc0 = mfma4(av, Sm[j][cat][tt], acc0);
+            else acc1 = mfma4(av, Sm[j][cat][tt], acc1);
           }
         const double l0 = acc0 + acc1;                 // lanes kq == 0: l0 of the site
         const double l1 = __shfl_down(l0, 16), l2 = __shfl_down(l0, 32);
@@ -300,10 +353,10 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
       }
       double ft, dft;
       wave_sum2(fl, dfl, ft, dft);
-      if (lane == 0) { sh.bc[wv] = ft; sh.bc[4 + wv] = dft; }
-      __syncthreads();
+      if (lane == 0) { sh.bc[wv] = ft; sh.bc[8 + wv] = dft; }
+      __syncthreads();   // also: every wave is past its table reads
       f = (sh.bc[0] + sh.bc[1]) + (sh.bc[2] + sh.bc[3]);
-      df = (sh.bc[4] + sh.bc[5]) + (sh.bc[6] + sh.bc[7]);
+      df = (sh.bc[8] + sh.bc[9]) + (sh.bc[10] + sh.bc[11]);
       ++evals;
     };
 
@@ -340,6 +393,13 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     double tp = a.blo.pendant_default, td = orig * 0.5, tx = orig * 0.5;
     uint32_t rounds = 0, reverted = 0;
     double lnl_now = 0.0;
+#ifdef AAM_PROFILE
+#define AAM_T0 const long long t0_ = clock64();
+#define AAM_T1(x) x += clock64() - t0_;
+#else
+#define AAM_T0
+#define AAM_T1(x)
+#endif
     publish(td, tx, tp);
     if (a.refI) phase(2, lnl_now); else phase(0, lnl_now);
     double loglikelihood = -lnl_now;
@@ -349,20 +409,24 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
       double xmin = a.blo.min_branch, xmax = a.blo.max_branch, xtol = xmin / 10.0;
       double xguess = tp;
       if (xguess < xmin || xguess > xmax) xguess = a.blo.default_branch;
-      double xres = newton(xmin, xguess, xmax, xtol, (int)a.blo.max_newton);
+      double xres;
+      { AAM_T0 xres = newton(xmin, xguess, xmax, xtol, (int)a.blo.max_newton); AAM_T1(cyc_newton) }
       if (xres > 0.0) tp = xres;
-      publish(tp, tx, tp);
+      { AAM_T0 publish(tp, tx, tp); AAM_T1(cyc_pub) }
       double dummy;
-      phase(1, dummy);
+      { AAM_T0 phase(1, dummy); AAM_T1(cyc_phase) }
       xguess = td;
       xmin = fmin(a.blo.min_branch / 2.0, orig / 2.0);
       xtol = xmin / 10.0;
       xmax = orig - xtol;
       if (xguess < xmin || xguess > xmax) xguess = orig / 2.0;
-      xres = newton(xmin, xguess, xmax, xtol, (int)a.blo.max_newton);
+      { AAM_T0 xres = newton(xmin, xguess, xmax, xtol, (int)a.blo.max_newton); AAM_T1(cyc_newton) }
       if (xres > 0.0) { td = xres; tx = orig - xres; }
-      publish(td, tx, tp);
-      phase(0, lnl_now);
+      { AAM_T0 publish(td, tx, tp); AAM_T1(cyc_pub) }
+      { AAM_T0 phase(0, lnl_now); AAM_T1(cyc_phase) }
+#ifdef AAM_PROFILE
+      n_phase += 2;
+#endif
       const double new_ll = -lnl_now;
       ++rounds;
       if (new_ll - loglikelihood > new_ll * 1e-14) {
@@ -386,7 +450,16 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
       }
     }
     wrounds += rounds; wevals += evals; wreverts += reverted;
+#ifdef AAM_PROFILE
+    ++n_pairs_done;
+#endif
   }
+#ifdef AAM_PROFILE
+  cyc_total = clock64() - cyc_begin;
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 777))
+    printf("AAM blk %d: pairs %lld total %lld phase %lld (%lld phases) newton %lld (%u evals) publish %lld\n", (int)blockIdx.x,
+           n_pairs_done, cyc_total, cyc_phase, n_phase, cyc_newton, wevals, cyc_pub);
+#endif
   if (tid == 0) {
     atomicAdd(&a.stats[0], (unsigned long long)wrounds);
     atomicAdd(&a.stats[1], (unsigned long long)wevals);
@@ -426,10 +499,25 @@ int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_
   uint32_t per_slot = 16;
   if (const char* e = getenv("EPA_TH_WAVES_PER_SLOT")) per_slot = (uint32_t)std::max(1, atoi(e));
   const uint32_t nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * 2 * per_slot);
-  if (max_span <= 64) hipLaunchKernelGGL(k_thorough_aa_mfma<1>, dim3(nwg), dim3(256), 0, ctx->stream, a);
-  else if (max_span <= 128) hipLaunchKernelGGL(k_thorough_aa_mfma<2>, dim3(nwg), dim3(256), 0, ctx->stream, a);
-  else if (max_span <= 192) hipLaunchKernelGGL(k_thorough_aa_mfma<3>, dim3(nwg), dim3(256), 0, ctx->stream, a);
-  else return epa_fail(ctx, EPA_ERR_INVALID_ARG, "thorough_aa_mfma: window longer than 192 sites");
+  if (max_span > 192) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "thorough_aa_mfma: window longer than 192 sites");
+  // LDS window cache: two workgroups share the CU's 160 KB; whole (side, category) blocks only:
+  // tiles -> blocks that fit in 80 KB - sizeof(SharedM): <= 4 -> 7, 5 -> 5, 6..7 -> 4, 8..9 -> 3, 10..12 -> 2
+  const uint32_t tiles = (max_span + 15) / 16;
+  auto go = [&](auto kern, uint32_t nblk) {
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), (size_t)nblk * tiles * NTS * 64 * 8, ctx->stream, a);
+  };
+  // The cache is OFF unless EPA_AAM_CACHE is set: measured (profiles/r2_aa_mfma_ab.txt) it removes a third
+  // of the kernel's HBM reads and is 1 - 6 % SLOWER -- the kernel is bound by LDS issue + MFMA at two
+  // waves per SIMD, not by HBM, and the cache adds LDS traffic.
+  if (!getenv("EPA_AAM_CACHE")) {
+    if (tiles <= 4) go(k_thorough_aa_mfma<1, 0>, 0);
+    else if (tiles <= 8) go(k_thorough_aa_mfma<2, 0>, 0);
+    else go(k_thorough_aa_mfma<3, 0>, 0);
+  } else if (tiles <= 4) go(k_thorough_aa_mfma<1, 7>, 7);
+  else if (tiles <= 7) go(k_thorough_aa_mfma<2, 4>, 4);
+  else if (tiles <= 8) go(k_thorough_aa_mfma<2, 3>, 3);
+  else if (tiles <= 9) go(k_thorough_aa_mfma<3, 3>, 3);
+  else go(k_thorough_aa_mfma<3, 2>, 2);
   EPA_HIP(ctx, hipGetLastError());
   return EPA_OK;
 }
