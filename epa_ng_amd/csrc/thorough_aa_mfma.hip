@@ -63,12 +63,21 @@ struct ThArgsAM {
   uint32_t W;
 };
 
+// LDS is read with ds_read_b128 wherever two neighbouring doubles go to the same lane: 256 B/clk from
+// one wave per SIMD, where the 8-byte reads need four waves per SIMD for half of that -- and this
+// kernel runs at two.
+constexpr int TAB_STRIDE = 104;   // doubles per table; = 64 B mod 256 B: the three Newton rows hit different banks
 struct SharedM {
-  double Ua[25 * 16];    // A-operand tiles of U:   [rt * 5 + t][k * 4 + i] = U[4 rt + i][4 t + k]
-  double Uia[25 * 16];   // the same of U^-1
-  double tab[3][80];     // wave-uniform exp tables, [slot][k * 20 + x]
-  double bc[24];         // cross-wave sums: f [0..8), f' [8..16), lnL [16..24)
+  // A-operand tiles of U in the order the products use them, q = 5 t + rt, two tiles interleaved:
+  // Ua[((q / 2) * 16 + k * 4 + i) * 2 + q % 2] = U[4 rt + i][4 t + k]
+  double Ua[13 * 32];
+  double Uia[13 * 32];             // the same of U^-1
+  // wave-uniform exp tables, entry (category c, eigen index 4 t + kq) at [(c * 4 + kq) * 6 + t]:
+  // the five values a lane needs are consecutive (the sixth is padding)
+  double tab[3][TAB_STRIDE];
+  double bc[24];                   // cross-wave sums: f [0..8), f' [8..16), lnL [16..24)
 };
+
 
 // 0 that the optimiser cannot see through, ordered after `v`: added to an LDS index it keeps the
 // (loop-invariant) matrix-tile and table reads where they are written -- hoisted out of the
@@ -80,6 +89,23 @@ __device__ __forceinline__ int zero_after(double v) {
 }
 __device__ __forceinline__ double mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+// five consecutive doubles at a 16-byte aligned LDS address: two 16-byte reads and one of 8
+__device__ __forceinline__ void lds5(const double* p, double (&v)[5]) {
+  const double2 x = *reinterpret_cast<const double2*>(p);
+  const double2 y = *reinterpret_cast<const double2*>(p + 2);
+  v[0] = x.x; v[1] = x.y; v[2] = y.x; v[3] = y.y; v[4] = p[4];
+}
+// tiles q = 2 p, 2 p + 1 of an interleaved A-operand array (tile 24 has no partner)
+__device__ __forceinline__ void lds_tiles(const double* U2, int p, int ao, double& u0, double& u1) {
+  if (p < 12) {
+    const double2 v = *reinterpret_cast<const double2*>(U2 + (p * 16 + ao) * 2);
+    u0 = v.x;
+    u1 = v.y;
+  } else {
+    u0 = U2[(12 * 16 + ao) * 2];
+    u1 = 0.0;
+  }
 }
 // (wave-uniform pointer) + 32-bit byte offset: global_load with a scalar base
 __device__ __forceinline__ double ldg_off(const double* base, uint32_t byte_off) {
@@ -100,7 +126,7 @@ __device__ __forceinline__ double rows_max(double v) {
 template <int NT, int NBLK>
 __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
   constexpr int NW = 4, NTHR = 64 * NW;
-  __shared__ SharedM sh;
+  __shared__ alignas(16) SharedM sh;
   extern __shared__ double wcache[];   // [tile][block][reg t][lane]: see ThArgsAM::nblk
   const ModelDev* __restrict__ m = a.m;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -109,12 +135,14 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
   const int aoff = kq * 4 + (lane & 3);  // this lane's element of an A-operand tile
   constexpr int nblk = NBLK;   // (side, category) blocks of a tile held in LDS: proximal 0..3, distal 4..7
   for (int idx = tid; idx < 400; idx += NTHR) {
-    const int tile = idx >> 4, e = idx & 15, rt = tile / NTS, t = tile % NTS, kk = e >> 2, i = e & 3;
-    sh.Ua[idx] = m->U[(4 * rt + i) * S + 4 * t + kk];
-    sh.Uia[idx] = m->Ui[(4 * rt + i) * S + 4 * t + kk];
+    const int qq = idx >> 4, e = idx & 15, t = qq / NTS, rt = qq % NTS, kk = e >> 2, i = e & 3;
+    const int dst = ((qq >> 1) * 16 + e) * 2 + (qq & 1);
+    sh.Ua[dst] = m->U[(4 * rt + i) * S + 4 * t + kk];
+    sh.Uia[dst] = m->Ui[(4 * rt + i) * S + 4 * t + kk];
   }
   // per-thread table constants: thread t < 240 owns (slot = t / 80, kx = t % 80)
   const int tslot = tid / 80, tkx = tid % 80;
+  const int tpos = ((tkx / S) * 4 + (tkx % S) % 4) * 6 + (tkx % S) / 4;
   double t_lr = 0.0, t_w = 0.0, t_c = 0.0;
   if (tid < 240) {
     t_lr = m->lam[tkx % S] * m->rate[tkx / S];
@@ -181,7 +209,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
       if (tid < 240) {
         const double t = tslot == 0 ? t0 : (tslot == 1 ? t1 : t2);
         const double e = exp(t_lr * t);
-        sh.tab[tslot][tkx] = tslot == 2 ? e * t_w : e;
+        sh.tab[tslot][tpos] = tslot == 2 ? e * t_w : e;
       }
       __syncthreads();
     };
@@ -234,6 +262,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
           // hoisted out of the category loop (150 VGPRs of them) and the kernel lives in scratch.
           const int zt = zero_after(Bn[NTS - 1]);
           const int ao = aoff + zt;
+          const int tp5 = (cat * 4 + kq) * 6;   // this lane's five table entries of the category
           double It[NTS], Dv[NTS];
           if (mode == 2) {
 #pragma unroll
@@ -241,26 +270,33 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
             if (cat < 3) fetch(cat + 1, zt);
           } else {
             double Av[NTS], Bv[NTS];
+            {
+              double e0[NTS], e1[NTS];
+              lds5(&sh.tab[0][tp5 + zt], e0);
+              lds5(&sh.tab[1][tp5 + zt], e1);
 #pragma unroll
-            for (int t = 0; t < NTS; ++t) {
-              const double e0 = sh.tab[0][cat * S + 4 * t + kq + zt], e1 = sh.tab[1][cat * S + 4 * t + kq + zt];
-              Dv[t] = Dn[t];
-              Av[t] = (mode == 0 ? Dn[t] : qv[j][t]) * e0;
-              Bv[t] = Bn[t] * e1;
+              for (int t = 0; t < NTS; ++t) {
+                Dv[t] = Dn[t];
+                Av[t] = (mode == 0 ? Dn[t] : qv[j][t]) * e0[t];
+                Bv[t] = Bn[t] * e1[t];
+              }
             }
             if (cat < 3) fetch(cat + 1, zt);
-            // a = U (e0 o A), b = U (e1 o B): one read of every U tile feeds both products
+            // a = U (e0 o A), b = U (e1 o B): one read of a U tile pair feeds four MFMAs
             double ya[NTS], yb[NTS];
 #pragma unroll
             for (int rt = 0; rt < NTS; ++rt) { ya[rt] = 0.0; yb[rt] = 0.0; }
 #pragma unroll
-            for (int t = 0; t < NTS; ++t)
-#pragma unroll
-              for (int rt = 0; rt < NTS; ++rt) {
-                const double ua = sh.Ua[(rt * NTS + t) * 16 + ao];
-                ya[rt] = mfma4(ua, Av[t], ya[rt]);
-                yb[rt] = mfma4(ua, Bv[t], yb[rt]);
+            for (int p = 0; p < 13; ++p) {
+              double u0, u1;
+              lds_tiles(sh.Ua, p, ao, u0, u1);
+              ya[(2 * p) % NTS] = mfma4(u0, Av[(2 * p) / NTS], ya[(2 * p) % NTS]);
+              yb[(2 * p) % NTS] = mfma4(u0, Bv[(2 * p) / NTS], yb[(2 * p) % NTS]);
+              if (p < 12) {
+                ya[(2 * p + 1) % NTS] = mfma4(u1, Av[(2 * p + 1) / NTS], ya[(2 * p + 1) % NTS]);
+                yb[(2 * p + 1) % NTS] = mfma4(u1, Bv[(2 * p + 1) / NTS], yb[(2 * p + 1) % NTS]);
               }
+            }
             double Iv[NTS];
 #pragma unroll
             for (int rt = 0; rt < NTS; ++rt) {
@@ -269,15 +305,20 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
               It[rt] = 0.0;
             }
 #pragma unroll
-            for (int t = 0; t < NTS; ++t)
-#pragma unroll
-              for (int rt = 0; rt < NTS; ++rt) It[rt] = mfma4(sh.Uia[(rt * NTS + t) * 16 + ao], Iv[t], It[rt]);
+            for (int p = 0; p < 13; ++p) {
+              double u0, u1;
+              lds_tiles(sh.Uia, p, ao, u0, u1);
+              It[(2 * p) % NTS] = mfma4(u0, Iv[(2 * p) / NTS], It[(2 * p) % NTS]);
+              if (p < 12) It[(2 * p + 1) % NTS] = mfma4(u1, Iv[(2 * p + 1) / NTS], It[(2 * p + 1) % NTS]);
+            }
           }
+          double e2[NTS];
+          if (mode != 1) lds5(&sh.tab[2][tp5 + zt], e2);
 #pragma unroll
           for (int t = 0; t < NTS; ++t) {
             const double sv = It[t] * (mode == 1 ? Dv[t] : qv[j][t]);
             Sm[j][cat][t] = sv;
-            if (mode != 1) l0 = fma(sv, sh.tab[2][cat * S + 4 * t + kq + zt], l0);
+            if (mode != 1) l0 = fma(sv, e2[t], l0);
           }
         }
         // pll_update_partials per-site scaling: ALL 80 entries of the site below 2^-256
@@ -324,7 +365,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     // Newton tables; D row i of a site is l_i (i = 0, 1, 2; row 3 is a zero row of the A operand)
     uint32_t evals = 0;
     auto derivatives = [&](double t, double& f, double& df) {
-      if (tid < 240) sh.tab[tslot][tkx] = exp(t_lr * t) * t_c;
+      if (tid < 240) sh.tab[tslot][tpos] = exp(t_lr * t) * t_c;
       __syncthreads();
       const int row = lane & 3;
       double fl = 0.0, dfl = 0.0;
@@ -334,14 +375,16 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
         double acc0 = 0.0, acc1 = 0.0;   // two chains: categories 0,1 and 2,3
         const int zt = zero_after(fl);
 #pragma unroll
-        for (int cat = 0; cat < 4; ++cat)
+        for (int cat = 0; cat < 4; ++cat) {
+          double av[NTS];
+          lds5(&sh.tab[row < 3 ? row : 0][(cat * 4 + kq) * 6 + zt], av);
 #pragma unroll
           for (int tt = 0; tt < NTS; ++tt) {
-            double av = sh.tab[row < 3 ? row : 0][cat * S + 4 * tt + kq + zt];
-            if (row == 3) av = 0.0;
-            if (cat < 2) acc0 = mfma4(av, Sm[j][cat][tt], acc0);
-            else acc1 = mfma4(av, Sm[j][cat][tt], acc1);
+            const double avv = row == 3 ? 0.0 : av[tt];
+            if (cat < 2) acc0 = mfma4(avv, Sm[j][cat][tt], acc0);
+            else acc1 = mfma4(avv, Sm[j][cat][tt], acc1);
           }
+        }
         const double l0 = acc0 + acc1;                 // lanes kq == 0: l0 of the site
         const double l1 = __shfl_down(l0, 16), l2 = __shfl_down(l0, 32);
         if (kq == 0 && valid[j]) {
