@@ -90,6 +90,14 @@ __device__ __forceinline__ int zero_after(double v) {
 __device__ __forceinline__ double mfma4(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
+// value of lane (quad base + Q) in every lane of the quad (DPP quad_perm, no LDS)
+template <int Q>
+__device__ __forceinline__ double quad_bcast(double v) {
+  constexpr int CTRL = Q | (Q << 2) | (Q << 4) | (Q << 6);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
 // five consecutive doubles at a 16-byte aligned LDS address: two 16-byte reads and one of 8
 __device__ __forceinline__ void lds5(const double* p, double (&v)[5]) {
   const double2 x = *reinterpret_cast<const double2*>(p);
@@ -361,8 +369,9 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
       }
     };
 
-    // f, f' at proposal t: per tile 20 MFMAs contract the register-resident sumtable with the
-    // Newton tables; D row i of a site is l_i (i = 0, 1, 2; row 3 is a zero row of the A operand)
+    // f, f' at proposal t: per tile 20 MFMAs contract the register-resident sumtable (A operand:
+    // rows = the four sites of a block) with the Newton tables (B operand: column i = table i,
+    // column 3 zeros); D puts l_0, l_1, l_2 of a site in lanes 0, 1, 2 of one quad
     uint32_t evals = 0;
     auto derivatives = [&](double t, double& f, double& df) {
       if (tid < 240) sh.tab[tslot][tpos] = exp(t_lr * t) * t_c;
@@ -381,13 +390,15 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
 #pragma unroll
           for (int tt = 0; tt < NTS; ++tt) {
             const double avv = row == 3 ? 0.0 : av[tt];
-            if (cat < 2) acc0 = mfma4(avv, Sm[j][cat][tt], acc0);
-            else acc1 = mfma4(avv, Sm[j][cat][tt], acc1);
+            if (cat < 2) acc0 = mfma4(Sm[j][cat][tt], avv, acc0);
+            else acc1 = mfma4(Sm[j][cat][tt], avv, acc1);
           }
         }
-        const double l0 = acc0 + acc1;                 // lanes kq == 0: l0 of the site
-        const double l1 = __shfl_down(l0, 16), l2 = __shfl_down(l0, 32);
-        if (kq == 0 && valid[j]) {
+        // lane (i = lane / 16, block, r): l_r of site 4 block + i of the tile
+        const double lr = acc0 + acc1;
+        const double l0 = lr, l1 = quad_bcast<1>(lr), l2 = quad_bcast<2>(lr);
+        const uint32_t dsite = 16u * (uint32_t)(wv + NW * j) + (uint32_t)(((lane >> 2) & 3) * 4 + kq);
+        if (row == 0 && dsite < n) {
           const double inv = fast_rcp(l0);
           const double d1 = -l1 * inv;
           fl += d1;
