@@ -61,6 +61,7 @@ struct ThArgsAM {
   unsigned long long* stats;
   uint64_t n_pairs;
   uint32_t W;
+  uint32_t* qctr;          // one work counter per XCD slice of the pair list (resident workgroups), or null
 };
 
 // LDS is read with ds_read_b128 wherever two neighbouring doubles go to the same lane: 256 B/clk from
@@ -76,6 +77,7 @@ struct SharedM {
   // the five values a lane needs are consecutive (the sixth is padding)
   double tab[3][TAB_STRIDE];
   double bc[24];                   // cross-wave sums: f [0..8), f' [8..16), lnL [16..24)
+  uint32_t next_pair;              // work-queue hand-out of the workgroup
 };
 
 
@@ -164,7 +166,26 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
   long long cyc_phase = 0, cyc_newton = 0, cyc_pub = 0, cyc_total = 0, n_phase = 0, n_pairs_done = 0;
   const long long cyc_begin = clock64();
 #endif
-  for (uint64_t pidx = blockIdx.x; pidx < a.n_pairs; pidx += gridDim.x) {
+  // Workgroup g runs on XCD g % 8 (observed; used for speed only): XCD x owns the x-th eighth of the
+  // branch-sorted pair list, so one branch's windows are served by one L2.  Resident workgroups
+  // take the pairs of their slice from a counter (requested one pair ahead); without a counter the
+  // slice is dealt round-robin to an oversubscribed grid.
+  const uint32_t xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+  const uint64_t per_xcd = (a.n_pairs + 7) / 8;
+  const uint64_t slice_lo = (uint64_t)xcd * per_xcd;
+  const uint64_t slice_hi = slice_lo + per_xcd < a.n_pairs ? slice_lo + per_xcd : a.n_pairs;
+  const uint32_t slice_n = (uint32_t)(slice_hi > slice_lo ? slice_hi - slice_lo : 0);
+  uint32_t* const ctr = a.qctr ? a.qctr + xcd : nullptr;
+  uint32_t cur = wg_in_xcd;
+  if (ctr) {
+    if (tid == 0) sh.next_pair = atomicAdd(ctr, 1u);
+    __syncthreads();
+    cur = sh.next_pair;
+  }
+  while (cur < slice_n) {
+    uint32_t ahead = 0;
+    if (ctr && tid == 0) ahead = atomicAdd(ctr, 1u);
+    const uint64_t pidx = slice_lo + cur;
     const uint64_t pid = a.order ? a.order[pidx] : pidx;
     const epa_pair pr = a.pairs[pid];
     const uint32_t b = pr.branch_id, q = pr.seq_id;
@@ -507,6 +528,14 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
 #ifdef AAM_PROFILE
     ++n_pairs_done;
 #endif
+    if (ctr) {
+      // the last phase of the pair ended with a workgroup barrier: next_pair has been read by all
+      if (tid == 0) sh.next_pair = ahead;
+      __syncthreads();
+      cur = sh.next_pair;
+    } else {
+      cur += wgs_per_xcd;
+    }
   }
 #ifdef AAM_PROFILE
   cyc_total = clock64() - cyc_begin;
@@ -552,7 +581,15 @@ int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_
   // spread of the pairs (as k_thorough_aa)
   uint32_t per_slot = 16;
   if (const char* e = getenv("EPA_TH_WAVES_PER_SLOT")) per_slot = (uint32_t)std::max(1, atoi(e));
-  const uint32_t nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * 2 * per_slot);
+  uint32_t nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * 2 * per_slot);
+  // resident workgroups + a work counter per XCD slice (EPA_TH_QUEUE=0: the oversubscribed static grid)
+  a.qctr = nullptr;
+  if (!(getenv("EPA_TH_QUEUE") && atoi(getenv("EPA_TH_QUEUE")) == 0) && ctx->th_ctr) {
+    EPA_HIP(ctx, hipMemsetAsync(ctx->th_ctr, 0, 64, ctx->stream));
+    a.qctr = ctx->th_ctr;
+    nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * 2);
+  }
+  nwg = (nwg + 7) / 8 * 8;
   if (max_span > 192) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "thorough_aa_mfma: window longer than 192 sites");
   // LDS window cache: two workgroups share the CU's 160 KB; whole (side, category) blocks only:
   // tiles -> blocks that fit in 80 KB - sizeof(SharedM): <= 4 -> 7, 5 -> 5, 6..7 -> 4, 8..9 -> 3, 10..12 -> 2
