@@ -302,7 +302,8 @@ def main():
     exec_tflops = pairs * flops_exec / t_th / 1e12
     alg_tflops = pairs * flops_pair / t_th / 1e12
     traffic = traffic_pre = None   # HBM bytes per launch from the committed PMC passes, same workload only
-    kname = "k_thorough_dna" if states == 4 else "k_thorough_aa"
+    aa_mfma = states == 20 and a.read_len <= 192 and not os.environ.get("EPA_AA_VALU")
+    kname = "k_thorough_dna" if states == 4 else ("k_thorough_aa_mfma" if aa_mfma else "k_thorough_aa")
     for tf in ("r2_traffic.json", "r1_traffic.json"):
         try:
             tall = json.load(open(os.path.join(ROOT, "profiles", tf)))
@@ -316,12 +317,14 @@ def main():
                 break
         except (OSError, KeyError, ValueError):
             pass
-    roof = {"bound": "fp64-valu", "kernel": kname,
+    roof = {"bound": "mfma" if aa_mfma else "fp64-valu", "kernel": kname,
             "achieved": round(exec_tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(exec_tflops / FP64_PEAK_TFLOPS, 4),
             "traffic": traffic,
-            "note": "achieved / frac price the fp64 flop the kernel EXECUTES (zero MFMA instructions: "
-                    "fp64 vector FMA kernel); *_algorithmic price SURVEY 8d's per-pair figure",
+            "note": ("achieved / frac price the fp64 flop the kernel EXECUTES (its 20 x 20 products and the Newton "
+                     "contraction are v_mfma_f64_4x4x4_4b_f64, no padding); " if aa_mfma else
+                     "achieved / frac price the fp64 flop the kernel EXECUTES (zero MFMA instructions: "
+                     "fp64 vector FMA kernel); ") + "*_algorithmic price SURVEY 8d's per-pair figure",
             "peak_source": "AMD MI355X spec sheet, fp64 vector = fp64 matrix = 78.6 TFLOP/s (the microarch "
                            "guide lists no fp64 row); measured ceiling of a dependency-free v_fma_f64 "
                            "stream on this chip: %.1f TFLOP/s (profiles/r1_mfma_overlap.txt)" % FP64_MEASURED_CEILING,
@@ -341,7 +344,11 @@ def main():
                 "achieved": round(pre_bytes / t_pre / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(pre_bytes / t_pre / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic_pre,
                 "algorithmic_bytes_per_launch": pre_bytes,
-                "ms_per_launch": round(t_pre * 1e3, 4)}
+                "ms_per_launch": round(t_pre * 1e3, 4),
+                # the kernel's own unit of work: one 8-byte LDS gather per (query, branch, site pair) [DNA]
+                # or site [20 states], against the LDS rate of ds_read_b64 (32 lanes / clk / CU, 256 CUs, 2.4 GHz)
+                "lds_gathers_per_launch": float(Q) * B * (nq / 2.0 if states == 4 else nq),
+                "lds_gather_frac": round(float(Q) * B * (nq / 2.0 if states == 4 else nq) / t_pre / (256 * 32 * 2.4e9), 4)}
 
     extras = {}
     # ---------------- CPU baseline: the oracle's OpenMP restatement on a bounded sample

@@ -20,3 +20,20 @@ bash profiles/run_pmc.sh ${tag} \
   "SQ_INSTS_SALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" \
   "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum" > gpurun_out/${tag}_pmc_summary.txt 2>&1
 grep -A22 "== k_thorough" gpurun_out/${tag}_pmc_summary.txt | head -30
+# 20-state workload (BASELINE.json configs[3] shape): bench line, kernel trace, counters of the matrix-core kernel
+AA="--workload aa --tips 2000 --width 500 --read-len 100 --chunk 10000"
+python bench.py $AA > gpurun_out/${tag}_aa_bench.json 2> gpurun_out/${tag}_aa_bench.err
+tail -1 gpurun_out/${tag}_aa_bench.json | cut -c1-300
+cd /tmp
+rm -rf $R/gpurun_out/${tag}_aa_stats
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_aa_stats -o st -- \
+  python $R/bench.py $AA --no-cpu-baseline --no-extras > $R/gpurun_out/${tag}_aa_stats.log 2>&1
+cd $R
+python profiles/db_to_txt.py gpurun_out/${tag}_aa_stats/st_results.db > gpurun_out/${tag}_aa_kernel_trace_stats.txt
+head -8 gpurun_out/${tag}_aa_kernel_trace_stats.txt
+BENCH_ARGS="$AA" bash profiles/run_pmc.sh ${tag}_aa \
+  "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
+  "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" \
+  "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+  "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum" > gpurun_out/${tag}_aa_pmc_summary.txt 2>&1
+grep -A16 "== k_thorough" gpurun_out/${tag}_aa_pmc_summary.txt | head -20
