@@ -97,6 +97,21 @@ int epa_host_parse_model(const char* file, char* out, size_t cap) {
   return (int)s.size();
 }
 
+// premasking column mask of a (reference file, query file) pair: MSA_Info of both + or_mask
+// (src/main.cpp:470-490).  mask[i] = 1: column i is removed.  Returns the number of sites, -1 on error.
+long epa_host_premask(const char* ref_file, const char* query_file, uint8_t* mask, size_t cap) {
+  long sites = -1;
+  if (guarded([&] {
+        epa::MSA_Info r = epa::MSA_Info::from_file(ref_file), q = epa::MSA_Info::from_file(query_file);
+        epa::MSA_Info::or_mask(r, q);
+        if (r.sites() > cap) throw std::runtime_error{"epa_host_premask: mask buffer too small"};
+        std::memcpy(mask, r.gap_mask().data(), r.sites());
+        sites = (long)r.sites();
+      }))
+    return -1;
+  return sites;
+}
+
 // rooted input tree: placement (edge, distal) on the unrooted working tree -> on the rooted tree
 // (rtree_mapper::in_rtree).  Returns 1 when no mapping is active (unrooted input / preserve off).
 int epa_host_ref_in_rtree(void* h, uint32_t branch, double distal, uint32_t* out_branch, double* out_distal) {

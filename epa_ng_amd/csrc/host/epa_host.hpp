@@ -66,6 +66,34 @@ private:
 
 using MSA = std::vector<Sequence>;
 
+// Column premasking (src/seq/MSA_Info.hpp:13-111, src/main.cpp:470-494): a column that is a gap in
+// EVERY sequence of the reference file, or in every sequence of the query file, is removed from both
+// alignments before anything else happens (`or_mask`, "like masking in pplacer").  It changes no
+// LWR (such a column multiplies every branch's likelihood of a query by the same factor) but it is
+// what makes the absolute `likelihood` field of the jplace equal to the reference's.
+// Gap characters: genesis' gap_sites() default, the "undetermined" nucleic-acid codes N O X . - ?
+// in either case -- also for protein data, as the reference calls it (a recollection of
+// genesis/sequence/functions/functions.hpp; genesis is an empty submodule in the reference checkout).
+class MSA_Info {
+public:
+  using mask_type = std::vector<uint8_t>;   // 1 = gap in every sequence seen
+  MSA_Info() = default;
+  explicit MSA_Info(const MSA& msa);                 // one pass over sequences already in memory
+  // one streamed pass over a (binary) fasta file; stops early once no column can stay masked
+  static MSA_Info from_file(const std::string& path);
+  size_t sites() const { return sites_; }
+  size_t sequences() const { return sequences_; }    // sequences looked at (a lower bound after an early stop)
+  const mask_type& gap_mask() const { return gap_mask_; }
+  size_t gap_count() const;
+  void add(const std::string& seq);                  // gap_mask &= gap sites of seq
+  static void or_mask(MSA_Info& lhs, MSA_Info& rhs); // throws on unequal widths
+private:
+  size_t sites_ = 0, sequences_ = 0;
+  mask_type gap_mask_;
+};
+std::string subset_sequence(const std::string& seq, const MSA_Info::mask_type& mask);
+MSA subset_msa(const MSA& msa, const MSA_Info::mask_type& mask);
+
 class Placement {  // src/sample/Placement.hpp:7-54
 public:
   Placement() = default;
@@ -373,5 +401,10 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
 // same, one worker thread per listed GPU; the jplace does not depend on the device count
 Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std::string& outdir,
                      const Options& options, const std::string& invocation, const std::vector<int>& devices);
+// as the reference's signature (src/core/place.cpp:173): with the premasking column mask the query
+// reader applies to every sequence (src/seq/MSA_Stream.cpp:26); an empty mask = no column removed
+Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_Info& msa_info,
+                     const std::string& outdir, const Options& options, const std::string& invocation,
+                     const std::vector<int>& devices);
 
 }  // namespace epa

@@ -174,6 +174,74 @@ size_t Fasta_Stream::read_next(MSA& out, size_t max_seqs) {
   return m;
 }
 
+// ---- column premasking (src/seq/MSA_Info.hpp)
+namespace {
+inline bool is_mask_gap(char c) {
+  switch (c) {
+    case 'N': case 'n': case 'O': case 'o': case 'X': case 'x': case '.': case '-': case '?': return true;
+    default: return false;
+  }
+}
+}  // namespace
+
+MSA_Info::MSA_Info(const MSA& msa) {
+  for (const auto& s : msa) add(s.sequence());
+}
+
+void MSA_Info::add(const std::string& seq) {
+  if (sequences_ == 0) {
+    sites_ = seq.size();
+    gap_mask_.assign(sites_, 1);
+  } else if (seq.size() != sites_) {
+    throw std::runtime_error{"MSA does not contain equal size sequences! (" + std::to_string(seq.size()) +
+                             " vs. " + std::to_string(sites_) + " sites)"};
+  }
+  ++sequences_;
+  for (size_t i = 0; i < sites_; ++i) gap_mask_[i] &= (uint8_t)is_mask_gap(seq[i]);
+}
+
+size_t MSA_Info::gap_count() const {
+  size_t n = 0;
+  for (uint8_t g : gap_mask_) n += g;
+  return n;
+}
+
+MSA_Info MSA_Info::from_file(const std::string& path) {
+  MSA_Info info;
+  Fasta_Stream in(path);
+  MSA part;
+  for (;;) {
+    part.clear();
+    if (in.read_next(part, 4096) == 0) break;
+    for (const auto& s : part) info.add(s.sequence());
+    // the mask only ever loses bits: once it is empty the rest of the file cannot change it
+    if (info.gap_count() == 0) break;
+  }
+  return info;
+}
+
+void MSA_Info::or_mask(MSA_Info& lhs, MSA_Info& rhs) {
+  if (lhs.sites() != rhs.sites())
+    throw std::runtime_error{"MSA_Infos are unequal site width: " + std::to_string(lhs.sites()) + " vs. " +
+                             std::to_string(rhs.sites())};
+  for (size_t i = 0; i < lhs.gap_mask_.size(); ++i) lhs.gap_mask_[i] = rhs.gap_mask_[i] = lhs.gap_mask_[i] | rhs.gap_mask_[i];
+}
+
+std::string subset_sequence(const std::string& seq, const MSA_Info::mask_type& mask) {
+  if (seq.size() != mask.size()) throw std::runtime_error{"In subset_sequence: mask and seq incompatible"};
+  std::string out;
+  out.reserve(seq.size());
+  for (size_t i = 0; i < seq.size(); ++i) if (!mask[i]) out.push_back(seq[i]);
+  return out;
+}
+
+MSA subset_msa(const MSA& msa, const MSA_Info::mask_type& mask) {
+  MSA out;
+  out.reserve(msa.size());
+  for (const auto& s : msa) out.emplace_back(s.header(), subset_sequence(s.sequence(), mask));
+  return out;
+}
+
 MSA read_fasta(const std::string& path) {
   Fasta_Stream in(path);
   MSA out;

@@ -101,7 +101,21 @@ int main(int argc, char** argv) {
     if (!tf) throw std::runtime_error{"file_check failed: " + tree_file};
     std::stringstream ss;
     ss << tf.rdbuf();
-    const MSA ref = read_fasta(ref_file);
+    MSA ref = read_fasta(ref_file);
+    // "Peeking into MSA files and generating masks" (src/main.cpp:468-494): columns that are all-gap in
+    // the reference or in the whole query file leave both alignments (unless --no-pre-mask)
+    MSA_Info ref_info(ref), qry_info = MSA_Info::from_file(query_file);
+    if (ref_info.sites() != qry_info.sites()) {
+      std::cerr << "The reference and query alignment files do not seem to have the same alignment width! ("
+                << ref_info.sites() << " vs. " << qry_info.sites() << "). Are the query sequences not aligned?\n";
+      return 1;
+    }
+    MSA_Info::or_mask(ref_info, qry_info);
+    if (opt.premasking && ref_info.gap_count() > 0) {
+      std::cout << "Premasking: " << ref_info.gap_count() << " of " << ref_info.sites()
+                << " columns are gaps in the whole reference or the whole query alignment and are removed." << std::endl;
+      ref = subset_msa(ref, ref_info.gap_mask());
+    }
     {  // --model may name a RAxML 8 info / RAxML-NG .bestModel / IQ-TREE report file (src/main.cpp:433-436)
       std::ifstream mf(model_desc);
       if (mf.good()) model_desc = parse_model(model_desc);
@@ -116,7 +130,7 @@ int main(int argc, char** argv) {
                 << std::endl;
     const double secs_tree = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tree).count();
     if (devices.empty()) devices.push_back(device);
-    const Run_Stats st = simple_mpi(tree, query_file, outdir, opt, invocation, devices);
+    const Run_Stats st = simple_mpi(tree, query_file, qry_info, outdir, opt, invocation, devices);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
     std::cout << "Reference tree log-likelihood: " << st.ref_tree_logl << "\n";
     std::cout << st.queries << " Sequences done! (" << st.pairs << " thorough pairs)\n"

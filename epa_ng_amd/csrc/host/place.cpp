@@ -468,7 +468,15 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
 // does not depend on the number of devices.
 Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std::string& outdir,
                      const Options& options, const std::string& invocation, const std::vector<int>& devices) {
+  return simple_mpi(tree, query_file, MSA_Info{}, outdir, options, invocation, devices);
+}
+
+Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_Info& msa_info,
+                     const std::string& outdir, const Options& options, const std::string& invocation,
+                     const std::vector<int>& devices) {
   using clk = std::chrono::steady_clock;
+  // premasking: masked columns are dropped from every query as it is read (src/seq/MSA_Stream.cpp:26)
+  const bool premask = options.premasking && msa_info.gap_count() > 0;
   if (devices.empty()) throw std::runtime_error{"no device given"};
   Run_Stats st;
   configure_host_threads();
@@ -497,6 +505,7 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std:
         reader.read_next(s.chunk, options.chunk_size);
         const double rd = std::chrono::duration<double>(clk::now() - r0).count();
         if (s.chunk.empty()) break;
+        if (premask) s.chunk = subset_msa(s.chunk, msa_info.gap_mask());
         s.index = index++;
         s.offset = offset;
         offset += s.chunk.size();

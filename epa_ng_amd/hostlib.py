@@ -243,6 +243,18 @@ def parse_model(path):
     return buf.value.decode()
 
 
+def premask(ref_file, query_file):
+    """column mask of the reference's premasking (1 = all-gap in the reference or in the query file)"""
+    lib = host_lib()
+    lib.epa_host_premask.restype = C.c_long
+    buf = np.zeros(1 << 24, np.uint8)
+    n = lib.epa_host_premask(str(ref_file).encode(), str(query_file).encode(),
+                             buf.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_size_t(buf.size))
+    if n < 0:
+        raise RuntimeError(lib.epa_host_last_error().decode())
+    return buf[:n].copy()
+
+
 def heuristic(lnl, mode="dynamic", thresh=0.99999):
     lnl = np.ascontiguousarray(lnl, np.float64)
     Q, B = lnl.shape

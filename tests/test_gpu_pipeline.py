@@ -157,6 +157,74 @@ def test_cli_binary_matches_golden(tmp_path):
             assert abs(lnl - g["thorough"][qi][edge]["lnl"]) < 1e-6
 
 
+def test_cli_premasking_removes_all_gap_columns(tmp_path):
+    """or_mask premasking of the reference front end (src/main.cpp:470-494, src/seq/MSA_Info.hpp:75-82,
+    src/seq/MSA_Stream.cpp:26): a column that is all-gap in the reference file, or in the whole query
+    file, is cut out of both alignments.  Files with such columns inserted must give the placements
+    of the files without them (same edges, lnL, lengths); --no-pre-mask keeps the columns, and the
+    reference-gap column (where the queries do carry characters) then shifts every lnL."""
+    import subprocess
+    g = load_case("dna8_gtr_fu_g4")
+    data = os.path.join(GOLDEN, "data")
+    ref = []
+    name = None
+    for line in open(os.path.join(data, "aln.fasta")):
+        line = line.strip()
+        if line.startswith(">"):
+            name = line[1:]
+            ref.append([name, ""])
+        elif line:
+            ref[-1][1] += line
+    rng = np.random.RandomState(5)
+
+    def insert(seq, cols):   # cols: ascending list of (position in the ORIGINAL numbering, char)
+        out, last = [], 0
+        for pos, ch in cols:
+            out.append(seq[last:pos])
+            out.append(ch)
+            last = pos
+        out.append(seq[last:])
+        return "".join(out)
+
+    pos_refgap, pos_qrygap = 7, 123
+    def write(dirp, padded):
+        os.makedirs(dirp, exist_ok=True)
+        with open(os.path.join(dirp, "r.fasta"), "w") as f:
+            for n, s in ref:
+                if padded:   # column A: gap in every reference row; column B: a real character
+                    s = insert(s, [(pos_refgap, "-"), (pos_qrygap, "ACGT"[rng.randint(4)])])
+                f.write(">%s\n%s\n" % (n, s))
+        with open(os.path.join(dirp, "q.fasta"), "w") as f:
+            for q in g["queries"]:
+                s = q["seq"]
+                if padded:   # column A: the queries carry a character; column B: gap in every query
+                    s = insert(s, [(pos_refgap, "A"), (pos_qrygap, "-")])
+                f.write(">%s\n%s\n" % (q["name"], s))
+
+    exe = hostlib.cli_exe()
+    model = ("GTR{0.787874/1.821672/1.294006/0.698421/3.034135/1.0}+FU{0.256465/0.222535/0.308594/"
+             "0.212406}+G4{0.478218}")
+
+    def run(dirp, *extra):
+        r = subprocess.run([exe, "-t", os.path.join(data, "ref.tre"), "-s", os.path.join(dirp, "r.fasta"),
+                            "-q", os.path.join(dirp, "q.fasta"), "-m", model, "-w", dirp, "--filter-max", "13",
+                            "--filter-min-lwr", "0"] + list(extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return json.load(open(os.path.join(dirp, "epa_result.jplace")))["placements"], r.stdout
+
+    base, _ = run(str(tmp_path / "base"), *(write(str(tmp_path / "base"), False) or ()))
+    padded, out = run(str(tmp_path / "pad"), *(write(str(tmp_path / "pad"), True) or ()))
+    assert "Premasking: " in out
+    assert len(base) == len(padded) == len(g["queries"])
+    for a, b in zip(base, padded):
+        assert a["n"] == b["n"] and len(a["p"]) == len(b["p"])
+        for x, y in zip(a["p"], b["p"]):
+            assert x[0] == y[0] and abs(x[1] - y[1]) < 1e-9 and abs(x[3] - y[3]) < 1e-9 and abs(x[4] - y[4]) < 1e-9
+    nomask, _ = run(str(tmp_path / "pad"), "--no-pre-mask")
+    d = [x[1] - y[1] for a, b in zip(base, nomask) for x, y in zip(a["p"], b["p"]) if x[0] == y[0]]
+    assert d and min(abs(v) for v in d) > 0.1     # log(pi_A) and the extra reference column
+
+
 def test_edge_cases_single_query_unsorted_pairs_many_branches():
     # B > 1024 exercises the 32-values-per-lane selection kernel; Q = 1; pairs in arbitrary order
     w = synth.dna_workload(600, 200, 3, 120, (81, 82, 83))
@@ -901,6 +969,12 @@ def test_cli_named_models_rate_scalers_raxml_blo(tmp_path, states, model, flags,
     assert r.returncode == 0, r.stdout + r.stderr
     jp = json.load(open(tmp_path / "epa_result.jplace"))
     assert len(jp["placements"]) == len(reads)
+    # the executable premasks like the reference's front end (columns that are gaps in all of the
+    # reference or in all of the 60 reads are cut out of both): the same columns for the API calls
+    keep = hostlib.premask(aln, qf) == 0
+    assert 0 < keep.sum() <= 200
+    cut = lambda s: "".join(np.array(list(s))[keep])   # noqa: E731
+    seqs, reads = [cut(s) for s in seqs], [cut(s) for s in reads]
     ref = hostlib.Reference(nw, labels, seqs, model=model)
     assert ref.s == states
     ev = ref.evaluator(**kw)

@@ -571,3 +571,21 @@ def test_compact_read_generator_equals_ascii_reads_encoded():
         c2, b2, s2 = synth.make_reads_compact(seqs, 500, rl, 0.03, 17, states=states)
         assert np.array_equal(wb, b2) and np.array_equal(ws, s2) and np.array_equal(codes, c2)
         assert synth.compact_to_ascii(c2, b2, s2, W, states) == list(reads)
+
+
+def test_premasking_column_mask(tmp_path):
+    """MSA_Info + or_mask (src/seq/MSA_Info.hpp:22-82, src/main.cpp:470-490): a column is masked when
+    it is a gap (N O X . - ?, either case: genesis' gap_sites default) in every reference sequence OR
+    in every query sequence; unequal widths are an error."""
+    ref = [("a", "AC-GTN-A"), ("b", "AC-GTx-A"), ("c", "ACNGT?-C")]
+    qry = [("q1", "A--GT-CA"), ("q2", "-C-GT--n"), ("q3", "-.-GT---")]
+    rf, qf = tmp_path / "r.fasta", tmp_path / "q.fasta"
+    rf.write_text("".join(">%s\n%s\n" % x for x in ref))
+    qf.write_text("".join(">%s\n%s\n" % x for x in qry))
+    m = hostlib.premask(rf, qf)
+    #            A C - G T N - A      ref all-gap: col 2 (-,-,N), 5 (N,x,?), 6 (-)
+    #            query all-gap: col 2, 5 (-,-,-) -- col 6 has a C, col 7 (A,n,-) has an A
+    assert m.tolist() == [0, 0, 1, 0, 0, 1, 1, 0]
+    qf.write_text(">q1\nACGT\n")
+    with pytest.raises(RuntimeError, match="unequal site width"):
+        hostlib.premask(rf, qf)
