@@ -89,6 +89,10 @@ class AsyncResultGather:
             buf[:n, 0] = pairs_i32[:n].contiguous().view(torch.int64).view(torch.float64).reshape(-1).to(self.cdev)
             buf[:n, 1:4] = results_f64[:n].to(self.cdev)
         buf[m, 0] = float(n)
+        if self.cdev.type == "cuda":
+            # the caller's buffers are rewritten by the next chunk's kernels on the library's own HIP
+            # stream, which knows nothing of torch's: the staging copy above has to be complete first
+            torch.cuda.current_stream().synchronize()
         out = [r[:m + 1] for r in self.recv[slot]] if self.rank == self.dst else None
         self.work[slot] = self.dist.gather(buf[:m + 1], out, dst=self.dst, async_op=True)
         self.rows[slot] = m
