@@ -30,6 +30,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -267,7 +268,7 @@ __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, 
   return NAN;
 }
 
-template <int NCH, bool ZERO0, bool INV, int NW>
+template <int NCH, bool ZERO0, bool INV, int NW, bool LOCAL>
 __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pidx, const int lane,
                                              double* tab, const double* qts, const LaneConst& lc,
                                              Comb<NW>& cb, uint32_t (&wstat)[3]) {
@@ -351,9 +352,11 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
     return window_lnl<NCH, ZERO0, NW>(st, ew, cb, lane);
   };
-  // inner CLV toward distal: I' = (P_pend q) o (P_prox X); S = Dt o (U^-1 I')
-  auto distal_sumtable = [&](double tp_, double tx_) {
-    table_publish(tab, lane, exp(lc.lr * (lc.slot == 0 ? tp_ : tx_)));
+  // inner CLV toward distal: I' = (P_pend q) o (P_prox X); S = Dt o (U^-1 I').  TOWARD_PROX (the
+  // --raxml-blo loop only): the same toward the proximal node, I' = (P_pend q) o (P_dist D), S = Xt o ...
+  auto side_sumtable = [&](double tp_, double tother_, auto toward_prox) {
+    constexpr bool TOWARD_PROX = decltype(toward_prox)::value;
+    table_publish(tab, lane, exp(lc.lr * (lc.slot == 0 ? tp_ : tother_)));
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const uint32_t s = (st.valid[ch] ? site0 + ch * 64 + lane : 0) * 8u + chain;
@@ -368,14 +371,15 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
       for (int c = 0; c < 16; ++c) { X[c] = ldX(c, s); D[c] = ldD(c, s); }
       asm volatile("" ::: "memory");  // issue the whole batch up front (see score)
       uint32_t r;
-      inner_site(m, Qv, tab, X, tab + 16, It, r);
+      inner_site(m, Qv, tab, TOWARD_PROX ? D : X, tab + 16, It, r);
 #pragma unroll
-      for (int c = 0; c < 16; ++c) st.S[ch][c] = D[c] * It[c];
+      for (int c = 0; c < 16; ++c) st.S[ch][c] = (TOWARD_PROX ? X[c] : D[c]) * It[c];
       if constexpr (INV) st.S[ch][0] += cinv_of(ch);
       fold0(ch);
       chain = zero_after(st.S[ch][15]);
     }
   };
+  auto distal_sumtable = [&](double tp_, double tx_) { side_sumtable(tp_, tx_, std::false_type{}); };
 
   // Initial score at the starting lengths (orig/2, orig/2, default pendant): the inner CLV does
   // not depend on the query, k_build_lookup stored its U^-1 image per (branch, site) -> 16 loads
@@ -416,7 +420,42 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   double loglikelihood = a.refI ? -score_first(tp) : -score(td, tx, tp);
 
   uint32_t smoothings = a.blo.max_rounds;
-  while (smoothings) {
+  if constexpr (LOCAL) {
+    // --raxml-blo: pllmod_opt_optimize_branch_lengths_local(radius 1, keep_update 1) on the triplet
+    // (optimize.cpp:274-279; pll-modules source absent: restated in oracle/epa_oracle.c opt_local).
+    // Per smoothing round: NR on the pendant edge, on the distal edge (inner CLV re-aimed at it), on
+    // the proximal edge (with the new distal length), the inner CLV re-aimed at the query, NR on the
+    // pendant edge once more, then the edge lnL from the sumtable in registers.  The three lengths
+    // are independent (no sliding): the result rescales distal by orig / (distal + proximal).
+    const double xmin = a.blo.min_branch, xmax = a.blo.max_branch, xtol = xmin / 10.0;
+    auto solve = [&](double cur) -> double {
+      double g = cur;
+      if (g < xmin || g > xmax) g = a.blo.default_branch;
+      const double r = newton<NCH, ZERO0, NW>(st, tab, lane, lc, cb, xmin, g, xmax, xtol, (int)a.blo.max_newton, evals);
+      chain = zero_after(r);
+      // keep_update: the length is replaced when the solver moved it
+      return (isfinite(r) && fabs(cur - r) > 1e-10) ? r : cur;
+    };
+    while (smoothings) {
+      tp = solve(tp);
+      side_sumtable(tp, tx, std::false_type{});
+      td = solve(td);
+      side_sumtable(tp, td, std::true_type{});
+      tx = solve(tx);
+      (void)score(td, tx, tp);   // inner CLV back toward the query + the pendant sumtable
+      tp = solve(tp);
+      table_publish(tab, lane, exp(lc.lr * tp) * (lc.slot == 2 ? lc.w : 1.0));
+      double ew[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
+      const double new_ll = -window_lnl<NCH, ZERO0, NW>(st, ew, cb, lane);
+      ++rounds;
+      --smoothings;
+      if (fabs(new_ll - loglikelihood) < a.blo.epsilon) smoothings = 0;
+      loglikelihood = new_ll;
+    }
+  }
+  while (!LOCAL && smoothings) {
     const double old_td = td, old_tp = tp;
     // ---- NR for the pendant length (optimize.cpp:135-166); S already holds the pendant sumtable
     double xmin = a.blo.min_branch, xmax = a.blo.max_branch, xtol = xmin / 10.0;
@@ -473,7 +512,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 // and every wave gets a ~25-pair random sample of the 10x cost spread (1..32 NR rounds).
 // INV: the model has +I (instantiated for ZERO0 only; a separate instantiation so that the
 // default kernel's register allocation is untouched: the runtime-flag version cost 40 more spills)
-template <int NCH, bool ZERO0, bool INV, int NW>
+template <int NCH, bool ZERO0, bool INV, int NW, bool LOCAL = false>
 __global__ void __launch_bounds__(64 * NW, 2) k_thorough_dna(const ThArgs a) {
   __shared__ double tab[64 * NW];  // broadcast table of each wave
   __shared__ double qts[64];       // U^-1 image of the 16 query column codes
@@ -511,14 +550,14 @@ __global__ void __launch_bounds__(64 * NW, 2) k_thorough_dna(const ThArgs a) {
         const uint32_t cur = nxt;
         uint32_t f = 0;
         if (lane == 0) f = atomicAdd(ctr, 1u);
-        process_pair<NCH, ZERO0, INV, NW>(a, lo + cur, lane, tab + cb.wv * 64, qts, lc, cb, wstat);
+        process_pair<NCH, ZERO0, INV, NW, LOCAL>(a, lo + cur, lane, tab + cb.wv * 64, qts, lc, cb, wstat);
         nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
       }
     }
   }
   if (!queued)
     for (uint64_t p = lo + w; p < hi; p += stride)
-      process_pair<NCH, ZERO0, INV, NW>(a, p, lane, tab + cb.wv * 64, qts, lc, cb, wstat);
+      process_pair<NCH, ZERO0, INV, NW, LOCAL>(a, p, lane, tab + cb.wv * 64, qts, lc, cb, wstat);
   if (threadIdx.x == 0) {
     atomicAdd(&a.stats[0], (unsigned long long)wstat[0]);
     atomicAdd(&a.stats[1], (unsigned long long)wstat[1]);
@@ -797,7 +836,8 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
     }                                                                                              \
     if (want > n_pairs) want = n_pairs;                                                            \
     const uint32_t nwg = (uint32_t)((want + 7) / 8 * 8);                                           \
-    if (a.cinv) hipLaunchKernelGGL((k_thorough_dna<N, true, true, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
+    if (!ctx->blo.sliding) hipLaunchKernelGGL((k_thorough_dna<N, true, false, NW_, true>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
+    else if (a.cinv) hipLaunchKernelGGL((k_thorough_dna<N, true, true, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
     else if (ctx->dna_zero0) hipLaunchKernelGGL((k_thorough_dna<N, true, false, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
     else hipLaunchKernelGGL((k_thorough_dna<N, false, false, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
   } while (0)
@@ -829,7 +869,9 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
                     const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
                     epa_result* d_out, unsigned long long* d_stats) {
   if (n_pairs > 0xffffffffull) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "thorough: more than 2^32 pairs per call");
-  if (ctx->generic_thorough) {  // any category count, per-rate scalers, --raxml-blo
+  // any category count, Newton variants, --raxml-blo outside the tuned instantiation (20 states, +I,
+  // windows beyond the multi-wave classes)
+  if (ctx->generic_thorough || (!ctx->blo.sliding && max_span > 1536)) {
     ctx->cls_hist_pairs = 0;
     return launch_thorough_generic(ctx, d_pairs, n_pairs, d_codes, d_begin, d_span, max_span, d_out, d_stats);
   }

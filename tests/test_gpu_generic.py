@@ -134,6 +134,35 @@ def test_raxml_blo_local_optimisation(states, rs):
     assert np.all(res["lnl"] >= sliding["lnl"] - 0.5)
 
 
+def test_raxml_blo_tuned_dna_kernel_equals_general_kernel(monkeypatch):
+    """--raxml-blo on nucleotide data runs on the LOCAL instantiation of k_thorough_dna (register
+    sumtable, 1 - 8 waves per pair); the general kernel (EPA_TH_GENERIC=1) is the cross-check.  Windows
+    of 20 ... 500 sites cover the single-wave and the multi-wave span classes."""
+    root = synth.random_tree(40, 61)
+    rates = synth.gamma_rates(0.5)
+    labels, seqs = synth.simulate_msa(root, 700, synth.CFG2_SUBST, synth.CFG2_FREQS, rates, 62)
+    nw = synth.newick(root)
+    reads = []
+    for k, rl in enumerate((20, 64, 150, 192, 300, 500)):
+        r, _ = synth.make_reads(seqs, 6, rl, 0.03, 63 + k, states=4)
+        reads += list(r)
+    ref = hostlib.Reference(nw, labels, seqs, states=4, subst=synth.CFG2_SUBST, freqs=synth.CFG2_FREQS, rates=rates)
+    o = Oracle(nw, labels, seqs, 4, synth.CFG2_SUBST, synth.CFG2_FREQS, rates)
+    o.set_raxml_blo(True)
+    ev = ref.evaluator(raxml_blo=True)
+    _, pairs, res = check_against_oracle(ev, o, reads, 4)
+    tuned_stats = dict(ev.last_stats)
+    monkeypatch.setenv("EPA_TH_GENERIC", "1")
+    evg = ref.evaluator(raxml_blo=True)
+    monkeypatch.delenv("EPA_TH_GENERIC")
+    codes, wb, ws = epa.encode_queries(4, reads, compact=True)
+    gen = evg.thorough(pairs, codes, wb, ws)
+    assert np.max(np.abs(gen["lnl"] - res["lnl"])) < 1e-8
+    assert np.max(np.abs(gen["pendant_length"] - res["pendant_length"])) < 1e-7
+    assert np.max(np.abs(gen["distal_length"] - res["distal_length"])) < 1e-7
+    assert evg.last_stats["rounds"] == tuned_stats["rounds"]
+
+
 @pytest.mark.parametrize("states,cats", [(4, 4), (20, 4), (4, 5)])
 def test_recollected_optimiser_constants_are_runtime_parameters(states, cats):
     """PLLMOD_OPT_MIN_BRANCH_LEN and the two variable details of pllmod_opt_minimize_newton are
