@@ -18,7 +18,11 @@
  *   - is pinned against an independent brute-force numpy/scipy evaluator (tests/gen_golden.py,
  *     scipy.linalg.expm on Q, whole-tree pruning with the query inserted) whose outputs are the
  *     committed fixtures tests/golden/*.json, and against the reference's own literal test
- *     vectors that do exist for this path (edge numbering: test/src/pll_util.cpp:134-143).
+ *     vectors that do exist for this path (edge numbering: test/src/pll_util.cpp:134-143);
+ *   - is anchored (edge numbers, winning edge, lnL to a few 1e-1 in 4400, lengths to a few 1e-3 --
+ *     not a 1e-6 pin) on the one program output the reference checkout holds for this path:
+ *     test/data/raxml_output.jplace, RAxML 8.2.4's EPA on the 10-taxon fixture
+ *     (tests/test_external_anchor.py, tests/fit_raxml_anchor.py).
  *
  * Layout conventions (libpll's): CLV [site][cat][state], P-matrix
  * [cat][from][to], scaler uint32[site].  DNA state order A,C,G,T; tip codes are state bitmasks.
