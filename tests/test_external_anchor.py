@@ -40,6 +40,8 @@ def check(name, exp, lnl, pendant, distal, lengths, local):
     assert e == exp["edge"], (name, e)
     assert abs(lnl[e] - exp["lnl"]) < LNL_TOL, (name, lnl[e])
     assert abs(pendant[e] - exp["pendant"]) < LEN_TOL[local], (name, pendant[e])
+    w = np.exp(lnl - lnl[e])
+    assert abs(1.0 / w.sum() - exp["lwr"]) < 1e-6      # like_weight_ratio 1.000000 in RAxML's six digits
     # RAxML measures the attachment point from the other end of the edge
     assert min(abs(distal[e] - exp["distal"]), abs(lengths[e] - distal[e] - exp["distal"])) < LEN_TOL[local], (name, distal[e])
     return e
