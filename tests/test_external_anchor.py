@@ -105,3 +105,30 @@ def test_device_reproduces_raxml_epa_placements(local):
         e = check(name, exp[name], res["lnl"][m], res["pendant_length"][m], res["distal_length"][m], lengths, local)
         # and the lookup-sum preplacement already ranks RAxML's edge first
         assert int(np.argmax(ev.preplace(codes, wb, ws)[qi])) == e
+
+
+@pytest.mark.gpu
+def test_cli_jplace_against_raxml_jplace(tmp_path):
+    """the same through the executable: tree + reference MSA + query file in, jplace out -- the file a
+    user would diff against RAxML's"""
+    import subprocess
+    from epa_ng_amd import hostlib
+    nw, labels, ref, queries, exp = expected()
+    (tmp_path / "ref.tre").write_text(nw + "\n")
+    (tmp_path / "ref.fasta").write_text("".join(">%s\n%s\n" % x for x in zip(labels, ref)))
+    (tmp_path / "q.fasta").write_text("".join(">%s\n%s\n" % x for x in queries.items()))
+    model = "GTR{%s}+FU{%s}+G4{%.8f}" % ("/".join("%.8f" % v for v in RATES), "/".join("%.8f" % v for v in FREQS), ALPHA)
+    r = subprocess.run([hostlib.cli_exe(), "-t", str(tmp_path / "ref.tre"), "-s", str(tmp_path / "ref.fasta"),
+                        "-q", str(tmp_path / "q.fasta"), "-m", model, "-w", str(tmp_path), "--raxml-blo"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    jp = json.load(open(tmp_path / "epa_result.jplace"))
+    assert jp["fields"] == ["edge_num", "likelihood", "like_weight_ratio", "distal_length", "pendant_length"]
+    theirs = json.load(open(os.path.join(DATA, "raxml_output.jplace")))
+    num = lambda t: re.findall(r"\{(\d+)\}", t)    # noqa: E731
+    assert num(jp["tree"]) == num(theirs["tree"])
+    got = {p["n"][0]: p["p"][0] for p in jp["placements"]}
+    for name, e in exp.items():
+        edge, lnl, lwr, distal, pendant = got[name]
+        assert edge == e["edge"] and abs(lnl - e["lnl"]) < LNL_TOL and abs(lwr - e["lwr"]) < 1e-6
+        assert abs(pendant - e["pendant"]) < LEN_TOL[True]
