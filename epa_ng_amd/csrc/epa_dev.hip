@@ -575,9 +575,10 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   ctx->rate_scalers = (d->flags & EPA_FLAG_RATE_SCALERS) != 0;
   // the tuned thorough kernels are built for 4 categories (the Newton-variant switches exist to pin
   // parity once a reference build is at hand, not for production runs: they are served by the general
-  // kernel too, the tuned kernels cost 1.7 % with them).  --raxml-blo has a tuned instantiation for
-  // nucleotide models without +I (k_thorough_dna<.., LOCAL>); everything else local goes general.
-  const bool tuned_local = s == 4 && ctx->dna_zero0 && !(pinv > 0.0);
+  // kernel too, the tuned kernels cost 1.7 % with them).  --raxml-blo has tuned instantiations for
+  // nucleotide models without +I (k_thorough_dna<.., LOCAL>) and for 20-state models
+  // (k_thorough_aa_mfma<.., LOCAL>); everything else local goes general.
+  const bool tuned_local = (s == 4 && ctx->dna_zero0 && !(pinv > 0.0)) || s == 20;
   ctx->generic_thorough = c != 4 || (!ctx->blo.sliding && !tuned_local) || ctx->blo.newton_variant != 0 ||
                           getenv("EPA_TH_GENERIC") != nullptr;   // (diagnostic switch: measure the general kernel)
 

@@ -133,7 +133,7 @@ __device__ __forceinline__ double rows_max(double v) {
   return v;
 }
 
-template <int NT, int NBLK>
+template <int NT, int NBLK, bool LOCAL = false>
 __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
   constexpr int NW = 4, NTHR = 64 * NW;
   __shared__ alignas(16) SharedM sh;
@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     bool valid[NT], tile_on[NT];
     double qv[NT][NTS];             // query tip vector in the eigenbasis, vector layout
     double Sm[NT][4][NTS];          // sumtable of the branch being optimised: [tile][category][reg]
+    bool resc_keep[NT];             // LOCAL: rescale flag of the last inner vector toward the query
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const uint32_t site = 16u * (uint32_t)(wv + NW * j) + (uint32_t)sl;
@@ -245,8 +246,10 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
 
     // mode 0: inner CLV toward the query from (distal, proximal), sumtable folded with the query,
     //         window lnL; mode 1: toward distal from (query, proximal), sumtable folded with the
-    //         distal vector; mode 2: as 0 from the per-branch precomputed inner CLV (refI).
+    //         distal vector; mode 2: as 0 from the per-branch precomputed inner CLV (refI); mode 3
+    //         (--raxml-blo only): the mirror image of 1, toward proximal from (query, distal).
     auto phase = [&](int mode, double& lnl_out) {
+      const bool side = mode == 1 || mode == 3;   // sumtable of a side branch: no window lnL
       double mant = 1.0;
       int ex = 0;
       const double* I0 = a.refI + (size_t)b * 80 * cW + begin;
@@ -267,19 +270,21 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
             for (int t = 0; t < NTS; ++t) Bn[t] = ldg_off(I0 + c0 + (size_t)(4 * t) * cW, lof);
             return;
           }
-          if (cat < nblk) {
+          const double* Pb = mode == 3 ? Dt : Xt;   // the side that goes through the matrix products
+          const double* Pf = mode == 3 ? Xt : Dt;   // the side the result is folded with (modes 1, 3) / the first factor (mode 0)
+          if (cat < nblk && mode != 3) {
 #pragma unroll
             for (int t = 0; t < NTS; ++t) Bn[t] = wc[(cat * NTS + t) * 64 + zf];
           } else {
 #pragma unroll
-            for (int t = 0; t < NTS; ++t) Bn[t] = ldg_off(Xt + c0 + (size_t)(4 * t) * cW, lof);
+            for (int t = 0; t < NTS; ++t) Bn[t] = ldg_off(Pb + c0 + (size_t)(4 * t) * cW, lof);
           }
-          if (4 + cat < nblk) {
+          if (4 + cat < nblk && mode != 3) {
 #pragma unroll
             for (int t = 0; t < NTS; ++t) Dn[t] = wc[((4 + cat) * NTS + t) * 64 + zf];
           } else {
 #pragma unroll
-            for (int t = 0; t < NTS; ++t) Dn[t] = ldg_off(Dt + c0 + (size_t)(4 * t) * cW, lof);
+            for (int t = 0; t < NTS; ++t) Dn[t] = ldg_off(Pf + c0 + (size_t)(4 * t) * cW, lof);
           }
         };
         fetch(0, zero_after(mant));
@@ -342,12 +347,12 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
             }
           }
           double e2[NTS];
-          if (mode != 1) lds5(&sh.tab[2][tp5 + zt], e2);
+          if (!side) lds5(&sh.tab[2][tp5 + zt], e2);
 #pragma unroll
           for (int t = 0; t < NTS; ++t) {
-            const double sv = It[t] * (mode == 1 ? Dv[t] : qv[j][t]);
+            const double sv = It[t] * (side ? Dv[t] : qv[j][t]);
             Sm[j][cat][t] = sv;
-            if (mode != 1) l0 = fma(sv, e2[t], l0);
+            if (!side) l0 = fma(sv, e2[t], l0);
           }
         }
         // pll_update_partials per-site scaling: ALL 80 entries of the site below 2^-256
@@ -369,9 +374,10 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
         if (a.cinv && kq == 0) {
           const double add = a.cinv[begin + s] * a.inv_w0;
           Sm[j][0][0] += add;
-          if (mode != 1) l0 = fma(add, sh.tab[2][0], l0);
+          if (!side) l0 = fma(add, sh.tab[2][0], l0);
         }
-        if (mode != 1) {
+        if (LOCAL && !side) resc_keep[j] = resc;
+        if (!side) {
           double ls = rows_sum(l0);
           const bool mine = valid[j] && kq == 0;
           if (!mine) ls = 1.0;
@@ -380,7 +386,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
           ex += __builtin_amdgcn_frexp_exp(ls) - 256 * sc;
         }
       }
-      if (mode != 1) {
+      if (!side) {
         const double tot = wave_sum(log(mant) + (double)ex * LOG_2);
         if (lane == 0) sh.bc[16 + wv] = tot;
         __syncthreads();   // also: every wave is past its last table read
@@ -467,6 +473,36 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
 
     double tp = a.blo.pendant_default, td = orig * 0.5, tx = orig * 0.5;
     uint32_t rounds = 0, reverted = 0;
+    // window lnL at the pendant length of table slot 2 from the sumtable in registers (LOCAL only:
+    // the edge lnL after the last pendant solve of a round)
+    auto lnl_from_sumtable = [&](double& lnl_out) {
+      double mant = 1.0;
+      int ex = 0;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (!tile_on[j]) continue;
+        double l0 = 0.0;
+        const int zt = zero_after(mant);
+#pragma unroll
+        for (int cat = 0; cat < 4; ++cat) {
+          double e2[NTS];
+          lds5(&sh.tab[2][(cat * 4 + kq) * 6 + zt], e2);
+#pragma unroll
+          for (int t = 0; t < NTS; ++t) l0 = fma(Sm[j][cat][t], e2[t], l0);
+        }
+        double ls = rows_sum(l0);
+        const bool mine = valid[j] && kq == 0;
+        if (!mine) ls = 1.0;
+        const int sc = mine ? (int)(scp[sscl[j]] + (resc_keep[j] ? 1u : 0u)) : 0;
+        mant *= __builtin_amdgcn_frexp_mant(ls);
+        ex += __builtin_amdgcn_frexp_exp(ls) - 256 * sc;
+      }
+      const double tot = wave_sum(log(mant) + (double)ex * LOG_2);
+      if (lane == 0) sh.bc[16 + wv] = tot;
+      __syncthreads();   // also: every wave is past its last table read
+      lnl_out = (sh.bc[16] + sh.bc[17]) + (sh.bc[18] + sh.bc[19]);
+    };
+
     double lnl_now = 0.0;
 #ifdef AAM_PROFILE
 #define AAM_T0 const long long t0_ = clock64();
@@ -479,7 +515,40 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     if (a.refI) phase(2, lnl_now); else phase(0, lnl_now);
     double loglikelihood = -lnl_now;
     uint32_t smoothings = a.blo.max_rounds;
-    while (smoothings) {
+    if constexpr (LOCAL) {
+      // --raxml-blo: pllmod_opt_optimize_branch_lengths_local(radius 1, keep_update 1) on the triplet
+      // (optimize.cpp:274-279; restated in oracle/epa_oracle.c opt_local): NR on the pendant edge, on
+      // the distal edge (inner vector re-aimed at it), on the proximal edge (with the new distal
+      // length), the inner vector re-aimed at the query, NR on the pendant edge once more, edge lnL.
+      const double xmin = a.blo.min_branch, xmax = a.blo.max_branch, xtol = xmin / 10.0;
+      auto solve = [&](double cur) -> double {
+        double g = cur;
+        if (g < xmin || g > xmax) g = a.blo.default_branch;
+        const double r = newton(xmin, g, xmax, xtol, (int)a.blo.max_newton);
+        return (isfinite(r) && fabs(cur - r) > 1e-10) ? r : cur;   // keep_update
+      };
+      double dummy;
+      while (smoothings) {
+        tp = solve(tp);
+        publish(tp, tx, tp);
+        phase(1, dummy);
+        td = solve(td);
+        publish(tp, td, tp);
+        phase(3, dummy);
+        tx = solve(tx);
+        publish(td, tx, tp);
+        phase(0, lnl_now);
+        tp = solve(tp);
+        publish(td, tx, tp);
+        lnl_from_sumtable(lnl_now);
+        const double new_ll = -lnl_now;
+        ++rounds;
+        --smoothings;
+        if (fabs(new_ll - loglikelihood) < a.blo.epsilon) smoothings = 0;
+        loglikelihood = new_ll;
+      }
+    }
+    while (!LOCAL && smoothings) {
       const double old_td = td, old_tp = tp;
       double xmin = a.blo.min_branch, xmax = a.blo.max_branch, xtol = xmin / 10.0;
       double xguess = tp;
@@ -594,6 +663,14 @@ int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_
   // LDS window cache: two workgroups share the CU's 160 KB; whole (side, category) blocks only:
   // tiles -> blocks that fit in 80 KB - sizeof(SharedM): <= 4 -> 7, 5 -> 5, 6..7 -> 4, 8..9 -> 3, 10..12 -> 2
   const uint32_t tiles = (max_span + 15) / 16;
+  if (!ctx->blo.sliding) {   // --raxml-blo
+    const uint32_t tl = (max_span + 15) / 16;
+    if (tl <= 4) hipLaunchKernelGGL((k_thorough_aa_mfma<1, 0, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
+    else if (tl <= 8) hipLaunchKernelGGL((k_thorough_aa_mfma<2, 0, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_thorough_aa_mfma<3, 0, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
+    EPA_HIP(ctx, hipGetLastError());
+    return EPA_OK;
+  }
   auto go = [&](auto kern, uint32_t nblk) {
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), (size_t)nblk * tiles * NTS * 64 * 8, ctx->stream, a);
   };

@@ -871,7 +871,7 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
   if (n_pairs > 0xffffffffull) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "thorough: more than 2^32 pairs per call");
   // any category count, Newton variants, --raxml-blo outside the tuned instantiation (20 states, +I,
   // windows beyond the multi-wave classes)
-  if (ctx->generic_thorough || (!ctx->blo.sliding && max_span > 1536)) {
+  if (ctx->generic_thorough || (!ctx->blo.sliding && max_span > (ctx->s == 4 ? 1536u : 192u))) {
     ctx->cls_hist_pairs = 0;
     return launch_thorough_generic(ctx, d_pairs, n_pairs, d_codes, d_begin, d_span, max_span, d_out, d_stats);
   }

@@ -134,28 +134,31 @@ def test_raxml_blo_local_optimisation(states, rs):
     assert np.all(res["lnl"] >= sliding["lnl"] - 0.5)
 
 
-def test_raxml_blo_tuned_dna_kernel_equals_general_kernel(monkeypatch):
-    """--raxml-blo on nucleotide data runs on the LOCAL instantiation of k_thorough_dna (register
-    sumtable, 1 - 8 waves per pair); the general kernel (EPA_TH_GENERIC=1) is the cross-check.  Windows
-    of 20 ... 500 sites cover the single-wave and the multi-wave span classes."""
+@pytest.mark.parametrize("states,pinv", [(4, 0.0), (20, 0.0), (20, 0.2)])
+def test_raxml_blo_tuned_kernels_equal_general_kernel(monkeypatch, states, pinv):
+    """--raxml-blo runs on the LOCAL instantiations of k_thorough_dna (register sumtable, 1 - 8 waves per
+    pair) and k_thorough_aa_mfma (windows up to 192 sites; +I included); the general kernel
+    (EPA_TH_GENERIC=1) is the cross-check.  The window lengths cover every span class of the tuned
+    kernels and, for 20 states, the hand-over to the general kernel beyond 192 sites."""
     root = synth.random_tree(40, 61)
     rates = synth.gamma_rates(0.5)
-    labels, seqs = synth.simulate_msa(root, 700, synth.CFG2_SUBST, synth.CFG2_FREQS, rates, 62)
+    subst, freqs = (synth.CFG2_SUBST, synth.CFG2_FREQS) if states == 4 else synth.aa_model(17)
+    labels, seqs = synth.simulate_msa(root, 700, subst, freqs, rates, 62)
     nw = synth.newick(root)
     reads = []
-    for k, rl in enumerate((20, 64, 150, 192, 300, 500)):
-        r, _ = synth.make_reads(seqs, 6, rl, 0.03, 63 + k, states=4)
+    for k, rl in enumerate((20, 64, 150, 192, 300, 500) if states == 4 else (20, 64, 100, 128, 160, 192)):
+        r, _ = synth.make_reads(seqs, 6, rl, 0.03, 63 + k, states=states)
         reads += list(r)
-    ref = hostlib.Reference(nw, labels, seqs, states=4, subst=synth.CFG2_SUBST, freqs=synth.CFG2_FREQS, rates=rates)
-    o = Oracle(nw, labels, seqs, 4, synth.CFG2_SUBST, synth.CFG2_FREQS, rates)
+    ref = hostlib.Reference(nw, labels, seqs, states=states, subst=subst, freqs=freqs, rates=rates, pinv=pinv)
+    o = Oracle(nw, labels, seqs, states, subst, freqs, rates, pinv=pinv)
     o.set_raxml_blo(True)
     ev = ref.evaluator(raxml_blo=True)
-    _, pairs, res = check_against_oracle(ev, o, reads, 4)
+    _, pairs, res = check_against_oracle(ev, o, reads, states)
     tuned_stats = dict(ev.last_stats)
     monkeypatch.setenv("EPA_TH_GENERIC", "1")
     evg = ref.evaluator(raxml_blo=True)
     monkeypatch.delenv("EPA_TH_GENERIC")
-    codes, wb, ws = epa.encode_queries(4, reads, compact=True)
+    codes, wb, ws = epa.encode_queries(states, reads, compact=True)
     gen = evg.thorough(pairs, codes, wb, ws)
     assert np.max(np.abs(gen["lnl"] - res["lnl"])) < 1e-8
     assert np.max(np.abs(gen["pendant_length"] - res["pendant_length"])) < 1e-7
