@@ -133,6 +133,69 @@ __device__ __forceinline__ void inner_site(const ModelDNA& m, const double (&A)[
     }
 }
 
+// ---- "tail half-chunk" (TAILH instantiations): the last 64-lane chunk of a window that ends within
+// 32 sites of a chunk boundary (150-site reads: 64 + 64 + 22) is laid out as lane = (site, half) --
+// lanes 0..31 carry categories 0, 1 of sites 0..31 of the chunk, lanes 32..63 categories 2, 3 of the
+// SAME sites -- so the chunk costs half the loads and products of a full one.  What has to see all
+// four categories (the rescale test, the site likelihood, l0 / l1 / l2 of a Newton evaluation) is
+// combined across the halves with v_permlane32_swap.
+__device__ __forceinline__ double xhalf_add(double v) {   // v[l] + v[l ^ 32], in every lane
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+// lanes 0..31: x[l] + x[l + 32];  lanes 32..63: y[l - 32] + y[l]
+__device__ __forceinline__ double xhalf_add2(double x, double y) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double xhalf_max(double v) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return fmax(__hiloint2double(hi[0], lo[0]), __hiloint2double(hi[1], lo[1]));
+}
+// inner_site for the two categories of a half: A, Bv, It hold [kk][x], kk = 0, 1 (category 2 h + kk);
+// ea / eb point at this half's table entries.  Returns the rescale flag of the SITE (both halves).
+__device__ __forceinline__ uint32_t inner_site_half(const ModelDNA& m, const double (&A)[8], const double* ea,
+                                                    const double (&Bv)[8], const double* eb, double (&It)[8]) {
+  double I[8];
+  double mx = 0.0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    double av[4], bv[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      av[x] = A[k * 4 + x] * ea[k * 4 + x];
+      bv[x] = Bv[k * 4 + x] * eb[k * 4 + x];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double a = m.U[i * 4] * av[0], b = m.U[i * 4] * bv[0];
+#pragma unroll
+      for (int x = 1; x < 4; ++x) {
+        a = fma(m.U[i * 4 + x], av[x], a);
+        b = fma(m.U[i * 4 + x], bv[x], b);
+      }
+      const double v = a * b;
+      I[k * 4 + i] = v;
+      mx = fmax(mx, v);
+    }
+  }
+  const uint32_t resc = (xhalf_max(mx) < 0x1p-256) ? 1u : 0u;   // all 16 entries of the site
+  const double mult = resc ? 0x1p+256 : 1.0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      double acc = m.Ui[x * 4] * I[k * 4];
+#pragma unroll
+      for (int i = 1; i < 4; ++i) acc = fma(m.Ui[x * 4 + i], I[k * 4 + i], acc);
+      It[k * 4 + x] = acc * mult;
+    }
+  return resc;
+}
+
 template <int NCH>
 struct SiteState {
   double S[NCH][16];   // sumtable of the branch currently being optimised.  ZERO0: entry [0] holds
@@ -172,7 +235,7 @@ struct Comb {
 // ZERO0: eigenvalue 0 is exactly 0 (stationary mode) -> its e1/e2 columns vanish.
 // Then  f = sum_sites -l1/l0,  f' = sum_sites (l1/l0)^2 - l2/l0   (pll_compute_likelihood_
 // derivatives): 40 (48) FMAs per site.
-template <int NCH, bool ZERO0, int NW>
+template <int NCH, bool ZERO0, int NW, bool TAILH = false>
 __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* tab, int lane,
                                             const LaneConst& lc, Comb<NW>& cb, double t, double& f,
                                             double& df) {
@@ -185,6 +248,26 @@ __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* ta
   double fl = 0.0, dfl = 0.0;
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
+    if (TAILH && ch == NCH - 1) {
+      // half-chunk: 8 sumtable entries per lane against this half's table entries; l0 is needed
+      // in both halves, l1 lands in the lower and l2 in the upper one
+      const double* th = tab + ((lane >> 5) << 3);
+      double l0 = ZERO0 ? st.S[ch][0] : 0.0, l1 = 0.0, l2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (!(ZERO0 && (i & 3) == 0)) {
+          l0 = fma(st.S[ch][i], th[i], l0);
+          l1 = fma(st.S[ch][i], th[16 + i], l1);
+          l2 = fma(st.S[ch][i], th[32 + i], l2);
+        }
+      }
+      l0 = xhalf_add(l0);
+      const double l12 = xhalf_add2(l1, l2);
+      const double qv = -l12 * fast_rcp(l0);   // lower half: -l1 / l0 = d1;  upper half: -l2 / l0
+      const bool lower = lane < 32;
+      if (st.valid[ch]) { fl += lower ? qv : 0.0; dfl += lower ? qv * qv : qv; }
+      continue;
+    }
     double l0 = ZERO0 ? st.S[ch][0] : 0.0, l1 = 0.0, l2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -208,19 +291,29 @@ __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* ta
 // and exponent (v_frexp_*), mantissas multiplied, exponents and scaler counts added as integers:
 //   sum_ch log(L_ch) + sc_ch log 2^-256  =  log(prod mant) + ln2 * (sum exp - 256 sum sc)
 // -> ONE log() per lane instead of NCH.
-template <int NCH, bool ZERO0, int NW>
+template <int NCH, bool ZERO0, int NW, bool TAILH = false>
 __device__ __forceinline__ double window_lnl(const SiteState<NCH>& st, const double (&ew)[16], Comb<NW>& cb,
-                                             int lane) {
+                                             int lane, const double* tab = nullptr) {
   double mant = 1.0;
   int ex = 0;
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     double l0 = ZERO0 ? st.S[ch][0] : 0.0;
+    bool mine = st.valid[ch];
+    if (TAILH && ch == NCH - 1) {   // half-chunk: this half's two categories, then both halves
+      const double* ewh = tab + 32 + ((lane >> 5) << 3);
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-      if (!(ZERO0 && (i & 3) == 0)) l0 = fma(st.S[ch][i], ew[i], l0);
-    if (!st.valid[ch]) l0 = 1.0;
-    const int sc = st.valid[ch] ? (int)(st.sc[ch] + st.resc[ch]) : 0;
+      for (int i = 0; i < 8; ++i)
+        if (!(ZERO0 && (i & 3) == 0)) l0 = fma(st.S[ch][i], ewh[i], l0);
+      l0 = xhalf_add(l0);
+      mine = mine && lane < 32;     // a site is counted once
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (!(ZERO0 && (i & 3) == 0)) l0 = fma(st.S[ch][i], ew[i], l0);
+    }
+    if (!mine) l0 = 1.0;
+    const int sc = mine ? (int)(st.sc[ch] + st.resc[ch]) : 0;
     mant *= __builtin_amdgcn_frexp_mant(l0);
     ex += __builtin_amdgcn_frexp_exp(l0) - 256 * sc;
     if ((ch & 7) == 7) {  // long windows: keep the running product normalised
@@ -234,14 +327,14 @@ __device__ __forceinline__ double window_lnl(const SiteState<NCH>& st, const dou
 }
 
 // pllmod_opt_minimize_newton (pll-modules; rtsafe-style safeguarded Newton).  Wave-uniform.
-template <int NCH, bool ZERO0, int NW>
+template <int NCH, bool ZERO0, int NW, bool TAILH = false>
 __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, int lane,
                                          const LaneConst& lc, Comb<NW>& cb, double x1, double xguess,
                                          double x2, double tol, int max_iters, uint32_t& evals) {
   double rts = xguess, f, df, xl, xh, dx;
   if (rts < x1) rts = x1;
   if (rts > x2) rts = x2;
-  derivatives<NCH, ZERO0, NW>(st, tab, lane, lc, cb, rts, f, df);
+  derivatives<NCH, ZERO0, NW, TAILH>(st, tab, lane, lc, cb, rts, f, df);
   ++evals;
   if (!isfinite(f) || !isfinite(df)) return NAN;
   if (df >= 0.0 && fabs(f) < tol) return rts;
@@ -259,7 +352,7 @@ __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, 
     }
     if (fabs(dx) < tol || i == max_iters) return rts;
     if (rts < x1) rts = x1;
-    derivatives<NCH, ZERO0, NW>(st, tab, lane, lc, cb, rts, f, df);
+    derivatives<NCH, ZERO0, NW, TAILH>(st, tab, lane, lc, cb, rts, f, df);
     ++evals;
     if (!isfinite(f) || !isfinite(df)) return NAN;
     if (df > 0.0 && fabs(f) < tol) return rts;
@@ -268,7 +361,7 @@ __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, 
   return NAN;
 }
 
-template <int NCH, bool ZERO0, bool INV, int NW, bool LOCAL>
+template <int NCH, bool ZERO0, bool INV, int NW, bool LOCAL, bool TAILH = false>
 __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pidx, const int lane,
                                              double* tab, const double* qts, const LaneConst& lc,
                                              Comb<NW>& cb, uint32_t (&wstat)[3]) {
@@ -291,9 +384,16 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   const double orig = a.blen[b];
 
   SiteState<NCH> st;
+  // TAILH: the last chunk is a half-chunk, lane = (site = lane & 31, half = lane >> 5)
+  const uint32_t half = TAILH ? (uint32_t)lane >> 5 : 0u;
+  const uint32_t hoff = half * 8u * W8;            // rows of categories 2 h, 2 h + 1
+  double* const tabh = tab + (half << 3);          // this half's entries of a 16-entry table block
+  auto lane_site = [&](int ch) -> uint32_t {        // window site of this lane in chunk ch
+    return site0 + ch * 64 + ((TAILH && ch == NCH - 1) ? (uint32_t)lane & 31u : (uint32_t)lane);
+  };
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
-    const uint32_t s = site0 + ch * 64 + lane;
+    const uint32_t s = lane_site(ch);
     st.valid[ch] = s < n;
     const uint32_t sc = st.valid[ch] ? s : 0;  // clamp: inactive lanes recompute site 0
     st.sc[ch] = scp[sc];
@@ -309,15 +409,34 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   // is exactly 0 (ZERO0), so its table entries are w_0 (order 0) and 0 (orders 1, 2): adding
   // c / w_0 to sumtable entry (category 0, eigen index 0) adds c to L_0 and nothing to L_1, L_2.
   auto cinv_of = [&](int ch) -> double {
-    const uint32_t s = st.valid[ch] ? site0 + ch * 64 + lane : 0;
-    return a.cinv[begin + s] * a.inv_w0;
+    const uint32_t s = st.valid[ch] ? lane_site(ch) : 0;
+    const double v = a.cinv[begin + s] * a.inv_w0;
+    return (TAILH && ch == NCH - 1 && half) ? 0.0 : v;   // category 0 lives in the lower half
   };
   // ZERO0: the four zero-eigenvalue entries of a site only ever appear as sum_k w_k S_k0 (their
   // table entries are w_k for L_0 and 0 for L_1, L_2): keep that one number (6 fewer live VGPRs
   // per chunk, 3 fewer FMAs per chunk and evaluation)
+  const double wh0 = half ? m.w[2] : m.w[0], wh1 = half ? m.w[3] : m.w[1];   // TAILH: this half's weights
   auto fold0 = [&](int ch) {
-    if constexpr (ZERO0)
-      st.S[ch][0] = fma(m.w[3], st.S[ch][12], fma(m.w[2], st.S[ch][8], fma(m.w[1], st.S[ch][4], m.w[0] * st.S[ch][0])));
+    if constexpr (ZERO0) {
+      if (TAILH && ch == NCH - 1) st.S[ch][0] = fma(wh1, st.S[ch][4], wh0 * st.S[ch][0]);
+      else st.S[ch][0] = fma(m.w[3], st.S[ch][12], fma(m.w[2], st.S[ch][8], fma(m.w[1], st.S[ch][4], m.w[0] * st.S[ch][0])));
+    }
+  };
+  // the half-chunk's version of one phase step: 8 rows per side, this half's table entries
+  auto half_fold_query = [&](int ch, const double (&It)[8]) {
+    const double* qv = qts + st.code[ch] * 4;
+    const double q0 = qv[0], q1 = qv[1], q2 = qv[2], q3 = qv[3];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      st.S[ch][k * 4 + 0] = It[k * 4 + 0] * q0;
+      st.S[ch][k * 4 + 1] = It[k * 4 + 1] * q1;
+      st.S[ch][k * 4 + 2] = It[k * 4 + 2] * q2;
+      st.S[ch][k * 4 + 3] = It[k * 4 + 3] * q3;
+    }
+    if constexpr (INV) st.S[ch][0] += cinv_of(ch);
+    fold0(ch);
+    chain = zero_after(st.S[ch][7]);
   };
   // Inner CLV toward the query at (td, tx) folded with the query, S = (U^-1 I) o qt, and the
   // window lnL at pendant length tp_.  One table pass: slot 0 -> exp(lr td), slot 1 ->
@@ -327,6 +446,16 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     table_publish(tab, lane, exp(lc.lr * tl) * (lc.slot == 2 ? lc.w : 1.0));
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
+      if (TAILH && ch == NCH - 1) {
+        const uint32_t s = (st.valid[ch] ? lane_site(ch) : 0) * 8u + chain + hoff;
+        double D[8], X[8], It[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { D[c] = ldD(c, s); X[c] = ldX(c, s); }
+        asm volatile("" ::: "memory");
+        st.resc[ch] = inner_site_half(m, D, tabh, X, tabh + 16, It);
+        half_fold_query(ch, It);
+        continue;
+      }
       // one chunk's 32 loads in flight at a time (VGPR budget)
       const uint32_t s = (st.valid[ch] ? site0 + ch * 64 + lane : 0) * 8u + chain;
       double D[16], X[16], It[16];
@@ -350,7 +479,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     double ew[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
-    return window_lnl<NCH, ZERO0, NW>(st, ew, cb, lane);
+    return window_lnl<NCH, ZERO0, NW, TAILH>(st, ew, cb, lane, tab);
   };
   // inner CLV toward distal: I' = (P_pend q) o (P_prox X); S = Dt o (U^-1 I').  TOWARD_PROX (the
   // --raxml-blo loop only): the same toward the proximal node, I' = (P_pend q) o (P_dist D), S = Xt o ...
@@ -359,6 +488,23 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     table_publish(tab, lane, exp(lc.lr * (lc.slot == 0 ? tp_ : tother_)));
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
+      if (TAILH && ch == NCH - 1) {
+        const uint32_t s = (st.valid[ch] ? lane_site(ch) : 0) * 8u + chain + hoff;
+        double Qv[8], X[8], D[8], It[8];
+        const double* qv = qts + st.code[ch] * 4;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { Qv[x] = qv[x]; Qv[4 + x] = qv[x]; }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { X[c] = ldX(c, s); D[c] = ldD(c, s); }
+        asm volatile("" ::: "memory");
+        (void)inner_site_half(m, Qv, tabh, TOWARD_PROX ? D : X, tabh + 16, It);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) st.S[ch][c] = (TOWARD_PROX ? X[c] : D[c]) * It[c];
+        if constexpr (INV) st.S[ch][0] += cinv_of(ch);
+        fold0(ch);
+        chain = zero_after(st.S[ch][7]);
+        continue;
+      }
       const uint32_t s = (st.valid[ch] ? site0 + ch * 64 + lane : 0) * 8u + chain;
       double Qv[16], X[16], D[16], It[16];
       const double* qv = qts + st.code[ch] * 4;
@@ -390,6 +536,17 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     const uint8_t* r0 = a.resc0 + (size_t)b * cW + begin;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
+      if (TAILH && ch == NCH - 1) {
+        const uint32_t si = st.valid[ch] ? lane_site(ch) : 0;
+        const uint32_t s = si * 8u + chain + hoff;
+        double It[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) It[c] = *reinterpret_cast<const double*>(refi + (s + (uint32_t)c * W8));
+        st.resc[ch] = r0[si];
+        asm volatile("" ::: "memory");
+        half_fold_query(ch, It);
+        continue;
+      }
       const uint32_t si = st.valid[ch] ? site0 + ch * 64 + lane : 0;
       const uint32_t s = si * 8u + chain;
       double It[16];
@@ -413,7 +570,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     double ew[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
-    return window_lnl<NCH, ZERO0, NW>(st, ew, cb, lane);
+    return window_lnl<NCH, ZERO0, NW, TAILH>(st, ew, cb, lane, tab);
   };
 
   // traverse_update_partials + initial score (optimize.cpp:15-42,111-113)
@@ -431,7 +588,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     auto solve = [&](double cur) -> double {
       double g = cur;
       if (g < xmin || g > xmax) g = a.blo.default_branch;
-      const double r = newton<NCH, ZERO0, NW>(st, tab, lane, lc, cb, xmin, g, xmax, xtol, (int)a.blo.max_newton, evals);
+      const double r = newton<NCH, ZERO0, NW, TAILH>(st, tab, lane, lc, cb, xmin, g, xmax, xtol, (int)a.blo.max_newton, evals);
       chain = zero_after(r);
       // keep_update: the length is replaced when the solver moved it
       return (isfinite(r) && fabs(cur - r) > 1e-10) ? r : cur;
@@ -448,7 +605,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
       double ew[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
-      const double new_ll = -window_lnl<NCH, ZERO0, NW>(st, ew, cb, lane);
+      const double new_ll = -window_lnl<NCH, ZERO0, NW, TAILH>(st, ew, cb, lane, tab);
       ++rounds;
       --smoothings;
       if (fabs(new_ll - loglikelihood) < a.blo.epsilon) smoothings = 0;
@@ -461,7 +618,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     double xmin = a.blo.min_branch, xmax = a.blo.max_branch, xtol = xmin / 10.0;
     double xguess = tp;
     if (xguess < xmin || xguess > xmax) xguess = a.blo.default_branch;
-    double xres = newton<NCH, ZERO0, NW>(st, tab, lane, lc, cb, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
+    double xres = newton<NCH, ZERO0, NW, TAILH>(st, tab, lane, lc, cb, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
     if (xres > 0.0) tp = xres;
     chain = zero_after(tp);
     // ---- NR for the distal length with the proximal P-matrix held fixed (:170-211)
@@ -471,7 +628,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     xtol = xmin / 10.0;
     xmax = orig - xtol;
     if (xguess < xmin || xguess > xmax) xguess = orig / 2.0;
-    xres = newton<NCH, ZERO0, NW>(st, tab, lane, lc, cb, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
+    xres = newton<NCH, ZERO0, NW, TAILH>(st, tab, lane, lc, cb, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
     if (xres > 0.0) { td = xres; tx = orig - xres; }
     chain = zero_after(td);
     // ---- score (:217-222)
@@ -512,7 +669,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 // and every wave gets a ~25-pair random sample of the 10x cost spread (1..32 NR rounds).
 // INV: the model has +I (instantiated for ZERO0 only; a separate instantiation so that the
 // default kernel's register allocation is untouched: the runtime-flag version cost 40 more spills)
-template <int NCH, bool ZERO0, bool INV, int NW, bool LOCAL = false>
+template <int NCH, bool ZERO0, bool INV, int NW, bool LOCAL = false, bool TAILH = false>
 __global__ void __launch_bounds__(64 * NW, 2) k_thorough_dna(const ThArgs a) {
   __shared__ double tab[64 * NW];  // broadcast table of each wave
   __shared__ double qts[64];       // U^-1 image of the 16 query column codes
@@ -550,14 +707,14 @@ __global__ void __launch_bounds__(64 * NW, 2) k_thorough_dna(const ThArgs a) {
         const uint32_t cur = nxt;
         uint32_t f = 0;
         if (lane == 0) f = atomicAdd(ctr, 1u);
-        process_pair<NCH, ZERO0, INV, NW, LOCAL>(a, lo + cur, lane, tab + cb.wv * 64, qts, lc, cb, wstat);
+        process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH>(a, lo + cur, lane, tab + cb.wv * 64, qts, lc, cb, wstat);
         nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
       }
     }
   }
   if (!queued)
     for (uint64_t p = lo + w; p < hi; p += stride)
-      process_pair<NCH, ZERO0, INV, NW, LOCAL>(a, p, lane, tab + cb.wv * 64, qts, lc, cb, wstat);
+      process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH>(a, p, lane, tab + cb.wv * 64, qts, lc, cb, wstat);
   if (threadIdx.x == 0) {
     atomicAdd(&a.stats[0], (unsigned long long)wstat[0]);
     atomicAdd(&a.stats[1], (unsigned long long)wstat[1]);
@@ -836,11 +993,18 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
     }                                                                                              \
     if (want > n_pairs) want = n_pairs;                                                            \
     const uint32_t nwg = (uint32_t)((want + 7) / 8 * 8);                                           \
-    if (!ctx->blo.sliding) hipLaunchKernelGGL((k_thorough_dna<N, true, false, NW_, true>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
+    if (tailh && (NW_) == 1 && (N) >= 2 && ctx->blo.sliding && !a.cinv && ctx->dna_zero0)                              \
+      hipLaunchKernelGGL((k_thorough_dna<N, true, false, 1, false, ((NW_) == 1 && (N) >= 2)>), dim3(nwg), dim3(64), 0, ctx->stream, a); \
+    else if (!ctx->blo.sliding) hipLaunchKernelGGL((k_thorough_dna<N, true, false, NW_, true>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
     else if (a.cinv) hipLaunchKernelGGL((k_thorough_dna<N, true, true, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
     else if (ctx->dna_zero0) hipLaunchKernelGGL((k_thorough_dna<N, true, false, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
     else hipLaunchKernelGGL((k_thorough_dna<N, false, false, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
   } while (0)
+  // half-chunk tail (TAILH): every window of the launch ends within 32 sites of its last chunk's start
+  // (150-site reads: 64 + 64 + 22).  Same-box A/B on the cfg2 bench: 6.57 - 6.69 -> 6.42 ms per launch;
+  // EPA_TH_TAIL=0 switches it off.
+  static const bool tail_off = getenv("EPA_TH_TAIL") && atoi(getenv("EPA_TH_TAIL")) == 0;
+  const bool tailh = !tail_off && (cls == 1 || cls == 2) && max_span <= (cls == 1 ? 96u : 160u);
   switch (cls) {
     case 0: LAUNCH(1, 1); break;
     case 1: LAUNCH(2, 1); break;
