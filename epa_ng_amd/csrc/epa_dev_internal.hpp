@@ -168,10 +168,14 @@ void epa_timer_stop(epa_ctx* ctx, EvTimer& t);
 // variant.  DNA: sites per lane NCH in {1,2,3,4,6,8,12,16,24} (class 0..8), 9 = HBM-slab kernel;
 // 20 states: 0 / 1 / 2 = windows up to 64 / 128 / 192 sites (k_thorough_aa_mfma<1/2/3>: sumtable
 // in registers), 3 = longer (k_thorough_aa with the HBM slab).
-constexpr int EPA_N_CLS = 10;
+constexpr int EPA_N_CLS = 12;
 constexpr uint32_t EPA_AA_LDS_MAX_SPAN = 102;
 __host__ __device__ inline int epa_span_class(int states, uint32_t span) {
   if (states != 4) return span <= 64 ? 0 : span <= 128 ? 1 : span <= 192 ? 2 : 3;
+  // DNA classes 10 / 11: windows of 65..96 / 129..160 sites, whose last 64-lane chunk is at most half
+  // full: the half-chunk instantiations of k_thorough_dna (thorough_dna.hip, TAILH)
+  if (span > 64 && span <= 96) return 10;
+  if (span > 128 && span <= 160) return 11;
   const uint32_t nch = (span + 63) / 64;
   return nch <= 4 ? (nch ? (int)nch - 1 : 0) : nch <= 6 ? 4 : nch <= 8 ? 5 : nch <= 12 ? 6 : nch <= 16 ? 7 : nch <= 24 ? 8 : 9;
 }

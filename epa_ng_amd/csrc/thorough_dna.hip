@@ -1000,15 +1000,16 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
     else if (ctx->dna_zero0) hipLaunchKernelGGL((k_thorough_dna<N, true, false, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
     else hipLaunchKernelGGL((k_thorough_dna<N, false, false, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
   } while (0)
-  // half-chunk tail (TAILH): every window of the launch ends within 32 sites of its last chunk's start
-  // (150-site reads: 64 + 64 + 22).  Same-box A/B on the cfg2 bench: 6.57 - 6.69 -> 6.42 ms per launch;
-  // EPA_TH_TAIL=0 switches it off.
+  // half-chunk tail (TAILH), classes 10 / 11: every window of the class ends within 32 sites of its
+  // last chunk's start (150-site reads: 64 + 64 + 22).  Same-box A/B on the cfg2 bench: 6.57 - 6.69
+  // -> 6.42 ms per launch.  EPA_TH_TAIL=0 runs these classes on the full-chunk kernels; so do the
+  // +I and --raxml-blo instantiations.
   static const bool tail_off = getenv("EPA_TH_TAIL") && atoi(getenv("EPA_TH_TAIL")) == 0;
-  const bool tailh = !tail_off && (cls == 1 || cls == 2) && max_span <= (cls == 1 ? 96u : 160u);
+  const bool tailh = !tail_off && (cls == 10 || cls == 11);
   switch (cls) {
     case 0: LAUNCH(1, 1); break;
-    case 1: LAUNCH(2, 1); break;
-    case 2: LAUNCH(3, 1); break;
+    case 1: case 10: LAUNCH(2, 1); break;
+    case 2: case 11: LAUNCH(3, 1); break;
     case 3: LAUNCH(2, 2); break;   // <= 256 sites
     case 4: LAUNCH(3, 2); break;   // <= 384
     case 5: LAUNCH(2, 4); break;   // <= 512
@@ -1095,7 +1096,7 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
   int rc = EPA_OK;
   uint64_t off = 0;
   // window bound of a class (slab sizing of the 20-state LDS kernel, the long-window kernel)
-  static const uint32_t dna_bound[EPA_N_CLS] = {64, 128, 192, 256, 384, 512, 768, 1024, 1536, 0xffffffffu};
+  static const uint32_t dna_bound[EPA_N_CLS] = {64, 128, 192, 256, 384, 512, 768, 1024, 1536, 0xffffffffu, 96, 160};
   for (int c = 0; c < EPA_N_CLS && rc == EPA_OK; ++c) {
     if (!hist[c]) continue;
     const uint32_t* ord = order ? order + off : nullptr;

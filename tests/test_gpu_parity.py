@@ -325,3 +325,30 @@ def test_randomised_odd_shapes_lnl_parity(seed):
     assert (~same).mean() <= FLAT_MAX_FRACTION
     if same.all():
         assert ev.last_stats["rounds"] == o.last_stats["rounds"]
+
+
+def test_every_span_class_in_one_chunk_incl_half_chunk_tails():
+    """Read lengths on both sides of every class boundary of the nucleotide thorough kernels (64 / 96 /
+    128 / 160 / 192 sites and a multi-wave one) in ONE chunk: the per-class launches, the stable class
+    partition and the half-chunk tail instantiations (windows of 65..96 and 129..160 sites: the last
+    64-lane chunk carries lane = site x category half) against the oracle, counters included."""
+    from epa_ng_amd import hostlib, synth
+    root = synth.random_tree(40, 5)
+    rates = synth.gamma_rates(0.5)
+    labels, seqs = synth.simulate_msa(root, 700, synth.CFG2_SUBST, synth.CFG2_FREQS, rates, 6)
+    nw = synth.newick(root)
+    reads = []
+    for k, rl in enumerate((30, 64, 65, 80, 96, 97, 128, 129, 150, 160, 161, 192, 193, 300)):
+        r, _ = synth.make_reads(seqs, 5, rl, 0.02, 70 + k, states=4)
+        reads += list(r)
+    ref = hostlib.Reference(nw, labels, seqs, states=4, subst=synth.CFG2_SUBST, freqs=synth.CFG2_FREQS, rates=rates)
+    o = Oracle(nw, labels, seqs, 4, synth.CFG2_SUBST, synth.CFG2_FREQS, rates)
+    for pinv_ev in (ref.evaluator(),):
+        codes, wb, ws = epa.encode_queries(4, reads, compact=True)
+        assert {65, 96, 129, 160}.issubset(set(ws.tolist()))
+        pairs, res = pinv_ev.place_chunk(codes, wb, ws)
+        tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
+        assert np.max(np.abs(res["lnl"] - tl)) < LNL_TOL
+        assert np.max(np.abs(res["pendant_length"] - tp)) < 1e-6 and np.max(np.abs(res["distal_length"] - td)) < 1e-6
+        assert pinv_ev.last_stats["rounds"] == o.last_stats["rounds"]
+        assert pinv_ev.last_stats["newton_evals"] == o.last_stats["newton_evals"]
