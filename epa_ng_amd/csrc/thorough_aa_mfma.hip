@@ -133,17 +133,15 @@ __device__ __forceinline__ double rows_max(double v) {
   return v;
 }
 
-template <int NT, int NBLK, bool LOCAL = false>
+template <int NT, bool LOCAL = false>
 __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
   constexpr int NW = 4, NTHR = 64 * NW;
   __shared__ alignas(16) SharedM sh;
-  extern __shared__ double wcache[];   // [tile][block][reg t][lane]: see ThArgsAM::nblk
   const ModelDev* __restrict__ m = a.m;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int kq = lane >> 4;            // component residue of this lane (state 4 t + kq of vector register t)
   const int sl = lane & 15;            // site inside a 16-site tile
   const int aoff = kq * 4 + (lane & 3);  // this lane's element of an A-operand tile
-  constexpr int nblk = NBLK;   // (side, category) blocks of a tile held in LDS: proximal 0..3, distal 4..7
   for (int idx = tid; idx < 400; idx += NTHR) {
     const int qq = idx >> 4, e = idx & 15, t = qq / NTS, rt = qq % NTS, kk = e >> 2, i = e & 3;
     const int dst = ((qq >> 1) * 16 + e) * 2 + (qq & 1);
@@ -216,22 +214,6 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
 #pragma unroll
       for (int t = 0; t < NTS; ++t) qv[j][t] = m->qt[code * S + 4 * t + kq];
     }
-    // The window of the two reference vectors is read by every phase of the pair (4 - 7 times):
-    // as many of its eight (side, category) blocks as fit are parked in LDS for the life of the
-    // pair -- proximal side first: the first phase (mode 2) does not touch it.  A block of a tile
-    // is read by the wave that wrote it, in the lanes that wrote it: no barrier, no bank conflict.
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      if (!tile_on[j]) continue;
-      double* wc = wcache + (size_t)(wv + NW * j) * nblk * (NTS * 64) + lane;
-#pragma unroll
-      for (int blk = 0; blk < nblk; ++blk) {
-        const double* src = (blk < 4 ? Xt : Dt) + (size_t)((blk & 3) * S) * cW;   // uniform
-#pragma unroll
-        for (int t = 0; t < NTS; ++t) wc[(blk * NTS + t) * 64] = ldg_off(src + (size_t)(4 * t) * cW, lo[j]);
-      }
-    }
-
     // ---- table publication: every thread < 240 computes one exp()
     // (no barrier in front: whatever ran before ended with a workgroup barrier behind its last
     // table read -- the phases and the Newton evaluations below keep that invariant)
@@ -257,7 +239,6 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
       for (int j = 0; j < NT; ++j) {
         if (!tile_on[j]) continue;   // wave-uniform
         const uint32_t s = sscl[j];
-        const double* wc = wcache + (size_t)(wv + NW * j) * nblk * (NTS * 64) + lane;
         double l0 = 0.0, mx = 0.0;
         bool resc = false;
         // the operands of category `cat + 1` are requested while category `cat` is on the matrix cores
@@ -272,19 +253,10 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
           }
           const double* Pb = mode == 3 ? Dt : Xt;   // the side that goes through the matrix products
           const double* Pf = mode == 3 ? Xt : Dt;   // the side the result is folded with (modes 1, 3) / the first factor (mode 0)
-          if (cat < nblk && mode != 3) {
 #pragma unroll
-            for (int t = 0; t < NTS; ++t) Bn[t] = wc[(cat * NTS + t) * 64 + zf];
-          } else {
-#pragma unroll
-            for (int t = 0; t < NTS; ++t) Bn[t] = ldg_off(Pb + c0 + (size_t)(4 * t) * cW, lof);
-          }
-          if (4 + cat < nblk && mode != 3) {
-#pragma unroll
-            for (int t = 0; t < NTS; ++t) Dn[t] = wc[((4 + cat) * NTS + t) * 64 + zf];
-          } else {
-#pragma unroll
-            for (int t = 0; t < NTS; ++t) Dn[t] = ldg_off(Pf + c0 + (size_t)(4 * t) * cW, lof);
+          for (int t = 0; t < NTS; ++t) {
+            Bn[t] = ldg_off(Pb + c0 + (size_t)(4 * t) * cW, lof);
+            Dn[t] = ldg_off(Pf + c0 + (size_t)(4 * t) * cW, lof);
           }
         };
         fetch(0, zero_after(mant));
@@ -660,32 +632,18 @@ int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_
   }
   nwg = (nwg + 7) / 8 * 8;
   if (max_span > 192) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "thorough_aa_mfma: window longer than 192 sites");
-  // LDS window cache: two workgroups share the CU's 160 KB; whole (side, category) blocks only:
-  // tiles -> blocks that fit in 80 KB - sizeof(SharedM): <= 4 -> 7, 5 -> 5, 6..7 -> 4, 8..9 -> 3, 10..12 -> 2
+  // (an LDS cache of the pair's reference windows was measured and dropped: a third fewer HBM reads,
+  // 1 - 6 % slower -- profiles/r2_aa_mfma_ab.txt)
   const uint32_t tiles = (max_span + 15) / 16;
   if (!ctx->blo.sliding) {   // --raxml-blo
-    const uint32_t tl = (max_span + 15) / 16;
-    if (tl <= 4) hipLaunchKernelGGL((k_thorough_aa_mfma<1, 0, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
-    else if (tl <= 8) hipLaunchKernelGGL((k_thorough_aa_mfma<2, 0, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((k_thorough_aa_mfma<3, 0, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
-    EPA_HIP(ctx, hipGetLastError());
-    return EPA_OK;
+    if (tiles <= 4) hipLaunchKernelGGL((k_thorough_aa_mfma<1, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
+    else if (tiles <= 8) hipLaunchKernelGGL((k_thorough_aa_mfma<2, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_thorough_aa_mfma<3, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
+  } else {
+    if (tiles <= 4) hipLaunchKernelGGL((k_thorough_aa_mfma<1>), dim3(nwg), dim3(256), 0, ctx->stream, a);
+    else if (tiles <= 8) hipLaunchKernelGGL((k_thorough_aa_mfma<2>), dim3(nwg), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_thorough_aa_mfma<3>), dim3(nwg), dim3(256), 0, ctx->stream, a);
   }
-  auto go = [&](auto kern, uint32_t nblk) {
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), (size_t)nblk * tiles * NTS * 64 * 8, ctx->stream, a);
-  };
-  // The cache is OFF unless EPA_AAM_CACHE is set: measured (profiles/r2_aa_mfma_ab.txt) it removes a third
-  // of the kernel's HBM reads and is 1 - 6 % SLOWER -- the kernel is bound by LDS issue + MFMA at two
-  // waves per SIMD, not by HBM, and the cache adds LDS traffic.
-  if (!getenv("EPA_AAM_CACHE")) {
-    if (tiles <= 4) go(k_thorough_aa_mfma<1, 0>, 0);
-    else if (tiles <= 8) go(k_thorough_aa_mfma<2, 0>, 0);
-    else go(k_thorough_aa_mfma<3, 0>, 0);
-  } else if (tiles <= 4) go(k_thorough_aa_mfma<1, 7>, 7);
-  else if (tiles <= 7) go(k_thorough_aa_mfma<2, 4>, 4);
-  else if (tiles <= 8) go(k_thorough_aa_mfma<2, 3>, 3);
-  else if (tiles <= 9) go(k_thorough_aa_mfma<3, 3>, 3);
-  else go(k_thorough_aa_mfma<3, 2>, 2);
   EPA_HIP(ctx, hipGetLastError());
   return EPA_OK;
 }
