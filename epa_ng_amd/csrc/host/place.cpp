@@ -201,19 +201,31 @@ Work apply_heuristic(const std::vector<double>& lnl, size_t Q, size_t B, const O
 // one PQuery per query, in query order (quirk D8: the reference's order is thread-dependent)
 static void build_sample(const Work& to_place, const epa_result* res, const MSA& chunk,
                          Sample& sample, size_t seq_id_offset) {
+  // pairs arrive branch-major; a counting sort by query keeps that order inside every pquery, then
+  // the pqueries (one small vector each) are built in parallel
   const size_t n = to_place.size(), Q = chunk.size();
+  std::vector<uint32_t> first(Q + 1, 0);
+  for (size_t i = 0; i < n; ++i) ++first[to_place[i].sequence_id + 1];
   std::vector<long> slot(Q, -1);
+  size_t used = 0;
+  for (size_t q = 0; q < Q; ++q) {
+    if (first[q + 1]) slot[q] = (long)used++;
+    first[q + 1] += first[q];
+  }
+  std::vector<uint32_t> idx(n), cur(first.begin(), first.end() - 1);
+  for (size_t i = 0; i < n; ++i) idx[cur[to_place[i].sequence_id]++] = (uint32_t)i;
   sample.clear();
-  for (size_t i = 0; i < n; ++i) slot[to_place[i].sequence_id] = 0;
-  for (size_t q = 0; q < Q; ++q)
-    if (slot[q] == 0) {
-      slot[q] = (long)sample.size();
-      sample.emplace_back(seq_id_offset + q, chunk[q].header());
+  sample.resize(used);
+#pragma omp parallel for schedule(static)
+  for (long q = 0; q < (long)Q; ++q) {
+    if (slot[q] < 0) continue;
+    PQuery pq(seq_id_offset + (size_t)q, chunk[q].header());
+    pq.placements().reserve(first[q + 1] - first[q]);
+    for (uint32_t k = first[q]; k < first[q + 1]; ++k) {
+      const uint32_t i = idx[k];
+      pq.emplace_back(to_place[i].branch_id, res[i].lnl, res[i].pendant_length, res[i].distal_length);
     }
-  for (size_t i = 0; i < n; ++i) {
-    const size_t q = to_place[i].sequence_id;
-    sample[slot[q]].emplace_back(to_place[i].branch_id, res[i].lnl, res[i].pendant_length,
-                                 res[i].distal_length);
+    sample[slot[q]] = std::move(pq);
   }
 }
 
@@ -358,15 +370,15 @@ size_t place_all(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, D
 
 void compute_and_set_lwr(Sample& sample) {
   configure_host_threads();
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(static)
   for (long j = 0; j < (long)sample.size(); ++j) {
     auto& pq = sample[j];
     double mx = -std::numeric_limits<double>::infinity();
     for (auto& p : pq) mx = std::max(mx, p.likelihood());
     double total = 0.0;
-    std::vector<double> e(pq.size());
-    for (size_t i = 0; i < pq.size(); ++i) { e[i] = std::exp(pq[i].likelihood() - mx); total += e[i]; }
-    for (size_t i = 0; i < pq.size(); ++i) pq[i].lwr(e[i] / total);
+    // exp(lnl - max) is parked in the lwr field, then normalised: no scratch vector per pquery
+    for (size_t i = 0; i < pq.size(); ++i) { const double e = std::exp(pq[i].likelihood() - mx); pq[i].lwr(e); total += e; }
+    for (size_t i = 0; i < pq.size(); ++i) pq[i].lwr(pq[i].lwr() / total);
   }
 }
 
@@ -382,7 +394,7 @@ void filter(Sample& sample, const Options& options) {
     throw std::range_error{"thresh is not a valid likelihood weight ratio (outside of [0,1])"};
   if (options.filter_min < 1) throw std::range_error{"Filter min cannot be smaller than 1!"};
   const size_t mn = options.filter_min, mx = options.filter_max;
-#pragma omp parallel for schedule(dynamic)
+#pragma omp parallel for schedule(static)
   for (long i = 0; i < (long)sample.size(); ++i) {
     auto& pq = sample[i];
     sort_by_lwr(pq);
