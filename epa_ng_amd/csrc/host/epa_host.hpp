@@ -312,6 +312,8 @@ private:
   std::vector<uint64_t> bfast_offsets_;
   size_t bfast_next_ = 0;
   std::FILE* f_ = nullptr;
+  const char* map_ = nullptr;             // regular fasta files are mapped (no copy through a read buffer)
+  size_t map_len_ = 0;
   std::vector<char> buf_;
   size_t pos_ = 0, len_ = 0, scan_ = 0;  // unparsed region [pos_, len_), record index built up to scan_
   std::vector<size_t> starts_;            // offsets of the '>' of the records found so far

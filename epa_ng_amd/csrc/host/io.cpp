@@ -7,7 +7,12 @@
 
 #include <cctype>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "epa_host.hpp"
 
@@ -98,10 +103,26 @@ Fasta_Stream::Fasta_Stream(const std::string& path) : f_(std::fopen(path.c_str()
   if (!f_) throw std::runtime_error{"file_check failed: " + path};
   for (int c = 0; c < 256; ++c) up_[c] = std::isspace(c) ? 0 : (char)std::toupper(c);
   if (open_bfast()) return;  // like the reference: try bfast first, fall back to fasta (msa_reader.hpp:15-24)
+  // a regular file is mapped: the parser reads the page cache directly (a 1.5 GB query file spent
+  // 0.3 s of its 0.55 s in fread's copy); pipes and the like go through the read buffer
+  struct stat sb;
+  if (::fstat(::fileno(f_), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && !std::getenv("EPA_NO_MMAP")) {
+    void* m = ::mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, ::fileno(f_), 0);
+    if (m != MAP_FAILED) {
+      ::madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);
+      map_ = static_cast<const char*>(m);
+      map_len_ = len_ = (size_t)sb.st_size;
+      eof_ = true;   // nothing more to read; `scan_` tells how far the record index has got
+      return;
+    }
+  }
   buf_.resize(1 << 24);
 }
 
-Fasta_Stream::~Fasta_Stream() { if (f_) std::fclose(f_); }
+Fasta_Stream::~Fasta_Stream() {
+  if (map_) ::munmap(const_cast<char*>(map_), map_len_);
+  if (f_) std::fclose(f_);
+}
 
 // appends more of the file behind the unparsed region [pos_, len_); false at end of file
 bool Fasta_Stream::refill() {
@@ -127,9 +148,9 @@ size_t Fasta_Stream::read_next(MSA& out, size_t max_seqs) {
   if (max_seqs == 0) return 0;
   if (bfast_) return read_next_bfast(out, max_seqs);
   for (;;) {
-    // extend the index of record starts over the bytes not scanned yet
-    const char* base = buf_.data();
-    while (scan_ < len_) {
+    // extend the index of record starts over the bytes not scanned yet (as far as this call needs)
+    const char* base = map_ ? map_ : buf_.data();
+    while (scan_ < len_ && starts_.size() <= max_seqs) {
       const char* p = (const char*)std::memchr(base + scan_, '>', len_ - scan_);
       if (!p) { scan_ = len_; break; }
       const size_t o = (size_t)(p - base);
@@ -137,19 +158,21 @@ size_t Fasta_Stream::read_next(MSA& out, size_t max_seqs) {
       scan_ = o + 1;
     }
     // a record is complete once the next one has started (or the file has ended)
-    const size_t complete = eof_ ? starts_.size() : (starts_.empty() ? 0 : starts_.size() - 1);
-    if (complete >= max_seqs || eof_) break;
+    const bool done = eof_ && scan_ >= len_;
+    const size_t complete = done ? starts_.size() : (starts_.empty() ? 0 : starts_.size() - 1);
+    if (complete >= max_seqs || done) break;
     if (starts_.empty() && len_ > 0) pos_ = len_ - 1;  // junk before the first record: keep 1 byte of context
     first_block_ = first_block_ && len_ == 0;
     refill();
   }
   first_block_ = false;
-  const size_t complete = eof_ ? starts_.size() : (starts_.empty() ? 0 : starts_.size() - 1);
+  const bool done = eof_ && scan_ >= len_;
+  const size_t complete = done ? starts_.size() : (starts_.empty() ? 0 : starts_.size() - 1);
   const size_t m = std::min(max_seqs, complete);
-  if (m == 0) { if (eof_) { pos_ = len_; starts_.clear(); } return 0; }
+  if (m == 0) { if (done) { pos_ = len_; starts_.clear(); } return 0; }
   const size_t first = out.size();
   out.resize(first + m);
-  const char* base = buf_.data();
+  const char* base = map_ ? map_ : buf_.data();
 #pragma omp parallel for schedule(static)
   for (long i = 0; i < (long)m; ++i) {
     const char* b = base + starts_[i] + 1;
