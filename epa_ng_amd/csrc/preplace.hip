@@ -33,6 +33,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+
+// rocprim's radix sort falls back to a merge sort (block sort + log2 n merge passes: ~19 launches for
+// the 262k candidate keys of a chunk) below one million items; the sorts here use a few key bits only
+// (branch id, window start, span class), where Onesweep digit passes do: 4 - 5 launches.
+using epa_radix_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                 rocprim::default_config, 0>;
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
@@ -1097,7 +1103,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
                         : sites ? (span_bound + CHS - 1) / CHS * CHS : 0;
   // scratch 6: [status 256 B | iota Q | sorted_keys Q | perm Q | keys Q | groups | packed | tails | rocprim temp]
   size_t temp_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, temp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
+  (void)rocprim::radix_sort_pairs<epa_radix_cfg>(nullptr, temp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                   (uint32_t*)nullptr, (uint32_t*)nullptr, Q, 0, 32, ctx->stream);
   const size_t qb = align256(sizeof(uint32_t) * Q);
   const size_t gb = align256(sizeof(Group) * max_groups);
@@ -1123,21 +1129,21 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   if (pairs) {
     hipLaunchKernelGGL(k_pack_pairs, dim3((Q + 3) / 4), dim3(256), 0, ctx->stream, d_codes, d_begin,
                        d_span, Q, ctx->W, cstride, crel, span_bound, Wp, NP16, packed, tails, keys, status);
-    EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, keys, sorted_keys, iota, perm, Q, 0,
+    EPA_HIP(ctx, rocprim::radix_sort_pairs<epa_radix_cfg>(temp, temp_bytes, keys, sorted_keys, iota, perm, Q, 0,
                                            key_bits, ctx->stream));
   } else if (sites) {
     int wbits = 1;
     while (wbits < 32 && (1ull << wbits) <= (uint64_t)ctx->W) ++wbits;
     hipLaunchKernelGGL(k_pack_sites<24>, dim3((Q + 3) / 4), dim3(256), 0, ctx->stream, d_codes, d_begin,
                        d_span, Q, ctx->W, cstride, crel, span_bound, NP16, packed, tails, keys, status);
-    EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, keys, sorted_keys, iota, perm, Q, 0, wbits,
+    EPA_HIP(ctx, rocprim::radix_sort_pairs<epa_radix_cfg>(temp, temp_bytes, keys, sorted_keys, iota, perm, Q, 0, wbits,
                                            ctx->stream));
   } else {
     hipLaunchKernelGGL(k_validate, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, d_begin, d_span, Q,
                        ctx->W, std::min(span_bound, crel ? cstride : 0xffffffffu), status);
     int wbits = 1;
     while (wbits < 32 && (1ull << wbits) <= (uint64_t)ctx->W) ++wbits;
-    EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, d_begin, sorted_keys, iota, perm, Q, 0, wbits,
+    EPA_HIP(ctx, rocprim::radix_sort_pairs<epa_radix_cfg>(temp, temp_bytes, d_begin, sorted_keys, iota, perm, Q, 0, wbits,
                                            ctx->stream));
   }
   hipLaunchKernelGGL(k_make_groups, dim3(1), dim3(256),
@@ -1238,7 +1244,7 @@ int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshol
     (void)rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, Q,
                                   rocprim::plus<uint32_t>(), ctx->stream);
     const size_t worst = std::min<uint64_t>(max_pairs, (uint64_t)Q * cap);
-    (void)rocprim::radix_sort_keys(nullptr, sort_bytes, (unsigned long long*)nullptr,
+    (void)rocprim::radix_sort_keys<epa_radix_cfg>(nullptr, sort_bytes, (unsigned long long*)nullptr,
                                    (unsigned long long*)nullptr, worst, 0, 64, ctx->stream);
     // scratch 7: [status | counts Q+1 | offsets Q+1 | stage Q*cap | keys_a worst | keys_b worst | temp]
     const size_t qb = align256(sizeof(uint32_t) * (Q + 1));
@@ -1292,7 +1298,7 @@ int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshol
       // STABLE sort on the branch bits alone gives (branch, query) order: 2 digit passes, not 6.
       int bits = 33;
       while ((1ull << (bits - 32)) <= B && bits < 64) ++bits;
-      EPA_HIP(ctx, rocprim::radix_sort_keys(temp, sort_bytes, keys_a, keys_b, (size_t)total, 32, bits, ctx->stream));
+      EPA_HIP(ctx, rocprim::radix_sort_keys<epa_radix_cfg>(temp, sort_bytes, keys_a, keys_b, (size_t)total, 32, bits, ctx->stream));
       hipLaunchKernelGGL(k_keys_to_pairs, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, keys_b,
                          (uint64_t)total, d_pairs);
     }

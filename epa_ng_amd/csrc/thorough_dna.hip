@@ -29,6 +29,12 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
+// rocprim's radix sort falls back to a merge sort (block sort + log2 n merge passes: ~19 launches for
+// the 262k candidate keys of a chunk) below one million items; the sorts here use a few key bits only
+// (branch id, window start, span class), where Onesweep digit passes do: 4 - 5 launches.
+using epa_radix_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                 rocprim::default_config, 0>;
+
 #include <algorithm>
 #include <type_traits>
 #include <cstdlib>
@@ -1052,7 +1058,7 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
   ctx->cls_hist_pairs = 0;
   // scratch 8: [hist 64 B | keys n | idx n | keys_out n | order n | rocprim temp]
   size_t temp_bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, temp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
+  (void)rocprim::radix_sort_pairs<epa_radix_cfg>(nullptr, temp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                   (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n_pairs, 0, 4, ctx->stream);
   const size_t nb = (sizeof(uint32_t) * n_pairs + 255) & ~(size_t)255;
   uint32_t* d_hist = nullptr;
@@ -1088,7 +1094,7 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
                          d_keys, d_idx, (uint32_t*)nullptr);
     }
     void* temp = (char*)d_order + nb;
-    EPA_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, d_keys, d_keys2, d_idx, d_order, (size_t)n_pairs, 0, 4,
+    EPA_HIP(ctx, rocprim::radix_sort_pairs<epa_radix_cfg>(temp, temp_bytes, d_keys, d_keys2, d_idx, d_order, (size_t)n_pairs, 0, 4,
                                            ctx->stream));
     order = d_order;
   }
