@@ -999,8 +999,13 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
     }                                                                                              \
     if (want > n_pairs) want = n_pairs;                                                            \
     const uint32_t nwg = (uint32_t)((want + 7) / 8 * 8);                                           \
-    if (tailh && (NW_) == 1 && (N) >= 2 && ctx->blo.sliding && !a.cinv && ctx->dna_zero0)                              \
-      hipLaunchKernelGGL((k_thorough_dna<N, true, false, 1, false, ((NW_) == 1 && (N) >= 2)>), dim3(nwg), dim3(64), 0, ctx->stream, a); \
+    constexpr bool TH_ = (NW_) == 1 && (N) >= 2;   /* half-chunk tail instantiations exist for these */               \
+    if (tailh && TH_ && ctx->dna_zero0 && !ctx->blo.sliding && !a.cinv)                                                \
+      hipLaunchKernelGGL((k_thorough_dna<N, true, false, 1, true, TH_>), dim3(nwg), dim3(64), 0, ctx->stream, a);      \
+    else if (tailh && TH_ && ctx->dna_zero0 && ctx->blo.sliding && a.cinv)                                            \
+      hipLaunchKernelGGL((k_thorough_dna<N, true, true, 1, false, TH_>), dim3(nwg), dim3(64), 0, ctx->stream, a);      \
+    else if (tailh && TH_ && ctx->dna_zero0 && ctx->blo.sliding)                                                       \
+      hipLaunchKernelGGL((k_thorough_dna<N, true, false, 1, false, TH_>), dim3(nwg), dim3(64), 0, ctx->stream, a);     \
     else if (!ctx->blo.sliding) hipLaunchKernelGGL((k_thorough_dna<N, true, false, NW_, true>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
     else if (a.cinv) hipLaunchKernelGGL((k_thorough_dna<N, true, true, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
     else if (ctx->dna_zero0) hipLaunchKernelGGL((k_thorough_dna<N, true, false, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
@@ -1008,8 +1013,7 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
   } while (0)
   // half-chunk tail (TAILH), classes 10 / 11: every window of the class ends within 32 sites of its
   // last chunk's start (150-site reads: 64 + 64 + 22).  Same-box A/B on the cfg2 bench: 6.57 - 6.69
-  // -> 6.42 ms per launch.  EPA_TH_TAIL=0 runs these classes on the full-chunk kernels; so do the
-  // +I and --raxml-blo instantiations.
+  // -> 6.42 ms per launch.  EPA_TH_TAIL=0 runs these classes on the full-chunk kernels.
   static const bool tail_off = getenv("EPA_TH_TAIL") && atoi(getenv("EPA_TH_TAIL")) == 0;
   const bool tailh = !tail_off && (cls == 10 || cls == 11);
   switch (cls) {
