@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <condition_variable>
 #include <deque>
+#include <cstdio>
 #include <fstream>
 #include <mutex>
 #include <thread>
@@ -506,6 +507,38 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
   std::exception_ptr failure;
   const size_t depth = devices.size() + 1;  // staged chunks in flight
   std::vector<std::string> results;  // jplace text per chunk, in chunk order
+  // the jplace is written while the run goes on: a chunk's text leaves as soon as every chunk before
+  // it has (any worker that finds the file free drains what is ready, in chunk order)
+  std::string dir = outdir;
+  if (!dir.empty() && dir.back() != '/') dir += "/";
+  const std::string out_path = dir + "epa_result.jplace";
+  std::ofstream os(out_path);
+  if (!os) throw std::runtime_error{"cannot open " + out_path};
+  os << "{\n  \"tree\": \"" << tree.numbered_newick(options.precision) << "\",\n  \"placements\": \n  [\n";
+  std::mutex wmu;
+  std::vector<char> ready;
+  size_t next_write = 0;
+  bool first_chunk = true;
+  auto drain = [&] {   // caller holds wmu
+    for (;;) {
+      std::string t;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (next_write >= ready.size() || !ready[next_write]) return;
+        t = std::move(results[next_write]);
+        results[next_write] = std::string();
+        ++next_write;
+      }
+      if (t.empty()) continue;
+      const auto tw = clk::now();
+      if (!first_chunk) os << ",\n";   // chunks separated by ",\n" (jplace_writer.hpp:141)
+      first_chunk = false;
+      os.write(t.data(), (std::streamsize)t.size());
+      const double secs = std::chrono::duration<double>(clk::now() - tw).count();
+      std::lock_guard<std::mutex> lk(mu);
+      st.seconds_write += secs;
+    }
+  };
 
   std::thread stager([&] {
     try {
@@ -558,15 +591,20 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
         const auto tf = clk::now();
         std::string text = jplace_chunk_text(smp, options.precision, &tree.mapper());
         const double secs_text = std::chrono::duration<double>(clk::now() - tf).count();
-        std::lock_guard<std::mutex> lk(mu);
-        if (results.size() <= done.index) results.resize(done.index + 1);
-        results[done.index] = std::move(text);
-        st.seconds_write += secs_text;
-        st.queries += done.chunk.size();
-        st.pairs += tm.pairs;
-        st.seconds_place += tm.place;
-        st.seconds_thorough += tm.thorough;
-        st.seconds_post += tm.post;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          if (results.size() <= done.index) { results.resize(done.index + 1); ready.resize(done.index + 1, 0); }
+          results[done.index] = std::move(text);
+          ready[done.index] = 1;
+          st.seconds_write += secs_text;
+          st.queries += done.chunk.size();
+          st.pairs += tm.pairs;
+          st.seconds_place += tm.place;
+          st.seconds_thorough += tm.thorough;
+          st.seconds_post += tm.post;
+        }
+        std::unique_lock<std::mutex> wl(wmu, std::try_to_lock);
+        if (wl.owns_lock()) drain();
       };
       if (!pipelined) {
         for (;;) {
@@ -627,15 +665,21 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
     cv_put.notify_all();
   }
   stager.join();
-  if (failure) std::rethrow_exception(failure);
-
-  std::string dir = outdir;
-  if (!dir.empty() && dir.back() != '/') dir += "/";
+  if (failure) {
+    os.close();
+    std::remove(out_path.c_str());   // no half-written result file
+    std::rethrow_exception(failure);
+  }
+  {
+    std::lock_guard<std::mutex> wl(wmu);
+    drain();
+  }
   ts = clk::now();
-  std::ofstream os(dir + "epa_result.jplace");
-  if (!os) throw std::runtime_error{"cannot open " + dir + "epa_result.jplace"};
-  write_jplace_text(os, results, tree.numbered_newick(options.precision), invocation);
+  os << "  ],\n  \"metadata\": {\"invocation\": \"" << invocation << "\"},\n  \"version\": 3,\n"
+     << "  \"fields\": [\"edge_num\", \"likelihood\", \"like_weight_ratio\", \"distal_length\""
+     << ", \"pendant_length\"]\n}\n";
   os.flush();
+  if (!os) throw std::runtime_error{"writing " + out_path + " failed"};
   st.seconds_write += std::chrono::duration<double>(clk::now() - ts).count();
   return st;
 }
