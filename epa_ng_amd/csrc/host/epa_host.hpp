@@ -292,6 +292,8 @@ private:
 // a container that sees 256 CPUs but is limited to 16 crawls with 256 spinning threads).
 // Called once by the entry points; returns the thread count in effect.
 int configure_host_threads();
+// user limit on the host threads (-T/--threads, src/main.cpp:256-258); call before the first host stage
+void set_host_thread_limit(int n);
 
 // ---- readers / writers
 MSA read_fasta(const std::string& path);

@@ -32,6 +32,7 @@ static void usage() {
       "  --raxml-blo           radius-1 local branch-length optimisation instead of the sliding rule\n"
       "  --rate-scalers auto|on|off  per-rate-category numerical scaling (auto: on above 2000 tips)\n"
       "  --preserve-rooting on|off  rooted reference tree: report on the rooted tree (default on)\n"
+      "  -T,--threads N        upper limit on the host threads (parsing, encoding, LWR / filter, jplace text)\n"
       "  --device N            GPU ordinal (default 0)\n"
       "  --devices a,b,..      place on several GPUs of the node (chunks are dealt to them in turn)\n";
 }
@@ -82,8 +83,7 @@ int main(int argc, char** argv) {
     }
     else if (a == "-T" || a == "--threads") {
       opt.num_threads = (unsigned)std::stoul(need(i));
-      std::cerr << "note: -T/--threads is accepted for command-line compatibility; the placement runs on the "
-                   "GPU and the host stages use the CPUs the process is allowed to use\n";
+      set_host_thread_limit((int)opt.num_threads);   // caps the OpenMP host stages; the placement itself runs on the GPU
     }
     else if (a == "--device") device = std::stoi(need(i));
     else if (a == "--devices") {

@@ -22,9 +22,13 @@
 
 namespace epa {
 
+namespace { int g_thread_limit = 0; }   // -T/--threads of the command line; 0 = no user limit
+void set_host_thread_limit(int n) { g_thread_limit = n > 0 ? n : 0; }
+
 int configure_host_threads() {
   static const int n = [] {
     int v = omp_get_max_threads();
+    if (g_thread_limit > 0) v = std::min(v, g_thread_limit);
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) v = std::min(v, std::max(1, CPU_COUNT(&set)));
     std::ifstream f("/sys/fs/cgroup/cpu.max");  // cgroup v2: "<quota> <period>" or "max <period>"
