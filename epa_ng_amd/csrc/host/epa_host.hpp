@@ -306,7 +306,12 @@ public:
   Fasta_Stream(const Fasta_Stream&) = delete;
   // appends up to max_seqs sequences to `out`; returns how many (0 = end of file)
   size_t read_next(MSA& out, size_t max_seqs);
+  // zero-copy variant (mapped files, one sequence line of `sites` characters per record): headers in
+  // `out`, pointers into the mapping in `rows`; 0 = not applicable for the next chunk, use read_next()
+  size_t read_next_views(MSA& out, std::vector<const char*>& rows, size_t sites, size_t max_seqs);
 private:
+  size_t index_records(size_t max_seqs, bool& done);
+  void consume(size_t m);
   bool refill();
   bool open_bfast();                                  // binary fasta (src/io/Binary_Fasta.hpp)?
   size_t read_next_bfast(MSA& out, size_t max_seqs);
@@ -361,6 +366,9 @@ struct Encoded_Chunk {
   uint32_t stride = 0;
 };
 Encoded_Chunk encode_chunk(const MSA& chunk, const Tree& tree, const Options& options);
+// the same from `sites`-long character rows (not NUL-terminated); `chunk` supplies the headers for the messages
+Encoded_Chunk encode_rows(const std::vector<const char*>& rows, const MSA& chunk, const Tree& tree,
+                          const Options& options);
 
 // Hot loop 1: dense Q x B preplacement table (src/core/place.cpp:41-95).  lnl is Q x B row-major;
 // sample[q][b] = Placement{b, lnl, pendant = -ln 0.9, distal = len/2} is materialised lazily by

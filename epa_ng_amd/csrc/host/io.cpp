@@ -141,14 +141,11 @@ bool Fasta_Stream::refill() {
   return got != 0;
 }
 
-// Records are located first ('>' at the start of a line), then parsed in parallel: the header
-// line is the label, the sequence lines are upper-cased with white space dropped.
-size_t Fasta_Stream::read_next(MSA& out, size_t max_seqs) {
-  configure_host_threads();
-  if (max_seqs == 0) return 0;
-  if (bfast_) return read_next_bfast(out, max_seqs);
+// Extends the index of record starts as far as a chunk of max_seqs needs and returns how many
+// complete records are available (a record is complete once the next one has started, or the file
+// has ended); `done` = nothing is left behind them.
+size_t Fasta_Stream::index_records(size_t max_seqs, bool& done) {
   for (;;) {
-    // extend the index of record starts over the bytes not scanned yet (as far as this call needs)
     const char* base = map_ ? map_ : buf_.data();
     while (scan_ < len_ && starts_.size() <= max_seqs) {
       const char* p = (const char*)std::memchr(base + scan_, '>', len_ - scan_);
@@ -157,18 +154,31 @@ size_t Fasta_Stream::read_next(MSA& out, size_t max_seqs) {
       if (o == 0 ? first_block_ : base[o - 1] == '\n') starts_.push_back(o);
       scan_ = o + 1;
     }
-    // a record is complete once the next one has started (or the file has ended)
-    const bool done = eof_ && scan_ >= len_;
+    done = eof_ && scan_ >= len_;
     const size_t complete = done ? starts_.size() : (starts_.empty() ? 0 : starts_.size() - 1);
-    if (complete >= max_seqs || done) break;
+    if (complete >= max_seqs || done) {
+      first_block_ = false;
+      return std::min(max_seqs, complete);
+    }
     if (starts_.empty() && len_ > 0) pos_ = len_ - 1;  // junk before the first record: keep 1 byte of context
     first_block_ = first_block_ && len_ == 0;
     refill();
   }
-  first_block_ = false;
-  const bool done = eof_ && scan_ >= len_;
-  const size_t complete = done ? starts_.size() : (starts_.empty() ? 0 : starts_.size() - 1);
-  const size_t m = std::min(max_seqs, complete);
+}
+
+void Fasta_Stream::consume(size_t m) {
+  pos_ = m < starts_.size() ? starts_[m] : len_;
+  starts_.erase(starts_.begin(), starts_.begin() + m);
+}
+
+// Records are located first ('>' at the start of a line), then parsed in parallel: the header
+// line is the label, the sequence lines are upper-cased with white space dropped.
+size_t Fasta_Stream::read_next(MSA& out, size_t max_seqs) {
+  configure_host_threads();
+  if (max_seqs == 0) return 0;
+  if (bfast_) return read_next_bfast(out, max_seqs);
+  bool done = false;
+  const size_t m = index_records(max_seqs, done);
   if (m == 0) { if (done) { pos_ = len_; starts_.clear(); } return 0; }
   const size_t first = out.size();
   out.resize(first + m);
@@ -192,8 +202,51 @@ size_t Fasta_Stream::read_next(MSA& out, size_t max_seqs) {
     }
     out[first + i] = Sequence(std::move(header), std::move(seq));
   }
-  pos_ = m < starts_.size() ? starts_[m] : len_;
-  starts_.erase(starts_.begin(), starts_.begin() + m);
+  consume(m);
+  return m;
+}
+
+// Zero-copy variant for mapped files whose next records are all one header line + ONE sequence line
+// of exactly `sites` characters (what alignment tools write for short reads): `out` gets the
+// headers (empty sequences), rows[i] points at record i's sequence inside the mapping (not
+// NUL-terminated, upper / lower case as in the file; valid as long as this reader lives).  Returns 0
+// and consumes nothing when the file is not mapped or a record has another shape: the caller then
+// takes the chunk with read_next().
+size_t Fasta_Stream::read_next_views(MSA& out, std::vector<const char*>& rows, size_t sites, size_t max_seqs) {
+  configure_host_threads();
+  if (!map_ || bfast_ || max_seqs == 0 || sites == 0) return 0;
+  bool done = false;
+  const size_t m = index_records(max_seqs, done);
+  if (m == 0) return 0;
+  const size_t first = out.size();
+  out.resize(first + m);
+  rows.assign(m, nullptr);
+  int ok = 1;
+#pragma omp parallel for schedule(static) reduction(&& : ok)
+  for (long i = 0; i < (long)m; ++i) {
+    const char* b = map_ + starts_[i] + 1;
+    const char* e = map_ + (i + 1 < (long)starts_.size() ? starts_[i + 1] : len_);
+    const char* nl = (const char*)std::memchr(b, '\n', (size_t)(e - b));
+    if (!nl) { ok = 0; continue; }
+    const char* sb = nl + 1;
+    const char* se = e;
+    while (se > sb && (se[-1] == '\n' || se[-1] == '\r')) --se;
+    bool good = (size_t)(se - sb) == sites;
+    if (good)
+      for (const char* p = sb; p < se; ++p)
+        if ((unsigned char)*p <= ' ') { good = false; break; }   // a second line, or blanks inside the line
+    if (!good) { ok = 0; continue; }
+    const char* h = nl;
+    while (h > b && (h[-1] == '\r' || h[-1] == ' ' || h[-1] == '\t')) --h;
+    out[first + i] = Sequence(std::string(b, h), std::string());
+    rows[i] = sb;
+  }
+  if (!ok) {
+    out.resize(first);
+    rows.clear();
+    return 0;
+  }
+  consume(m);
   return m;
 }
 

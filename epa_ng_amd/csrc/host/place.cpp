@@ -91,16 +91,22 @@ double Device_Evaluator::ref_tree_logl(size_t branch) const {
 Device_Evaluator::~Device_Evaluator() { epa_dev_destroy(ctx_); }
 
 Encoded_Chunk encode_chunk(const MSA& chunk, const Tree& tree, const Options& options) {
-  Encoded_Chunk e;
   const size_t Q = chunk.size(), W = tree.num_sites();
-  e.win_begin.resize(Q);
-  e.win_span.resize(Q);
   std::vector<const char*> rows(Q);
   for (size_t q = 0; q < Q; ++q) {
     if (chunk[q].sequence().size() != W)  // Tiny_Tree.cpp:145-147
       throw std::runtime_error{"Query sequence length not same as reference alignment!"};
     rows[q] = chunk[q].sequence().c_str();
   }
+  return encode_rows(rows, chunk, tree, options);
+}
+
+Encoded_Chunk encode_rows(const std::vector<const char*>& rows, const MSA& chunk, const Tree& tree,
+                          const Options& options) {
+  Encoded_Chunk e;
+  const size_t Q = rows.size(), W = tree.num_sites();
+  e.win_begin.resize(Q);
+  e.win_span.resize(Q);
   uint32_t bad = 0;
   auto check = [&](int rc) {
     if (rc == EPA_ERR_QUERY_ALL_GAP)  // Tiny_Tree.cpp:153-156
@@ -551,14 +557,17 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
       for (;;) {
         Staged s;
         const auto r0 = clk::now();
-        reader.read_next(s.chunk, options.chunk_size);
+        // one-line records of a mapped file are encoded straight from the mapping (no sequence strings)
+        std::vector<const char*> rows;
+        if (!premask) reader.read_next_views(s.chunk, rows, tree.num_sites(), options.chunk_size);
+        if (rows.empty()) reader.read_next(s.chunk, options.chunk_size);
         const double rd = std::chrono::duration<double>(clk::now() - r0).count();
         if (s.chunk.empty()) break;
         if (premask) s.chunk = subset_msa(s.chunk, msa_info.gap_mask());
         s.index = index++;
         s.offset = offset;
         offset += s.chunk.size();
-        s.enc = encode_chunk(s.chunk, tree, options);
+        s.enc = rows.empty() ? encode_chunk(s.chunk, tree, options) : encode_rows(rows, s.chunk, tree, options);
         std::unique_lock<std::mutex> lk(mu);
         st.seconds_read += rd;
         cv_put.wait(lk, [&] { return queue.size() < depth || failure; });
