@@ -45,8 +45,8 @@ HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md (spec; 62
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=4)
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--chunk", type=int, default=100000,
                    help="reads per step (EPA-ng --chunk-size; default = the whole cfg2 query set)")
     p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
