@@ -84,7 +84,7 @@ __global__ void k_iota(uint32_t* v, uint32_t n) {
 __global__ void __launch_bounds__(256) k_make_groups(const uint32_t* __restrict__ sorted_keys, uint32_t Q,
                                                      uint32_t Wp, uint32_t n_blocks,
                                                      uint32_t class_blocks, uint32_t gq0, uint32_t gq1,
-                                                     uint32_t max_runs, Group* __restrict__ groups,
+                                                     uint32_t spr0, uint32_t max_runs, Group* __restrict__ groups,
                                                      uint32_t max_groups, uint32_t* __restrict__ status) {
   extern __shared__ uint32_t sh[];
   uint32_t* lo = sh;                       // [n_blocks + 1] first sorted index of each block
@@ -120,9 +120,10 @@ __global__ void __launch_bounds__(256) k_make_groups(const uint32_t* __restrict_
     const uint32_t gq = b >= class_blocks ? gq1 : gq0;
     const uint32_t start = lo[b] + (r - runbase[b]) * gq, end = min(lo[b + 1], start + gq);
     const uint32_t k0 = sorted_keys[start], k1 = sorted_keys[end - 1];
+    const uint32_t spr = b >= class_blocks ? (uint32_t)SPREAD : spr0;   // class 0 may stage wider slices
     run_start[r] = start;
     run_end[r] = end;
-    run_off[r] = (k1 - k0 < (uint32_t)SPREAD) ? 1u : (k1 / SPREAD - k0 / SPREAD + 1);
+    run_off[r] = (k1 - k0 < spr) ? 1u : (k1 / spr - k0 / spr + 1);
   }
   __syncthreads();
   // exclusive scan of the group counts: a few hundred runs, every thread sums its own prefix
@@ -149,10 +150,11 @@ __global__ void __launch_bounds__(256) k_make_groups(const uint32_t* __restrict_
     if (n == 1) {
       if (g0 < max_groups) groups[g0] = Group{start, end - start, 0, cls};
     } else {
-      const uint32_t kb = sorted_keys[start] / SPREAD;
+      const uint32_t spr = cls ? (uint32_t)SPREAD : spr0;
+      const uint32_t kb = sorted_keys[start] / spr;
       uint32_t a = start;
       for (uint32_t k = 0; k < n; ++k) {
-        const uint32_t e = k + 1 == n ? end : lower_bound(a, end, (uint64_t)(kb + k + 1) * SPREAD);
+        const uint32_t e = k + 1 == n ? end : lower_bound(a, end, (uint64_t)(kb + k + 1) * spr);
         if (g0 + k < max_groups) groups[g0 + k] = Group{a, e - a, 0, cls};
         a = e;
       }
@@ -437,15 +439,21 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
   if (lane == 0) keys[q] = (any_rare ? 2 * Wp : 0) + (begin & 1u) * Wp + begin;
 }
 
-template <bool ACC>
+// SPR: window starts of a group lie within SPR sites.  96 for large chunks (many reads per window
+// start: 1024 consecutive reads of the sorted order span few starts); 288 for small ones (the
+// reference's default --chunk-size 5000 puts ~2 reads on a start: a 96-site bucket holds ~180 reads,
+// a workgroup's 1024 lanes would be 18 % full) -- the 16-bit LDS offsets still fit:
+// (288 / 2 + 79) * 288 + 35 * 8 < 65536.
+template <bool ACC, int SPR = SPREAD>
 __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     const double* __restrict__ lookup2, const uint16_t* __restrict__ packed,
     const uint16_t* __restrict__ tails, const uint32_t* __restrict__ win_begin,
     const uint32_t* __restrict__ win_span, const uint32_t* __restrict__ perm,
     const Group* __restrict__ groups, uint32_t W, uint32_t B, uint32_t pitch, uint32_t NP16,
     const uint32_t* __restrict__ status, double* __restrict__ lnl) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [TROWS2][PE] doubles, then accs
-  double* accs = reinterpret_cast<double*>(smem + (size_t)TROWS2 * PROWB);  // [NB2_ACC][GQ2] (ACC only)
+  constexpr int TR2 = (CH + SPR) / 2;   // pair rows staged per (branch, chunk)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [TR2][PE] doubles, then accs
+  double* accs = reinterpret_cast<double*>(smem + (size_t)TR2 * PROWB);  // [NB2_ACC][GQ2] (ACC only)
   __shared__ uint32_t s_maxspan;
   constexpr uint32_t NBP = ACC ? NB2_ACC : NB2;
   // persistent grid over (group, branch tile) items of class 0, see k_preplace
@@ -504,12 +512,12 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
       for (int i = 0; i < PW; ++i) cw[i] = 0;
     }
     const uint32_t row0 = gmin + cbase;  // alignment site of pair row 0 of the staged slice
-    const uint32_t need = min((uint32_t)TROWS2, (gspread >> 1) + (min((uint32_t)CH, s_maxspan - cbase) + 1) / 2);
+    const uint32_t need = min((uint32_t)TR2, (gspread >> 1) + (min((uint32_t)CH, s_maxspan - cbase) + 1) / 2);
     // The slice of branch j+1 is requested (into registers) before the gathers of branch j start
     // and written to LDS after them: its HBM latency hides under the gather phase.
     const uint32_t rows = (row0 < W) ? min(need, (W - row0 + 1) / 2) : 0;
     const uint32_t n2 = rows * (PE / 2);
-    constexpr int PF = (TROWS2 * (PE / 2) + GQ2 - 1) / GQ2;
+    constexpr int PF = (TR2 * (PE / 2) + GQ2 - 1) / GQ2;
     double2 pf[PF];
     auto request = [&](uint32_t j) {
       // pair row r = table row (row0 + 2r); the rows of one parity are contiguous in lookup2
@@ -1146,10 +1154,15 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     EPA_HIP(ctx, rocprim::radix_sort_pairs<epa_radix_cfg>(temp, temp_bytes, d_begin, sorted_keys, iota, perm, Q, 0, wbits,
                                            ctx->stream));
   }
+  // wide slices for the pair path when a chunk puts few reads on a window start (see k_preplace_pairs)
+  const bool acc_early = max_span == 0 || max_span > (uint32_t)CH || getenv("EPA_PREPLACE_ACC");
+  static const bool narrow_only = getenv("EPA_PREPLACE_NARROW") != nullptr;
+  const bool wide = pairs && !acc_early && !narrow_only && (uint64_t)Q * SPREAD < (uint64_t)1400 * ctx->W;   // < ~700 reads per 96-site bucket and parity
+  constexpr int SPREAD_WIDE = 288;
   hipLaunchKernelGGL(k_make_groups, dim3(1), dim3(256),
                      sizeof(uint32_t) * (2 * (n_blocks + 1) + 4 * (size_t)max_runs + 2), ctx->stream,
-                     sorted_keys, Q, pairs ? Wp : 0xffffffffu, n_blocks, class_blocks, gq0, gq1, max_runs,
-                     groups, max_groups, status);
+                     sorted_keys, Q, pairs ? Wp : 0xffffffffu, n_blocks, class_blocks, gq0, gq1,
+                     (uint32_t)(wide ? SPREAD_WIDE : SPREAD), max_runs, groups, max_groups, status);
   // persistent grids: every resident workgroup slot of the device, work items strided over them
   const uint32_t ntiles = (ctx->B + NB - 1) / NB;
   // max_span: upper bound of the window spans when the caller knows it (0 = unknown)
@@ -1173,7 +1186,13 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     hipLaunchKernelGGL((k_preplace_pairs<A>), grid2, dim3(GQ2), lds2, ctx->stream, ctx->lookup2, packed, \
                        tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl);    \
   } while (0)
-  if (pairs) { if (acc) PRE2(true); else PRE2(false); }
+  if (pairs && wide) {
+    const size_t lds2w = (size_t)((CH + SPREAD_WIDE) / 2) * PROWB + sizeof(double) * NB2_ACC * GQ2;
+    EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<false, SPREAD_WIDE>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2w));
+    hipLaunchKernelGGL((k_preplace_pairs<false, SPREAD_WIDE>), grid2, dim3(GQ2), lds2w, ctx->stream, ctx->lookup2,
+                       packed, tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl);
+  } else if (pairs) { if (acc) PRE2(true); else PRE2(false); }
 #undef PRE2
   if (sites) {
     const bool acc_s = max_span == 0 || max_span > (uint32_t)CHS || getenv("EPA_PREPLACE_ACC");
