@@ -999,7 +999,7 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
     }                                                                                              \
     if (want > n_pairs) want = n_pairs;                                                            \
     const uint32_t nwg = (uint32_t)((want + 7) / 8 * 8);                                           \
-    constexpr bool TH_ = (NW_) == 1 && (N) >= 2;   /* half-chunk tail instantiations exist for these */               \
+    constexpr bool TH_ = (NW_) == 1 && ((N) == 2 || (N) == 3);   /* half-chunk tail instantiations exist for these */  \
     if (tailh && TH_ && ctx->dna_zero0 && !ctx->blo.sliding && !a.cinv)                                                \
       hipLaunchKernelGGL((k_thorough_dna<N, true, false, 1, true, TH_>), dim3(nwg), dim3(64), 0, ctx->stream, a);      \
     else if (tailh && TH_ && ctx->dna_zero0 && ctx->blo.sliding && a.cinv)                                            \
@@ -1016,11 +1016,15 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
   // -> 6.42 ms per launch.  EPA_TH_TAIL=0 runs these classes on the full-chunk kernels.
   static const bool tail_off = getenv("EPA_TH_TAIL") && atoi(getenv("EPA_TH_TAIL")) == 0;
   const bool tailh = !tail_off && (cls == 10 || cls == 11);
+  static const bool n4_off = getenv("EPA_TH_N4") && atoi(getenv("EPA_TH_N4")) == 0;
   switch (cls) {
     case 0: LAUNCH(1, 1); break;
     case 1: case 10: LAUNCH(2, 1); break;
     case 2: case 11: LAUNCH(3, 1); break;
-    case 3: LAUNCH(2, 2); break;   // <= 256 sites
+    // <= 256 sites: ONE wave with four chunks beats two waves with two (one barrier per Newton
+    // evaluation and 2-wave workgroups cost more than the 82 spilled registers of NCH = 4): len 224
+    // 7.60 -> 6.11 ms, len 256 6.88 -> 5.68 ms per launch.  NCH = 5 / 6 lose (9.6 / 11.4 vs 7.8 / 7.4 ms).
+    case 3: if (n4_off) LAUNCH(2, 2); else LAUNCH(4, 1); break;
     case 4: LAUNCH(3, 2); break;   // <= 384
     case 5: LAUNCH(2, 4); break;   // <= 512
     case 6: LAUNCH(3, 4); break;   // <= 768
