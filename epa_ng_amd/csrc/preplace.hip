@@ -360,7 +360,10 @@ constexpr int TROWS2 = TROWS / 2;       // pair rows staged per (branch, chunk)
 constexpr int GQ2 = 1024;               // queries (threads) per group of the pair path: one
                                         // workgroup per CU, the staged slice is shared by 1024 queries
 constexpr int NB2 = 32;                 // branches per item of the fast paths (single-chunk variant)
-constexpr int NB2_ACC = 8;              // branches per workgroup when partial sums live in LDS
+constexpr int NB2_ACC = 15;             // branches per work item when partial sums live in LDS (multi-chunk
+                                        // windows): 15 x 1024 doubles + the 36 KB slice fill the CU's 160 KB
+constexpr int NB2_ACC_S = 14;           // the same for the 20-state site path (43 KB slice)
+constexpr int NB2_BURST = 8;            // single-chunk variants: result rows staged per 64-byte burst
 constexpr uint32_t ZERO_OFF = (PE - 1) * 8;  // (none, none) of the thread's own first row: exact +0.0
 
 // state-set code (4-bit mask) -> symbol; 6 = any other ambiguity code (generic kernel)
@@ -658,7 +661,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [TROWS_S][NCOLS] doubles, then accs
   double* accs = reinterpret_cast<double*>(smem + (size_t)TROWS_S * ROWB);  // [NB2_ACC][GQ2] (ACC only)
   __shared__ uint32_t s_maxspan;
-  constexpr uint32_t NBP = ACC ? NB2_ACC : NB2;
+  constexpr uint32_t NBP = ACC ? NB2_ACC_S : NB2;
   const uint32_t ng = status[5], ntiles = (B + NBP - 1) / NBP;
   const int t = threadIdx.x;
   auto at = [&](uint32_t off) -> double { return *reinterpret_cast<const double*>(smem + off); };
@@ -1168,7 +1171,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   // max_span: upper bound of the window spans when the caller knows it (0 = unknown)
   const bool acc = max_span == 0 || max_span > (uint32_t)CH || getenv("EPA_PREPLACE_ACC");
   const size_t lds = sizeof(double) * ((size_t)TROWS * ctx->ncols + (acc ? (size_t)NB * GQ : 0));
-  const size_t lds2 = (size_t)TROWS2 * PROWB + sizeof(double) * NB2_ACC * GQ2;  // accs / result staging
+  const size_t lds2 = (size_t)TROWS2 * PROWB + sizeof(double) * (acc ? NB2_ACC : NB2_BURST) * GQ2;  // accs / result staging
   const uint32_t ntiles2 = (ctx->B + (acc ? NB2_ACC : NB2) - 1) / (acc ? NB2_ACC : NB2);
   const dim3 grid2((uint32_t)std::min<uint64_t>((uint64_t)max_groups * ntiles2, (uint64_t)ctx->n_cu));  // 1 per CU
   // generic kernel: with the pair path on it only sees the few groups of queries with rare
@@ -1187,7 +1190,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
                        tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl);    \
   } while (0)
   if (pairs && wide) {
-    const size_t lds2w = (size_t)((CH + SPREAD_WIDE) / 2) * PROWB + sizeof(double) * NB2_ACC * GQ2;
+    const size_t lds2w = (size_t)((CH + SPREAD_WIDE) / 2) * PROWB + sizeof(double) * NB2_BURST * GQ2;
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<false, SPREAD_WIDE>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2w));
     hipLaunchKernelGGL((k_preplace_pairs<false, SPREAD_WIDE>), grid2, dim3(GQ2), lds2w, ctx->stream, ctx->lookup2,
@@ -1196,8 +1199,8 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
 #undef PRE2
   if (sites) {
     const bool acc_s = max_span == 0 || max_span > (uint32_t)CHS || getenv("EPA_PREPLACE_ACC");
-    const size_t lds_s = (size_t)TROWS_S * 24 * 8 + sizeof(double) * NB2_ACC * GQ2;  // accs / result staging
-    const uint32_t ntiles_s = (ctx->B + (acc_s ? NB2_ACC : NB2) - 1) / (acc_s ? NB2_ACC : NB2);
+    const size_t lds_s = (size_t)TROWS_S * 24 * 8 + sizeof(double) * (acc_s ? NB2_ACC_S : NB2_BURST) * GQ2;  // accs / result staging
+    const uint32_t ntiles_s = (ctx->B + (acc_s ? NB2_ACC_S : NB2) - 1) / (acc_s ? NB2_ACC_S : NB2);
     const dim3 grid_s((uint32_t)std::min<uint64_t>((uint64_t)max_groups * ntiles_s, (uint64_t)ctx->n_cu));
 #define PRES(A)                                                                                      \
   do {                                                                                               \
