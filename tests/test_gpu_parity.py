@@ -338,7 +338,7 @@ def test_every_span_class_in_one_chunk_incl_half_chunk_tails():
     labels, seqs = synth.simulate_msa(root, 700, synth.CFG2_SUBST, synth.CFG2_FREQS, rates, 6)
     nw = synth.newick(root)
     reads = []
-    for k, rl in enumerate((30, 64, 65, 80, 96, 97, 128, 129, 150, 160, 161, 192, 193, 300)):
+    for k, rl in enumerate((30, 64, 65, 80, 96, 97, 128, 129, 150, 160, 161, 192, 193, 224, 256, 257, 300)):
         r, _ = synth.make_reads(seqs, 5, rl, 0.02, 70 + k, states=4)
         reads += list(r)
     ref = hostlib.Reference(nw, labels, seqs, states=4, subst=synth.CFG2_SUBST, freqs=synth.CFG2_FREQS, rates=rates)
