@@ -14,10 +14,15 @@ Two timed loops over the SAME chunks, both in the JSON line:
   pcie_inclusive   SURVEY 8d's definition (H2D of the queries + D2H of the results inside the
                    step): the double-buffered epa_dev_chunk_stage / _launch / _finish pipeline,
                    4-bit wire format up, pairs + results down, copies on the copy stream.
-N > 1: one process per GPU; --scaling weak (default): every rank its own --chunk reads per step;
---scaling strong: a step is --chunk reads GLOBALLY, sharded with the reference's
-local_seq_package formula (--reads R sets steps = ceil(R / chunk), e.g. cfg4: --reads 10000000).
-The only exchange is the RCCL gather of the per-pair results to rank 0, overlapped.
+N > 1: one process per GPU, every rank --chunk reads per step in BOTH scaling modes (a step of the
+job is --chunk x N reads, sharded with the reference's local_seq_package formula: contiguous
+slices).  --scaling weak (default, the bench contract's K steps): per-GPU work fixed, total work
+grows with N.  --scaling strong --reads R: the job is R reads whatever N is, steps =
+ceil(R / (chunk x N)) -- BASELINE configs[3] (cfg4) is `--gpus 8 --scaling strong --reads 10000000`.
+Every default run ALSO times that fixed 10^7-read job on its N GPUs (`strong_cfg4` in the line), so
+that the driver's N = 1, 2, 4, 8 lines carry a strong-scaling curve next to the weak one.
+The only exchange is the RCCL gather of the per-pair results to rank 0, overlapped; no per-chunk
+host synchronisation (epa_ng_amd/parallel.py).
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps 5 --warmup 1
@@ -51,7 +56,11 @@ def parse():
                    help="reads per step (EPA-ng --chunk-size; default = the whole cfg2 query set)")
     p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     p.add_argument("--reads", type=int, default=0,
-                   help="strong scaling: total reads of the job (steps = ceil(reads / chunk))")
+                   help="strong scaling: total reads of the job (steps = ceil(reads / (chunk x N)))")
+    p.add_argument("--strong-reads", type=int, default=10000000,
+                   help="size of the fixed job timed as `strong_cfg4` (BASELINE configs[3]: 10^7 reads); 0 = skip")
+    p.add_argument("--pool", type=int, default=12,
+                   help="distinct synthetic chunks resident per GPU; longer runs cycle through them")
     p.add_argument("--tips", type=int, default=512)
     p.add_argument("--width", type=int, default=1500)
     p.add_argument("--read-len", type=int, default=150)
@@ -134,8 +143,9 @@ def main():
 
     # ---------------- workload (identical reference on every rank)
     if a.scaling == "strong" and a.reads:
-        a.steps = -(-a.reads // a.chunk)
-    n_chunks = a.steps + a.warmup
+        a.steps = -(-a.reads // (a.chunk * world))
+    n_steps = a.steps + a.warmup
+    n_chunks = min(n_steps, max(a.pool, a.warmup + 2))   # distinct chunks per rank; step i uses chunk i % n_chunks
     states = 4 if a.workload == "dna" else 20
     if a.workload == "dna":
         subst, freqs, alpha, seeds = synth.CFG2_SUBST, synth.CFG2_FREQS, synth.CFG2_ALPHA, (1, 2, 3)
@@ -148,27 +158,27 @@ def main():
     newick = synth.newick(root)
     ref = hostlib.Reference(newick, labels, seqs, states=states, subst=subst, freqs=freqs, rates=rates)
     ev = ref.evaluator(device=local)
+    # the library's kernels go to torch's current stream: everything torch enqueues around a chunk
+    # call (the packing for the result gather) is stream-ordered with it, no host synchronisation
+    ev.set_stream(torch.cuda.current_stream().cuda_stream)
     ev.build_lookup()
     torch.cuda.synchronize()
     lookup_ms = ev.kernel_ms("lookup")
     B, W = ref.B, ref.W
 
-    # reads of step c on this rank, generated straight in the compact wire layout.  weak: the rank's
-    # own chunk of the stream (global chunk index rank * n_chunks + c); strong: this rank's
-    # local_seq_package slice of the global chunk c (src/net/epa_mpi_util.cpp:10-30)
+    # reads of this rank, generated straight in the compact wire layout.  A step of the job is
+    # chunk x world consecutive reads of the stream; rank r holds the contiguous slice
+    # local_seq_package gives it (src/net/epa_mpi_util.cpp:10-30), i.e. its own `chunk` reads: slice
+    # (step c, rank r) of the stream is generated from seed index c * world + r, nothing else.
+    assert parallel.local_seq_package(a.chunk * world, rank, world) == (a.chunk * rank, a.chunk)
     host_chunks = []
     for c in range(n_chunks):
-        if a.scaling == "weak":
-            g = rank * n_chunks + c
-            codes, wb, ws = synth.make_reads_compact(seqs, a.chunk, a.read_len, 0.03, seeds[2] + 1000003 * g, states)
-        else:
-            codes, wb, ws = synth.make_reads_compact(seqs, a.chunk, a.read_len, 0.03, seeds[2] + 1000003 * c, states)
-            off, cnt = parallel.local_seq_package(a.chunk, rank, world)
-            codes, wb, ws = codes[off:off + cnt].copy(), wb[off:off + cnt].copy(), ws[off:off + cnt].copy()
+        g = c * world + rank
+        codes, wb, ws = synth.make_reads_compact(seqs, a.chunk, a.read_len, 0.03, seeds[2] + 1000003 * g, states)
         wire = epa.pack_codes_4bit(codes) if states == 4 else codes   # what crosses PCIe
         host_chunks.append((codes, wb, ws, wire))
     Q = len(host_chunks[0][1])                    # reads per step on this rank
-    step_reads = a.chunk * world if a.scaling == "weak" else a.chunk   # reads per step, whole job
+    step_reads = a.chunk * world                  # reads per step, whole job
     dev_chunks = [(torch.from_numpy(c).to(dev), torch.from_numpy(b.view(np.int32)).to(dev),
                    torch.from_numpy(s.view(np.int32)).to(dev)) for c, b, s, _ in host_chunks]
     cap = max(Q, 1) * 64   # pair capacity per step (dynamic heuristic selects a handful per read)
@@ -177,19 +187,25 @@ def main():
 
     th_ms, th_pairs, th_rounds, th_evals, pre_ms, sel_ms = [], [], [], [], [], []
 
-    def timed(loop_body, finish):
-        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks"""
-        for i in range(a.warmup):
+    rank_elapsed = {}
+
+    def timed(loop_body, finish, tag, n_timed=None, n_warm=None, record=True):
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks;
+        the per-rank times (before the MAX) are kept in rank_elapsed[tag]"""
+        n_warm = a.warmup if n_warm is None else n_warm
+        n_timed = a.steps if n_timed is None else n_timed
+        for i in range(n_warm):
             loop_body(i, False)
         finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(a.warmup, n_chunks):
-            loop_body(i, True)
+        for i in range(n_warm, n_warm + n_timed):
+            loop_body(i, record)
         finish()
         torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
         if world > 1:
             dist.barrier()
         el = time.perf_counter() - t0
@@ -197,13 +213,22 @@ def main():
             t = torch.tensor([el], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
+            mt = torch.tensor([mine], dtype=torch.float64, device=cdev)
+            allm = [torch.zeros_like(mt) for _ in range(world)]
+            dist.all_gather(allm, mt)
+            rank_elapsed[tag] = [float(x.item()) for x in allm]
+        else:
+            rank_elapsed[tag] = [mine]
         return el
 
     # ---------------- loop 1: inputs resident in HBM (the contract's `value`)
-    exch = parallel.AsyncResultGather(dist, min(cap, 8 * max(Q, 1)), dev) if world > 1 else None
+    # rows per gather: 4 candidates per read on average is ample for the dynamic heuristic at
+    # 0.99999 (2.6 measured on cfg2); a chunk beyond it is carried into the next gather
+    rows_cap = min(cap, 4 * max(Q, 1))
+    exch = parallel.AsyncResultGather(dist, rows_cap, dev) if world > 1 else None
 
     def step_resident(i, record):
-        dc, dwb, dws = dev_chunks[i]
+        dc, dwb, dws = dev_chunks[i % n_chunks]
         # one fused call = the reference's chunk body: place() -> apply_heuristic() -> place_thorough()
         n = ev.place_chunk(dc, dwb, dws, Q=Q, threshold=0.99999, max_span=a.read_len, max_pairs=cap,
                            pairs_out=d_pairs, results_out=d_res) if Q else 0
@@ -219,16 +244,17 @@ def main():
             th_evals.append(ev.last_stats["newton_evals"])
         return n
 
-    elapsed = timed(step_resident, (lambda: exch.finish()) if world > 1 else (lambda: None))
+    fin_resident = (lambda: exch.finish()) if world > 1 else (lambda: None)
+    elapsed = timed(step_resident, fin_resident, "resident")
 
     # ---------------- loop 2: PCIe inside the step, overlapped on the copy stream
-    exch2 = parallel.AsyncResultGather(dist, min(cap, 8 * max(Q, 1)), dev, host_copy=True) if world > 1 else None
+    exch2 = parallel.AsyncResultGather(dist, rows_cap, dev, host_copy=True) if world > 1 else None
     state = {"staged": None, "inflight": None, "bytes_up": 0, "bytes_down": 0,
              "t_stage": 0.0, "t_launch": 0.0, "t_finish": 0.0, "timed": False}
     bufs = [(d_pairs, d_res), (torch.empty_like(d_pairs), torch.empty_like(d_res))]
 
     def stage(i):
-        _, hb, hs, wire = host_chunks[i]
+        _, hb, hs, wire = host_chunks[i % n_chunks]
         t = time.perf_counter()
         ev.chunk_stage(i & 1, wire, hb, hs)                  # host -> pinned -> async H2D (copy stream)
         state["t_stage"] += (time.perf_counter() - t) if i > a.warmup else 0.0   # timed steps only
@@ -264,7 +290,7 @@ def main():
         if state["inflight"] is not None:                    # previous chunk: its D2H ran under this preplace
             retire(state["inflight"])
         state["inflight"] = slot
-        if i + 1 < n_chunks and i + 1 != a.warmup:           # upload of the next chunk under this one's kernels
+        if i + 1 < n_steps and i + 1 != a.warmup:            # upload of the next chunk under this one's kernels
             stage(i + 1)                                     # (never across the warmup / timed boundary)
 
     def finish_pcie():
@@ -273,7 +299,22 @@ def main():
         if world > 1:
             exch2.finish()
 
-    elapsed_pcie = timed(step_pcie, finish_pcie)
+    elapsed_pcie = timed(step_pcie, finish_pcie, "pcie")
+
+    # ---------------- the fixed-size job of BASELINE configs[3] (cfg4: 10^7 reads) on these N GPUs:
+    # ceil(R / (chunk x N)) steps of `chunk` reads per rank, inputs resident, gather to rank 0 included
+    strong = None
+    if a.strong_reads and states == 4 and not a.no_extras and not (a.scaling == "strong" and a.reads):
+        s_steps = -(-a.strong_reads // (a.chunk * world))
+        el_s = timed(step_resident, fin_resident, "strong", n_timed=s_steps, n_warm=1, record=False)
+        strong = {"reads": s_steps * a.chunk * world, "value": round(s_steps * a.chunk * world / el_s, 2),
+                  "unit": "placements/s", "seconds": round(el_s, 4), "steps_per_rank": s_steps,
+                  "reads_per_step_per_gpu": Q,
+                  "per_rank_seconds": [round(x, 4) for x in rank_elapsed["strong"]],
+                  "note": "BASELINE configs[3] (cfg4): a fixed job of 10^7 reads dealt over the N GPUs in "
+                          "contiguous slices, %d-read chunks per GPU cycling through %d distinct resident "
+                          "synthetic chunks, result gather to rank 0 inside the clock; compare `value` across "
+                          "the N = 1, 2, 4, 8 lines for the strong-scaling curve" % (Q, n_chunks)}
 
     if rank != 0:
         if world > 1:
@@ -358,26 +399,39 @@ def main():
         # the oracle's OpenMP threads = the CPUs this process may really use (a container can see
         # 256 CPUs and be limited to 16 by its cgroup quota: oversubscribing would slow the baseline)
         eff = hostlib.configure_threads()
-        from oracle_lib import Oracle, lib as orc_lib
+        import oracle_lib
+        from oracle_lib import Oracle
         ns = min(a.cpu_sample, Q)
-        hc, hb, hs, _ = host_chunks[a.warmup]
+        hc, hb, hs, _ = host_chunks[a.warmup % n_chunks]
         sample = synth.compact_to_ascii(hc[:ns], hb[:ns], hs[:ns], W, states)
-        o = Oracle(newick, labels, seqs, states, subst, freqs, rates)
-        o.preplace(sample[:8])                      # builds the per-branch lookups (one-off)
         codes, wb, ws = epa.encode_queries(states, sample)
         lnl_gpu = ev.preplace(codes, wb, ws)
         prs = ev.select(lnl_gpu, ns, 0.99999)
         res_gpu = ev.thorough(prs, codes, wb, ws)
+        # timed leg: the oracle's source built with full optimisation for THIS host CPU
+        # (oracle_lib.FAST_CFLAGS); parity leg: the strict build (-O2, no FMA contraction), untimed
+        of = Oracle(newick, labels, seqs, states, subst, freqs, rates, fast=True)
+        of.preplace(sample[:8])                     # builds the per-branch lookups (one-off)
         c0 = time.perf_counter()
+        of.preplace(sample)
+        of.thorough(prs["branch_id"], prs["seq_id"], sample)
+        cpu_t = time.perf_counter() - c0
+        cores = min(eff, of.L.orc_max_threads())
+        del of
+        o = Oracle(newick, labels, seqs, states, subst, freqs, rates)
+        s0 = time.perf_counter()
         lnl_cpu = o.preplace(sample)
         tl, tp, td = o.thorough(prs["branch_id"], prs["seq_id"], sample)
-        cpu_t = time.perf_counter() - c0
-        cores = min(eff, orc_lib().orc_max_threads())
+        strict_t = time.perf_counter() - s0         # includes the strict build's lookup construction
+        sc_at = o.score_at(prs["branch_id"], prs["seq_id"], sample, res_gpu["pendant_length"], res_gpu["distal_length"])
         cpu = {"value": round(ns / cpu_t, 2), "unit": "placements/s", "cores": cores, "kind": "port",
+               "cflags": oracle_lib.FAST_CFLAGS,
                "sample": "%d reads of step 0 through the oracle's OpenMP preplace (B=%d) + thorough "
-                         "(%d pairs), lookups prebuilt" % (ns, B, len(prs))}
+                         "(%d pairs), lookups prebuilt" % (ns, B, len(prs)),
+               "strict_build_seconds_same_sample": round(strict_t, 2)}
         parity = {"preplace_max_abs_dlnl": float(np.max(np.abs(lnl_gpu - lnl_cpu))),
                   "thorough_max_abs_dlnl": float(np.max(np.abs(res_gpu["lnl"] - tl))),
+                  "evaluator_max_abs_dlnl_at_device_lengths": float(np.max(np.abs(res_gpu["lnl"] - sc_at))),
                   "pairs_checked": int(len(prs))}
         if not a.no_extras:
             # the reference's own executable, if the box happens to have one (it never did so far)
@@ -397,7 +451,7 @@ def main():
     if world == 1 and not a.no_extras and Q >= 5000:
         # the reference's default chunk size (--chunk-size 5000, src/util/Options.hpp) through the
         # same double-buffered pipeline: 40 chunks cut from step 0's reads, PCIe inside the clock
-        hc, hb, hs, wire = host_chunks[a.warmup]
+        hc, hb, hs, wire = host_chunks[a.warmup % n_chunks]
         nsm = min(40, Q // 5000)
         small = []
         for k in range(nsm):
@@ -424,8 +478,8 @@ def main():
               else "query placements/sec (whole node), AA PROTGTR+G4 ref (cfg3 shape), preplace+thorough")
     pcie = {"value": round(total_reads / elapsed_pcie, 2), "unit": "placements/s",
             "ms_per_step": round(elapsed_pcie / a.steps * 1e3, 3),
-            "h2d_bytes_per_step": state["bytes_up"] // max(1, n_chunks),
-            "d2h_bytes_per_step": state["bytes_down"] // max(1, n_chunks),
+            "h2d_bytes_per_step": state["bytes_up"] // max(1, n_steps),
+            "d2h_bytes_per_step": state["bytes_down"] // max(1, n_steps),
             "host_ms_per_step": {"stage (memcpy to pinned + H2D enqueue)": round(state["t_stage"] / max(1, a.steps - 1) * 1e3, 3),
                                  "launch (returns when the candidate count is known)": round(state["t_launch"] / a.steps * 1e3, 3),
                                  "finish (wait for the previous chunk's D2H)": round(state["t_finish"] / max(1, a.steps - 1) * 1e3, 3)},
@@ -450,7 +504,9 @@ def main():
                       "kernel_ms_per_step": {"preplace": round(float(np.mean(pre_ms)), 3),
                                              "select": round(float(np.mean(sel_ms)), 3),
                                              "thorough": round(float(np.mean(th_ms)), 3)}},
-           "pcie_inclusive": pcie,
+           "pcie_inclusive": pcie, "strong_cfg4": strong,
+           "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
+           "per_rank_ms_per_step": [round(x / a.steps * 1e3, 3) for x in rank_elapsed["resident"]],
            "roofline": roof, "roofline_preplace": roof_pre, "cpu_baseline": cpu, "parity": parity}
     out.update(extras)
     print(json.dumps(out))

@@ -67,7 +67,29 @@ typedef struct {
   double pinv;
   int rate_scalers; /* PLL_ATTRIB_RATE_SCALERS: scaler arrays are [site][cat] (src/tree/tiny_util.cpp:37-44,
                      * auto-on for > 2000 tips, src/io/file_io.cpp:211-214) */
+  uint64_t rounding_variant; /* 0 = this file's arithmetic as written.  != 0: a "faithfully rounded
+                     * sibling" of it (orc_set_rounding_variant): every TERM of the sumtable's dot
+                     * products and of the derivative contractions (what another summation order
+                     * amounts to) and every site likelihood of the edge score is moved by
+                     * -a / 0 / +a ulp (hash of the seed and the operand bits; a = 2^(bits 16..19 of the
+                     * seed): sums of s products in another order differ by a few ulp, not one), and odd
+                     * seeds sum the sites of f, f' from the far end.  It stands for ANY other correct evaluation order (another SIMD width,
+                     * libm, reduction tree): tests use it to show that a pair on which the device and
+                     * this oracle end at different lengths is one on which the oracle disagrees with
+                     * itself. */
 } orc_model;
+
+/* -1 / 0 / +1 from a hash of (seed, salt, bits of v); v * (1 + sigma 2^-52) */
+static inline double orc_ulp_noise(uint64_t seed, uint64_t salt, double v) {
+  if (!seed) return v;
+  uint64_t h;
+  memcpy(&h, &v, 8);
+  h ^= seed * 0x9E3779B97F4A7C15ull + salt * 0xBF58476D1CE4E5B9ull;
+  h ^= h >> 31; h *= 0x94D049BB133111EBull; h ^= h >> 29;
+  const int sg = (int)(h % 3) - 1;
+  const int amp = 1 << ((seed >> 16) & 15); /* bits 16..19 of the seed: amplitude 2^0 .. 2^15 ulp */
+  return sg ? v * (1.0 + sg * amp * 0x1p-52) : v;
+}
 
 /* libpll PLL_SCALE_RATE_MAXDIFF and the scale_minlh table (recollection, like the other pll
  * constants): with per-rate scalers a category whose count exceeds the site minimum by d is
@@ -596,6 +618,7 @@ static double edge_lnl(const orc_model* m, const orc_side* par, const orc_side* 
     }
     uint32_t sc = m->rate_scalers ? rmin
                                   : (par->scaler ? par->scaler[site] : 0) + (ch->scaler ? ch->scaler[site] : 0);
+    if (m->rounding_variant) terma = orc_ulp_noise(m->rounding_variant, site, terma);
     double site_lk = log(terma);
     if (sc) site_lk += sc * log_thr;
     if (persite) persite[site] = site_lk;
@@ -620,10 +643,16 @@ static void update_sumtable(const orc_model* m, const orc_side* A, const orc_sid
                              : (((A->tipmask[site] >> i) & 1u) ? 1.0 : 0.0);
           double bv = Bs->clv ? Bs->clv[(site * c + k) * s + i]
                               : (((Bs->tipmask[site] >> i) & 1u) ? 1.0 : 0.0);
-          lt += av * m->freqs[i] * m->u[i * s + j];
-          rt += m->uinv[j * s + i] * bv;
+          if (m->rounding_variant) { /* noise on every TERM: what another summation order amounts to */
+            lt += orc_ulp_noise(m->rounding_variant, (site * 64 + k * 20 + j) * 41 + i, av * m->freqs[i] * m->u[i * s + j]);
+            rt += orc_ulp_noise(m->rounding_variant, (site * 64 + k * 20 + j) * 43 + i, m->uinv[j * s + i] * bv);
+          } else {
+            lt += av * m->freqs[i] * m->u[i * s + j];
+            rt += m->uinv[j * s + i] * bv;
+          }
         }
-        S[((site - b) * c + k) * s + j] = m->rate_scalers ? lt * rt * rfac[k] : lt * rt;
+        double sv = m->rate_scalers ? lt * rt * rfac[k] : lt * rt;
+        S[((site - b) * c + k) * s + j] = sv;
       }
   }
 }
@@ -634,21 +663,39 @@ static void lk_derivatives(const orc_model* m, const double* S, size_t n, double
                            const int8_t* invariant, size_t b, double* d1, double* d2) {
   const int s = m->s, c = m->c;
   double dg[ORC_MAX_C * ORC_MAX_S * 3];
+  /* rounding variants with bit 11 / bit 12 set: the eigenvalue of the stationary mode -- 0 in exact
+   * arithmetic, a few 1e-17 of either sign out of any numerical eigen-solver -- taken as exactly 0 /
+   * with the opposite sign.  At saturated lengths (every other exp() underflown) its residue IS f. */
+  int jz = -1;
+  if (m->rounding_variant & 0x1800) {
+    jz = 0;
+    for (int j = 1; j < s; ++j) if (fabs(m->evals[j]) < fabs(m->evals[jz])) jz = j;
+  }
   for (int k = 0; k < c; ++k) {
     double ki = m->rates[k] / (1.0 - m->pinv);
     for (int j = 0; j < s; ++j) {
-      double e0 = exp(m->evals[j] * ki * t);
+      double ev = m->evals[j];
+      if (j == jz) ev = (m->rounding_variant & 0x800) ? 0.0 : -ev;
+      double e0 = exp(ev * ki * t);
       dg[(k * s + j) * 3 + 0] = e0;
-      dg[(k * s + j) * 3 + 1] = m->evals[j] * ki * e0;
-      dg[(k * s + j) * 3 + 2] = m->evals[j] * ki * m->evals[j] * ki * e0;
+      dg[(k * s + j) * 3 + 1] = ev * ki * e0;
+      dg[(k * s + j) * 3 + 2] = ev * ki * ev * ki * e0;
     }
   }
   double f = 0.0, df = 0.0;
-  for (size_t x = 0; x < n; ++x) {
+  for (size_t xi = 0; xi < n; ++xi) {
+    const size_t x = (m->rounding_variant & 1) ? n - 1 - xi : xi;
     double l0 = 0, l1 = 0, l2 = 0;
     for (int k = 0; k < c; ++k) {
       double c0 = 0, c1 = 0, c2 = 0;
       const double* sm = S + (x * c + k) * s;
+      if (m->rounding_variant) { /* noise on every term of the three contractions */
+        for (int j = 0; j < s; ++j) {
+          c0 += orc_ulp_noise(m->rounding_variant, 3 * j, sm[j] * dg[(k * s + j) * 3 + 0]);
+          c1 += orc_ulp_noise(m->rounding_variant, 3 * j + 1, sm[j] * dg[(k * s + j) * 3 + 1]);
+          c2 += orc_ulp_noise(m->rounding_variant, 3 * j + 2, sm[j] * dg[(k * s + j) * 3 + 2]);
+        }
+      } else
       for (int j = 0; j < s; ++j) {
         c0 += sm[j] * dg[(k * s + j) * 3 + 0];
         c1 += sm[j] * dg[(k * s + j) * 3 + 1];
@@ -682,12 +729,28 @@ typedef struct {
   int variant;
 } nr_ctx;
 
+/* optional trace of one pair's optimisation (orc_trace_pair): rows of 4 doubles
+ *   {1 | 2, t, f, f'}   a derivative evaluation of the pendant (1) / distal (2) solve
+ *   {3, new -lnL, old -lnL, reverted}   the score at the end of a round (optimize.cpp:217-232) */
+typedef struct { double* rows; long cap, n; int phase; } orc_trace;
+static __thread orc_trace* g_trace = NULL;
+static inline void trace_row(double kind, double a, double b, double c) {
+  if (!g_trace) return;
+  if (g_trace->n < g_trace->cap) {
+    double* r = g_trace->rows + 4 * g_trace->n;
+    r[0] = kind; r[1] = a; r[2] = b; r[3] = c;
+  }
+  g_trace->n++;
+}
+#define TRACE_EVAL() do { if (g_trace) trace_row(g_trace->phase, rts, f, df); } while (0)
+
 static double minimize_newton(double x1, double xguess, double x2, double tol, int max_iters,
                               nr_ctx* cx) {
   double rts = xguess, f, df, xl, xh, dx, dxold;
   if (rts < x1) rts = x1;
   if (rts > x2) rts = x2;
   lk_derivatives(cx->m, cx->S, cx->n, rts, cx->inv, cx->b, &f, &df); cx->n_evals++;
+  TRACE_EVAL();
   if (!isfinite(f) || !isfinite(df)) return NAN;
   if (((cx->variant & 2) ? df > 0.0 : df >= 0.0) && fabs(f) < tol) return rts;
   if (f < 0.0) { xl = rts; xh = x2; } else { xh = rts; xl = x1; }
@@ -708,6 +771,7 @@ static double minimize_newton(double x1, double xguess, double x2, double tol, i
     if (fabs(dx) < tol || i == max_iters) return rts;
     if (rts < x1) rts = x1;
     lk_derivatives(cx->m, cx->S, cx->n, rts, cx->inv, cx->b, &f, &df); cx->n_evals++;
+    TRACE_EVAL();
     if (!isfinite(f) || !isfinite(df)) return NAN;
     if (df > 0.0 && fabs(f) < tol) return rts;
     if (f < 0.0) xl = rts; else xh = rts;
@@ -984,6 +1048,7 @@ static double opt_pplacer(orc_tiny* tt, const orc_side* tip, size_t b, size_t n,
     double xguess = tt->len_pend;
     if (xguess < xmin || xguess > xmax) xguess = x->blo_default;
     update_sumtable(m, &in, tip, tt->sumtable, b, n);
+    if (g_trace) g_trace->phase = 1;
     double xres = minimize_newton(xmin, xguess, xmax, xtol, max_iters, &cx);
     if (xres > 0.0) {
       tt->len_pend = xres;
@@ -997,6 +1062,7 @@ static double opt_pplacer(orc_tiny* tt, const orc_side* tip, size_t b, size_t n,
     xmax = original_length - xtol;
     if (xguess < xmin || xguess > xmax) xguess = original_length / 2.0;
     update_sumtable(m, &tt->dist, &in, tt->sumtable, b, n);
+    if (g_trace) g_trace->phase = 2;
     xres = minimize_newton(xmin, xguess, xmax, xtol, max_iters, &cx);
     if (xres > 0.0) {
       tt->len_dist = xres;
@@ -1008,6 +1074,7 @@ static double opt_pplacer(orc_tiny* tt, const orc_side* tip, size_t b, size_t n,
     update_partial(m, &tt->dist, tt->P_dist, &tt->prox, tt->P_prox, tt->inner, tt->inner_sc, b, n);
     double new_ll = -edge_lnl(m, tip, &in, tt->P_pend, x->invariant, NULL, b, n);
     if (stat) stat[0]++;
+    trace_row(3, new_ll, loglikelihood, (new_ll - loglikelihood > new_ll * 1e-14) ? 1.0 : 0.0);
     if (new_ll - loglikelihood > new_ll * 1e-14) { /* worse: restore lengths, keep old lnL */
       tt->len_pend = old_pend;
       tt->len_dist = old_dist;
@@ -1280,6 +1347,76 @@ void orc_pendant_derivatives(const orc_ctx* x, int b, const char* q, double t, d
   *lnl_at_t = edge_lnl(&x->m, &tip, &in, tt->P_pend, x->invariant, NULL, 0, x->W);
   free(mk);
   tiny_free(tt);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Evaluator without the optimiser: the edge log-likelihood of query q on branch b at GIVEN
+ * lengths -- what Tiny_Tree::place computes when the lengths are fixed: the three P-matrices and
+ * the inner CLV over the window (traverse_update_partials, src/core/pll/optimize.cpp:15-42) and
+ * pll_compute_edge_loglikelihood (:281-283), i.e. the quantity the reference's own sanity test
+ * looks at for a returned Placement (test/src/Tiny_Tree.cpp:39-48).  proximal == NULL: the
+ * sliding rule's proximal = original - distal (optimize.cpp:206-210).  Tests use it to check the
+ * DEVICE's log-likelihood at the DEVICE's lengths, whatever path its optimiser took.
+ * ---------------------------------------------------------------------------------------- */
+int orc_score_at(orc_ctx* x, long n_pairs, const int* pair_branch, const int* pair_seq,
+                 const char** queries, int premask, const double* pendant, const double* distal,
+                 const double* proximal, double* lnl) {
+  int err = 0;
+#pragma omp parallel
+  {
+    orc_tiny* tt = NULL;
+#pragma omp for schedule(dynamic)
+    for (long i = 0; i < n_pairs; ++i) {
+      if (!tt || tt->branch != pair_branch[i]) {
+        tiny_free(tt);
+        tt = tiny_create(x, pair_branch[i]);
+      }
+      const char* q = queries[pair_seq[i]];
+      size_t begin = 0, span = x->W;
+      if (premask) valid_range(q, x->W, &begin, &span);
+      uint32_t* mk = (uint32_t*)malloc(sizeof(uint32_t) * x->W);
+      int bad = span == 0;
+      for (size_t w = 0; w < x->W; ++w) {
+        mk[w] = orc_char_mask(x->m.s, q[w]);
+        if (!mk[w]) bad = 1;
+      }
+      if (bad) {
+#pragma omp critical(orc_err)
+        err = 1;
+        lnl[i] = NAN;
+      } else {
+        orc_side tip = {NULL, mk, NULL};
+        orc_side in = {tt->inner, NULL, tt->inner_sc};
+        const double lp = proximal ? proximal[i] : tt->orig - distal[i];
+        orc_pmatrix(&x->m, lp, tt->P_prox);
+        orc_pmatrix(&x->m, distal[i], tt->P_dist);
+        orc_pmatrix(&x->m, pendant[i], tt->P_pend);
+        update_partial(&x->m, &tt->dist, tt->P_dist, &tt->prox, tt->P_prox, tt->inner, tt->inner_sc,
+                       begin, span);
+        lnl[i] = edge_lnl(&x->m, &tip, &in, tt->P_pend, x->invariant, NULL, begin, span);
+      }
+      free(mk);
+    }
+    tiny_free(tt);
+  }
+  return err;
+}
+
+/* see orc_model.rounding_variant; 0 = off.  Affects the optimiser's path (derivative tables, edge
+ * score), not the reference CLVs (those are computed at create time). */
+void orc_set_rounding_variant(orc_ctx* x, uint64_t seed) { x->m.rounding_variant = seed; }
+
+/* one pair through tiny_place_thorough with the trace on (rows documented at orc_trace).
+ * Returns the number of rows the run produced (may exceed cap; only cap are stored). */
+long orc_trace_pair(orc_ctx* x, int b, const char* q, int premask, double* rows, long cap,
+                    double* lnl, double* pendant, double* distal) {
+  orc_trace tr = {rows, cap, 0, 0};
+  orc_tiny* tt = tiny_create(x, b);
+  g_trace = &tr;
+  tiny_place_thorough(tt, q, premask, lnl, pendant, distal, NULL);
+  g_trace = NULL;
+  tiny_free(tt);
+  return tr.n;
 }
 
 int orc_max_threads(void) {

@@ -1016,7 +1016,10 @@ def test_bench_two_ranks_on_one_gpu(scaling):
     env = dict(os.environ, EPA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                WORLD_SIZE="2", LOCAL_RANK="0")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--chunk", "6000", "--tips", "64", "--width", "600", "--scaling", scaling, "--no-extras"]
+           "--chunk", "6000", "--tips", "64", "--width", "600", "--scaling", scaling, "--no-cpu-baseline"]
+    # strong: a fixed job of 36 000 reads = 3 steps of 2 x 6000; weak: the 3 steps asked for, plus the
+    # fixed-size `strong_cfg4` leg (48 000 reads = 4 steps per rank, cycling through the resident chunks)
+    cmd += ["--reads", "36000", "--pool", "2"] if scaling == "strong" else ["--strong-reads", "48000", "--pool", "3"]
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                               text=True) for r in (1, 0)]
     outs = [p.communicate(timeout=600) for p in procs]
@@ -1024,8 +1027,105 @@ def test_bench_two_ranks_on_one_gpu(scaling):
     assert not [l for l in outs[0][0].splitlines() if l.startswith("{")]     # rank 1 prints no result line
     line = json.loads([l for l in outs[1][0].splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["steps"] == 3
-    per_step = 12000 if scaling == "weak" else 6000
+    if scaling == "weak":
+        sc = line["strong_cfg4"]
+        assert sc["reads"] == 48000 and sc["steps_per_rank"] == 4 and sc["value"] > 0
+        assert len(sc["per_rank_seconds"]) == 2
+    else:
+        assert line["strong_cfg4"] is None
+    per_step = 12000          # every rank its own --chunk reads per step in both modes
     assert line["config"]["reads_per_step_whole_job"] == per_step
-    assert line["config"]["reads_per_step_per_gpu"] == (6000 if scaling == "weak" else 3000)
+    assert line["config"]["reads_per_step_per_gpu"] == 6000
+    assert len(line["per_rank_ms_per_step"]) == 2 and line["rccl_ranks"] == 0   # gloo here
     assert abs(line["value"] - 3 * per_step / (line["ms_per_step"] * 3e-3)) < 1e-3 * line["value"]
     assert line["pcie_inclusive"]["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+NCCL_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["EPA_ROOT"])
+import torch
+import torch.distributed as dist
+from epa_ng_amd import parallel
+local = int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+dist.init_process_group("nccl", device_id=dev)
+rank, world = dist.get_rank(), dist.get_world_size()
+ag = parallel.AsyncResultGather(dist, rows_cap=16, device=dev, host_copy=True)
+want = []
+for step in range(5):
+    n = (40 if step == 2 and rank == world - 1 else 6) + step + rank     # one chunk overflows rows_cap: carry path
+    p = torch.zeros((64, 2), dtype=torch.int32, device=dev)
+    r = torch.zeros((64, 3), dtype=torch.float64, device=dev)
+    p[:n, 0] = torch.arange(n, dtype=torch.int32, device=dev) + 100 * step
+    p[:n, 1] = 1000 * rank + step
+    r[:n, 0] = -(p[:n, 0].double() * 7 + p[:n, 1].double())
+    r[:n, 1] = 0.25 * step
+    ag.post(p, r, n, keep=True)
+    want.append(n)
+ag.finish(keep=True)
+if rank == 0:
+    for rk in range(world):
+        rows = np.concatenate([parts[rk] for parts in ag.collected], 0)
+        exp_n = [(40 if st == 2 and rk == world - 1 else 6) + st + rk for st in range(5)]
+        assert rows.shape[0] == sum(exp_n), (rk, rows.shape, exp_n)
+        b, s_, lnl, pen, _ = parallel.unpack_rows(rows)
+        assert np.array_equal(b, np.concatenate([np.arange(n) + 100 * st for st, n in enumerate(exp_n)]))
+        assert np.array_equal(s_, np.concatenate([np.full(n, 1000 * rk + st) for st, n in enumerate(exp_n)]))
+        assert np.array_equal(lnl, -(b * 7.0 + s_))
+    # the pinned host copy of the last retired gather holds the same valid rows as the device slot
+    last = ag.counts[-1]
+    slot = (ag.step - 1) % ag.depth
+    for rk, k in enumerate(last):
+        assert np.array_equal(ag.host[slot][rk, :k].numpy(), ag.collected[-1][rk])
+    print("NCCL_GATHER_OK world=%d backend=%s" % (world, dist.get_backend()))
+dist.destroy_process_group()
+"""
+
+
+def _run_ranks(script_path, n, extra_env=None, timeout=600):
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, EPA_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    procs = [subprocess.Popen([sys.executable] + script_path, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(n)]
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    return outs
+
+
+def test_result_gather_on_the_rccl_backend(tmp_path):
+    """AsyncResultGather over backend "nccl" (= RCCL): device send / receive slots, the gather on
+    RCCL's stream, the side-stream host copy on rank 0, the carry path.  One rank per visible GPU (up
+    to 8); on the 1-GPU box that is a 1-rank group -- no xGMI traffic, but every RCCL call of the
+    exchange runs (device tensors, async gather, stream-level wait)."""
+    n = max(1, min(8, epa.device_count()))
+    script = tmp_path / "nccl_worker.py"
+    script.write_text(NCCL_WORKER)
+    outs = _run_ranks([str(script)], n)
+    assert "NCCL_GATHER_OK world=%d backend=nccl" % n in outs[0][0], outs[0]
+
+
+def test_bench_over_rccl_on_all_visible_gpus():
+    """bench.py's N > 1 branch on RCCL, one rank per GPU: runs wherever at least 2 GPUs are visible
+    (the driver's 8-GPU box), skipped on the 1-GPU box."""
+    n = min(8, epa.device_count())
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL wants one device per rank)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = _run_ranks([os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1",
+                       "--chunk", "20000", "--strong-reads", str(20000 * n * 4), "--pool", "3",
+                       "--no-cpu-baseline"], n, timeout=900)
+    line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == n and line["rccl_ranks"] == n
+    assert line["config"]["reads_per_step_whole_job"] == 20000 * n
+    assert line["strong_cfg4"]["steps_per_rank"] == 4 and line["strong_cfg4"]["value"] > 0

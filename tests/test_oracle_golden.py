@@ -180,3 +180,80 @@ def test_prop_invariant_sites_matches_bruteforce():
         assert abs(dis[i] - e["distal"]) < 1e-7
     assert o.last_stats["rounds"] == sum(e["rounds"] for row in g["thorough"] for e in row)
     assert o.last_stats["reverts"] == sum(e["reverted"] for row in g["thorough"] for e in row)
+
+
+# ---- round 3: the evaluator apart from the optimiser (orc_score_at) and the oracle's rounding siblings
+
+def _sweep_oracle(seed):
+    import sweep_util as su
+    c = su.make_case(seed)
+    o = Oracle(c["newick"], c["labels"], c["seqs"], c["states"], c["subst"], c["freqs"], c["rates"], pinv=c["pinv"])
+    B, Q = o.B, c["nreads"]
+    return c, o, np.repeat(np.arange(B), Q), np.tile(np.arange(Q), B)
+
+
+def test_score_at_returned_lengths_is_the_returned_lnl():
+    """Tiny_Tree::place returns the edge lnL of the triplet at the lengths it returns (also after the
+    'worse -> restore lengths, keep old lnL' exit, optimize.cpp:224-232): orc_score_at at the
+    optimiser's output reproduces its lnL, and at the starting lengths it is the preplacement value."""
+    c, o, pb, ps = _sweep_oracle(7)
+    tl, tp, td = o.thorough(pb, ps, c["reads"])
+    at = o.score_at(pb, ps, c["reads"], tp, td)
+    assert np.max(np.abs(at - tl)) < 1e-9
+    assert o.last_stats["reverts"] > 0            # the restore exit is exercised
+    orig = np.array([o.branch_info(b)[0] for b in range(o.B)])
+    pre = o.preplace(c["reads"])
+    at0 = o.score_at(pb, ps, c["reads"], np.full(len(pb), -np.log(0.9)), orig[pb] / 2)
+    assert np.max(np.abs(at0 - pre[ps, pb])) < 1e-8
+
+
+def test_trace_rows_follow_the_optimiser():
+    c, o, pb, ps = _sweep_oracle(7)
+    rows, l, p, d = o.trace_pair(3, c["reads"][0])
+    tl, tp, td = o.thorough([3], [0], c["reads"])
+    assert (l, p, d) == (tl[0], tp[0], td[0])
+    kinds = rows[:, 0]
+    assert kinds[0] == 1 and kinds[-1] == 3 and set(kinds) <= {1.0, 2.0, 3.0}
+    assert (kinds == 3).sum() == o.last_stats["rounds"]
+    assert (kinds != 3).sum() == o.last_stats["newton_evals"]
+    assert rows[0, 1] == -np.log(0.9)             # first row: the pendant solve starts at -ln 0.9
+
+
+def test_rounding_siblings_agree_where_the_optimum_is_well_conditioned():
+    """a sibling (terms of the dot products moved by a few ulp, stationary eigenvalue exactly 0) walks
+    the same path on an ordinary configuration: same lengths, lnL within 1e-9"""
+    c, o, pb, ps = _sweep_oracle(3)
+    tl, tp, td = o.thorough(pb, ps, c["reads"])
+    import sweep_util as su
+    for v in (1, 2, 0x801, 0x1003, (4 << 16) | 5):
+        o.set_rounding_variant(v)
+        l2, p2, d2 = o.thorough(pb, ps, c["reads"])
+        same = ~su.lengths_differ(p2, d2, tp, td)
+        assert same.mean() > 0.99
+        assert np.max(np.abs(l2 - tl)[same]) < 1e-9
+    o.set_rounding_variant(0)
+    assert np.array_equal(o.thorough(pb, ps, c["reads"])[0], tl)
+
+
+def test_oracle_disagrees_with_itself_on_the_known_bimodal_seeds():
+    """Seeds 1070 and 2692 of the randomised sweep (reads of 1 and 2 sites): the pendant likelihood
+    has two local optima and the first bisection lands where f is 0+ and f' is rounding noise.  The
+    ORACLE ALONE, evaluated by its faithfully rounded siblings, ends in either of them -- with the
+    lnL gaps round 2 saw between device and oracle (0.766 and 1.95) -- while the evaluator
+    (score_at at whatever lengths came out) stays exact.  This is the CPU-side half of the rule the GPU
+    sweep applies to diverging pairs (tests/test_gpu_parity.py)."""
+    import sweep_util as su
+    for seed, gap in ((1070, 0.766), (2692, 1.95)):
+        c, o, pb, ps = _sweep_oracle(seed)
+        tl, tp, td = o.thorough(pb, ps, c["reads"])
+        worst = 0.0
+        for v in (1, 2, 3, 4, 5, 6, 0x801, 0x802):
+            o.set_rounding_variant(v)
+            l2, p2, d2 = o.thorough(pb, ps, c["reads"])
+            o.set_rounding_variant(0)
+            at = o.score_at(pb, ps, c["reads"], p2, d2)
+            assert np.max(np.abs(at - l2)) < 1e-9      # the evaluator does not care which optimum
+            fl = su.lengths_differ(p2, d2, tp, td)
+            if fl.any():
+                worst = max(worst, float(np.abs(l2 - tl)[fl].max()))
+        assert abs(worst - gap) < 0.01, (seed, worst)

@@ -40,7 +40,7 @@ else:
     assert out is None
 # overlapped exchange used by bench.py: three chunks through two slots
 import torch
-ag = parallel.AsyncResultGather(dist, max_rows=64, device=torch.device("cpu"))
+ag = parallel.AsyncResultGather(dist, rows_cap=64, device=torch.device("cpu"))
 for step in range(3):
     n = 5 + 3 * rank + step
     p = torch.zeros((64, 2), dtype=torch.int32)
@@ -60,7 +60,33 @@ if rank == 0:
             assert np.array_equal(b, np.arange(len(b)) + 100 * step)
             assert np.array_equal(s_, np.arange(len(b)) + 1000 * rk)
             assert np.array_equal(lnl, -(b * 7.0 + s_))
+    assert ag.carried_rows == 0
     print("ASYNC_OK")
+# a rank whose chunk exceeds rows_cap carries the rest into its next gathers; finish() drains it
+ag = parallel.AsyncResultGather(dist, rows_cap=8, device=torch.device("cpu"))
+sent = []
+for step in range(3):
+    n = (21 if rank == 1 and step == 1 else 3) + step
+    p = torch.zeros((32, 2), dtype=torch.int32)
+    r = torch.zeros((32, 3), dtype=torch.float64)
+    p[:n, 0] = torch.arange(n, dtype=torch.int32) + 100 * step
+    p[:n, 1] = 1000 * rank
+    r[:n, 0] = torch.arange(n, dtype=torch.float64) + 0.5 * step
+    ag.post(p, r, n, keep=True)
+    sent.append(n)
+ag.finish(keep=True)
+if rank == 0:
+    for rk in range(world):
+        rows = np.concatenate([parts[rk] for parts in ag.collected], 0)
+        want = [(21 if rk == 1 and st == 1 else 3) + st for st in range(3)]
+        assert rows.shape[0] == sum(want), (rows.shape, want)
+        b, s_, lnl, _, _ = parallel.unpack_rows(rows)
+        assert np.array_equal(b, np.concatenate([np.arange(n) + 100 * st for st, n in enumerate(want)]))   # order kept
+        assert np.all(s_ == 1000 * rk)
+    assert len(ag.collected) > 3                  # the drain rounds of finish()
+    print("CARRY_OK")
+elif rank == 1:
+    assert ag.carried_rows > 0
 dist.destroy_process_group()
 '''
 
@@ -93,4 +119,4 @@ def test_two_rank_gloo_gather(tmp_path):
                                       stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
-    assert "GATHER_OK" in outs[0] and "ASYNC_OK" in outs[0]
+    assert "GATHER_OK" in outs[0] and "ASYNC_OK" in outs[0] and "CARRY_OK" in outs[0]
