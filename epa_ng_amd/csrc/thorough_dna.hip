@@ -202,6 +202,42 @@ __device__ __forceinline__ uint32_t inner_site_half(const ModelDNA& m, const dou
   return resc;
 }
 
+// one category of one site: I_i = (U (e0 o F))_i (U (e1 o G))_i, It = U^-1 I (unscaled; the caller
+// keeps the running maximum for the per-site rescale test).  The streamed phases (TH_STREAM_DEPTH)
+// walk a window category by category with this.
+__device__ __forceinline__ void cat_inner(const ModelDNA& m, const double (&F)[4], const double* e0,
+                                          const double (&G)[4], const double* e1, double (&It)[4], double& mx) {
+  double av[4], bv[4], I[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) { av[x] = F[x] * e0[x]; bv[x] = G[x] * e1[x]; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double a = m.U[i * 4] * av[0], b = m.U[i * 4] * bv[0];
+#pragma unroll
+    for (int x = 1; x < 4; ++x) {
+      a = fma(m.U[i * 4 + x], av[x], a);
+      b = fma(m.U[i * 4 + x], bv[x], b);
+    }
+    I[i] = a * b;
+    mx = fmax(mx, I[i]);
+  }
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    double acc = m.Ui[x * 4] * I[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) acc = fma(m.Ui[x * 4 + i], I[i], acc);
+    It[x] = acc;
+  }
+}
+
+// Prefetch depth of the streamed phases: a phase is the sequence of (64-site chunk, rate category)
+// steps of the window; the 8 operand loads of step i + DEPTH are requested before step i is
+// computed, ACROSS chunk boundaries, so that one load latency is exposed per phase instead of one
+// per chunk.  0 = the batch form (32 loads per chunk up front, chunks serialised).
+#ifndef TH_STREAM_DEPTH
+#define TH_STREAM_DEPTH 2
+#endif
+
 template <int NCH>
 struct SiteState {
   double S[NCH][16];   // sumtable of the branch currently being optimised.  ZERO0: entry [0] holds
@@ -444,14 +480,100 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     fold0(ch);
     chain = zero_after(st.S[ch][7]);
   };
+  // ---- streamed phase (TH_STREAM_DEPTH > 0): all (chunk, category) steps of the window in one
+  // software pipeline.  The table of the phase must have been published before the call.
+  //   MODE 0: inner vector toward the query from (distal e0, proximal e1), folded with the query
+  //   MODE 1: toward distal from (query e0, proximal e1), folded with the distal vector
+  //   MODE 3: toward proximal from (query e0, distal e1), folded with the proximal vector
+  //   MODE 2: the precomputed inner vector of the starting lengths (refI), folded with the query
+  // The per-site rescale (pll_update_partials: all c * s entries < 2^-256) is applied to the finished
+  // sumtable entries of the chunk instead of to the inner vector (the same 16 multiplications).
+  const char* refi_s = reinterpret_cast<const char*>(a.refI + (size_t)b * 16 * cW + begin);
+  auto stream_phase = [&](auto mode_c) {
+    constexpr int MODE = decltype(mode_c)::value;
+    constexpr int DEPTH = TH_STREAM_DEPTH > 0 ? TH_STREAM_DEPTH : 1;
+    constexpr int NKL = TAILH ? 2 : 4;             // categories per lane in the last chunk
+    constexpr int NS = 4 * (NCH - 1) + NKL;
+    constexpr int R = DEPTH + 1;
+    double An[R][4], Bn[R][4];
+    uint32_t soff[NCH], sidx[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      sidx[ch] = st.valid[ch] ? lane_site(ch) : 0;
+      soff[ch] = sidx[ch] * 8u + ((TAILH && ch == NCH - 1) ? hoff : 0u);
+    }
+    uint32_t tok = chain;
+    auto issue = [&](int stp, uint32_t tk) {
+      const int ch = stp >> 2, k = stp & 3, sl = stp % R;
+      const uint32_t s0 = soff[ch] + tk;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        if (MODE == 2) An[sl][x] = *reinterpret_cast<const double*>(refi_s + (s0 + (uint32_t)(k * 4 + x) * W8));
+        else { An[sl][x] = ldD(k * 4 + x, s0); Bn[sl][x] = ldX(k * 4 + x, s0); }
+      }
+    };
+#pragma unroll
+    for (int p = 0; p < DEPTH; ++p)
+      if (p < NS) issue(p, tok);
+    double mx = 0.0;
+    double qf[4];
+#pragma unroll
+    for (int stp = 0; stp < NS; ++stp) {
+      const int ch = stp >> 2, k = stp & 3, sl = stp % R;
+      const bool halfc = TAILH && ch == NCH - 1;
+      const int NK = halfc ? 2 : 4;
+      const double* tb = halfc ? tabh : tab;
+      if (k == 0) {
+        const double* qv = qts + st.code[ch] * 4;
+        qf[0] = qv[0]; qf[1] = qv[1]; qf[2] = qv[2]; qf[3] = qv[3];
+      }
+      if (stp + DEPTH < NS) issue(stp + DEPTH, tok);
+      asm volatile("" ::: "memory");   // the prefetch is issued here, not at its use
+      double It[4];
+      if (MODE == 2) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) It[x] = An[sl][x];
+      } else if (MODE == 0) {
+        cat_inner(m, An[sl], tb + k * 4 + tok, Bn[sl], tb + 16 + k * 4 + tok, It, mx);
+      } else {
+        cat_inner(m, qf, tb + k * 4 + tok, MODE == 1 ? Bn[sl] : An[sl], tb + 16 + k * 4 + tok, It, mx);
+      }
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+        st.S[ch][k * 4 + x] = It[x] * ((MODE == 0 || MODE == 2) ? qf[x] : (MODE == 1 ? An[sl][x] : Bn[sl][x]));
+      tok = zero_after(st.S[ch][k * 4 + 3]);
+      if (k == NK - 1) {   // chunk complete
+        if (MODE == 2) {
+          st.resc[ch] = (a.resc0 + (size_t)b * cW + begin)[sidx[ch]];
+        } else {
+          const double mxs = halfc ? xhalf_max(mx) : mx;
+          const uint32_t resc = (mxs < 0x1p-256) ? 1u : 0u;
+          const double mult = resc ? 0x1p+256 : 1.0;
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (i < NK * 4) st.S[ch][i] *= mult;
+          if (MODE == 0) st.resc[ch] = resc;
+          mx = 0.0;
+        }
+        if constexpr (INV) st.S[ch][0] += cinv_of(ch);
+        fold0(ch);
+        tok = zero_after(st.S[ch][halfc ? 7 : 15]);
+      }
+    }
+    chain = tok;
+  };
+  constexpr bool STREAM = TH_STREAM_DEPTH > 0;
+
   // Inner CLV toward the query at (td, tx) folded with the query, S = (U^-1 I) o qt, and the
   // window lnL at pendant length tp_.  One table pass: slot 0 -> exp(lr td), slot 1 ->
   // exp(lr tx), slot 2 -> w exp(lr tp).
   auto score = [&](double td_, double tx_, double tp_) -> double {
     const double tl = lc.slot == 0 ? td_ : (lc.slot == 1 ? tx_ : tp_);
     table_publish(tab, lane, exp(lc.lr * tl) * (lc.slot == 2 ? lc.w : 1.0));
+    if constexpr (STREAM) stream_phase(std::integral_constant<int, 0>{});
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
+      if (STREAM) break;
       if (TAILH && ch == NCH - 1) {
         const uint32_t s = (st.valid[ch] ? lane_site(ch) : 0) * 8u + chain + hoff;
         double D[8], X[8], It[8];
@@ -492,8 +614,10 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   auto side_sumtable = [&](double tp_, double tother_, auto toward_prox) {
     constexpr bool TOWARD_PROX = decltype(toward_prox)::value;
     table_publish(tab, lane, exp(lc.lr * (lc.slot == 0 ? tp_ : tother_)));
+    if constexpr (STREAM) stream_phase(std::integral_constant<int, TOWARD_PROX ? 3 : 1>{});
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
+      if (STREAM) break;
       if (TAILH && ch == NCH - 1) {
         const uint32_t s = (st.valid[ch] ? lane_site(ch) : 0) * 8u + chain + hoff;
         double Qv[8], X[8], D[8], It[8];
@@ -540,8 +664,10 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     table_publish(tab, lane, exp(lc.lr * tp_) * (lc.slot == 2 ? lc.w : 1.0));
     const char* refi = reinterpret_cast<const char*>(a.refI + (size_t)b * 16 * cW + begin);
     const uint8_t* r0 = a.resc0 + (size_t)b * cW + begin;
+    if constexpr (STREAM) stream_phase(std::integral_constant<int, 2>{});
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
+      if (STREAM) break;
       if (TAILH && ch == NCH - 1) {
         const uint32_t si = st.valid[ch] ? lane_site(ch) : 0;
         const uint32_t s = si * 8u + chain + hoff;
@@ -1121,7 +1247,8 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
       static const uint32_t aa_bound[4] = {64, 128, 192, 0xffffffffu};
       static const bool aa_valu = getenv("EPA_AA_VALU") != nullptr;
       const uint32_t bound = std::min(max_span, aa_bound[c < 4 ? c : 3]);
-      if (c < 3 && !aa_valu)
+      // (the VALU kernel has no --raxml-blo instantiation: the A/B switch applies to the sliding rule only)
+      if (c < 3 && (!aa_valu || !ctx->blo.sliding))
         rc = launch_thorough_aa_mfma(ctx, d_pairs, ord, hist[c], d_codes, d_begin, d_span, bound, d_out, d_stats);
       else
         rc = launch_thorough_aa(ctx, d_pairs, ord, hist[c], d_codes, d_begin, d_span, bound,
