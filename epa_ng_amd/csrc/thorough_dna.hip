@@ -79,6 +79,29 @@ __device__ __forceinline__ uint32_t zero_after(double v) {
   return z;
 }
 
+// The kernel's argument block, re-read through an opaque pointer: U, U^-1 and the weights (72 scalar
+// registers) are needed inside the phases only.  Held as ordinary kernel arguments they stay live
+// across the Newton loops, and the compiler parks ~270 scalar registers in vector-register lanes
+// (v_writelane / v_readlane around every use).  A phase instead reloads them from the kernarg
+// segment with a few s_load_dwordx16 (scalar cache hits) -- the asm makes the pointer unknown to the
+// optimiser, so the loads cannot be merged with earlier ones or kept alive after the phase.
+using KArgs = const __attribute__((address_space(4))) ThArgs*;
+__device__ __forceinline__ KArgs kargs_fresh() {
+  KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+struct PhaseModel {   // what a phase needs of ModelDNA, in scalar registers for the phase's duration
+  double U[16], Ui[16], w[4];
+  __device__ __forceinline__ void load() {
+    KArgs p = kargs_fresh();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { U[i] = p->m.U[i]; Ui[i] = p->m.Ui[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = p->m.w[i];
+  }
+};
+
 // ---- wave-uniform tables through LDS: every lane computes ONE exp(), writes it to the
 // workgroup's (= wave's) 64-entry table, then all lanes read the entries they need with
 // uniform-address ds_read (broadcast, no bank conflicts).  Lane l holds pair kx = l & 15
@@ -88,6 +111,7 @@ struct LaneConst {
   double cN;   // Newton table coefficient: w_k * lr^slot (slot 0,1,2), 0 for slot 3
   double w;    // w_k
   int slot;
+  const double* e2t;  // LDS: 2^(j/64), j = 0..63 (exp_tab)
 };
 
 __device__ __forceinline__ void table_publish(double* tab, int lane, double v) {
@@ -205,8 +229,13 @@ __device__ __forceinline__ uint32_t inner_site_half(const ModelDNA& m, const dou
 // one category of one site: I_i = (U (e0 o F))_i (U (e1 o G))_i, It = U^-1 I (unscaled; the caller
 // keeps the running maximum for the per-site rescale test).  The streamed phases (TH_STREAM_DEPTH)
 // walk a window category by category with this.
-__device__ __forceinline__ void cat_inner(const ModelDNA& m, const double (&F)[4], const double* e0,
-                                          const double (&G)[4], const double* e1, double (&It)[4], double& mx) {
+// mx: running maximum of the HIGH WORDS of the inner vector's entries, as signed integers.  The
+// per-site rescale test of pll_update_partials -- every entry < 2^-256 -- is  max_hi < 0x2ff00000
+// (2^-256 has a zero low word; negative rounding residues compare below it either way, NaN above):
+// two entries per v_max3_i32 instead of one per v_max_f64.
+template <class Model>
+__device__ __forceinline__ void cat_inner(const Model& m, const double (&F)[4], const double* e0,
+                                          const double (&G)[4], const double* e1, double (&It)[4], int& mx) {
   double av[4], bv[4], I[4];
 #pragma unroll
   for (int x = 0; x < 4; ++x) { av[x] = F[x] * e0[x]; bv[x] = G[x] * e1[x]; }
@@ -219,8 +248,9 @@ __device__ __forceinline__ void cat_inner(const ModelDNA& m, const double (&F)[4
       b = fma(m.U[i * 4 + x], bv[x], b);
     }
     I[i] = a * b;
-    mx = fmax(mx, I[i]);
   }
+  mx = max(max(mx, __double2hiint(I[0])), __double2hiint(I[1]));
+  mx = max(max(mx, __double2hiint(I[2])), __double2hiint(I[3]));
 #pragma unroll
   for (int x = 0; x < 4; ++x) {
     double acc = m.Ui[x * 4] * I[0];
@@ -234,6 +264,12 @@ __device__ __forceinline__ void cat_inner(const ModelDNA& m, const double (&F)[4
 // steps of the window; the 8 operand loads of step i + DEPTH are requested before step i is
 // computed, ACROSS chunk boundaries, so that one load latency is exposed per phase instead of one
 // per chunk.  0 = the batch form (32 loads per chunk up front, chunks serialised).
+// TH_EXP(x): the table-driven exp of wave_util.hpp (default) or the library exp (A/B: -DTH_LIBM_EXP)
+#ifdef TH_LIBM_EXP
+#define TH_EXP(x) exp(x)
+#else
+#define TH_EXP(x) exp_tab((x), lc.e2t)
+#endif
 #ifndef TH_STREAM_DEPTH
 #define TH_STREAM_DEPTH 2
 #endif
@@ -281,7 +317,7 @@ template <int NCH, bool ZERO0, int NW, bool TAILH = false>
 __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* tab, int lane,
                                             const LaneConst& lc, Comb<NW>& cb, double t, double& f,
                                             double& df) {
-  table_publish(tab, lane, exp(lc.lr * t) * lc.cN);
+  table_publish(tab, lane, TH_EXP(lc.lr * t) * lc.cN);
   double e[16], e1[16], e2[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -411,8 +447,11 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   const ModelDNA& m = a.m;
   const uint64_t pid = a.order ? a.order[pidx] : pidx;
   const epa_pair pr = a.pairs[pid];
-  const uint32_t b = pr.branch_id, q = pr.seq_id;
-  const uint32_t begin = a.win_begin[q], n = a.win_span[q];
+  // wave-uniform by construction; said explicitly so that every base address below is scalar
+  const uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.branch_id);
+  const uint32_t q = (uint32_t)__builtin_amdgcn_readfirstlane((int)pr.seq_id);
+  const uint32_t begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.win_begin[q]);
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.win_span[q]);
   const size_t cW = a.W;
   // one uniform base (SGPR pair) + 32-bit per-lane byte offsets: component c of the proximal
   // CLV sits at c*W*8, of the distal CLV at (16+c)*W*8 (saddr + voffset addressing, no
@@ -436,7 +475,9 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     const uint32_t s = lane_site(ch);
-    st.valid[ch] = s < n;
+    // single-wave classes: a window of class NCH is longer than (NCH - 1) x 64 sites, so only its LAST
+    // chunk can have idle lanes (known at compile time: no masks on the other chunks)
+    st.valid[ch] = (NW == 1 && ch < NCH - 1) ? true : s < n;
     const uint32_t sc = st.valid[ch] ? s : 0;  // clamp: inactive lanes recompute site 0
     st.sc[ch] = scp[sc];
     st.code[ch] = qc[sc];
@@ -495,6 +536,10 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     constexpr int NKL = TAILH ? 2 : 4;             // categories per lane in the last chunk
     constexpr int NS = 4 * (NCH - 1) + NKL;
     constexpr int R = DEPTH + 1;
+    PhaseModel pm;
+    pm.load();
+    uint32_t W8p = W8;
+    asm volatile("" : "+s"(W8p));
     double An[R][4], Bn[R][4];
     uint32_t soff[NCH], sidx[NCH];
 #pragma unroll
@@ -508,14 +553,20 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
       const uint32_t s0 = soff[ch] + tk;
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        if (MODE == 2) An[sl][x] = *reinterpret_cast<const double*>(refi_s + (s0 + (uint32_t)(k * 4 + x) * W8));
-        else { An[sl][x] = ldD(k * 4 + x, s0); Bn[sl][x] = ldX(k * 4 + x, s0); }
+        // one scalar base + 32-bit lane offsets (saddr + voffset loads).  The row stride is opaque per
+        // phase (W8p): with the full chunks' lane offsets now pair-invariant the compiler otherwise
+        // hoists all 32 row offsets out of the pair loop and parks them in scratch
+        if (MODE == 2) An[sl][x] = *reinterpret_cast<const double*>(refi_s + (s0 + (uint32_t)(k * 4 + x) * W8p));
+        else {
+          An[sl][x] = *reinterpret_cast<const double*>(ref + (s0 + (uint32_t)(16 + k * 4 + x) * W8p));
+          Bn[sl][x] = *reinterpret_cast<const double*>(ref + (s0 + (uint32_t)(k * 4 + x) * W8p));
+        }
       }
     };
 #pragma unroll
     for (int p = 0; p < DEPTH; ++p)
       if (p < NS) issue(p, tok);
-    double mx = 0.0;
+    int mx = 0;
     double qf[4];
 #pragma unroll
     for (int stp = 0; stp < NS; ++stp) {
@@ -534,9 +585,9 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 #pragma unroll
         for (int x = 0; x < 4; ++x) It[x] = An[sl][x];
       } else if (MODE == 0) {
-        cat_inner(m, An[sl], tb + k * 4 + tok, Bn[sl], tb + 16 + k * 4 + tok, It, mx);
+        cat_inner(pm, An[sl], tb + k * 4 + tok, Bn[sl], tb + 16 + k * 4 + tok, It, mx);
       } else {
-        cat_inner(m, qf, tb + k * 4 + tok, MODE == 1 ? Bn[sl] : An[sl], tb + 16 + k * 4 + tok, It, mx);
+        cat_inner(pm, qf, tb + k * 4 + tok, MODE == 1 ? Bn[sl] : An[sl], tb + 16 + k * 4 + tok, It, mx);
       }
 #pragma unroll
       for (int x = 0; x < 4; ++x)
@@ -546,17 +597,26 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
         if (MODE == 2) {
           st.resc[ch] = (a.resc0 + (size_t)b * cW + begin)[sidx[ch]];
         } else {
-          const double mxs = halfc ? xhalf_max(mx) : mx;
-          const uint32_t resc = (mxs < 0x1p-256) ? 1u : 0u;
-          const double mult = resc ? 0x1p+256 : 1.0;
+          int mxs = mx;
+          if (halfc) {   // both halves of the site
+            const auto sw = __builtin_amdgcn_permlane32_swap(mx, mx, false, false);
+            mxs = max((int)sw[0], (int)sw[1]);
+          }
+          const uint32_t resc = (mxs < 0x2ff00000) ? 1u : 0u;
+          if (__builtin_amdgcn_ballot_w64(resc != 0) != 0) {   // rare: some site of the chunk underflowed
+            const double mult = resc ? 0x1p+256 : 1.0;
 #pragma unroll
-          for (int i = 0; i < 16; ++i)
-            if (i < NK * 4) st.S[ch][i] *= mult;
+            for (int i = 0; i < 16; ++i)
+              if (i < NK * 4) st.S[ch][i] *= mult;
+          }
           if (MODE == 0) st.resc[ch] = resc;
-          mx = 0.0;
+          mx = 0;
         }
         if constexpr (INV) st.S[ch][0] += cinv_of(ch);
-        fold0(ch);
+        if constexpr (ZERO0) {   // fold0 with the phase's copy of the weights
+          if (halfc) st.S[ch][0] = fma(half ? pm.w[3] : pm.w[1], st.S[ch][4], (half ? pm.w[2] : pm.w[0]) * st.S[ch][0]);
+          else st.S[ch][0] = fma(pm.w[3], st.S[ch][12], fma(pm.w[2], st.S[ch][8], fma(pm.w[1], st.S[ch][4], pm.w[0] * st.S[ch][0])));
+        }
         tok = zero_after(st.S[ch][halfc ? 7 : 15]);
       }
     }
@@ -569,7 +629,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   // exp(lr tx), slot 2 -> w exp(lr tp).
   auto score = [&](double td_, double tx_, double tp_) -> double {
     const double tl = lc.slot == 0 ? td_ : (lc.slot == 1 ? tx_ : tp_);
-    table_publish(tab, lane, exp(lc.lr * tl) * (lc.slot == 2 ? lc.w : 1.0));
+    table_publish(tab, lane, TH_EXP(lc.lr * tl) * (lc.slot == 2 ? lc.w : 1.0));
     if constexpr (STREAM) stream_phase(std::integral_constant<int, 0>{});
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -613,7 +673,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   // --raxml-blo loop only): the same toward the proximal node, I' = (P_pend q) o (P_dist D), S = Xt o ...
   auto side_sumtable = [&](double tp_, double tother_, auto toward_prox) {
     constexpr bool TOWARD_PROX = decltype(toward_prox)::value;
-    table_publish(tab, lane, exp(lc.lr * (lc.slot == 0 ? tp_ : tother_)));
+    table_publish(tab, lane, TH_EXP(lc.lr * (lc.slot == 0 ? tp_ : tother_)));
     if constexpr (STREAM) stream_phase(std::integral_constant<int, TOWARD_PROX ? 3 : 1>{});
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -661,7 +721,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   // not depend on the query, k_build_lookup stored its U^-1 image per (branch, site) -> 16 loads
   // and the fold with the query instead of 32 loads and the two 4x4 products per category.
   auto score_first = [&](double tp_) -> double {
-    table_publish(tab, lane, exp(lc.lr * tp_) * (lc.slot == 2 ? lc.w : 1.0));
+    table_publish(tab, lane, TH_EXP(lc.lr * tp_) * (lc.slot == 2 ? lc.w : 1.0));
     const char* refi = reinterpret_cast<const char*>(a.refI + (size_t)b * 16 * cW + begin);
     const uint8_t* r0 = a.resc0 + (size_t)b * cW + begin;
     if constexpr (STREAM) stream_phase(std::integral_constant<int, 2>{});
@@ -733,7 +793,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
       tx = solve(tx);
       (void)score(td, tx, tp);   // inner CLV back toward the query + the pendant sumtable
       tp = solve(tp);
-      table_publish(tab, lane, exp(lc.lr * tp) * (lc.slot == 2 ? lc.w : 1.0));
+      table_publish(tab, lane, TH_EXP(lc.lr * tp) * (lc.slot == 2 ? lc.w : 1.0));
       double ew[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
@@ -806,10 +866,12 @@ __global__ void __launch_bounds__(64 * NW, 2) k_thorough_dna(const ThArgs a) {
   __shared__ double tab[64 * NW];  // broadcast table of each wave
   __shared__ double qts[64];       // U^-1 image of the 16 query column codes
   __shared__ double red[2 * NW * 2];
+  __shared__ double e2t[64];
   const int lane = threadIdx.x & 63;
   Comb<NW> cb{red, (int)(threadIdx.x >> 6), 0};
-  if (threadIdx.x < 64) qts[lane] = a.qt[lane];
+  if (threadIdx.x < 64) { qts[lane] = a.qt[lane]; e2t[lane] = exp2((double)lane * 0.015625); }
   LaneConst lc;
+  lc.e2t = e2t;
   {
     const int lk = (lane >> 2) & 3, lx = lane & 3;
     lc.slot = lane >> 4;
@@ -897,9 +959,12 @@ template <bool ZERO0>
 __global__ void __launch_bounds__(64, 2) k_thorough_dna_long(const ThArgs a) {
   __shared__ double tab[64];
   __shared__ double qts[64];
+  __shared__ double e2t[64];
   const int lane = threadIdx.x;
   qts[lane] = a.qt[lane];
+  e2t[lane] = exp2((double)lane * 0.015625);
   LaneConst lc;
+  lc.e2t = e2t;
   {
     const int lk = (lane >> 2) & 3, lx = lane & 3;
     lc.slot = lane >> 4;
@@ -927,7 +992,7 @@ __global__ void __launch_bounds__(64, 2) k_thorough_dna_long(const ThArgs a) {
     // inner CLV toward the query at (td, tx), S = (U^-1 I) o qt -> slab; returns the window lnL
     auto score = [&](double td_, double tx_, double tp_, bool first) -> double {
       const double tl = lc.slot == 0 ? td_ : (lc.slot == 1 ? tx_ : tp_);
-      table_publish(tab, lane, exp(lc.lr * tl) * (lc.slot == 2 ? lc.w : 1.0));
+      table_publish(tab, lane, TH_EXP(lc.lr * tl) * (lc.slot == 2 ? lc.w : 1.0));
       double ew[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
@@ -974,7 +1039,7 @@ __global__ void __launch_bounds__(64, 2) k_thorough_dna_long(const ThArgs a) {
     };
     // inner CLV toward distal: I' = (P_pend q) o (P_prox X); S = Dt o (U^-1 I') -> slab
     auto distal_sumtable = [&](double tp_, double tx_) {
-      table_publish(tab, lane, exp(lc.lr * (lc.slot == 0 ? tp_ : tx_)));
+      table_publish(tab, lane, TH_EXP(lc.lr * (lc.slot == 0 ? tp_ : tx_)));
       for (uint32_t ch = 0; ch < nch; ++ch) {
         const uint32_t site = ch * 64 + lane;
         const bool valid = site < n;
@@ -999,7 +1064,7 @@ __global__ void __launch_bounds__(64, 2) k_thorough_dna_long(const ThArgs a) {
       __threadfence_block();
     };
     auto deriv = [&](double t, double& f, double& df) {
-      table_publish(tab, lane, exp(lc.lr * t) * lc.cN);
+      table_publish(tab, lane, TH_EXP(lc.lr * t) * lc.cN);
       double e[16], e1[16], e2[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) { e[i] = tab[i]; e1[i] = tab[16 + i]; e2[i] = tab[32 + i]; }

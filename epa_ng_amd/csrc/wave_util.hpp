@@ -57,4 +57,24 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return fma(r, e, r);
 }
 
+// exp(x) for the arguments of the Newton / P-matrix tables (x = lambda r t <= 0, |x| < 1e7):
+//   x = n ln2/64 + r,  |r| <= ln2/128;  e^x = 2^(n >> 6) * 2^((n & 63)/64) * e^r
+// e2t = the 64-entry table 2^(j/64) (LDS), e^r - 1 by a degree-6 Taylor polynomial (truncation
+// 1e-19 relative), result T + T (e^r - 1) with one fma: ~1 ulp, 16 vector instructions where the
+// general-purpose exp() (overflow / NaN handling, degree-11 polynomial) takes ~40.
+__device__ __forceinline__ double exp_tab(double x, const double* e2t) {
+  const double n = __builtin_rint(x * 92.33248261689366);
+  double r = fma(n, -0.010830424696249145, x);      // ln2 / 64, high part
+  r = fma(n, -3.623510646634843e-19, r);            //            low part
+  const int ni = (int)n;
+  const double T = e2t[ni & 63];
+  double q = fma(r, 0.001388888888888889, 0.008333333333333333);
+  q = fma(q, r, 0.041666666666666664);
+  q = fma(q, r, 0.16666666666666666);
+  q = fma(q, r, 0.5);
+  q = fma(q, r, 1.0);
+  q *= r;                                            // e^r - 1
+  return __builtin_ldexp(fma(T, q, T), ni >> 6);     // underflows to 0 like exp()
+}
+
 }  // namespace epa_wave
