@@ -260,6 +260,34 @@ __device__ __forceinline__ void cat_inner(const Model& m, const double (&F)[4], 
   }
 }
 
+// the same with the first factor given: a_i = (U (e0 o q))_i depends on the query's column code and the
+// category only, so the phases toward the distal / proximal node read it from a per-wave table of
+// 16 codes x 16 (category, state) entries (built once per phase by the wave's 64 lanes) instead of
+// forming it per site: 2 LDS reads replace 20 of the ~66 vector instructions of a category step.
+template <class Model>
+__device__ __forceinline__ void cat_inner_pre(const Model& m, const double (&Ap)[4], const double (&G)[4],
+                                              const double* e1, double (&It)[4], int& mx) {
+  double bv[4], I[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) bv[x] = G[x] * e1[x];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double b = m.U[i * 4] * bv[0];
+#pragma unroll
+    for (int x = 1; x < 4; ++x) b = fma(m.U[i * 4 + x], bv[x], b);
+    I[i] = Ap[i] * b;
+  }
+  mx = max(max(mx, __double2hiint(I[0])), __double2hiint(I[1]));
+  mx = max(max(mx, __double2hiint(I[2])), __double2hiint(I[3]));
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    double acc = m.Ui[x * 4] * I[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) acc = fma(m.Ui[x * 4 + i], I[i], acc);
+    It[x] = acc;
+  }
+}
+
 // Prefetch depth of the streamed phases: a phase is the sequence of (64-site chunk, rate category)
 // steps of the window; the 8 operand loads of step i + DEPTH are requested before step i is
 // computed, ACROSS chunk boundaries, so that one load latency is exposed per phase instead of one
@@ -441,7 +469,7 @@ __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, 
 
 template <int NCH, bool ZERO0, bool INV, int NW, bool LOCAL, bool TAILH = false>
 __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pidx, const int lane,
-                                             double* tab, const double* qts, const LaneConst& lc,
+                                             double* tab, const double* qts, double* qa, const LaneConst& lc,
                                              Comb<NW>& cb, uint32_t (&wstat)[3]) {
   const uint32_t site0 = NW > 1 ? (uint32_t)cb.wv * NCH * 64 : 0u;  // first window site of this wave
   const ModelDNA& m = a.m;
@@ -548,6 +576,26 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
       soff[ch] = sidx[ch] * 8u + ((TAILH && ch == NCH - 1) ? hoff : 0u);
     }
     uint32_t tok = chain;
+    if constexpr (MODE == 1 || MODE == 3) {
+      // lane = (code = lane >> 2, category = lane & 3): the four entries a_i of (code, category)
+      const int kq = lane & 3;
+      const double* qv = qts + (lane >> 2) * 4;
+      const double* e0 = tab + kq * 4;
+      double av[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) av[x] = qv[x] * e0[x];
+      double* dst = qa + (lane >> 2) * 16 + kq * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double v = pm.U[i * 4] * av[0];
+#pragma unroll
+        for (int x = 1; x < 4; ++x) v = fma(pm.U[i * 4 + x], av[x], v);
+        dst[i] = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     auto issue = [&](int stp, uint32_t tk) {
       const int ch = stp >> 2, k = stp & 3, sl = stp % R;
       const uint32_t s0 = soff[ch] + tk;
@@ -587,7 +635,10 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
       } else if (MODE == 0) {
         cat_inner(pm, An[sl], tb + k * 4 + tok, Bn[sl], tb + 16 + k * 4 + tok, It, mx);
       } else {
-        cat_inner(pm, qf, tb + k * 4 + tok, MODE == 1 ? Bn[sl] : An[sl], tb + 16 + k * 4 + tok, It, mx);
+        // this half's categories are 2 h, 2 h + 1 in a half-chunk
+        const double* ap = qa + st.code[ch] * 16 + ((halfc ? (int)half * 2 : 0) + k) * 4 + tok;
+        const double Ap[4] = {ap[0], ap[1], ap[2], ap[3]};
+        cat_inner_pre(pm, Ap, MODE == 1 ? Bn[sl] : An[sl], tb + 16 + k * 4 + tok, It, mx);
       }
 #pragma unroll
       for (int x = 0; x < 4; ++x)
@@ -867,6 +918,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_thorough_dna(const ThArgs a) {
   __shared__ double qts[64];       // U^-1 image of the 16 query column codes
   __shared__ double red[2 * NW * 2];
   __shared__ double e2t[64];
+  __shared__ double qa[256 * NW];  // per wave: (U (e o q_code))_i for 16 codes x 16 (category, state)
   const int lane = threadIdx.x & 63;
   Comb<NW> cb{red, (int)(threadIdx.x >> 6), 0};
   if (threadIdx.x < 64) { qts[lane] = a.qt[lane]; e2t[lane] = exp2((double)lane * 0.015625); }
@@ -901,14 +953,14 @@ __global__ void __launch_bounds__(64 * NW, 2) k_thorough_dna(const ThArgs a) {
         const uint32_t cur = nxt;
         uint32_t f = 0;
         if (lane == 0) f = atomicAdd(ctr, 1u);
-        process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH>(a, lo + cur, lane, tab + cb.wv * 64, qts, lc, cb, wstat);
+        process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH>(a, lo + cur, lane, tab + cb.wv * 64, qts, qa + cb.wv * 256, lc, cb, wstat);
         nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
       }
     }
   }
   if (!queued)
     for (uint64_t p = lo + w; p < hi; p += stride)
-      process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH>(a, p, lane, tab + cb.wv * 64, qts, lc, cb, wstat);
+      process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH>(a, p, lane, tab + cb.wv * 64, qts, qa + cb.wv * 256, lc, cb, wstat);
   if (threadIdx.x == 0) {
     atomicAdd(&a.stats[0], (unsigned long long)wstat[0]);
     atomicAdd(&a.stats[1], (unsigned long long)wstat[1]);
