@@ -102,6 +102,9 @@ def dev_lib():
         L.epa_dev_chunk_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.epa_dev_chunk_launch.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_double, C.c_void_p,
                                            C.c_void_p, C.c_uint64, C.c_uint32]
+        L.epa_dev_chunk_launch_begin.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_double, C.c_void_p,
+                                           C.c_void_p, C.c_uint64, C.c_uint32]
+        L.epa_dev_chunk_launch_end.argtypes = [C.c_void_p, C.c_int]
         L.epa_dev_chunk_finish.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(_Stats)]
         L.epa_dev_tree_logl.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
@@ -369,6 +372,18 @@ class Evaluator:
         assert max_pairs is not None
         self._check(self.L.epa_dev_chunk_launch(self.h, slot, max_span, threshold, _ptr(pairs_out),
                                                 _ptr(results_out), max_pairs, 1 if keep_on_device else 0))
+
+    def chunk_launch_begin(self, slot, threshold=0.99999, max_span=0, max_pairs=None, pairs_out=None,
+                           results_out=None, keep_on_device=False):
+        """first half of chunk_launch: preplacement + candidate selection queued on the slot's own
+        stream, returns without waiting"""
+        assert max_pairs is not None
+        self._check(self.L.epa_dev_chunk_launch_begin(self.h, slot, max_span, threshold, _ptr(pairs_out),
+                                                      _ptr(results_out), max_pairs, 1 if keep_on_device else 0))
+
+    def chunk_launch_end(self, slot):
+        """second half: waits for the candidate count, queues the thorough kernels + result D2H"""
+        self._check(self.L.epa_dev_chunk_launch_end(self.h, slot))
 
     def chunk_finish(self, slot, copy=True):
         """waits for the slot's results -> (pairs, results) numpy views of the slot's pinned buffer

@@ -18,6 +18,7 @@ int epa_fail(epa_ctx* ctx, int code, const std::string& msg) {
 }
 
 void* epa_scratch(epa_ctx* ctx, int slot, size_t bytes) {
+  slot += ctx->bank * epa_ctx::N_SCRATCH;
   if (bytes <= ctx->scratch_sz[slot]) return ctx->scratch[slot];
   if (ctx->scratch[slot]) (void)hipFree(ctx->scratch[slot]);
   ctx->scratch[slot] = nullptr;
@@ -446,7 +447,7 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
-  for (int i = 0; i < epa_ctx::N_SCRATCH; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+  for (int i = 0; i < epa_ctx::N_BANKS * epa_ctx::N_SCRATCH; ++i) if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
   if (ctx->refT) (void)hipFree(ctx->refT);
   if (ctx->scSum) (void)hipFree(ctx->scSum);
   if (ctx->blen) (void)hipFree(ctx->blen);
@@ -461,12 +462,14 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
     if (sl.h_in) (void)hipHostFree(sl.h_in);
     if (sl.h_out) (void)hipHostFree(sl.h_out);
     if (sl.h_stats) (void)hipHostFree(sl.h_stats);
+    if (sl.h_sel) (void)hipHostFree(sl.h_sel);
     if (sl.d_in) (void)hipFree(sl.d_in);
     if (sl.d_unpacked) (void)hipFree(sl.d_unpacked);
     if (sl.d_pairs) (void)hipFree(sl.d_pairs);
     if (sl.d_res) (void)hipFree(sl.d_res);
     if (sl.d_stats) (void)hipFree(sl.d_stats);
-    for (hipEvent_t e : {sl.ev_up, sl.ev_done, sl.ev_down}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {sl.ev_up, sl.ev_done, sl.ev_down, sl.ev_base}) if (e) (void)hipEventDestroy(e);
+    if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
@@ -587,7 +590,7 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
 
   const size_t W = ctx->W, B = ctx->B, cs = (size_t)c * s;
   EPA_HIP(ctx, hipMalloc(&ctx->refT, sizeof(double) * 2 * B * cs * W));
-  EPA_HIP(ctx, hipMalloc(&ctx->th_ctr, 256));
+  EPA_HIP(ctx, hipMalloc(&ctx->th_ctr, 256 * epa_ctx::N_BANKS));
   EPA_HIP(ctx, hipMalloc(&ctx->scSum, sizeof(uint32_t) * B * W));
   EPA_HIP(ctx, hipMemset(ctx->scSum, 0, sizeof(uint32_t) * B * W));
   EPA_HIP(ctx, hipMalloc(&ctx->blen, sizeof(double) * B));
@@ -1222,9 +1225,12 @@ extern "C" int epa_dev_select_candidates(epa_ctx* ctx, const double* lnl, uint32
 // place() -> apply_heuristic() -> place_thorough().  The Q x B table never leaves HBM; ONE host
 // sync in the middle (the candidate count sizes the thorough launch); the thorough kernels are
 // queued on return, nothing is waited for after them.
-static int chunk_body(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span,
-                      uint32_t Q, uint32_t max_span, double threshold, epa_pair* d_pairs, epa_result* d_res,
-                      uint64_t max_pairs, unsigned long long* d_stats, uint64_t* n_out) {
+// begin: preplacement + first half of the selection, nothing waited for; end: the wait for the
+// candidate count (and the window-validation words, read back in the same copy), compaction / sort,
+// the thorough launches.  rb: 64-word host block (pinned in the chunk pipeline).
+static int chunk_body_begin(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span,
+                            uint32_t Q, uint32_t max_span, double threshold, epa_pair* d_pairs,
+                            uint64_t max_pairs, uint32_t* rb, SelectPending* sp) {
   // internal table: rows padded to whole 64-byte sectors (the preplacement kernels write 8
   // consecutive branches per burst; with rows of B doubles every burst straddled two sectors)
   const uint32_t pitch = (ctx->B + 7u) & ~7u;
@@ -1232,17 +1238,36 @@ static int chunk_body(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_be
   if (!d_lnl) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(chunk table)");
   ctx->lnl_pitch = pitch;
   int rc = launch_preplace(ctx, d_codes, d_begin, d_span, Q, d_lnl, max_span);
+  if (!rc) rc = launch_select_begin(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, d_span, rb, sp);
+  ctx->lnl_pitch = 0;
+  return rc;
+}
+
+static int chunk_body_end(epa_ctx* ctx, SelectPending* sp, const uint8_t* d_codes, const uint32_t* d_begin,
+                          const uint32_t* d_span, uint32_t max_span, epa_pair* d_pairs, epa_result* d_res,
+                          unsigned long long* d_stats, uint64_t* n_out) {
+  const uint32_t pitch = (ctx->B + 7u) & ~7u;
+  ctx->lnl_pitch = pitch;   // a widened re-run of the selection reads the same table
   uint64_t n = 0;
-  if (!rc) rc = launch_select(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, &n, d_span);  // syncs once
+  int rc = launch_select_end(ctx, sp, &n);  // syncs once
   ctx->lnl_pitch = 0;
   if (rc) return rc;
-  rc = preplace_check_status(ctx);
+  rc = select_check_status(ctx, sp);
   if (rc) return rc;
-
   *n_out = n;
   EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, ctx->stream));
   if (n == 0) return EPA_OK;
   return launch_thorough(ctx, d_pairs, n, d_codes, d_begin, d_span, max_span, d_res, d_stats);
+}
+
+static int chunk_body(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span,
+                      uint32_t Q, uint32_t max_span, double threshold, epa_pair* d_pairs, epa_result* d_res,
+                      uint64_t max_pairs, unsigned long long* d_stats, uint64_t* n_out) {
+  uint32_t rb[64] = {};
+  SelectPending sp;
+  int rc = chunk_body_begin(ctx, d_codes, d_begin, d_span, Q, max_span, threshold, d_pairs, max_pairs, rb, &sp);
+  if (rc) return rc;
+  return chunk_body_end(ctx, &sp, d_codes, d_begin, d_span, max_span, d_pairs, d_res, d_stats, n_out);
 }
 
 static int chunk_stats(epa_ctx* ctx, uint64_t n, const unsigned long long* hst, epa_thorough_stats* stats) {
@@ -1290,7 +1315,7 @@ extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const u
   epa_result* d_res = res_dev ? results : (epa_result*)epa_scratch(ctx, 5, sizeof(epa_result) * max_pairs);
   if (!d_pairs || !d_res) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(chunk buffers)");
   // thorough counters: second half of the context's 256-byte counter block
-  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->th_ctr) + 128);
+  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(epa_th_ctr(ctx)) + 128);
   uint64_t n = 0;
   rc = chunk_body(ctx, d_codes, d_begin, d_span, Q, max_span, threshold, d_pairs, d_res, max_pairs, d_stats, &n);
   if (rc) return rc;
@@ -1319,7 +1344,10 @@ static int slot_of(epa_ctx* ctx, int slot, ChunkSlot** out) {
     EPA_HIP(ctx, hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming));
     EPA_HIP(ctx, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
     EPA_HIP(ctx, hipEventCreateWithFlags(&s.ev_down, hipEventDisableTiming));
+    EPA_HIP(ctx, hipEventCreateWithFlags(&s.ev_base, hipEventDisableTiming));
+    EPA_HIP(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     EPA_HIP(ctx, hipHostMalloc((void**)&s.h_stats, 64, hipHostMallocDefault));
+    EPA_HIP(ctx, hipHostMalloc((void**)&s.h_sel, 256, hipHostMallocDefault));
     EPA_HIP(ctx, hipMalloc((void**)&s.d_stats, 128));
   }
   *out = &s;
@@ -1373,9 +1401,23 @@ extern "C" int epa_dev_chunk_stage(epa_ctx* ctx, int slot, const uint8_t* q_code
   return EPA_OK;
 }
 
-extern "C" int epa_dev_chunk_launch(epa_ctx* ctx, int slot, uint32_t max_span, double threshold,
-                                    epa_pair* d_pairs, epa_result* d_results, uint64_t max_pairs,
-                                    uint32_t flags) {
+namespace {
+// the context's stream / scratch bank are the slot's for the duration of a pipeline call only
+struct SlotScope {
+  epa_ctx* c; hipStream_t st; uint32_t stride; bool packed;
+  SlotScope(epa_ctx* ctx, ChunkSlot* s, int slot) : c(ctx), st(ctx->stream), stride(ctx->code_stride), packed(ctx->code_packed4) {
+    ctx->stream = s->stream;
+    ctx->bank = 1 + slot;
+    ctx->code_stride = s->stride == ctx->W ? 0 : s->stride;   // the kernels read the layout the chunk was staged with
+    ctx->code_packed4 = false;
+  }
+  ~SlotScope() { c->stream = st; c->bank = 0; c->code_stride = stride; c->code_packed4 = packed; }
+};
+}  // namespace
+
+extern "C" int epa_dev_chunk_launch_begin(epa_ctx* ctx, int slot, uint32_t max_span, double threshold,
+                                          epa_pair* d_pairs, epa_result* d_results, uint64_t max_pairs,
+                                          uint32_t flags) {
   ChunkSlot* s;
   int rc = slot_of(ctx, slot, &s);
   if (rc) return rc;
@@ -1402,40 +1444,60 @@ extern "C" int epa_dev_chunk_launch(epa_ctx* ctx, int slot, uint32_t max_span, d
     d_pairs = s->d_pairs;
     d_results = s->d_res;
   }
-  EPA_HIP(ctx, hipStreamWaitEvent(ctx->stream, s->ev_up, 0));
+  // The slot's kernels go to the slot's own stream and scratch bank, so that the two chunks in
+  // flight overlap on the device (chunk k + 1's preplacement and selection fill the tail of chunk
+  // k's Newton kernel) and the wait for chunk k + 1's candidate count does not wait for chunk k's
+  // kernels.  The slot stream starts behind what the caller's stream has queued so far (lookup
+  // build; with device-resident results, the caller's reads of the result buffers).
+  EPA_HIP(ctx, hipEventRecord(s->ev_base, ctx->stream));
+  EPA_HIP(ctx, hipStreamWaitEvent(s->stream, s->ev_base, 0));
+  EPA_HIP(ctx, hipStreamWaitEvent(s->stream, s->ev_up, 0));
+  SlotScope scope(ctx, s, slot);
   const char* d = (const char*)s->d_in;
   const uint8_t* d_codes = (const uint8_t*)d;
   const uint32_t* d_begin = (const uint32_t*)(d + s->codes_bytes);
   const uint32_t* d_span = d_begin + Q;
-  // the kernels read the layout the chunk was staged with
-  const uint32_t keep_stride = ctx->code_stride;
-  const bool keep_packed = ctx->code_packed4;
-  ctx->code_stride = s->stride == ctx->W ? 0 : s->stride;
-  ctx->code_packed4 = false;
   if (s->packed4) {
     size_t have = s->d_unpacked_sz;
     rc = grow_dev(ctx, &s->d_unpacked, &have, (size_t)Q * s->stride + 1024);
     s->d_unpacked_sz = have;
-    if (!rc) {
-      const size_t pstride = ((size_t)s->stride + 1) / 2;
-      const uint64_t nb = (uint64_t)Q * pstride;
-      hipLaunchKernelGGL(k_unpack4, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, ctx->stream, d_codes,
-                         s->d_unpacked, Q, s->stride, (uint32_t)pstride);
-      d_codes = s->d_unpacked;
-    }
+    if (rc) return rc;
+    const size_t pstride = ((size_t)s->stride + 1) / 2;
+    const uint64_t nb = (uint64_t)Q * pstride;
+    hipLaunchKernelGGL(k_unpack4, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, ctx->stream, d_codes,
+                       s->d_unpacked, Q, s->stride, (uint32_t)pstride);
+    d_codes = s->d_unpacked;
   }
+  s->l_codes = d_codes; s->l_begin = d_begin; s->l_span = d_span;
+  s->l_pairs = d_pairs; s->l_res = d_results; s->l_max_span = max_span; s->l_flags = flags;
+  rc = chunk_body_begin(ctx, d_codes, d_begin, d_span, Q, max_span, threshold, d_pairs, max_pairs, s->h_sel, &s->sel);
+  if (rc) return rc;   // the slot stays staged
+  s->state = 3;
+  return EPA_OK;
+}
+
+extern "C" int epa_dev_chunk_launch_end(epa_ctx* ctx, int slot) {
+  ChunkSlot* s;
+  int rc = slot_of(ctx, slot, &s);
+  if (rc) return rc;
+  if (s->state != 3) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_launch_end: no launch was begun on the slot");
+  EPA_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t base = ctx->stream;
   uint64_t n = 0;
-  if (!rc) rc = chunk_body(ctx, d_codes, d_begin, d_span, Q, max_span, threshold, d_pairs, d_results, max_pairs,
-                           s->d_stats, &n);
-  ctx->code_stride = keep_stride;
-  ctx->code_packed4 = keep_packed;
-  if (rc) return rc;  // candidate overflow etc.: the slot stays staged
+  epa_pair* d_pairs = s->l_pairs;
+  epa_result* d_results = s->l_res;
+  SlotScope scope(ctx, s, slot);
+  s->state = 1;        // candidate overflow etc.: the slot stays staged
+  rc = chunk_body_end(ctx, &s->sel, s->l_codes, s->l_begin, s->l_span, s->l_max_span, d_pairs, d_results, s->d_stats, &n);
+  if (rc) return rc;
   s->n = n;
   EPA_HIP(ctx, hipEventRecord(s->ev_done, ctx->stream));
   EPA_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, s->ev_done, 0));
-  if (flags & EPA_CHUNK_NO_D2H) {
+  if (s->l_flags & EPA_CHUNK_NO_D2H) {
     s->out_pairs = d_pairs;
     s->out_res = d_results;
+    // device-resident results are consumed on the caller's stream
+    EPA_HIP(ctx, hipStreamWaitEvent(base, s->ev_done, 0));
   } else {
     const size_t off_r = (sizeof(epa_pair) * n + 255) & ~(size_t)255;
     rc = grow_pinned(ctx, &s->h_out, &s->h_out_sz, off_r + sizeof(epa_result) * n);
@@ -1452,6 +1514,14 @@ extern "C" int epa_dev_chunk_launch(epa_ctx* ctx, int slot, uint32_t max_span, d
   EPA_HIP(ctx, hipEventRecord(s->ev_down, ctx->down_stream));
   s->state = 2;
   return EPA_OK;
+}
+
+extern "C" int epa_dev_chunk_launch(epa_ctx* ctx, int slot, uint32_t max_span, double threshold,
+                                    epa_pair* d_pairs, epa_result* d_results, uint64_t max_pairs,
+                                    uint32_t flags) {
+  int rc = epa_dev_chunk_launch_begin(ctx, slot, max_span, threshold, d_pairs, d_results, max_pairs, flags);
+  if (rc) return rc;
+  return epa_dev_chunk_launch_end(ctx, slot);
 }
 
 extern "C" int epa_dev_chunk_finish(epa_ctx* ctx, int slot, const epa_pair** pairs, const epa_result** results,

@@ -53,6 +53,22 @@ struct EvTimer {
 // One slot of the double-buffered chunk pipeline (epa_dev_chunk_stage / _launch / _finish): the
 // query upload of chunk k+1 and the result download of chunk k-1 run on the context's copy stream
 // while the kernels of chunk k run on its compute stream.
+// state of a candidate selection between launch_select_begin and launch_select_end (preplace.hip)
+struct SelectPending {
+  const double* d_lnl = nullptr;
+  uint32_t Q = 0, cap = 0;
+  double threshold = 0.0;
+  epa_pair* d_pairs = nullptr;
+  uint64_t max_pairs = 0;
+  const uint32_t* d_span = nullptr;
+  unsigned long long *stage = nullptr, *keys_a = nullptr, *keys_b = nullptr;
+  uint32_t *counts = nullptr, *offsets = nullptr;
+  void* temp = nullptr;
+  size_t sort_bytes = 0;
+  uint32_t* rb = nullptr;   // host read-back block, 64 words
+  bool have_status = false;
+};
+
 struct ChunkSlot {
   void* h_in = nullptr;       // pinned bounce buffer: codes | win_begin | win_span
   size_t h_in_sz = 0;
@@ -70,11 +86,20 @@ struct ChunkSlot {
   size_t h_out_sz = 0;
   unsigned long long* h_stats = nullptr;  // pinned, 8 words
   unsigned long long* d_stats = nullptr;  // 16 words in HBM
-  hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_down = nullptr;
+  hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_down = nullptr, ev_base = nullptr;
+  hipStream_t stream = nullptr;  // the slot's own compute stream: the kernels of the two chunks in flight overlap
   const epa_pair* out_pairs = nullptr;    // what finish() hands out
   const epa_result* out_res = nullptr;
   uint64_t n = 0;
-  int state = 0;              // 0 free, 1 staged, 2 launched
+  int state = 0;              // 0 free, 1 staged, 3 launch begun (selection in flight), 2 launched
+  // between launch_begin and launch_end
+  SelectPending sel;
+  uint32_t* h_sel = nullptr;  // pinned, 64 words: the selection's read-back block
+  const uint8_t* l_codes = nullptr;
+  const uint32_t *l_begin = nullptr, *l_span = nullptr;
+  epa_pair* l_pairs = nullptr;
+  epa_result* l_res = nullptr;
+  uint32_t l_max_span = 0, l_flags = 0;
 };
 
 struct epa_ctx {
@@ -118,9 +143,13 @@ struct epa_ctx {
   std::vector<double> h_blen;
 
   // per-call scratch (grown on demand)
+  // Three banks: 0 = the direct entry points (caller's stream), 1 / 2 = the two slots of the chunk
+  // pipeline, whose kernels run concurrently on their own streams and therefore share no scratch.
   static constexpr int N_SCRATCH = 11;
-  void* scratch[N_SCRATCH] = {};
-  size_t scratch_sz[N_SCRATCH] = {};
+  static constexpr int N_BANKS = 3;
+  int bank = 0;
+  void* scratch[N_BANKS * N_SCRATCH] = {};
+  size_t scratch_sz[N_BANKS * N_SCRATCH] = {};
 
   uint32_t* d_status = nullptr;   // window-validation words of the last preplace (in scratch 6)
   // span-class histogram of the candidate pairs of the last select (valid for the thorough call
@@ -128,7 +157,8 @@ struct epa_ctx {
   uint32_t cls_hist[16] = {};
   uint64_t cls_hist_pairs = 0;  // 0 = not valid
   uint32_t select_cap = 64;       // staging slots per query of the candidate selection
-  uint32_t* th_ctr = nullptr;  // work counters of the thorough kernel (one per XCD slice)
+  uint32_t* th_ctr = nullptr;  // work counters of the thorough kernel (one per XCD slice): 256 B per bank,
+                               // [0, 64) the counters, [128, 256) the fused chunk's statistics
   uint32_t lnl_pitch = 0;  // row pitch (doubles) of the table handed to launch_preplace / launch_select; 0 = B
   bool code_packed4 = false;  // q_codes arrive in the 4-bit wire format (epa_dev_set_query_packing)
   int heur_mode = 0;        // EPA_HEUR_* (epa_dev_set_heuristic)
@@ -146,6 +176,7 @@ struct epa_ctx {
 // ---- helpers (epa_dev.hip)
 int epa_fail(epa_ctx* ctx, int code, const std::string& msg);
 void* epa_scratch(epa_ctx* ctx, int slot, size_t bytes);
+inline uint32_t* epa_th_ctr(epa_ctx* ctx) { return ctx->th_ctr ? ctx->th_ctr + 64 * ctx->bank : nullptr; }
 bool epa_is_device_ptr(const void* p);
 // returns a device pointer holding `bytes` of *p (copying into scratch slot if p is on the host)
 const void* epa_to_device(epa_ctx* ctx, int slot, const void* p, size_t bytes);
@@ -203,3 +234,7 @@ int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_
 int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshold,
                   epa_pair* d_pairs, uint64_t max_pairs, uint64_t* n_pairs,
                   const uint32_t* d_span = nullptr);  // d_span: also histogram the span classes
+int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshold, epa_pair* d_pairs,
+                        uint64_t max_pairs, const uint32_t* d_span, uint32_t* rb, SelectPending* sp);
+int launch_select_end(epa_ctx* ctx, SelectPending* sp, uint64_t* n_pairs);
+int select_check_status(epa_ctx* ctx, const SelectPending* sp);

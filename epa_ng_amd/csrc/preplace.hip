@@ -1243,8 +1243,15 @@ int preplace_check_status(epa_ctx* ctx) {
   return EPA_OK;
 }
 
-int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshold,
-                  epa_pair* d_pairs, uint64_t max_pairs, uint64_t* n_pairs, const uint32_t* d_span) {
+// The candidate selection in two halves, so that a caller with something else to queue (the chunk
+// pipeline: the other slot's work) does not sit in the wait for the candidate count:
+//   begin  queues k_select, the offsets scan, the span-class histogram and the read-back of
+//          {total, status words, class histogram, window-validation words of the preplacement} into
+//          `rb` (pinned host memory for a truly asynchronous copy; 64 words) -- no synchronisation;
+//   end    waits for the stream, widens the staging rows and repeats on overflow (rare), then queues
+//          compaction, the stable sort into Work order and the key -> pair conversion.
+int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshold, epa_pair* d_pairs,
+                        uint64_t max_pairs, const uint32_t* d_span, uint32_t* rb, SelectPending* sp) {
   ctx->cls_hist_pairs = 0;
   const uint32_t B = ctx->B;
   const uint32_t pitch = ctx->lnl_pitch ? ctx->lnl_pitch : B;  // row pitch of d_lnl in doubles
@@ -1260,77 +1267,121 @@ int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshol
   } else if (mode == 2) {
     ctx->select_cap = std::max(ctx->select_cap, std::min(B, 48u));
   }
-  for (;;) {
-    const uint32_t cap = ctx->select_cap;
-    size_t scan_bytes = 0, sort_bytes = 0;
-    (void)rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, Q,
-                                  rocprim::plus<uint32_t>(), ctx->stream);
-    const size_t worst = std::min<uint64_t>(max_pairs, (uint64_t)Q * cap);
-    (void)rocprim::radix_sort_keys<epa_radix_cfg>(nullptr, sort_bytes, (unsigned long long*)nullptr,
-                                   (unsigned long long*)nullptr, worst, 0, 64, ctx->stream);
-    // scratch 7: [status | counts Q+1 | offsets Q+1 | stage Q*cap | keys_a worst | keys_b worst | temp]
-    const size_t qb = align256(sizeof(uint32_t) * (Q + 1));
-    const size_t sb = align256(sizeof(unsigned long long) * (size_t)Q * cap);
-    const size_t kb = align256(sizeof(unsigned long long) * worst);
-    const size_t tb = std::max(scan_bytes, sort_bytes);
-    char* base = (char*)epa_scratch(ctx, 7, 256 + 2 * qb + sb + 2 * kb + tb);
-    if (!base) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(select scratch)");
-    uint32_t* status = reinterpret_cast<uint32_t*>(base);
-    uint32_t* counts = reinterpret_cast<uint32_t*>(base + 256);
-    uint32_t* offsets = reinterpret_cast<uint32_t*>(base + 256 + qb);
-    unsigned long long* stage = reinterpret_cast<unsigned long long*>(base + 256 + 2 * qb);
-    unsigned long long* keys_a = reinterpret_cast<unsigned long long*>(base + 256 + 2 * qb + sb);
-    unsigned long long* keys_b = reinterpret_cast<unsigned long long*>(base + 256 + 2 * qb + sb + kb);
-    void* temp = base + 256 + 2 * qb + sb + 2 * kb;
-    EPA_HIP(ctx, hipMemsetAsync(status, 0, 256, ctx->stream));
-    EPA_HIP(ctx, hipMemsetAsync(counts + Q, 0, sizeof(uint32_t), ctx->stream));
-    epa_timer_start(ctx, ctx->t_select);
-    const dim3 grid((Q + 3) / 4);
-    const int nr = (int)((B + 63) / 64);
+  const uint32_t cap = ctx->select_cap;
+  size_t scan_bytes = 0, sort_bytes = 0;
+  (void)rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, Q,
+                                rocprim::plus<uint32_t>(), ctx->stream);
+  const size_t worst = std::min<uint64_t>(max_pairs, (uint64_t)Q * cap);
+  (void)rocprim::radix_sort_keys<epa_radix_cfg>(nullptr, sort_bytes, (unsigned long long*)nullptr,
+                                 (unsigned long long*)nullptr, worst, 0, 64, ctx->stream);
+  // scratch 7: [status | counts Q+1 | offsets Q+1 | stage Q*cap | keys_a worst | keys_b worst | temp]
+  const size_t qb = align256(sizeof(uint32_t) * (Q + 1));
+  const size_t sb = align256(sizeof(unsigned long long) * (size_t)Q * cap);
+  const size_t kb = align256(sizeof(unsigned long long) * worst);
+  const size_t tb = std::max(scan_bytes, sort_bytes);
+  char* base = (char*)epa_scratch(ctx, 7, 256 + 2 * qb + sb + 2 * kb + tb);
+  if (!base) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(select scratch)");
+  uint32_t* status = reinterpret_cast<uint32_t*>(base);
+  uint32_t* counts = reinterpret_cast<uint32_t*>(base + 256);
+  uint32_t* offsets = reinterpret_cast<uint32_t*>(base + 256 + qb);
+  sp->stage = reinterpret_cast<unsigned long long*>(base + 256 + 2 * qb);
+  sp->keys_a = reinterpret_cast<unsigned long long*>(base + 256 + 2 * qb + sb);
+  sp->keys_b = reinterpret_cast<unsigned long long*>(base + 256 + 2 * qb + sb + kb);
+  sp->temp = base + 256 + 2 * qb + sb + 2 * kb;
+  sp->sort_bytes = sort_bytes;
+  sp->counts = counts; sp->offsets = offsets;
+  sp->d_lnl = d_lnl; sp->Q = Q; sp->threshold = threshold; sp->d_pairs = d_pairs; sp->max_pairs = max_pairs;
+  sp->d_span = d_span; sp->cap = cap; sp->rb = rb;
+  // status words and the trailing count in one fill: counts[Q] sits in the same allocation
+  EPA_HIP(ctx, hipMemsetAsync(status, 0, 256, ctx->stream));
+  EPA_HIP(ctx, hipMemsetAsync(counts + Q, 0, sizeof(uint32_t), ctx->stream));
+  epa_timer_start(ctx, ctx->t_select);
+  const dim3 grid((Q + 3) / 4);
+  const int nr = (int)((B + 63) / 64);
+  unsigned long long* stage = sp->stage;
 #define SEL(N) hipLaunchKernelGGL(k_select<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, cap, stage, counts, status)
 #define SELBIG(N) hipLaunchKernelGGL(k_select_big<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, cap, stage, counts, status)
-    if (nr <= 2) SEL(2); else if (nr <= 4) SEL(4); else if (nr <= 8) SEL(8); else if (nr <= 16) SEL(16);
-    else if (nr <= 32) SEL(32); else if (nr <= 64) SEL(64);
-    else if (nr <= 128) hipLaunchKernelGGL(k_select_wg<32>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, cap, stage, counts, status);
-    else if (nr <= 256) hipLaunchKernelGGL(k_select_wg<64>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, cap, stage, counts, status);
-    else SELBIG(16);
+  if (nr <= 2) SEL(2); else if (nr <= 4) SEL(4); else if (nr <= 8) SEL(8); else if (nr <= 16) SEL(16);
+  else if (nr <= 32) SEL(32); else if (nr <= 64) SEL(64);
+  else if (nr <= 128) hipLaunchKernelGGL(k_select_wg<32>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, cap, stage, counts, status);
+  else if (nr <= 256) hipLaunchKernelGGL(k_select_wg<64>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, cap, stage, counts, status);
+  else SELBIG(16);
 #undef SELBIG
 #undef SEL
-    EPA_HIP(ctx, rocprim::exclusive_scan(temp, scan_bytes, counts, offsets, 0u, Q + 1,
-                                         rocprim::plus<uint32_t>(), ctx->stream));
-    uint32_t hst[8 + EPA_N_CLS] = {}, total = 0;
-    if (d_span)  // class histogram in status[8 ..]: read back with the total, no extra round trip
-      hipLaunchKernelGGL(k_class_hist, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, counts, d_span, Q,
-                         ctx->s, status + 8);
-    EPA_HIP(ctx, hipMemcpyAsync(&total, offsets + Q, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    EPA_HIP(ctx, hipMemcpyAsync(hst, status, sizeof(hst), hipMemcpyDeviceToHost, ctx->stream));
+  EPA_HIP(ctx, rocprim::exclusive_scan(sp->temp, scan_bytes, counts, offsets, 0u, Q + 1,
+                                       rocprim::plus<uint32_t>(), ctx->stream));
+  if (d_span)  // class histogram in status[8 ..]: read back with the total, no extra round trip
+    hipLaunchKernelGGL(k_class_hist, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, counts, d_span, Q,
+                       ctx->s, status + 8);
+  // rb: [0] total, [1 .. 8 + EPA_N_CLS] status words + class histogram, [32 .. 35] window validation
+  EPA_HIP(ctx, hipMemcpyAsync(rb, offsets + Q, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  EPA_HIP(ctx, hipMemcpyAsync(rb + 1, status, sizeof(uint32_t) * (8 + EPA_N_CLS), hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->d_status)
+    EPA_HIP(ctx, hipMemcpyAsync(rb + 32, ctx->d_status, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  sp->have_status = ctx->d_status != nullptr;
+  return EPA_OK;
+}
+
+int launch_select_end(epa_ctx* ctx, SelectPending* sp, uint64_t* n_pairs) {
+  const uint32_t B = ctx->B, Q = sp->Q;
+  for (;;) {
     EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t total = sp->rb[0];
+    const uint32_t* hst = sp->rb + 1;
     if (hst[2]) {  // some query selected more candidates than the staging row holds: widen, redo
-      ctx->select_cap = std::min<uint32_t>(B, std::max(cap * 4, hst[2]));
-      if (cap >= B) return epa_fail(ctx, EPA_ERR_HIP, "select_candidates: staging overflow");
+      if (sp->cap >= B) return epa_fail(ctx, EPA_ERR_HIP, "select_candidates: staging overflow");
+      ctx->select_cap = std::min<uint32_t>(B, std::max(sp->cap * 4, hst[2]));
+      uint32_t* rb = sp->rb;
+      int rc = launch_select_begin(ctx, sp->d_lnl, Q, sp->threshold, sp->d_pairs, sp->max_pairs, sp->d_span, rb, sp);
+      if (rc) return rc;
       continue;
     }
-    if (total > max_pairs)
+    if (total > sp->max_pairs)
       return epa_fail(ctx, EPA_ERR_INVALID_ARG,
                       "select_candidates: " + std::to_string(total) + " candidates exceed max_pairs");
     if (total) {
-      hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, ctx->stream, stage, counts, offsets, Q, cap, keys_a);
+      const dim3 grid((Q + 3) / 4);
+      hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, ctx->stream, sp->stage, sp->counts, sp->offsets, Q, sp->cap,
+                         sp->keys_a);
       // branch-major order == Work iteration order (std::map<branch, vector<seq>>).  The compacted
       // list is already ascending in the query id (and a query names a branch at most once), so a
       // STABLE sort on the branch bits alone gives (branch, query) order: 2 digit passes, not 6.
       int bits = 33;
       while ((1ull << (bits - 32)) <= B && bits < 64) ++bits;
-      EPA_HIP(ctx, rocprim::radix_sort_keys<epa_radix_cfg>(temp, sort_bytes, keys_a, keys_b, (size_t)total, 32, bits, ctx->stream));
-      hipLaunchKernelGGL(k_keys_to_pairs, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, keys_b,
-                         (uint64_t)total, d_pairs);
+      size_t sort_bytes = sp->sort_bytes;
+      EPA_HIP(ctx, rocprim::radix_sort_keys<epa_radix_cfg>(sp->temp, sort_bytes, sp->keys_a, sp->keys_b, (size_t)total,
+                                                           32, bits, ctx->stream));
+      hipLaunchKernelGGL(k_keys_to_pairs, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, sp->keys_b,
+                         (uint64_t)total, sp->d_pairs);
     }
     epa_timer_stop(ctx, ctx->t_select);
     EPA_HIP(ctx, hipGetLastError());
     *n_pairs = total;
-    if (d_span) {
+    if (sp->d_span) {
       for (int c = 0; c < EPA_N_CLS; ++c) ctx->cls_hist[c] = hst[8 + c];
       ctx->cls_hist_pairs = total;
     }
     return EPA_OK;
   }
+}
+
+// what the preplacement's window validation found (read back by launch_select_begin into rb[32..])
+int select_check_status(epa_ctx* ctx, const SelectPending* sp) {
+  if (!sp->have_status) return EPA_OK;
+  const uint32_t* st = sp->rb + 32;
+  if (st[0])
+    return epa_fail(ctx, EPA_ERR_QUERY_ALL_GAP, "Sequence " + std::to_string(st[0] & 0x7fffffffu) +
+                                                    " does not appear to have any non-gap sites!");
+  if (st[1])
+    return epa_fail(ctx, EPA_ERR_QUERY_WIDTH, "Query sequence length not same as reference alignment!");
+  return EPA_OK;
+}
+
+int launch_select(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double threshold,
+                  epa_pair* d_pairs, uint64_t max_pairs, uint64_t* n_pairs, const uint32_t* d_span) {
+  uint32_t rb[64] = {};
+  SelectPending sp;
+  int rc = launch_select_begin(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, d_span, rb, &sp);
+  if (rc) return rc;
+  return launch_select_end(ctx, &sp, n_pairs);
 }

@@ -626,8 +626,8 @@ int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_
   // resident workgroups + a work counter per XCD slice (EPA_TH_QUEUE=0: the oversubscribed static grid)
   a.qctr = nullptr;
   if (!(getenv("EPA_TH_QUEUE") && atoi(getenv("EPA_TH_QUEUE")) == 0) && ctx->th_ctr) {
-    EPA_HIP(ctx, hipMemsetAsync(ctx->th_ctr, 0, 64, ctx->stream));
-    a.qctr = ctx->th_ctr;
+    EPA_HIP(ctx, hipMemsetAsync(epa_th_ctr(ctx), 0, 64, ctx->stream));
+    a.qctr = epa_th_ctr(ctx);
     nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * 2);
   }
   nwg = (nwg + 7) / 8 * 8;

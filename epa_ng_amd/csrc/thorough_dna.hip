@@ -1236,8 +1236,8 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
     uint64_t want = (uint64_t)256 * 8 * per_slot / (NW_);                                          \
     a.qctr = nullptr;                                                                              \
     if ((NW_) == 1 && use_queue && ctx->th_ctr) {                                                  \
-      EPA_HIP(ctx, hipMemsetAsync(ctx->th_ctr, 0, 64, ctx->stream));                               \
-      a.qctr = ctx->th_ctr;                                                                        \
+      EPA_HIP(ctx, hipMemsetAsync(epa_th_ctr(ctx), 0, 64, ctx->stream));                               \
+      a.qctr = epa_th_ctr(ctx);                                                                        \
       want = 2048;                                                                                 \
     }                                                                                              \
     if (want > n_pairs) want = n_pairs;                                                            \

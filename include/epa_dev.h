@@ -317,6 +317,13 @@ int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* wi
  *           EPA_CHUNK_NO_D2H: results stay in HBM (finish() hands out the device pointers).
  *   finish  waits for the slot's download; *pairs / *results point into the slot's pinned host
  *           buffer (or HBM with EPA_CHUNK_NO_D2H), valid until the slot is staged again.
+ *   launch_begin / launch_end: launch in two halves for callers that keep two chunks in flight --
+ *           begin queues preplacement + candidate selection and returns WITHOUT waiting; end waits
+ *           for the candidate count (normally long there by then) and queues the rest.  Each slot
+ *           has its own stream and scratch, so chunk k + 1's begin-half overlaps chunk k's Newton
+ *           kernel on the device:
+ *               stage(0, c0); begin(0);
+ *               for k: { stage((k+1)&1, c[k+1]); begin((k+1)&1); end(k&1); finish((k-1)&1) ... }
  * A typical loop:  stage(0, c0); for k: { launch(k&1); finish((k-1)&1); stage((k+1)&1, c[k+1]); }
  * Candidate overflow (EPA_ERR_INVALID_ARG from launch, as epa_dev_place_chunk) leaves the slot
  * staged: launch again with a larger max_pairs.
@@ -327,6 +334,10 @@ int epa_dev_chunk_stage(epa_ctx* ctx, int slot, const uint8_t* q_codes, const ui
 int epa_dev_chunk_launch(epa_ctx* ctx, int slot, uint32_t max_span, double threshold,
                          epa_pair* d_pairs, epa_result* d_results, uint64_t max_pairs,
                          uint32_t flags);
+int epa_dev_chunk_launch_begin(epa_ctx* ctx, int slot, uint32_t max_span, double threshold,
+                               epa_pair* d_pairs, epa_result* d_results, uint64_t max_pairs,
+                               uint32_t flags);
+int epa_dev_chunk_launch_end(epa_ctx* ctx, int slot);
 int epa_dev_chunk_finish(epa_ctx* ctx, int slot, const epa_pair** pairs, const epa_result** results,
                          uint64_t* n_pairs, epa_thorough_stats* stats);
 
