@@ -353,7 +353,15 @@ __global__ void __launch_bounds__(GQ, ACC ? 2 : 4) k_preplace(const double* __re
 // ---------------------------------------------------------------------------------------------
 constexpr int NSYM = 6;                 // A C G T N(or gap) none
 constexpr int PE = NSYM * NSYM;         // entries per pair row: e = sym(site) * 6 + sym(site + 1)
-constexpr int PROWB = PE * 8;           // 288 bytes per pair row
+constexpr int PROWB = PE * 8;           // 288 bytes per pair row in HBM
+// Row stride of the staged slice in LDS.  With 288 B (36 doubles) row r starts on 8-byte bank 4 r mod
+// 16 (PMC round 2: 21 % of the LDS-active cycles were bank conflicts); 296 B (37 doubles) puts sixteen
+// consecutive rows on sixteen banks.  Measured round 3, same box, 100k-read launches: 1.295 / 1.353 ms
+// with 288, 1.297 / 1.353 ms with 296 -- the conflicts are not what bounds the kernel, so the
+// unpadded layout (and its 288-site wide variant for small chunks) stays; -DPROWL=296 rebuilds the other.
+#ifndef PROWL
+#define PROWL 288
+#endif
 constexpr int CP = CH / 2;              // pair slots per chunk
 constexpr int PW = CP / 2;              // packed words (2 x 16-bit LDS offsets) per chunk
 constexpr int TROWS2 = TROWS / 2;       // pair rows staged per (branch, chunk)
@@ -422,7 +430,7 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
     if (p < npairs) {
       const uint32_t s0 = dna_sym(c[2 * p]), s1 = dna_sym(c[2 * p + 1]);
       rare |= (s0 > 4) | (s1 > 4);
-      v = (p % CP) * PROWB + (min(s0, 5u) * NSYM + min(s1, 5u)) * 8;
+      v = (p % CP) * PROWL + (min(s0, 5u) * NSYM + min(s1, 5u)) * 8;
     }
     packed[(size_t)q * NP16 + p] = (uint16_t)v;
   }
@@ -434,7 +442,7 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
       sy = min(sy, 5u);
       const uint32_t kt = npairs % CP;  // row of the first tail site inside its chunk (even)
       const uint32_t e = lane == 1 ? 5 * NSYM + sy : sy * NSYM + 5;
-      v = (kt + (lane == 2 ? 1u : 0u)) * PROWB + e * 8;
+      v = (kt + (lane == 2 ? 1u : 0u)) * PROWL + e * 8;
     }
     tails[(size_t)q * 4 + lane] = (uint16_t)v;
   }
@@ -446,7 +454,7 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
 // start: 1024 consecutive reads of the sorted order span few starts); 288 for small ones (the
 // reference's default --chunk-size 5000 puts ~2 reads on a start: a 96-site bucket holds ~180 reads,
 // a workgroup's 1024 lanes would be 18 % full) -- the 16-bit LDS offsets still fit:
-// (288 / 2 + 79) * 288 + 35 * 8 < 65536.
+// (272 / 2 + 79) * 296 + 35 * 8 < 65536 (LDS rows are PROWL = 296 bytes apart).
 template <bool ACC, int SPR = SPREAD>
 __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     const double* __restrict__ lookup2, const uint16_t* __restrict__ packed,
@@ -456,7 +464,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     const uint32_t* __restrict__ status, double* __restrict__ lnl) {
   constexpr int TR2 = (CH + SPR) / 2;   // pair rows staged per (branch, chunk)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [TR2][PE] doubles, then accs
-  double* accs = reinterpret_cast<double*>(smem + (size_t)TR2 * PROWB);  // [NB2_ACC][GQ2] (ACC only)
+  double* accs = reinterpret_cast<double*>(smem + (size_t)TR2 * PROWL);  // [NB2_ACC][GQ2] (ACC only)
   __shared__ uint32_t s_maxspan;
   constexpr uint32_t NBP = ACC ? NB2_ACC : NB2;
   // persistent grid over (group, branch tile) items of class 0, see k_preplace
@@ -484,7 +492,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
   // all members share the parity of their window start: rel is even, pair rows line up
   const uint32_t gmin = win_begin[perm[g.start]];
   const uint32_t gspread = win_begin[perm[g.start + g.count - 1]] - gmin;  // < SPREAD
-  const uint32_t rowoff = ((begin - gmin) >> 1) * PROWB;
+  const uint32_t rowoff = ((begin - gmin) >> 1) * PROWL;
   const uint32_t rowoff2 = rowoff | (rowoff << 16);
   const uint32_t nchunks = ACC ? (s_maxspan + CH - 1) / CH : 1;
   uint32_t t0 = 0, t1 = 0, t2 = 0, tailchunk = 0xffffffffu;
@@ -537,11 +545,19 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     for (uint32_t j = 0; j < nb; ++j) {
       __syncthreads();  // previous consumers of the tile are done
       {
-        double2* dst = reinterpret_cast<double2*>(smem);
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-          const uint32_t i = u * GQ2 + t;
-          if (i < n2) dst[i] = pf[u];
+          const uint32_t i = u * GQ2 + t;   // double2 index in the compact [rows][PE / 2] slice
+          if (i < n2) {
+            if (PROWL == PROWB) {
+              reinterpret_cast<double2*>(smem)[i] = pf[u];
+            } else {                         // padded rows: odd rows are only 8-byte aligned
+              const uint32_t r = i / (PE / 2), c2 = i - r * (PE / 2);
+              double* dst = reinterpret_cast<double*>(smem + r * PROWL + c2 * 16);
+              dst[0] = pf[u].x;
+              dst[1] = pf[u].y;
+            }
+          }
         }
       }
       __syncthreads();
@@ -1161,7 +1177,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   const bool acc_early = max_span == 0 || max_span > (uint32_t)CH || getenv("EPA_PREPLACE_ACC");
   static const bool narrow_only = getenv("EPA_PREPLACE_NARROW") != nullptr;
   const bool wide = pairs && !acc_early && !narrow_only && (uint64_t)Q * SPREAD < (uint64_t)1400 * ctx->W;   // < ~700 reads per 96-site bucket and parity
-  constexpr int SPREAD_WIDE = 288;
+  constexpr int SPREAD_WIDE = PROWL == 288 ? 288 : 272;   // 16-bit LDS offsets: ((CH + SPREAD_WIDE) / 2 - 1) * PROWL + 35 * 8 < 65536
   hipLaunchKernelGGL(k_make_groups, dim3(1), dim3(256),
                      sizeof(uint32_t) * (2 * (n_blocks + 1) + 4 * (size_t)max_runs + 2), ctx->stream,
                      sorted_keys, Q, pairs ? Wp : 0xffffffffu, n_blocks, class_blocks, gq0, gq1,
@@ -1171,7 +1187,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   // max_span: upper bound of the window spans when the caller knows it (0 = unknown)
   const bool acc = max_span == 0 || max_span > (uint32_t)CH || getenv("EPA_PREPLACE_ACC");
   const size_t lds = sizeof(double) * ((size_t)TROWS * ctx->ncols + (acc ? (size_t)NB * GQ : 0));
-  const size_t lds2 = (size_t)TROWS2 * PROWB + sizeof(double) * (acc ? NB2_ACC : NB2_BURST) * GQ2;  // accs / result staging
+  const size_t lds2 = (size_t)TROWS2 * PROWL + sizeof(double) * (acc ? NB2_ACC : NB2_BURST) * GQ2;  // accs / result staging
   const uint32_t ntiles2 = (ctx->B + (acc ? NB2_ACC : NB2) - 1) / (acc ? NB2_ACC : NB2);
   const dim3 grid2((uint32_t)std::min<uint64_t>((uint64_t)max_groups * ntiles2, (uint64_t)ctx->n_cu));  // 1 per CU
   // generic kernel: with the pair path on it only sees the few groups of queries with rare
@@ -1190,7 +1206,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
                        tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl);    \
   } while (0)
   if (pairs && wide) {
-    const size_t lds2w = (size_t)((CH + SPREAD_WIDE) / 2) * PROWB + sizeof(double) * NB2_BURST * GQ2;
+    const size_t lds2w = (size_t)((CH + SPREAD_WIDE) / 2) * PROWL + sizeof(double) * NB2_BURST * GQ2;
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<false, SPREAD_WIDE>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2w));
     hipLaunchKernelGGL((k_preplace_pairs<false, SPREAD_WIDE>), grid2, dim3(GQ2), lds2w, ctx->stream, ctx->lookup2,
