@@ -345,23 +345,35 @@ def main():
     traffic = traffic_pre = None   # HBM bytes per launch from the committed PMC passes, same workload only
     aa_mfma = states == 20 and a.read_len <= 192 and not os.environ.get("EPA_AA_VALU")
     kname = "k_thorough_dna" if states == 4 else ("k_thorough_aa_mfma" if aa_mfma else "k_thorough_aa")
-    for tf in ("r2_traffic.json", "r1_traffic.json"):
+    # HBM bytes per launch come from the committed PMC passes of the SAME kernel sources (hash in the
+    # file, profiles/make_traffic.py) and the same workload; anything else reports null
+    traffic_note = "no PMC profile of these kernel sources and this workload under profiles/"
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        from make_traffic import src_hash
+        here = src_hash()
+    except Exception:  # noqa: BLE001
+        here = None
+    for tf in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
         try:
             tall = json.load(open(os.path.join(ROOT, "profiles", tf)))
             tj = tall[kname]
+            if tall.get("kernel_sources_sha16") != here:
+                continue
             if tj["reads_per_step"] == Q and abs(tj["pairs_per_launch"] - pairs) < 0.02 * pairs:
                 # FETCH_SIZE x its calibrated correction (2.0 on gfx950, profiles/r2_traffic_calibration.txt)
                 traffic = (tall.get("fetch_correction", 1.0) * tj["fetch_kb"] + tj["write_kb"]) * 1024.0
                 traffic_pre = tall.get("k_preplace_pairs")
                 if traffic_pre:
                     traffic_pre = (tall.get("fetch_correction", 1.0) * traffic_pre["fetch_kb"] + traffic_pre["write_kb"]) * 1024.0
+                traffic_note = "profiles/" + tf
                 break
         except (OSError, KeyError, ValueError):
             pass
     roof = {"bound": "mfma" if aa_mfma else "fp64-valu", "kernel": kname,
             "achieved": round(exec_tflops, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(exec_tflops / FP64_PEAK_TFLOPS, 4),
-            "traffic": traffic,
+            "traffic": traffic, "traffic_source": traffic_note,
             "note": ("achieved / frac price the fp64 flop the kernel EXECUTES (its 20 x 20 products and the Newton "
                      "contraction are v_mfma_f64_4x4x4_4b_f64, no padding); " if aa_mfma else
                      "achieved / frac price the fp64 flop the kernel EXECUTES (zero MFMA instructions: "

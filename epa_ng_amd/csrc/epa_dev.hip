@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <numeric>
+#include <atomic>
 #include <thread>
 
 static thread_local std::string g_create_err;
@@ -113,7 +114,8 @@ __global__ void __launch_bounds__(256) k_transform(const ModelDev* __restrict__ 
         for (int i = 0; i < s; ++i)
           if ((mask >> i) & 1u) acc += Ui[x * s + i];
       } else {
-        const double* v = clv + ((size_t)site * c_in + (k % c_in)) * s;  // c_in < c: replicated categories
+        const int ksrc = c_in <= 2 ? k % c_in : (k < c_in ? k : c_in - 1);       // c_in < c: replicated / padded categories
+        const double* v = clv + ((size_t)site * c_in + ksrc) * s;
         for (int i = 0; i < s; ++i) acc = fma(Ui[x * s + i], v[i], acc);
       }
       dst[(size_t)(k * s + x) * W + site] = acc;
@@ -290,6 +292,10 @@ static uint32_t column_mask(int s, int col) {
   return (1u << 20) - 1;  // '-' and 'X'
 }
 
+// upper limit on the host threads of the query encoder (0 = hardware concurrency, at most 32)
+static std::atomic<unsigned> g_encode_threads{0};
+extern "C" void epa_encode_set_threads(unsigned n) { g_encode_threads.store(n, std::memory_order_relaxed); }
+
 static int encode_impl(uint32_t states, uint32_t sites, uint32_t Q, const char* const* seqs,
                        int premasking, int aa_x_as_n, bool compact, uint32_t stride, uint8_t* codes,
                        uint32_t* win_begin, uint32_t* win_span, uint32_t* bad_query) {
@@ -312,8 +318,10 @@ static int encode_impl(uint32_t states, uint32_t sites, uint32_t Q, const char* 
   // copy of the 'N' column instead, so the same code rows serve both steps.
   (void)aa_x_as_n;
   map['?'] = map['-'];
-  // queries are independent: a few host threads (the first offender in query order is reported)
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  // queries are independent: a few host threads (the first offender in query order is reported);
+  // epa_encode_set_threads() caps them (the CLI's -T, a container's CPU quota)
+  const unsigned cap = g_encode_threads.load(std::memory_order_relaxed);
+  const unsigned hw = cap ? cap : std::max(1u, std::thread::hardware_concurrency());
   const unsigned nt = (unsigned)std::min<uint64_t>(std::min(hw, 32u), std::max<uint64_t>(1, (uint64_t)Q * sites >> 20));
   std::vector<uint32_t> bad(nt, 0xffffffffu);
   std::vector<int> code(nt, EPA_OK);
@@ -486,9 +494,14 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   const int s = (int)d->states, c_in = (int)d->rate_cats;
   if (!(s == 4 || s == 20)) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "states must be 4 or 20");
   if (c_in < 1 || c_in > EPA_MAX_CATS) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "rate_cats out of range");
-  // The thorough kernels are built for 4 rate categories.  1 or 2 categories (no +G, +G2) are
-  // replicated to 4 with the weights divided accordingly: sum_k w_k L_k is unchanged.
-  const int c = (c_in == 1 || c_in == 2) ? 4 : c_in;
+  // The tuned thorough kernels work on groups of 4 rate categories.  1 or 2 categories (no +G, +G2)
+  // are replicated to 4 with the weights divided accordingly: sum_k w_k L_k is unchanged.  Nucleotide
+  // models with 3 or 5 .. 16 categories (+G8, +R5, ...) are padded to the next multiple of 4 with copies
+  // of the last category at weight 0: every weighted sum gains exact zeros, the per-site rescale
+  // test (all entries < 2^-256) sees values it has already seen -- results are those of the
+  // unpadded model, and k_thorough_dna serves them with one wave per group of four.
+  int c = (c_in == 1 || c_in == 2) ? 4 : c_in;
+  if (s == 4 && c_in >= 3 && (c_in & 3) && !getenv("EPA_NO_CAT_PAD")) c = (c_in + 3) & ~3;
   if (c_in != c && (d->flags & EPA_FLAG_RATE_SCALERS) && !tree)
     return epa_fail(ctx, EPA_ERR_UNSUPPORTED,
                     "per-rate scaler arrays of a 1- or 2-category model: use epa_dev_create_from_tree");
@@ -522,8 +535,9 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   for (int k = 0; k < c; ++k) {
     // +I (libpll): every P-matrix uses r / (1 - p); the (1 - p) factor of the site likelihood
     // (1-p) sum_k w_k L_k + p pi_inv is folded into the weights
-    m.rate[k] = d->rates[k % c_in] / (1.0 - pinv);
-    m.w[k] = d->rate_weights[k % c_in] * (double)c_in / (double)c * (1.0 - pinv);
+    const int src = c_in <= 2 ? k % c_in : std::min(k, c_in - 1);
+    m.rate[k] = d->rates[src] / (1.0 - pinv);
+    m.w[k] = (c_in <= 2 ? d->rate_weights[src] * (double)c_in / (double)c : (k < c_in ? d->rate_weights[k] : 0.0)) * (1.0 - pinv);
   }
   {
     // Internal convention: eigenvalue 0 is the stationary (zero) one.  Swap the largest
@@ -556,12 +570,12 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   }
   if (s == 20 && ctx->aa_x_as_n)  // quirk D4: the lookup (preplacement) column of 'X' holds asparagine's numbers
     m.colmask[21] = m.colmask[11];  // AA_COLS[21] == 'X', AA_COLS[11] == 'N'
-  if (s == 4 && c == 4) {
+  const bool dna_groups = s == 4 && (c & 3) == 0 && c <= 16;   // 1 .. 4 groups of four categories
+  if (dna_groups) {
     for (int i = 0; i < 16; ++i) { ctx->dna.U[i] = m.U[i]; ctx->dna.Ui[i] = m.Ui[i]; }
-    for (int i = 0; i < 4; ++i) {
-      ctx->dna.lam[i] = m.lam[i]; ctx->dna.rate[i] = m.rate[i]; ctx->dna.w[i] = m.w[i];
-      ctx->dna.pi[i] = m.pi[i];
-    }
+    for (int i = 0; i < 4; ++i) { ctx->dna.lam[i] = m.lam[i]; ctx->dna.pi[i] = m.pi[i]; }
+    for (int k = 0; k < 16; ++k) { ctx->dna.rate[k] = k < c ? m.rate[k] : 1.0; ctx->dna.w[k] = k < c ? m.w[k] : 0.0; }
+    ctx->dna.ng = c / 4;
   }
   ctx->blo.min_branch = d->blo_min_branch > 0 ? d->blo_min_branch : 1e-4;
   ctx->blo.max_branch = d->blo_max_branch > 0 ? d->blo_max_branch : 100.0;
@@ -582,7 +596,10 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   // nucleotide models without +I (k_thorough_dna<.., LOCAL>) and for 20-state models
   // (k_thorough_aa_mfma<.., LOCAL>); everything else local goes general.
   const bool tuned_local = (s == 4 && ctx->dna_zero0 && !(pinv > 0.0)) || s == 20;
-  ctx->generic_thorough = c != 4 || (!ctx->blo.sliding && !tuned_local) || ctx->blo.newton_variant != 0 ||
+  // (more than 4 categories: tuned for nucleotide models, sliding rule, zero eigenvalue -- the class
+  // launcher of thorough_dna.hip sends what it does not serve to the general kernel itself)
+  const bool tuned_cats = c == 4 || (dna_groups && ctx->blo.sliding && ctx->dna_zero0 && !getenv("EPA_NO_CAT_GROUPS"));
+  ctx->generic_thorough = !tuned_cats || (!ctx->blo.sliding && !tuned_local) || ctx->blo.newton_variant != 0 ||
                           getenv("EPA_TH_GENERIC") != nullptr;   // (diagnostic switch: measure the general kernel)
 
   EPA_HIP(ctx, hipMalloc(&ctx->dmodel, sizeof(ModelDev)));

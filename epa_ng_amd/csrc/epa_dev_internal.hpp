@@ -19,9 +19,10 @@ struct ModelDNA {
   double U[16];     // [i][x]
   double Ui[16];    // [x][i]
   double lam[4];
-  double rate[4];   // r_k (prop_invar == 0)
-  double w[4];
+  double rate[16];  // r_k (prop_invar folded in); ng groups of four categories
+  double w[16];
   double pi[4];
+  int ng;           // category groups: 1 (4 categories) .. 4 (16)
 };
 
 struct BloConsts {
@@ -227,7 +228,8 @@ int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_
                        uint32_t max_span, bool want_lds, epa_result* d_out, unsigned long long* d_stats);
 int launch_thorough_generic(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
                             const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
-                            epa_result* d_out, unsigned long long* d_stats);
+                            epa_result* d_out, unsigned long long* d_stats,
+                            const uint32_t* d_order = nullptr);
 int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_order, uint64_t n_pairs,
                             const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span,
                             uint32_t max_span, epa_result* d_out, unsigned long long* d_stats);

@@ -23,7 +23,10 @@
 namespace epa {
 
 namespace { int g_thread_limit = 0; }   // -T/--threads of the command line; 0 = no user limit
-void set_host_thread_limit(int n) { g_thread_limit = n > 0 ? n : 0; }
+void set_host_thread_limit(int n) {
+  g_thread_limit = n > 0 ? n : 0;
+  epa_encode_set_threads((unsigned)g_thread_limit);   // the query encoder's std::threads honour -T too
+}
 
 int configure_host_threads() {
   static const int n = [] {
@@ -36,6 +39,7 @@ int configure_host_threads() {
     double period = 0;
     if (f >> quota >> period && quota != "max" && period > 0)
       v = std::min(v, std::max(1, (int)std::ceil(std::stod(quota) / period)));
+    epa_encode_set_threads((unsigned)v);   // affinity mask / cgroup quota apply to the query encoder as well
     return v;
   }();
   omp_set_num_threads(n);  // per calling thread (the device workers are separate host threads)
@@ -288,7 +292,7 @@ void place_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, D
                                        enc.win_span.data(), (uint32_t)Q, max_span,
                                        options.prescoring_threshold, pairs.data(), res.data(), cap, &n,
                                        nullptr);
-    if (rc == EPA_ERR_INVALID_ARG && cap < (uint64_t)Q * tree.num_branches()) {
+    if (rc == EPA_ERR_PAIR_OVERFLOW && cap < (uint64_t)Q * tree.num_branches()) {
       cap = std::min<uint64_t>(cap * 8, (uint64_t)Q * tree.num_branches());  // candidate overflow
       continue;
     }
@@ -325,7 +329,7 @@ void chunk_launch(const Encoded_Chunk& enc, size_t Q, const Tree& tree, Device_E
   if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
   for (;;) {
     rc = epa_dev_chunk_launch(dev.ctx(), slot, max_span, options.prescoring_threshold, nullptr, nullptr, cap, 0);
-    if (rc == EPA_ERR_INVALID_ARG && cap < (uint64_t)Q * nb) {
+    if (rc == EPA_ERR_PAIR_OVERFLOW && cap < (uint64_t)Q * nb) {
       cap = std::min<uint64_t>(cap * 8, (uint64_t)Q * nb);  // candidate overflow: the slot stays staged
       continue;
     }

@@ -1353,7 +1353,7 @@ int launch_select_end(epa_ctx* ctx, SelectPending* sp, uint64_t* n_pairs) {
       continue;
     }
     if (total > sp->max_pairs)
-      return epa_fail(ctx, EPA_ERR_INVALID_ARG,
+      return epa_fail(ctx, EPA_ERR_PAIR_OVERFLOW,
                       "select_candidates: " + std::to_string(total) + " candidates exceed max_pairs");
     if (total) {
       const dim3 grid((Q + 3) / 4);

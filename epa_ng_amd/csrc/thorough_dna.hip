@@ -93,12 +93,12 @@ __device__ __forceinline__ KArgs kargs_fresh() {
 }
 struct PhaseModel {   // what a phase needs of ModelDNA, in scalar registers for the phase's duration
   double U[16], Ui[16], w[4];
-  __device__ __forceinline__ void load() {
+  __device__ __forceinline__ void load(uint32_t grp) {
     KArgs p = kargs_fresh();
 #pragma unroll
     for (int i = 0; i < 16; ++i) { U[i] = p->m.U[i]; Ui[i] = p->m.Ui[i]; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = p->m.w[i];
+    for (int i = 0; i < 4; ++i) w[i] = p->m.w[grp * 4 + i];
   }
 };
 
@@ -317,11 +317,21 @@ struct SiteState {
 // the per-wave sums of f, f' and lnL are combined through LDS with one barrier per Newton
 // evaluation (double-buffered: a wave can be at most one barrier ahead of the slowest one).
 // All waves then hold identical scalars and walk the optimiser's control flow in lock step.
-template <int NW>
+// NG > 1 (8 / 12 / 16 rate categories): the workgroup's NG waves are the model's GROUPS OF FOUR
+// CATEGORIES instead -- wave g runs the four-category code on categories 4 g .. 4 g + 3 of ALL sites of
+// the window (its rows of the reference data, its rates and weights) -- and what a site needs from
+// all of its categories crosses the waves through LDS: l0 / l1 / l2 of a Newton evaluation, the
+// site likelihood of the window lnL, the maximum of the inner vector for the per-site rescale test.
+// Every wave then holds the same per-site values and the same scalars; the sums over the groups are
+// formed in group order by all of them.
+template <int NW, int NG = 1>
 struct Comb {
   double* red;  // LDS [2][NW][2]
-  int wv;
+  int wv;       // wave of the workgroup: site block (NW > 1) or category group (NG > 1)
   int phase;
+  double* xch;  // NG > 1: LDS [2][NG][XCH_MAX][64] per-lane exchange slots
+  int xphase;
+  static constexpr int XCH_MAX = 12;
   __device__ __forceinline__ void sum2(double& a, double& b, int lane) {
     if constexpr (NW > 1) {
       double* r = red + phase * NW * 2;
@@ -335,15 +345,38 @@ struct Comb {
       phase ^= 1;
     }
   }
+  // v[i] <- sum over the category groups of v[i] (MAXI: maximum of integers carried as doubles),
+  // per lane; one workgroup barrier (double-buffered like sum2)
+  template <int N, bool MAXI = false>
+  __device__ __forceinline__ void groups(double (&v)[N], int lane) {
+    if constexpr (NG > 1) {
+      static_assert(N <= XCH_MAX, "exchange slots");
+      double* x = xch + (size_t)xphase * NG * XCH_MAX * 64;
+#pragma unroll
+      for (int i = 0; i < N; ++i) x[(wv * XCH_MAX + i) * 64 + lane] = v[i];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        double acc = x[i * 64 + lane];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) {
+          const double o = x[(g * XCH_MAX + i) * 64 + lane];
+          acc = MAXI ? fmax(acc, o) : acc + o;
+        }
+        v[i] = acc;
+      }
+      xphase ^= 1;
+    }
+  }
 };
 
 // Newton tables for proposal t: e = w exp(lr t), e1 = w lr exp(lr t), e2 = w lr^2 exp(lr t).
 // ZERO0: eigenvalue 0 is exactly 0 (stationary mode) -> its e1/e2 columns vanish.
 // Then  f = sum_sites -l1/l0,  f' = sum_sites (l1/l0)^2 - l2/l0   (pll_compute_likelihood_
 // derivatives): 40 (48) FMAs per site.
-template <int NCH, bool ZERO0, int NW, bool TAILH = false>
+template <int NCH, bool ZERO0, int NW, bool TAILH = false, int NG = 1>
 __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* tab, int lane,
-                                            const LaneConst& lc, Comb<NW>& cb, double t, double& f,
+                                            const LaneConst& lc, Comb<NW, NG>& cb, double t, double& f,
                                             double& df) {
   table_publish(tab, lane, TH_EXP(lc.lr * t) * lc.cN);
   double e[16], e1[16], e2[16];
@@ -352,6 +385,55 @@ __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* ta
     if (!(ZERO0 && (i & 3) == 0)) { e[i] = tab[i]; e1[i] = tab[16 + i]; e2[i] = tab[32 + i]; }
   }
   double fl = 0.0, dfl = 0.0;
+  if constexpr (NG > 1) {
+    // this group's share of l0 / l1 / l2 of every site, summed over the groups, then the ratios
+    constexpr int NV = TAILH ? 3 * (NCH - 1) + 2 : 3 * NCH;
+    double lv[NV];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (TAILH && ch == NCH - 1) {
+        const double* th = tab + ((lane >> 5) << 3);
+        double l0 = ZERO0 ? st.S[ch][0] : 0.0, l1 = 0.0, l2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (!(ZERO0 && (i & 3) == 0)) {
+            l0 = fma(st.S[ch][i], th[i], l0);
+            l1 = fma(st.S[ch][i], th[16 + i], l1);
+            l2 = fma(st.S[ch][i], th[32 + i], l2);
+          }
+        }
+        lv[3 * ch] = xhalf_add(l0);
+        lv[3 * ch + 1] = xhalf_add2(l1, l2);
+        continue;
+      }
+      double l0 = ZERO0 ? st.S[ch][0] : 0.0, l1 = 0.0, l2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (!(ZERO0 && (i & 3) == 0)) {
+          l0 = fma(st.S[ch][i], e[i], l0);
+          l1 = fma(st.S[ch][i], e1[i], l1);
+          l2 = fma(st.S[ch][i], e2[i], l2);
+        }
+      }
+      lv[3 * ch] = l0; lv[3 * ch + 1] = l1; lv[3 * ch + 2] = l2;
+    }
+    cb.template groups<NV>(lv, lane);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (TAILH && ch == NCH - 1) {
+        const double qv = -lv[3 * ch + 1] * fast_rcp(lv[3 * ch]);
+        const bool lower = lane < 32;
+        if (st.valid[ch]) { fl += lower ? qv : 0.0; dfl += lower ? qv * qv : qv; }
+        continue;
+      }
+      const double inv = fast_rcp(lv[3 * ch]);
+      const double d1 = -lv[3 * ch + 1] * inv;
+      const double d2 = fma(d1, d1, -lv[3 * ch + 2] * inv);
+      if (st.valid[ch]) { fl += d1; dfl += d2; }
+    }
+    wave_sum2(fl, dfl, f, df);   // every wave holds every site's full values: no cross-wave sum
+    return;
+  }
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     if (TAILH && ch == NCH - 1) {
@@ -397,27 +479,34 @@ __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* ta
 // and exponent (v_frexp_*), mantissas multiplied, exponents and scaler counts added as integers:
 //   sum_ch log(L_ch) + sc_ch log 2^-256  =  log(prod mant) + ln2 * (sum exp - 256 sum sc)
 // -> ONE log() per lane instead of NCH.
-template <int NCH, bool ZERO0, int NW, bool TAILH = false>
-__device__ __forceinline__ double window_lnl(const SiteState<NCH>& st, const double (&ew)[16], Comb<NW>& cb,
+template <int NCH, bool ZERO0, int NW, bool TAILH = false, int NG = 1>
+__device__ __forceinline__ double window_lnl(const SiteState<NCH>& st, const double (&ew)[16], Comb<NW, NG>& cb,
                                              int lane, const double* tab = nullptr) {
   double mant = 1.0;
   int ex = 0;
+  double lsite[NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     double l0 = ZERO0 ? st.S[ch][0] : 0.0;
-    bool mine = st.valid[ch];
     if (TAILH && ch == NCH - 1) {   // half-chunk: this half's two categories, then both halves
       const double* ewh = tab + 32 + ((lane >> 5) << 3);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (!(ZERO0 && (i & 3) == 0)) l0 = fma(st.S[ch][i], ewh[i], l0);
       l0 = xhalf_add(l0);
-      mine = mine && lane < 32;     // a site is counted once
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i)
         if (!(ZERO0 && (i & 3) == 0)) l0 = fma(st.S[ch][i], ew[i], l0);
     }
+    lsite[ch] = l0;
+  }
+  cb.template groups<NCH>(lsite, lane);   // NG > 1: the site likelihood over all category groups
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    double l0 = lsite[ch];
+    bool mine = st.valid[ch];
+    if (TAILH && ch == NCH - 1) mine = mine && lane < 32;     // a site is counted once
     if (!mine) l0 = 1.0;
     const int sc = mine ? (int)(st.sc[ch] + st.resc[ch]) : 0;
     mant *= __builtin_amdgcn_frexp_mant(l0);
@@ -433,14 +522,14 @@ __device__ __forceinline__ double window_lnl(const SiteState<NCH>& st, const dou
 }
 
 // pllmod_opt_minimize_newton (pll-modules; rtsafe-style safeguarded Newton).  Wave-uniform.
-template <int NCH, bool ZERO0, int NW, bool TAILH = false>
+template <int NCH, bool ZERO0, int NW, bool TAILH = false, int NG = 1>
 __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, int lane,
-                                         const LaneConst& lc, Comb<NW>& cb, double x1, double xguess,
+                                         const LaneConst& lc, Comb<NW, NG>& cb, double x1, double xguess,
                                          double x2, double tol, int max_iters, uint32_t& evals) {
   double rts = xguess, f, df, xl, xh, dx;
   if (rts < x1) rts = x1;
   if (rts > x2) rts = x2;
-  derivatives<NCH, ZERO0, NW, TAILH>(st, tab, lane, lc, cb, rts, f, df);
+  derivatives<NCH, ZERO0, NW, TAILH, NG>(st, tab, lane, lc, cb, rts, f, df);
   ++evals;
   if (!isfinite(f) || !isfinite(df)) return NAN;
   if (df >= 0.0 && fabs(f) < tol) return rts;
@@ -458,7 +547,7 @@ __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, 
     }
     if (fabs(dx) < tol || i == max_iters) return rts;
     if (rts < x1) rts = x1;
-    derivatives<NCH, ZERO0, NW, TAILH>(st, tab, lane, lc, cb, rts, f, df);
+    derivatives<NCH, ZERO0, NW, TAILH, NG>(st, tab, lane, lc, cb, rts, f, df);
     ++evals;
     if (!isfinite(f) || !isfinite(df)) return NAN;
     if (df > 0.0 && fabs(f) < tol) return rts;
@@ -467,11 +556,13 @@ __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, 
   return NAN;
 }
 
-template <int NCH, bool ZERO0, bool INV, int NW, bool LOCAL, bool TAILH = false>
+template <int NCH, bool ZERO0, bool INV, int NW, bool LOCAL, bool TAILH = false, int NG = 1>
 __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pidx, const int lane,
                                              double* tab, const double* qts, double* qa, const LaneConst& lc,
-                                             Comb<NW>& cb, uint32_t (&wstat)[3]) {
+                                             Comb<NW, NG>& cb, uint32_t (&wstat)[3]) {
+  static_assert(NG == 1 || NW == 1, "category groups and site blocks do not combine");
   const uint32_t site0 = NW > 1 ? (uint32_t)cb.wv * NCH * 64 : 0u;  // first window site of this wave
+  const uint32_t grp = NG > 1 ? (uint32_t)cb.wv : 0u;               // this wave's category group
   const ModelDNA& m = a.m;
   const uint64_t pid = a.order ? a.order[pidx] : pidx;
   const epa_pair pr = a.pairs[pid];
@@ -484,10 +575,11 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   // one uniform base (SGPR pair) + 32-bit per-lane byte offsets: component c of the proximal
   // CLV sits at c*W*8, of the distal CLV at (16+c)*W*8 (saddr + voffset addressing, no
   // per-stream 64-bit pointers in VGPRs)
-  const char* ref = reinterpret_cast<const char*>(a.refT + (size_t)(2 * b) * 16 * cW + begin);
+  // component rows of this wave's category group: proximal block [16 NG rows], then the distal block
+  const char* ref = reinterpret_cast<const char*>(a.refT + ((size_t)(2 * b) * NG + grp) * 16 * cW + begin);
   const uint32_t W8 = a.W * 8u;
   auto ldX = [&](int c, uint32_t soff) { return *reinterpret_cast<const double*>(ref + (soff + (uint32_t)c * W8)); };
-  auto ldD = [&](int c, uint32_t soff) { return *reinterpret_cast<const double*>(ref + (soff + (uint32_t)(16 + c) * W8)); };
+  auto ldD = [&](int c, uint32_t soff) { return *reinterpret_cast<const double*>(ref + (soff + (uint32_t)(16 * NG + c) * W8)); };
   const uint32_t* scp = a.scSum + (size_t)b * cW + begin;
   const uint8_t* qc = a.codes + (size_t)q * a.cstride + (a.crel ? 0u : begin);
   const double orig = a.blen[b];
@@ -522,6 +614,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   auto cinv_of = [&](int ch) -> double {
     const uint32_t s = st.valid[ch] ? lane_site(ch) : 0;
     const double v = a.cinv[begin + s] * a.inv_w0;
+    if (NG > 1 && grp != 0) return 0.0;                  // ... and in the first category group
     return (TAILH && ch == NCH - 1 && half) ? 0.0 : v;   // category 0 lives in the lower half
   };
   // ZERO0: the four zero-eigenvalue entries of a site only ever appear as sum_k w_k S_k0 (their
@@ -557,7 +650,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   //   MODE 2: the precomputed inner vector of the starting lengths (refI), folded with the query
   // The per-site rescale (pll_update_partials: all c * s entries < 2^-256) is applied to the finished
   // sumtable entries of the chunk instead of to the inner vector (the same 16 multiplications).
-  const char* refi_s = reinterpret_cast<const char*>(a.refI + (size_t)b * 16 * cW + begin);
+  const char* refi_s = reinterpret_cast<const char*>(a.refI + ((size_t)b * NG + grp) * 16 * cW + begin);
   auto stream_phase = [&](auto mode_c) {
     constexpr int MODE = decltype(mode_c)::value;
     constexpr int DEPTH = TH_STREAM_DEPTH > 0 ? TH_STREAM_DEPTH : 1;
@@ -565,7 +658,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     constexpr int NS = 4 * (NCH - 1) + NKL;
     constexpr int R = DEPTH + 1;
     PhaseModel pm;
-    pm.load();
+    pm.load(grp);
     uint32_t W8p = W8;
     asm volatile("" : "+s"(W8p));
     double An[R][4], Bn[R][4];
@@ -606,7 +699,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
         // hoists all 32 row offsets out of the pair loop and parks them in scratch
         if (MODE == 2) An[sl][x] = *reinterpret_cast<const double*>(refi_s + (s0 + (uint32_t)(k * 4 + x) * W8p));
         else {
-          An[sl][x] = *reinterpret_cast<const double*>(ref + (s0 + (uint32_t)(16 + k * 4 + x) * W8p));
+          An[sl][x] = *reinterpret_cast<const double*>(ref + (s0 + (uint32_t)(16 * NG + k * 4 + x) * W8p));
           Bn[sl][x] = *reinterpret_cast<const double*>(ref + (s0 + (uint32_t)(k * 4 + x) * W8p));
         }
       }
@@ -653,6 +746,11 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
             const auto sw = __builtin_amdgcn_permlane32_swap(mx, mx, false, false);
             mxs = max((int)sw[0], (int)sw[1]);
           }
+          if constexpr (NG > 1) {   // the test spans all categories of the site: maximum over the groups
+            double mv[1] = {(double)mxs};
+            cb.template groups<1, true>(mv, lane);
+            mxs = (int)mv[0];
+          }
           const uint32_t resc = (mxs < 0x2ff00000) ? 1u : 0u;
           if (__builtin_amdgcn_ballot_w64(resc != 0) != 0) {   // rare: some site of the chunk underflowed
             const double mult = resc ? 0x1p+256 : 1.0;
@@ -674,6 +772,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     chain = tok;
   };
   constexpr bool STREAM = TH_STREAM_DEPTH > 0;
+  static_assert(NG == 1 || STREAM, "category groups are implemented in the streamed phases only");
 
   // Inner CLV toward the query at (td, tx) folded with the query, S = (U^-1 I) o qt, and the
   // window lnL at pendant length tp_.  One table pass: slot 0 -> exp(lr td), slot 1 ->
@@ -718,7 +817,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     double ew[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
-    return window_lnl<NCH, ZERO0, NW, TAILH>(st, ew, cb, lane, tab);
+    return window_lnl<NCH, ZERO0, NW, TAILH, NG>(st, ew, cb, lane, tab);
   };
   // inner CLV toward distal: I' = (P_pend q) o (P_prox X); S = Dt o (U^-1 I').  TOWARD_PROX (the
   // --raxml-blo loop only): the same toward the proximal node, I' = (P_pend q) o (P_dist D), S = Xt o ...
@@ -813,7 +912,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     double ew[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
-    return window_lnl<NCH, ZERO0, NW, TAILH>(st, ew, cb, lane, tab);
+    return window_lnl<NCH, ZERO0, NW, TAILH, NG>(st, ew, cb, lane, tab);
   };
 
   // traverse_update_partials + initial score (optimize.cpp:15-42,111-113)
@@ -831,7 +930,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     auto solve = [&](double cur) -> double {
       double g = cur;
       if (g < xmin || g > xmax) g = a.blo.default_branch;
-      const double r = newton<NCH, ZERO0, NW, TAILH>(st, tab, lane, lc, cb, xmin, g, xmax, xtol, (int)a.blo.max_newton, evals);
+      const double r = newton<NCH, ZERO0, NW, TAILH, NG>(st, tab, lane, lc, cb, xmin, g, xmax, xtol, (int)a.blo.max_newton, evals);
       chain = zero_after(r);
       // keep_update: the length is replaced when the solver moved it
       return (isfinite(r) && fabs(cur - r) > 1e-10) ? r : cur;
@@ -848,7 +947,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
       double ew[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
-      const double new_ll = -window_lnl<NCH, ZERO0, NW, TAILH>(st, ew, cb, lane, tab);
+      const double new_ll = -window_lnl<NCH, ZERO0, NW, TAILH, NG>(st, ew, cb, lane, tab);
       ++rounds;
       --smoothings;
       if (fabs(new_ll - loglikelihood) < a.blo.epsilon) smoothings = 0;
@@ -861,7 +960,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     double xmin = a.blo.min_branch, xmax = a.blo.max_branch, xtol = xmin / 10.0;
     double xguess = tp;
     if (xguess < xmin || xguess > xmax) xguess = a.blo.default_branch;
-    double xres = newton<NCH, ZERO0, NW, TAILH>(st, tab, lane, lc, cb, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
+    double xres = newton<NCH, ZERO0, NW, TAILH, NG>(st, tab, lane, lc, cb, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
     if (xres > 0.0) tp = xres;
     chain = zero_after(tp);
     // ---- NR for the distal length with the proximal P-matrix held fixed (:170-211)
@@ -871,7 +970,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     xtol = xmin / 10.0;
     xmax = orig - xtol;
     if (xguess < xmin || xguess > xmax) xguess = orig / 2.0;
-    xres = newton<NCH, ZERO0, NW, TAILH>(st, tab, lane, lc, cb, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
+    xres = newton<NCH, ZERO0, NW, TAILH, NG>(st, tab, lane, lc, cb, xmin, xguess, xmax, xtol, (int)a.blo.max_newton, evals);
     if (xres > 0.0) { td = xres; tx = orig - xres; }
     chain = zero_after(td);
     // ---- score (:217-222)
@@ -887,7 +986,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     loglikelihood = new_ll;
   }
 
-  if (lane == 0 && (NW == 1 || cb.wv == 0)) {
+  if (lane == 0 && ((NW == 1 && NG == 1) || cb.wv == 0)) {
     const double lnl = -loglikelihood;
     epa_result r;
     r.lnl = lnl;
@@ -912,23 +1011,26 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 // and every wave gets a ~25-pair random sample of the 10x cost spread (1..32 NR rounds).
 // INV: the model has +I (instantiated for ZERO0 only; a separate instantiation so that the
 // default kernel's register allocation is untouched: the runtime-flag version cost 40 more spills)
-template <int NCH, bool ZERO0, bool INV, int NW, bool LOCAL = false, bool TAILH = false>
-__global__ void __launch_bounds__(64 * NW, 2) k_thorough_dna(const ThArgs a) {
-  __shared__ double tab[64 * NW];  // broadcast table of each wave
+template <int NCH, bool ZERO0, bool INV, int NW, bool LOCAL = false, bool TAILH = false, int NG = 1>
+__global__ void __launch_bounds__(64 * NW * NG, 2) k_thorough_dna(const ThArgs a) {
+  constexpr int NWV = NW * NG;     // waves of the workgroup: site blocks (NW) or category groups (NG)
+  __shared__ double tab[64 * NWV];  // broadcast table of each wave
   __shared__ double qts[64];       // U^-1 image of the 16 query column codes
   __shared__ double red[2 * NW * 2];
   __shared__ double e2t[64];
-  __shared__ double qa[256 * NW];  // per wave: (U (e o q_code))_i for 16 codes x 16 (category, state)
+  __shared__ double qa[256 * NWV];  // per wave: (U (e o q_code))_i for 16 codes x 16 (category, state)
+  __shared__ double xch[NG > 1 ? 2 * NG * Comb<NW, NG>::XCH_MAX * 64 : 1];
   const int lane = threadIdx.x & 63;
-  Comb<NW> cb{red, (int)(threadIdx.x >> 6), 0};
+  Comb<NW, NG> cb{red, (int)(threadIdx.x >> 6), 0, xch, 0};
   if (threadIdx.x < 64) { qts[lane] = a.qt[lane]; e2t[lane] = exp2((double)lane * 0.015625); }
   LaneConst lc;
   lc.e2t = e2t;
   {
     const int lk = (lane >> 2) & 3, lx = lane & 3;
+    const int kg = (NG > 1 ? cb.wv * 4 : 0) + lk;   // category of this lane's table entry
     lc.slot = lane >> 4;
-    lc.lr = a.m.lam[lx] * a.m.rate[lk];
-    lc.w = a.m.w[lk];
+    lc.lr = a.m.lam[lx] * a.m.rate[kg];
+    lc.w = a.m.w[kg];
     lc.cN = lc.slot == 0 ? lc.w : (lc.slot == 1 ? lc.w * lc.lr : (lc.slot == 2 ? lc.w * lc.lr * lc.lr : 0.0));
   }
   __syncthreads();
@@ -939,7 +1041,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_thorough_dna(const ThArgs a) {
   const uint64_t hi = lo + per < a.n_pairs ? lo + per : a.n_pairs;
   uint32_t wstat[3] = {0, 0, 0};
   bool queued = false;
-  if constexpr (NW == 1) {
+  if constexpr (NW == 1 && NG == 1) {
     if (a.qctr) {
       // resident waves fetch the next pair of their XCD slice from a counter: no relaunches, no
       // tail of unlucky waves.  The next index is requested before the current pair is processed.
@@ -953,14 +1055,14 @@ __global__ void __launch_bounds__(64 * NW, 2) k_thorough_dna(const ThArgs a) {
         const uint32_t cur = nxt;
         uint32_t f = 0;
         if (lane == 0) f = atomicAdd(ctr, 1u);
-        process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH>(a, lo + cur, lane, tab + cb.wv * 64, qts, qa + cb.wv * 256, lc, cb, wstat);
+        process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH, NG>(a, lo + cur, lane, tab + cb.wv * 64, qts, qa + cb.wv * 256, lc, cb, wstat);
         nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
       }
     }
   }
   if (!queued)
     for (uint64_t p = lo + w; p < hi; p += stride)
-      process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH>(a, p, lane, tab + cb.wv * 64, qts, qa + cb.wv * 256, lc, cb, wstat);
+      process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH, NG>(a, p, lane, tab + cb.wv * 64, qts, qa + cb.wv * 256, lc, cb, wstat);
   if (threadIdx.x == 0) {
     atomicAdd(&a.stats[0], (unsigned long long)wstat[0]);
     atomicAdd(&a.stats[1], (unsigned long long)wstat[1]);
@@ -1257,6 +1359,32 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
   // half-chunk tail (TAILH), classes 10 / 11: every window of the class ends within 32 sites of its
   // last chunk's start (150-site reads: 64 + 64 + 22).  Same-box A/B on the cfg2 bench: 6.57 - 6.69
   // -> 6.42 ms per launch.  EPA_TH_TAIL=0 runs these classes on the full-chunk kernels.
+  // 8 / 12 / 16 rate categories (ctx->dna.ng = 2 / 3 / 4 groups of four): workgroup = NG waves = the
+  // category groups of one pair (see Comb); single-wave window classes only, longer windows, --raxml-blo
+  // and rate matrices without an exact zero eigenvalue take the general kernel
+  if (ctx->dna.ng > 1) {
+    const bool ok = ctx->blo.sliding && ctx->dna_zero0 && (cls <= 2 || cls == 10 || cls == 11);
+    if (!ok) {
+      a.Wpad = (std::max(max_span, 1u) + 63) / 64 * 64;
+      return launch_thorough_generic(ctx, a.pairs, n_pairs, a.codes, a.win_begin, a.win_span, max_span, a.out,
+                                     a.stats, a.order ? a.order : nullptr);
+    }
+    const int nch = cls == 0 ? 1 : (cls == 1 || cls == 10) ? 2 : 3;
+    uint64_t want = (uint64_t)256 * 8 * per_slot / (uint64_t)ctx->dna.ng;
+    if (want > n_pairs) want = n_pairs;
+    const uint32_t nwg = (uint32_t)((want + 7) / 8 * 8);
+    a.qctr = nullptr;
+#define LAUNCH_G(N, G)                                                                                          \
+    do {                                                                                                        \
+      if (a.cinv) hipLaunchKernelGGL((k_thorough_dna<N, true, true, 1, false, false, G>), dim3(nwg), dim3(64 * (G)), 0, ctx->stream, a); \
+      else hipLaunchKernelGGL((k_thorough_dna<N, true, false, 1, false, false, G>), dim3(nwg), dim3(64 * (G)), 0, ctx->stream, a);       \
+    } while (0)
+#define LAUNCH_GN(G) do { if (nch == 1) LAUNCH_G(1, G); else if (nch == 2) LAUNCH_G(2, G); else LAUNCH_G(3, G); } while (0)
+    if (ctx->dna.ng == 2) LAUNCH_GN(2); else if (ctx->dna.ng == 3) LAUNCH_GN(3); else LAUNCH_GN(4);
+#undef LAUNCH_GN
+#undef LAUNCH_G
+    return EPA_OK;
+  }
   static const bool tail_off = getenv("EPA_TH_TAIL") && atoi(getenv("EPA_TH_TAIL")) == 0;
   const bool tailh = !tail_off && (cls == 10 || cls == 11);
   static const bool n4_off = getenv("EPA_TH_N4") && atoi(getenv("EPA_TH_N4")) == 0;

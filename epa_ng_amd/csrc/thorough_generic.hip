@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(64) k_thorough_generic(const ThArgsG a) {
 
 int launch_thorough_generic(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
                             const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
-                            epa_result* d_out, unsigned long long* d_stats) {
+                            epa_result* d_out, unsigned long long* d_stats, const uint32_t* d_order) {
   ThArgsG a;
   a.m = ctx->dmodel;
   a.blo = ctx->blo;
@@ -368,7 +368,7 @@ int launch_thorough_generic(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pa
   a.inv_w0 = ctx->inv_w0;
   a.blen = ctx->blen;
   a.pairs = d_pairs;
-  a.order = nullptr;
+  a.order = d_order;   // pair indices of this launch (one span class of a mixed call), or all pairs
   a.codes = d_codes;
   a.crel = ctx->code_stride ? 1u : 0u;
   a.cstride = a.crel ? ctx->code_stride : ctx->W;
@@ -383,10 +383,10 @@ int launch_thorough_generic(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pa
   const size_t per = (size_t)(ctx->c * ctx->s + 1) * a.Wpad;
   a.slab = (double*)epa_scratch(ctx, 7, sizeof(double) * per * grid);
   if (!a.slab) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(generic sumtable scratch)");
-  epa_timer_start(ctx, ctx->t_thorough);
+  if (!d_order) epa_timer_start(ctx, ctx->t_thorough);   // a per-class launch is timed by its caller
   if (ctx->s == 4) hipLaunchKernelGGL(k_thorough_generic<4>, dim3(grid), dim3(64), 0, ctx->stream, a);
   else hipLaunchKernelGGL(k_thorough_generic<20>, dim3(grid), dim3(64), 0, ctx->stream, a);
-  epa_timer_stop(ctx, ctx->t_thorough);
+  if (!d_order) epa_timer_stop(ctx, ctx->t_thorough);
   EPA_HIP(ctx, hipGetLastError());
   return EPA_OK;
 }

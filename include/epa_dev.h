@@ -44,7 +44,9 @@ typedef enum {
   EPA_ERR_INVALID_CHAR = -6,  /* "char is invalid!" Lookup_Store.hpp:100-108 (quirk D5: the     *
                                *   reference does not validate; this library does on ingest)   */
   EPA_ERR_NEG_INF = -7,       /* "-INF logl at branch ..." Tiny_Tree.cpp:209-212               */
-  EPA_ERR_UNSUPPORTED = -8    /* feature marked "next" in SURVEY.md section 8f                 */
+  EPA_ERR_UNSUPPORTED = -8,   /* feature marked "next" in SURVEY.md section 8f                 */
+  EPA_ERR_PAIR_OVERFLOW = -9  /* the candidate selection found more pairs than max_pairs: call    *
+                               *   again with larger buffers (a staged chunk stays staged)       */
 } epa_status;
 
 /* flags of epa_ref_desc.flags */
@@ -227,6 +229,8 @@ int epa_encode_queries(uint32_t states, uint32_t sites, uint32_t Q, const char* 
  * preplace / thorough / place_chunk calls use: 0 (default) = Q x W rows as produced by
  * epa_encode_queries(), S > 0 = compact rows of S bytes.  Results are identical.
  */
+/* Upper limit on the host threads the encoders use (0 = the hardware concurrency, at most 32). */
+void epa_encode_set_threads(unsigned n);
 int epa_encode_queries_compact(uint32_t states, uint32_t sites, uint32_t Q, const char* const* seqs,
                                int premasking, int aa_x_as_n, uint32_t stride, uint8_t* codes,
                                uint32_t* win_begin, uint32_t* win_span, uint32_t* bad_query);
@@ -325,7 +329,7 @@ int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* wi
  *               stage(0, c0); begin(0);
  *               for k: { stage((k+1)&1, c[k+1]); begin((k+1)&1); end(k&1); finish((k-1)&1) ... }
  * A typical loop:  stage(0, c0); for k: { launch(k&1); finish((k-1)&1); stage((k+1)&1, c[k+1]); }
- * Candidate overflow (EPA_ERR_INVALID_ARG from launch, as epa_dev_place_chunk) leaves the slot
+ * Candidate overflow (EPA_ERR_PAIR_OVERFLOW from launch, as epa_dev_place_chunk) leaves the slot
  * staged: launch again with a larger max_pairs.
  */
 #define EPA_CHUNK_NO_D2H 0x1u

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything the committed profiles/<tag>_* files come from, in one gpurun call:
 #   bash profiles/run_round.sh <tag>
-tag=${1:-r1}
+tag=${1:-r3}
 R=$PWD
 mkdir -p gpurun_out
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
@@ -17,10 +17,10 @@ bash profiles/run_pmc.sh ${tag} \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" \
   "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" \
   "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
-  "SQ_INSTS_SALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE" \
+  "SQ_INSTS_SALU SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE SQ_INSTS_SMEM" \
   "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum" > gpurun_out/${tag}_pmc_summary.txt 2>&1
 grep -A22 "== k_thorough" gpurun_out/${tag}_pmc_summary.txt | head -30
-# 20-state workload (BASELINE.json configs[3] shape): bench line, kernel trace, counters of the matrix-core kernel
+# 20-state workload (BASELINE.json configs[2] shape): bench line, kernel trace, counters of the matrix-core kernel
 AA="--workload aa --tips 2000 --width 500 --read-len 100 --chunk 10000"
 python bench.py $AA > gpurun_out/${tag}_aa_bench.json 2> gpurun_out/${tag}_aa_bench.err
 tail -1 gpurun_out/${tag}_aa_bench.json | cut -c1-300
@@ -34,6 +34,25 @@ head -8 gpurun_out/${tag}_aa_kernel_trace_stats.txt
 BENCH_ARGS="$AA" bash profiles/run_pmc.sh ${tag}_aa \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
   "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" \
+  "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY" \
   "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
   "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum" > gpurun_out/${tag}_aa_pmc_summary.txt 2>&1
 grep -A16 "== k_thorough" gpurun_out/${tag}_aa_pmc_summary.txt | head -20
+# traffic file for bench.py (stamped with the kernel-source hash)
+python - <<PY
+import json
+d = json.loads(open("gpurun_out/${tag}_bench.json").read().strip().splitlines()[-1])
+a = json.loads(open("gpurun_out/${tag}_aa_bench.json").read().strip().splitlines()[-1])
+import subprocess
+subprocess.check_call(["python", "profiles/make_traffic.py", "${tag}", str(d["config"]["reads_per_step_per_gpu"]),
+                       str(d["roofline"]["pairs_per_launch"]), str(a["config"]["reads_per_step_per_gpu"]), str(a["roofline"]["pairs_per_launch"])])
+PY
+# cfg5 at per-GPU shard size (BASELINE configs[4]: 4k tips, 1M reads, --no-heur on 8 GPUs = 125k reads per GPU);
+# bounded here: the place_all path on a slice of the shard, kernel trace committed
+cd /tmp
+rm -rf $R/gpurun_out/${tag}_cfg5_stats
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_cfg5_stats -o st -- \
+  python $R/exp/noheur_cfg5.py > $R/gpurun_out/${tag}_cfg5.log 2>&1
+cd $R
+python profiles/db_to_txt.py gpurun_out/${tag}_cfg5_stats/st_results.db > gpurun_out/${tag}_cfg5_kernel_trace_stats.txt
+tail -3 gpurun_out/${tag}_cfg5.log; head -6 gpurun_out/${tag}_cfg5_kernel_trace_stats.txt

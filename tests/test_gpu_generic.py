@@ -64,6 +64,46 @@ def test_any_number_of_rate_categories(states, cats, pinv):
     assert np.max(np.abs(r["lnl"] - tl)) < LNL_TOL
 
 
+@pytest.mark.parametrize("cats,pinv", [(3, 0.0), (5, 0.0), (8, 0.0), (8, 0.25), (12, 0.0), (16, 0.0)])
+def test_category_group_kernel_equals_general_kernel(cats, pinv, monkeypatch):
+    """Nucleotide models with 3 / 5 .. 16 rate categories run on k_thorough_dna with one wave per group
+    of four categories (padded with weight-0 copies of the last category); EPA_TH_GENERIC=1 sends the
+    same context shape to k_thorough_generic.  Windows of every single-wave class (incl. the lengths
+    the four-category kernel serves with half-chunk tails) and one beyond them (general kernel in both
+    contexts): same pairs, lnL to 1e-9, lengths to 1e-9, identical round / Newton-evaluation counters;
+    and the oracle on the mixed chunk."""
+    rng = np.random.RandomState(300 + cats)
+    rates = np.sort(rng.gamma(0.6, 1.5, cats)) + 1e-3
+    weights = rng.dirichlet(np.full(cats, 3.0))
+    rates = rates / np.sum(rates * weights)
+    root = synth.random_tree(30, 50 + cats)
+    labels, seqs = synth.simulate_msa(root, 400, synth.CFG2_SUBST, synth.CFG2_FREQS, synth.gamma_rates(0.7), 51)
+    nw = synth.newick(root)
+    reads = []
+    for k, rl in enumerate((40, 64, 80, 100, 128, 150, 170, 192, 250)):
+        r, _ = synth.make_reads(seqs, 4, rl, 0.04, 60 + k, states=4)
+        reads += list(r)
+    ref = hostlib.Reference(nw, labels, seqs, states=4, subst=synth.CFG2_SUBST, freqs=synth.CFG2_FREQS,
+                            rates=rates, weights=weights, pinv=pinv)
+    codes, wb, ws = epa.encode_queries(4, reads, compact=True)
+    pairs = all_pairs(ref.B, len(reads))[::3].copy()
+    ev = ref.evaluator()
+    res = ev.thorough(pairs, codes, wb, ws)
+    st = dict(ev.last_stats)
+    monkeypatch.setenv("EPA_TH_GENERIC", "1")
+    evg = ref.evaluator()
+    resg = evg.thorough(pairs, codes, wb, ws)
+    monkeypatch.delenv("EPA_TH_GENERIC")
+    assert np.max(np.abs(res["lnl"] - resg["lnl"])) < 1e-9
+    assert np.max(np.abs(res["pendant_length"] - resg["pendant_length"])) < 1e-9
+    assert np.max(np.abs(res["distal_length"] - resg["distal_length"])) < 1e-9
+    assert st["rounds"] == evg.last_stats["rounds"] and st["newton_evals"] == evg.last_stats["newton_evals"]
+    o = Oracle(nw, labels, seqs, 4, synth.CFG2_SUBST, synth.CFG2_FREQS, rates, weights=weights, pinv=pinv)
+    tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
+    assert np.max(np.abs(res["lnl"] - tl)) < LNL_TOL
+    assert st["rounds"] == o.last_stats["rounds"]
+
+
 @pytest.mark.parametrize("states", [4, 20])
 def test_per_rate_scalers_equal_per_site_scalers_on_ordinary_data(states):
     """where nothing underflows the two scaling schemes give the same numbers (the device in
