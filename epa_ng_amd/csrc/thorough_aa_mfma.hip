@@ -78,6 +78,7 @@ struct SharedM {
   double tab[3][TAB_STRIDE];
   double bc[24];                   // cross-wave sums: f [0..8), f' [8..16), lnL [16..24)
   uint32_t next_pair;              // work-queue hand-out of the workgroup
+  double e2t[64];                  // 2^(j/64): table of exp_tab (wave_util.hpp)
 };
 
 
@@ -148,6 +149,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     sh.Ua[dst] = m->U[(4 * rt + i) * S + 4 * t + kk];
     sh.Uia[dst] = m->Ui[(4 * rt + i) * S + 4 * t + kk];
   }
+  if (tid < 64) sh.e2t[tid] = exp2((double)tid * 0.015625);
   // per-thread table constants: thread t < 240 owns (slot = t / 80, kx = t % 80)
   const int tslot = tid / 80, tkx = tid % 80;
   const int tpos = ((tkx / S) * 4 + (tkx % S) % 4) * 6 + (tkx % S) / 4;
@@ -220,7 +222,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     auto publish = [&](double t0, double t1, double t2) {
       if (tid < 240) {
         const double t = tslot == 0 ? t0 : (tslot == 1 ? t1 : t2);
-        const double e = exp(t_lr * t);
+        const double e = exp_tab(t_lr * t, sh.e2t);
         sh.tab[tslot][tpos] = tslot == 2 ? e * t_w : e;
       }
       __syncthreads();
@@ -373,7 +375,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     // column 3 zeros); D puts l_0, l_1, l_2 of a site in lanes 0, 1, 2 of one quad
     uint32_t evals = 0;
     auto derivatives = [&](double t, double& f, double& df) {
-      if (tid < 240) sh.tab[tslot][tpos] = exp(t_lr * t) * t_c;
+      if (tid < 240) sh.tab[tslot][tpos] = exp_tab(t_lr * t, sh.e2t) * t_c;
       __syncthreads();
       const int row = lane & 3;
       double fl = 0.0, dfl = 0.0;

@@ -298,6 +298,10 @@ __device__ __forceinline__ void cat_inner_pre(const Model& m, const double (&Ap)
 #else
 #define TH_EXP(x) exp_tab((x), lc.e2t)
 #endif
+// resident waves per SIMD the register allocation leaves room for (2: 256 VGPRs per lane)
+#ifndef TH_WAVES
+#define TH_WAVES 2
+#endif
 #ifndef TH_STREAM_DEPTH
 #define TH_STREAM_DEPTH 2
 #endif
@@ -380,11 +384,61 @@ __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* ta
                                             double& df) {
   table_publish(tab, lane, TH_EXP(lc.lr * t) * lc.cN);
   double e[16], e1[16], e2[16];
+  if (TH_WAVES < 3 || NG > 1) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    if (!(ZERO0 && (i & 3) == 0)) { e[i] = tab[i]; e1[i] = tab[16 + i]; e2[i] = tab[32 + i]; }
+    for (int i = 0; i < 16; ++i) {
+      if (!(ZERO0 && (i & 3) == 0)) { e[i] = tab[i]; e1[i] = tab[16 + i]; e2[i] = tab[32 + i]; }
+    }
   }
   double fl = 0.0, dfl = 0.0;
+#if TH_WAVES >= 3
+  if constexpr (NG == 1) {
+    // three-waves-per-SIMD register budget: the contraction order by order (12 table entries live
+    // instead of 36), partial sums of all chunks kept
+    double lm[3][NCH];
+#pragma unroll
+    for (int m3 = 0; m3 < 3; ++m3) {
+      double em[16];
+      const int tokm = (int)zero_after(m3 == 0 ? t : lm[m3 - 1][NCH - 1]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (!(ZERO0 && (i & 3) == 0)) em[i] = tab[16 * m3 + i + tokm];
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        double l = (ZERO0 && m3 == 0) ? st.S[ch][0] : 0.0;
+        if (TAILH && ch == NCH - 1) {
+          const double* th = tab + ((lane >> 5) << 3) + 16 * m3 + tokm;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if (!(ZERO0 && (i & 3) == 0)) l = fma(st.S[ch][i], th[i], l);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (!(ZERO0 && (i & 3) == 0)) l = fma(st.S[ch][i], em[i], l);
+        }
+        lm[m3][ch] = l;
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      if (TAILH && ch == NCH - 1) {
+        const double l0 = xhalf_add(lm[0][ch]);
+        const double l12 = xhalf_add2(lm[1][ch], lm[2][ch]);
+        const double qv = -l12 * fast_rcp(l0);
+        const bool lower = lane < 32;
+        if (st.valid[ch]) { fl += lower ? qv : 0.0; dfl += lower ? qv * qv : qv; }
+        continue;
+      }
+      const double inv = fast_rcp(lm[0][ch]);
+      const double d1 = -lm[1][ch] * inv;
+      const double d2 = fma(d1, d1, -lm[2][ch] * inv);
+      if (st.valid[ch]) { fl += d1; dfl += d2; }
+    }
+    wave_sum2(fl, dfl, f, df);
+    cb.sum2(f, df, lane);
+    return;
+  }
+#endif
   if constexpr (NG > 1) {
     // this group's share of l0 / l1 / l2 of every site, summed over the groups, then the ratios
     constexpr int NV = TAILH ? 3 * (NCH - 1) + 2 : 3 * NCH;
@@ -1012,7 +1066,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 // INV: the model has +I (instantiated for ZERO0 only; a separate instantiation so that the
 // default kernel's register allocation is untouched: the runtime-flag version cost 40 more spills)
 template <int NCH, bool ZERO0, bool INV, int NW, bool LOCAL = false, bool TAILH = false, int NG = 1>
-__global__ void __launch_bounds__(64 * NW * NG, 2) k_thorough_dna(const ThArgs a) {
+__global__ void __launch_bounds__(64 * NW * NG, TH_WAVES) k_thorough_dna(const ThArgs a) {
   constexpr int NWV = NW * NG;     // waves of the workgroup: site blocks (NW) or category groups (NG)
   __shared__ double tab[64 * NWV];  // broadcast table of each wave
   __shared__ double qts[64];       // U^-1 image of the 16 query column codes
@@ -1040,29 +1094,27 @@ __global__ void __launch_bounds__(64 * NW * NG, 2) k_thorough_dna(const ThArgs a
   const uint64_t lo = (uint64_t)x * per;
   const uint64_t hi = lo + per < a.n_pairs ? lo + per : a.n_pairs;
   uint32_t wstat[3] = {0, 0, 0};
-  bool queued = false;
   if constexpr (NW == 1 && NG == 1) {
-    if (a.qctr) {
-      // resident waves fetch the next pair of their XCD slice from a counter: no relaunches, no
-      // tail of unlucky waves.  The next index is requested before the current pair is processed.
-      queued = true;
-      uint32_t* ctr = a.qctr + x;
-      const uint32_t cnt = (uint32_t)(hi > lo ? hi - lo : 0);
-      uint32_t nxt = 0;
-      if (lane == 0) nxt = atomicAdd(ctr, 1u);
-      nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
-      while (nxt < cnt) {
-        const uint32_t cur = nxt;
-        uint32_t f = 0;
-        if (lane == 0) f = atomicAdd(ctr, 1u);
-        process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH, NG>(a, lo + cur, lane, tab + cb.wv * 64, qts, qa + cb.wv * 256, lc, cb, wstat);
-        nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
-      }
+    // resident waves fetch the next pair of their XCD slice from a counter: no relaunches, no
+    // tail of unlucky waves.  The next index is requested before the current pair is processed.
+    // (The single-wave classes are always launched with the counters; one loop, not two copies of
+    // the pair body: the second copy cost 16 spilled registers in the dominant instantiation.)
+    uint32_t* ctr = a.qctr + x;
+    const uint32_t cnt = (uint32_t)(hi > lo ? hi - lo : 0);
+    uint32_t nxt = 0;
+    if (lane == 0) nxt = atomicAdd(ctr, 1u);
+    nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+    while (nxt < cnt) {
+      const uint32_t cur = nxt;
+      uint32_t f = 0;
+      if (lane == 0) f = atomicAdd(ctr, 1u);
+      process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH, NG>(a, lo + cur, lane, tab + cb.wv * 64, qts, qa + cb.wv * 256, lc, cb, wstat);
+      nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
     }
-  }
-  if (!queued)
+  } else {
     for (uint64_t p = lo + w; p < hi; p += stride)
       process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH, NG>(a, p, lane, tab + cb.wv * 64, qts, qa + cb.wv * 256, lc, cb, wstat);
+  }
   if (threadIdx.x == 0) {
     atomicAdd(&a.stats[0], (unsigned long long)wstat[0]);
     atomicAdd(&a.stats[1], (unsigned long long)wstat[1]);
@@ -1330,17 +1382,16 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
   // class -> (wavefronts per pair NW, 64-site chunks per wavefront NCH): windows up to 192 sites
   // are one wave's job; longer ones are spread over 2 / 4 / 8 waves of a workgroup, each keeping
   // its part of the sumtable in registers (NCH stays <= 3: the kernel's register budget)
-  // single-wave classes: resident waves + a work counter per XCD slice (EPA_TH_QUEUE=0: the
-  // oversubscribed static grid instead; 262k pairs: 6.56 -> 6.47 ms)
-  static const bool use_queue = !(getenv("EPA_TH_QUEUE") && atoi(getenv("EPA_TH_QUEUE")) == 0);
+  // single-wave classes: resident waves + a work counter per XCD slice (round 1: the oversubscribed
+  // static grid instead cost 262k pairs 6.56 vs 6.47 ms)
 #define LAUNCH(N, NW_)                                                                            \
   do {                                                                                            \
     uint64_t want = (uint64_t)256 * 8 * per_slot / (NW_);                                          \
     a.qctr = nullptr;                                                                              \
-    if ((NW_) == 1 && use_queue && ctx->th_ctr) {                                                  \
+    if ((NW_) == 1) {                                                                              \
       EPA_HIP(ctx, hipMemsetAsync(epa_th_ctr(ctx), 0, 64, ctx->stream));                               \
       a.qctr = epa_th_ctr(ctx);                                                                        \
-      want = 2048;                                                                                 \
+      want = 1024 * TH_WAVES;                                                                                 \
     }                                                                                              \
     if (want > n_pairs) want = n_pairs;                                                            \
     const uint32_t nwg = (uint32_t)((want + 7) / 8 * 8);                                           \
