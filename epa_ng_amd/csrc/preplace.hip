@@ -29,6 +29,7 @@
 //      gives every query its output offset (no atomics on a shared counter, deterministic
 //      order); the keys (branch << 32 | query) are radix-sorted into Work's branch-major order.
 #include "epa_dev_internal.hpp"
+#include "wave_util.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -890,26 +891,25 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
     v[r] = i < B ? src[i] : -INFINITY;
     mx = fmax(mx, v[r]);
   }
-  mx = wave_max(mx);
+  // wave reductions on the DPP ladder (no LDS round trips: the extraction loop below was 18
+  // ds_bpermute per candidate), results wave-uniform
+  mx = epa_wave::wave_max_d(mx);
   double tot = 0.0;
 #pragma unroll
   for (int r = 0; r < NR; ++r) tot += exp(v[r] - mx);  // exp(-inf) == 0 for the padding
-  tot = wave_add(tot);
+  tot = epa_wave::wave_sum(tot);
   SelRule rule(mode, threshold, limit);
   uint32_t taken = 0;
   unsigned long long* out = stage + (size_t)q * cap;
   while (rule.more(taken, B)) {
-    double best = -INFINITY;
-    uint32_t bi = 0xffffffffu;
+    double lbest = -INFINITY;
+    uint32_t lbi = 0xffffffffu;
 #pragma unroll
     for (int r = 0; r < NR; ++r)
-      if (v[r] > best) { best = v[r]; bi = r * 64 + lane; }
-#pragma unroll
-    for (int o = 32; o; o >>= 1) {
-      const double ob = __shfl_xor(best, o);
-      const uint32_t oi = __shfl_xor(bi, o);
-      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
+      if (v[r] > lbest) { lbest = v[r]; lbi = r * 64 + lane; }
+    // the largest value, ties by the lowest branch id
+    const double best = epa_wave::wave_max_d(lbest);
+    const uint32_t bi = epa_wave::wave_min_u((lbest == best && lbest > -INFINITY) ? lbi : 0xffffffffu);
     if (bi == 0xffffffffu) break;
     if (!rule.accept(best, mx, tot, taken)) break;
 #pragma unroll

@@ -57,6 +57,39 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return fma(r, e, r);
 }
 
+// wave64 maximum of doubles / minimum of unsigned integers on the same DPP ladder as wave_sum (no LDS
+// round trips: __shfl_xor is ds_bpermute); lanes without a source take the identity (-inf / ~0u).
+// The result is wave-uniform (read from lane 63 through scalar registers).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_max(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)0xfff00000u, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return fmax(v, __hiloint2double(hi, lo));
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+  v = dpp_max<0x111, 0xf>(v);
+  v = dpp_max<0x112, 0xf>(v);
+  v = dpp_max<0x114, 0xf>(v);
+  v = dpp_max<0x118, 0xf>(v);
+  v = dpp_max<0x142, 0xa>(v);
+  v = dpp_max<0x143, 0xc>(v);
+  return readlane_d(v, 63);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_min_u(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xf, false);
+  return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_min_u(unsigned v) {
+  v = dpp_min_u<0x111, 0xf>(v);
+  v = dpp_min_u<0x112, 0xf>(v);
+  v = dpp_min_u<0x114, 0xf>(v);
+  v = dpp_min_u<0x118, 0xf>(v);
+  v = dpp_min_u<0x142, 0xa>(v);
+  v = dpp_min_u<0x143, 0xc>(v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // exp(x) for the arguments of the Newton / P-matrix tables (x = lambda r t <= 0, |x| < 1e7):
 //   x = n ln2/64 + r,  |r| <= ln2/128;  e^x = 2^(n >> 6) * 2^((n & 63)/64) * e^r
 // e2t = the 64-entry table 2^(j/64) (LDS), e^r - 1 by a degree-6 Taylor polynomial (truncation
