@@ -122,16 +122,34 @@ __device__ __forceinline__ void lds_tiles(const double* U2, int p, int ao, doubl
 __device__ __forceinline__ double ldg_off(const double* base, uint32_t byte_off) {
   return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
 }
-// combine the four component rows (lanes l, l ^ 16, l ^ 32, l ^ 48) of a site
+// combine the four component rows (lanes l, l ^ 16, l ^ 32, l ^ 48) of a site: v_permlane16_swap /
+// v_permlane32_swap of a register with itself put row r ^ 1 (half h ^ 1) beside row r -- four
+// cross-lane instructions and two adds, no LDS round trip (__shfl_xor is ds_bpermute)
+__device__ __forceinline__ void rows_pair16(double v, double& a, double& b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+  a = __hiloint2double(hi[0], lo[0]);
+  b = __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void rows_pair32(double v, double& a, double& b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  a = __hiloint2double(hi[0], lo[0]);
+  b = __hiloint2double(hi[1], lo[1]);
+}
 __device__ __forceinline__ double rows_sum(double v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
+  double a, b;
+  rows_pair16(v, a, b);
+  v = a + b;
+  rows_pair32(v, a, b);
+  return a + b;
 }
 __device__ __forceinline__ double rows_max(double v) {
-  v = fmax(v, __shfl_xor(v, 16));
-  v = fmax(v, __shfl_xor(v, 32));
-  return v;
+  double a, b;
+  rows_pair16(v, a, b);
+  v = fmax(a, b);
+  rows_pair32(v, a, b);
+  return fmax(a, b);
 }
 
 template <int NT, bool LOCAL = false>
