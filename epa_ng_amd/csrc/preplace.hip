@@ -1079,6 +1079,18 @@ __global__ void __launch_bounds__(256) k_class_hist(const uint32_t* __restrict__
   }
 }
 
+// everything the host reads after the selection, in one block: out[0] = total, out[1 ..] = the
+// selection's status words + class histogram, out[32 .. 35] = the preplacement's window validation
+__global__ void __launch_bounds__(64) k_pack_readback(const uint32_t* __restrict__ status,
+                                                     const uint32_t* __restrict__ total,
+                                                     const uint32_t* __restrict__ pre_status,
+                                                     uint32_t* __restrict__ out) {
+  const uint32_t t = threadIdx.x;
+  if (t == 0) out[0] = *total;
+  if (t < 8 + EPA_N_CLS) out[1 + t] = status[t];
+  if (t < 4) out[32 + t] = pre_status ? pre_status[t] : 0u;
+}
+
 __global__ void __launch_bounds__(256) k_compact(const unsigned long long* __restrict__ stage,
                                                  const uint32_t* __restrict__ counts,
                                                  const uint32_t* __restrict__ offsets, uint32_t Q,
@@ -1290,26 +1302,27 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
   const size_t worst = std::min<uint64_t>(max_pairs, (uint64_t)Q * cap);
   (void)rocprim::radix_sort_keys<epa_radix_cfg>(nullptr, sort_bytes, (unsigned long long*)nullptr,
                                  (unsigned long long*)nullptr, worst, 0, 64, ctx->stream);
-  // scratch 7: [status | counts Q+1 | offsets Q+1 | stage Q*cap | keys_a worst | keys_b worst | temp]
+  // scratch 7: [status 512 B | counts Q+1 | offsets Q+1 | stage Q*cap | keys_a worst | keys_b worst | temp]
+  // status words [0, 8 + EPA_N_CLS): selection status + class histogram; [64, 128): the packed read-back block
   const size_t qb = align256(sizeof(uint32_t) * (Q + 1));
   const size_t sb = align256(sizeof(unsigned long long) * (size_t)Q * cap);
   const size_t kb = align256(sizeof(unsigned long long) * worst);
   const size_t tb = std::max(scan_bytes, sort_bytes);
-  char* base = (char*)epa_scratch(ctx, 7, 256 + 2 * qb + sb + 2 * kb + tb);
+  char* base = (char*)epa_scratch(ctx, 7, 512 + 2 * qb + sb + 2 * kb + tb);
   if (!base) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(select scratch)");
   uint32_t* status = reinterpret_cast<uint32_t*>(base);
-  uint32_t* counts = reinterpret_cast<uint32_t*>(base + 256);
-  uint32_t* offsets = reinterpret_cast<uint32_t*>(base + 256 + qb);
-  sp->stage = reinterpret_cast<unsigned long long*>(base + 256 + 2 * qb);
-  sp->keys_a = reinterpret_cast<unsigned long long*>(base + 256 + 2 * qb + sb);
-  sp->keys_b = reinterpret_cast<unsigned long long*>(base + 256 + 2 * qb + sb + kb);
-  sp->temp = base + 256 + 2 * qb + sb + 2 * kb;
+  uint32_t* counts = reinterpret_cast<uint32_t*>(base + 512);
+  uint32_t* offsets = reinterpret_cast<uint32_t*>(base + 512 + qb);
+  sp->stage = reinterpret_cast<unsigned long long*>(base + 512 + 2 * qb);
+  sp->keys_a = reinterpret_cast<unsigned long long*>(base + 512 + 2 * qb + sb);
+  sp->keys_b = reinterpret_cast<unsigned long long*>(base + 512 + 2 * qb + sb + kb);
+  sp->temp = base + 512 + 2 * qb + sb + 2 * kb;
   sp->sort_bytes = sort_bytes;
   sp->counts = counts; sp->offsets = offsets;
   sp->d_lnl = d_lnl; sp->Q = Q; sp->threshold = threshold; sp->d_pairs = d_pairs; sp->max_pairs = max_pairs;
   sp->d_span = d_span; sp->cap = cap; sp->rb = rb;
   // status words and the trailing count in one fill: counts[Q] sits in the same allocation
-  EPA_HIP(ctx, hipMemsetAsync(status, 0, 256, ctx->stream));
+  EPA_HIP(ctx, hipMemsetAsync(status, 0, 512, ctx->stream));
   EPA_HIP(ctx, hipMemsetAsync(counts + Q, 0, sizeof(uint32_t), ctx->stream));
   epa_timer_start(ctx, ctx->t_select);
   const dim3 grid((Q + 3) / 4);
@@ -1329,11 +1342,11 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
   if (d_span)  // class histogram in status[8 ..]: read back with the total, no extra round trip
     hipLaunchKernelGGL(k_class_hist, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, counts, d_span, Q,
                        ctx->s, status + 8);
-  // rb: [0] total, [1 .. 8 + EPA_N_CLS] status words + class histogram, [32 .. 35] window validation
-  EPA_HIP(ctx, hipMemcpyAsync(rb, offsets + Q, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-  EPA_HIP(ctx, hipMemcpyAsync(rb + 1, status, sizeof(uint32_t) * (8 + EPA_N_CLS), hipMemcpyDeviceToHost, ctx->stream));
-  if (ctx->d_status)
-    EPA_HIP(ctx, hipMemcpyAsync(rb + 32, ctx->d_status, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  // rb: [0] total, [1 .. 8 + EPA_N_CLS] status words + class histogram, [32 .. 35] window validation:
+  // packed on the device so that ONE small copy brings everything the host waits for
+  hipLaunchKernelGGL(k_pack_readback, dim3(1), dim3(64), 0, ctx->stream, status, offsets + Q,
+                     (const uint32_t*)ctx->d_status, status + 64);
+  EPA_HIP(ctx, hipMemcpyAsync(rb, status + 64, sizeof(uint32_t) * 36, hipMemcpyDeviceToHost, ctx->stream));
   sp->have_status = ctx->d_status != nullptr;
   return EPA_OK;
 }
