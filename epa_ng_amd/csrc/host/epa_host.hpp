@@ -36,6 +36,12 @@ struct Options {  // defaults: src/util/Options.hpp:13-34
   bool prescoring_by_percentage = false;
   double prescoring_threshold = 0.99999;
   unsigned int chunk_size = 50000;  // the reference's CPU default is 5000 (Options.hpp:26); a GPU wants larger chunks
+  // `--chunk-size` is "number of query sequences to be read in at a time; may influence performance"
+  // (src/main.cpp:234-238): a memory / speed knob without an effect on the result.  The device
+  // runs 5000-read chunks at 42 % of its 100k-read rate, so the chunk loop reads
+  // at least this many sequences per device chunk, whatever smaller value was asked for (0: never
+  // more than chunk_size)
+  unsigned int device_min_chunk = 40000;
   unsigned int num_threads = 0;
   bool premasking = true;
   bool baseball = false;

@@ -28,6 +28,8 @@ static void usage() {
       "  --filter-acc-lwr X | --filter-min-lwr X | --filter-min N | --filter-max N\n"
       "  --precision N         output digits (default 10)\n"
       "  --chunk-size N        queries per chunk (default 50000; EPA-ng's CPU default is 5000)\n"
+      "  --device-min-chunk N  a device chunk holds at least N queries whatever --chunk-size says\n"
+      "                        (default 40000; 0: chunks of exactly --chunk-size)\n"
       "  --no-pre-mask         evaluate all sites of every query\n"
       "  --raxml-blo           radius-1 local branch-length optimisation instead of the sliding rule\n"
       "  --rate-scalers auto|on|off  per-rate-category numerical scaling (auto: on above 2000 tips)\n"
@@ -66,6 +68,7 @@ int main(int argc, char** argv) {
     else if (a == "--filter-max") opt.filter_max = (unsigned)std::stoul(need(i));
     else if (a == "--precision") opt.precision = (unsigned)std::stoul(need(i));
     else if (a == "--chunk-size") opt.chunk_size = (unsigned)std::stoul(need(i));
+    else if (a == "--device-min-chunk") opt.device_min_chunk = (unsigned)std::stoul(need(i));
     else if (a == "--no-pre-mask") opt.premasking = false;
     else if (a == "--raxml-blo") opt.sliding_blo = false;   // src/main.cpp:239-242
     else if (a == "--rate-scalers") {                       // src/main.cpp:248-250,399-407

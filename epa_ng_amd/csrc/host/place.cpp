@@ -563,8 +563,9 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
         const auto r0 = clk::now();
         // one-line records of a mapped file are encoded straight from the mapping (no sequence strings)
         std::vector<const char*> rows;
-        if (!premask) reader.read_next_views(s.chunk, rows, tree.num_sites(), options.chunk_size);
-        if (rows.empty()) reader.read_next(s.chunk, options.chunk_size);
+        const size_t per_chunk = std::max<size_t>(options.chunk_size, options.device_min_chunk);
+        if (!premask) reader.read_next_views(s.chunk, rows, tree.num_sites(), per_chunk);
+        if (rows.empty()) reader.read_next(s.chunk, per_chunk);
         const double rd = std::chrono::duration<double>(clk::now() - r0).count();
         if (s.chunk.empty()) break;
         if (premask) s.chunk = subset_msa(s.chunk, msa_info.gap_mask());

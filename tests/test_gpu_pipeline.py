@@ -610,11 +610,14 @@ def test_cli_several_devices_same_jplace(tmp_path):
     exe = hostlib.cli_exe()
     model = "GTR{%s}+FU{%s}+G4{0.478218}" % ("/".join(map(repr, w["subst"])), "/".join(map(repr, w["freqs"])))
     outs = []
-    for devs, extra in (("0", []), ("0,0", []), ("0,0,0", ["--no-heur"]), ("0", ["--no-heur"])):
-        od = tmp_path / ("out_" + devs.replace(",", "_") + ("_nh" if extra else ""))
+    # the last run keeps the default --device-min-chunk: the 100-read chunks the user asked for are
+    # read as one device chunk (the reference's --chunk-size is a memory / speed knob) -- same jplace
+    for devs, extra, exact in (("0", [], True), ("0,0", [], True), ("0,0,0", ["--no-heur"], True),
+                               ("0", ["--no-heur"], True), ("0", [], False)):
+        od = tmp_path / ("out_" + devs.replace(",", "_") + ("_nh" if extra else "") + ("" if exact else "_merged"))
         od.mkdir()
         r = subprocess.run([exe, "-t", str(tre), "-s", str(aln), "-q", str(qf), "-m", model, "-w", str(od),
-                            "--chunk-size", "100", "--devices", devs] + extra,
+                            "--chunk-size", "100", "--devices", devs] + (["--device-min-chunk", "0"] if exact else []) + extra,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         jp = json.load(open(od / "epa_result.jplace"))
@@ -623,6 +626,7 @@ def test_cli_several_devices_same_jplace(tmp_path):
         assert len(jp["placements"]) == 900
     assert outs[0] == outs[1]
     assert outs[2] == outs[3]
+    assert outs[4] == outs[0]
     assert [p["n"] for p in outs[0]["placements"]] == [["q%d" % i] for i in range(900)]
 
 
