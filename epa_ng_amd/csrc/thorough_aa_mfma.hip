@@ -75,7 +75,7 @@ struct SharedM {
   double Uia[13 * 32];             // the same of U^-1
   // wave-uniform exp tables, entry (category c, eigen index 4 t + kq) at [(c * 4 + kq) * 6 + t]:
   // the five values a lane needs are consecutive (the sixth is padding)
-  double tab[3][TAB_STRIDE];
+  double tab[4][TAB_STRIDE];       // [3]: zeros -- the B operand's fourth column in a Newton evaluation
   double bc[24];                   // cross-wave sums: f [0..8), f' [8..16), lnL [16..24)
   uint32_t next_pair;              // work-queue hand-out of the workgroup
   double e2t[64];                  // 2^(j/64): table of exp_tab (wave_util.hpp)
@@ -168,6 +168,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     sh.Uia[dst] = m->Ui[(4 * rt + i) * S + 4 * t + kk];
   }
   if (tid < 64) sh.e2t[tid] = exp2((double)tid * 0.015625);
+  for (int i = tid; i < TAB_STRIDE; i += NTHR) sh.tab[3][i] = 0.0;
   // per-thread table constants: thread t < 240 owns (slot = t / 80, kx = t % 80)
   const int tslot = tid / 80, tkx = tid % 80;
   const int tpos = ((tkx / S) * 4 + (tkx % S) % 4) * 6 + (tkx % S) / 4;
@@ -405,12 +406,11 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
 #pragma unroll
         for (int cat = 0; cat < 4; ++cat) {
           double av[NTS];
-          lds5(&sh.tab[row < 3 ? row : 0][(cat * 4 + kq) * 6 + zt], av);
+          lds5(&sh.tab[row][(cat * 4 + kq) * 6 + zt], av);   // row 3 reads the zero table: no per-value select
 #pragma unroll
           for (int tt = 0; tt < NTS; ++tt) {
-            const double avv = row == 3 ? 0.0 : av[tt];
-            if (cat < 2) acc0 = mfma4(Sm[j][cat][tt], avv, acc0);
-            else acc1 = mfma4(Sm[j][cat][tt], avv, acc1);
+            if (cat < 2) acc0 = mfma4(Sm[j][cat][tt], av[tt], acc0);
+            else acc1 = mfma4(Sm[j][cat][tt], av[tt], acc1);
           }
         }
         // lane (i = lane / 16, block, r): l_r of site 4 block + i of the tile
