@@ -498,6 +498,23 @@ def main():
                                "host_ms_per_chunk": {k_: round(v_ / nsm * 1e3, 3) for k_, v_ in hostt.items()},
                                "note": "reference default --chunk-size 5000, H2D/D2H inside the clock"}
 
+    if world == 1 and states == 4 and not a.no_extras and not os.environ.get("EPA_BENCH_NO_CFG3"):
+        # BASELINE configs[2] (cfg3: 2000-tip 20-state reference, 100-residue queries) as a short second
+        # measurement by the same script in its own process, so that the driver's line carries it too
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "aa", "--tips", "2000", "--width", "500",
+                                "--read-len", "100", "--chunk", "10000", "--steps", "6", "--warmup", "2",
+                                "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600)
+            aj = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            extras["cfg3_aa"] = {"value": aj["value"], "unit": aj["unit"], "ms_per_step": aj["ms_per_step"],
+                                 "workload": aj["config"]["workload"], "reads_per_step": aj["config"]["reads_per_step_per_gpu"],
+                                 "kernel_ms_per_step": aj["config"]["kernel_ms_per_step"],
+                                 "pcie_inclusive": aj["pcie_inclusive"]["value"],
+                                 "roofline": {k: aj["roofline"][k] for k in ("bound", "kernel", "achieved", "frac", "achieved_algorithmic",
+                                                                            "frac_algorithmic", "pairs_per_launch", "ms_per_launch")}}
+        except Exception as e:  # noqa: BLE001  (a secondary measurement must never take the bench line down)
+            extras["cfg3_aa"] = {"status": "failed: %r" % (e,)}
+
     metric = ("query placements/sec (whole node), 512-tip GTR+G4 DNA ref, preplace+thorough" if states == 4
               else "query placements/sec (whole node), AA PROTGTR+G4 ref (cfg3 shape), preplace+thorough")
     pcie = {"value": round(total_reads / elapsed_pcie, 2), "unit": "placements/s",
