@@ -1,4 +1,5 @@
-// Hot loop 2 on device, 4-state / 4-category models: one wavefront per (branch, query) pair.
+// Hot loop 2 on device, 4-state models (3 .. 16 rate categories): one wavefront per (branch, query)
+// pair and group of four rate categories.
 //
 // k_thorough_dna replaces, per pair, Tiny_Tree::place with opt_branches (src/tree/Tiny_Tree.cpp:
 // 159-204) -> call_focused (src/core/pll/pll_util.hpp:53-65) -> optimize_branch_triplet
@@ -18,10 +19,14 @@
 //    serves pll_compute_edge_loglikelihood and every Newton iteration:
 //        pendant:  S_kx = (U^-1 I)_kx * (U^-1 q)_x          I = inner CLV toward the query
 //        distal :  S_kx = Dt_kx * (U^-1 I')_kx              I' = inner CLV toward distal
-//  * lane = alignment site of the query's window (NCH sites per lane, S in VGPRs); f, f' and
-//    lnL are wave-wide butterfly reductions; the 16 exp() of a Newton proposal are computed by
-//    16 lanes and broadcast with v_readlane (SGPR operands); U / U^-1 / eigenvalues come in as
-//    kernel arguments (scalar registers).
+//  * lane = alignment site of the query's window (NCH 64-site chunks per lane, S in VGPRs); f, f'
+//    and lnL are DPP wave reductions; the wave-uniform numbers of a Newton proposal or a phase are
+//    computed one per lane (table-driven exp, wave_util.hpp), published in a 64-entry LDS table
+//    and read back with uniform-address ds_read.
+//  * a phase (inner vector + sumtable of a window) is ONE software pipeline over (chunk, category)
+//    steps: the 8 operand loads of step i + TH_STREAM_DEPTH are requested before step i is computed.
+//    U / U^-1 / weights are re-read per phase from the kernarg segment (scalar loads) instead of
+//    occupying 72 scalar registers across the Newton loops.
 //  * no P-matrix, no sumtable, no inner CLV ever touches memory.
 #include "epa_dev_internal.hpp"
 #include "wave_util.hpp"
@@ -185,47 +190,6 @@ __device__ __forceinline__ double xhalf_max(double v) {
   const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
   return fmax(__hiloint2double(hi[0], lo[0]), __hiloint2double(hi[1], lo[1]));
 }
-// inner_site for the two categories of a half: A, Bv, It hold [kk][x], kk = 0, 1 (category 2 h + kk);
-// ea / eb point at this half's table entries.  Returns the rescale flag of the SITE (both halves).
-__device__ __forceinline__ uint32_t inner_site_half(const ModelDNA& m, const double (&A)[8], const double* ea,
-                                                    const double (&Bv)[8], const double* eb, double (&It)[8]) {
-  double I[8];
-  double mx = 0.0;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    double av[4], bv[4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      av[x] = A[k * 4 + x] * ea[k * 4 + x];
-      bv[x] = Bv[k * 4 + x] * eb[k * 4 + x];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      double a = m.U[i * 4] * av[0], b = m.U[i * 4] * bv[0];
-#pragma unroll
-      for (int x = 1; x < 4; ++x) {
-        a = fma(m.U[i * 4 + x], av[x], a);
-        b = fma(m.U[i * 4 + x], bv[x], b);
-      }
-      const double v = a * b;
-      I[k * 4 + i] = v;
-      mx = fmax(mx, v);
-    }
-  }
-  const uint32_t resc = (xhalf_max(mx) < 0x1p-256) ? 1u : 0u;   // all 16 entries of the site
-  const double mult = resc ? 0x1p+256 : 1.0;
-#pragma unroll
-  for (int k = 0; k < 2; ++k)
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      double acc = m.Ui[x * 4] * I[k * 4];
-#pragma unroll
-      for (int i = 1; i < 4; ++i) acc = fma(m.Ui[x * 4 + i], I[k * 4 + i], acc);
-      It[k * 4 + x] = acc * mult;
-    }
-  return resc;
-}
-
 // one category of one site: I_i = (U (e0 o F))_i (U (e1 o G))_i, It = U^-1 I (unscaled; the caller
 // keeps the running maximum for the per-site rescale test).  The streamed phases (TH_STREAM_DEPTH)
 // walk a window category by category with this.
@@ -617,7 +581,6 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   static_assert(NG == 1 || NW == 1, "category groups and site blocks do not combine");
   const uint32_t site0 = NW > 1 ? (uint32_t)cb.wv * NCH * 64 : 0u;  // first window site of this wave
   const uint32_t grp = NG > 1 ? (uint32_t)cb.wv : 0u;               // this wave's category group
-  const ModelDNA& m = a.m;
   const uint64_t pid = a.order ? a.order[pidx] : pidx;
   const epa_pair pr = a.pairs[pid];
   // wave-uniform by construction; said explicitly so that every base address below is scalar
@@ -632,8 +595,6 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   // component rows of this wave's category group: proximal block [16 NG rows], then the distal block
   const char* ref = reinterpret_cast<const char*>(a.refT + ((size_t)(2 * b) * NG + grp) * 16 * cW + begin);
   const uint32_t W8 = a.W * 8u;
-  auto ldX = [&](int c, uint32_t soff) { return *reinterpret_cast<const double*>(ref + (soff + (uint32_t)c * W8)); };
-  auto ldD = [&](int c, uint32_t soff) { return *reinterpret_cast<const double*>(ref + (soff + (uint32_t)(16 * NG + c) * W8)); };
   const uint32_t* scp = a.scSum + (size_t)b * cW + begin;
   const uint8_t* qc = a.codes + (size_t)q * a.cstride + (a.crel ? 0u : begin);
   const double orig = a.blen[b];
@@ -671,32 +632,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     if (NG > 1 && grp != 0) return 0.0;                  // ... and in the first category group
     return (TAILH && ch == NCH - 1 && half) ? 0.0 : v;   // category 0 lives in the lower half
   };
-  // ZERO0: the four zero-eigenvalue entries of a site only ever appear as sum_k w_k S_k0 (their
-  // table entries are w_k for L_0 and 0 for L_1, L_2): keep that one number (6 fewer live VGPRs
-  // per chunk, 3 fewer FMAs per chunk and evaluation)
-  const double wh0 = half ? m.w[2] : m.w[0], wh1 = half ? m.w[3] : m.w[1];   // TAILH: this half's weights
-  auto fold0 = [&](int ch) {
-    if constexpr (ZERO0) {
-      if (TAILH && ch == NCH - 1) st.S[ch][0] = fma(wh1, st.S[ch][4], wh0 * st.S[ch][0]);
-      else st.S[ch][0] = fma(m.w[3], st.S[ch][12], fma(m.w[2], st.S[ch][8], fma(m.w[1], st.S[ch][4], m.w[0] * st.S[ch][0])));
-    }
-  };
-  // the half-chunk's version of one phase step: 8 rows per side, this half's table entries
-  auto half_fold_query = [&](int ch, const double (&It)[8]) {
-    const double* qv = qts + st.code[ch] * 4;
-    const double q0 = qv[0], q1 = qv[1], q2 = qv[2], q3 = qv[3];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      st.S[ch][k * 4 + 0] = It[k * 4 + 0] * q0;
-      st.S[ch][k * 4 + 1] = It[k * 4 + 1] * q1;
-      st.S[ch][k * 4 + 2] = It[k * 4 + 2] * q2;
-      st.S[ch][k * 4 + 3] = It[k * 4 + 3] * q3;
-    }
-    if constexpr (INV) st.S[ch][0] += cinv_of(ch);
-    fold0(ch);
-    chain = zero_after(st.S[ch][7]);
-  };
-  // ---- streamed phase (TH_STREAM_DEPTH > 0): all (chunk, category) steps of the window in one
+  // ---- a phase = all (chunk, category) steps of the window in one
   // software pipeline.  The table of the phase must have been published before the call.
   //   MODE 0: inner vector toward the query from (distal e0, proximal e1), folded with the query
   //   MODE 1: toward distal from (query e0, proximal e1), folded with the distal vector
@@ -707,7 +643,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   const char* refi_s = reinterpret_cast<const char*>(a.refI + ((size_t)b * NG + grp) * 16 * cW + begin);
   auto stream_phase = [&](auto mode_c) {
     constexpr int MODE = decltype(mode_c)::value;
-    constexpr int DEPTH = TH_STREAM_DEPTH > 0 ? TH_STREAM_DEPTH : 1;
+    constexpr int DEPTH = TH_STREAM_DEPTH;
     constexpr int NKL = TAILH ? 2 : 4;             // categories per lane in the last chunk
     constexpr int NS = 4 * (NCH - 1) + NKL;
     constexpr int R = DEPTH + 1;
@@ -825,99 +761,27 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     }
     chain = tok;
   };
-  constexpr bool STREAM = TH_STREAM_DEPTH > 0;
-  static_assert(NG == 1 || STREAM, "category groups are implemented in the streamed phases only");
-
   // Inner CLV toward the query at (td, tx) folded with the query, S = (U^-1 I) o qt, and the
   // window lnL at pendant length tp_.  One table pass: slot 0 -> exp(lr td), slot 1 ->
   // exp(lr tx), slot 2 -> w exp(lr tp).
-  auto score = [&](double td_, double tx_, double tp_) -> double {
-    const double tl = lc.slot == 0 ? td_ : (lc.slot == 1 ? tx_ : tp_);
-    table_publish(tab, lane, TH_EXP(lc.lr * tl) * (lc.slot == 2 ? lc.w : 1.0));
-    if constexpr (STREAM) stream_phase(std::integral_constant<int, 0>{});
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      if (STREAM) break;
-      if (TAILH && ch == NCH - 1) {
-        const uint32_t s = (st.valid[ch] ? lane_site(ch) : 0) * 8u + chain + hoff;
-        double D[8], X[8], It[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { D[c] = ldD(c, s); X[c] = ldX(c, s); }
-        asm volatile("" ::: "memory");
-        st.resc[ch] = inner_site_half(m, D, tabh, X, tabh + 16, It);
-        half_fold_query(ch, It);
-        continue;
-      }
-      // one chunk's 32 loads in flight at a time (VGPR budget)
-      const uint32_t s = (st.valid[ch] ? site0 + ch * 64 + lane : 0) * 8u + chain;
-      double D[16], X[16], It[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) { D[c] = ldD(c, s); X[c] = ldX(c, s); }
-      asm volatile("" ::: "memory");  // all 32 loads are issued here, none is sunk to its use
-      inner_site(m, D, tab, X, tab + 16, It, st.resc[ch]);
-      const double* qv = qts + st.code[ch] * 4;
-      const double q0 = qv[0], q1 = qv[1], q2 = qv[2], q3 = qv[3];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        st.S[ch][k * 4 + 0] = It[k * 4 + 0] * q0;
-        st.S[ch][k * 4 + 1] = It[k * 4 + 1] * q1;
-        st.S[ch][k * 4 + 2] = It[k * 4 + 2] * q2;
-        st.S[ch][k * 4 + 3] = It[k * 4 + 3] * q3;
-      }
-      if constexpr (INV) st.S[ch][0] += cinv_of(ch);
-      fold0(ch);
-      chain = zero_after(st.S[ch][15]);
-    }
+  auto window_score = [&]() -> double {
     double ew[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
     return window_lnl<NCH, ZERO0, NW, TAILH, NG>(st, ew, cb, lane, tab);
+  };
+  auto score = [&](double td_, double tx_, double tp_) -> double {
+    const double tl = lc.slot == 0 ? td_ : (lc.slot == 1 ? tx_ : tp_);
+    table_publish(tab, lane, TH_EXP(lc.lr * tl) * (lc.slot == 2 ? lc.w : 1.0));
+    stream_phase(std::integral_constant<int, 0>{});
+    return window_score();
   };
   // inner CLV toward distal: I' = (P_pend q) o (P_prox X); S = Dt o (U^-1 I').  TOWARD_PROX (the
   // --raxml-blo loop only): the same toward the proximal node, I' = (P_pend q) o (P_dist D), S = Xt o ...
   auto side_sumtable = [&](double tp_, double tother_, auto toward_prox) {
     constexpr bool TOWARD_PROX = decltype(toward_prox)::value;
     table_publish(tab, lane, TH_EXP(lc.lr * (lc.slot == 0 ? tp_ : tother_)));
-    if constexpr (STREAM) stream_phase(std::integral_constant<int, TOWARD_PROX ? 3 : 1>{});
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      if (STREAM) break;
-      if (TAILH && ch == NCH - 1) {
-        const uint32_t s = (st.valid[ch] ? lane_site(ch) : 0) * 8u + chain + hoff;
-        double Qv[8], X[8], D[8], It[8];
-        const double* qv = qts + st.code[ch] * 4;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) { Qv[x] = qv[x]; Qv[4 + x] = qv[x]; }
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { X[c] = ldX(c, s); D[c] = ldD(c, s); }
-        asm volatile("" ::: "memory");
-        (void)inner_site_half(m, Qv, tabh, TOWARD_PROX ? D : X, tabh + 16, It);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) st.S[ch][c] = (TOWARD_PROX ? X[c] : D[c]) * It[c];
-        if constexpr (INV) st.S[ch][0] += cinv_of(ch);
-        fold0(ch);
-        chain = zero_after(st.S[ch][7]);
-        continue;
-      }
-      const uint32_t s = (st.valid[ch] ? site0 + ch * 64 + lane : 0) * 8u + chain;
-      double Qv[16], X[16], D[16], It[16];
-      const double* qv = qts + st.code[ch] * 4;
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        const double v = qv[x];
-        Qv[x] = v; Qv[4 + x] = v; Qv[8 + x] = v; Qv[12 + x] = v;
-      }
-#pragma unroll
-      for (int c = 0; c < 16; ++c) { X[c] = ldX(c, s); D[c] = ldD(c, s); }
-      asm volatile("" ::: "memory");  // issue the whole batch up front (see score)
-      uint32_t r;
-      inner_site(m, Qv, tab, TOWARD_PROX ? D : X, tab + 16, It, r);
-#pragma unroll
-      for (int c = 0; c < 16; ++c) st.S[ch][c] = (TOWARD_PROX ? X[c] : D[c]) * It[c];
-      if constexpr (INV) st.S[ch][0] += cinv_of(ch);
-      fold0(ch);
-      chain = zero_after(st.S[ch][15]);
-    }
+    stream_phase(std::integral_constant<int, TOWARD_PROX ? 3 : 1>{});
   };
   auto distal_sumtable = [&](double tp_, double tx_) { side_sumtable(tp_, tx_, std::false_type{}); };
 
@@ -926,47 +790,8 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   // and the fold with the query instead of 32 loads and the two 4x4 products per category.
   auto score_first = [&](double tp_) -> double {
     table_publish(tab, lane, TH_EXP(lc.lr * tp_) * (lc.slot == 2 ? lc.w : 1.0));
-    const char* refi = reinterpret_cast<const char*>(a.refI + (size_t)b * 16 * cW + begin);
-    const uint8_t* r0 = a.resc0 + (size_t)b * cW + begin;
-    if constexpr (STREAM) stream_phase(std::integral_constant<int, 2>{});
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      if (STREAM) break;
-      if (TAILH && ch == NCH - 1) {
-        const uint32_t si = st.valid[ch] ? lane_site(ch) : 0;
-        const uint32_t s = si * 8u + chain + hoff;
-        double It[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) It[c] = *reinterpret_cast<const double*>(refi + (s + (uint32_t)c * W8));
-        st.resc[ch] = r0[si];
-        asm volatile("" ::: "memory");
-        half_fold_query(ch, It);
-        continue;
-      }
-      const uint32_t si = st.valid[ch] ? site0 + ch * 64 + lane : 0;
-      const uint32_t s = si * 8u + chain;
-      double It[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) It[c] = *reinterpret_cast<const double*>(refi + (s + (uint32_t)c * W8));
-      st.resc[ch] = r0[si];
-      asm volatile("" ::: "memory");
-      const double* qv = qts + st.code[ch] * 4;
-      const double q0 = qv[0], q1 = qv[1], q2 = qv[2], q3 = qv[3];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        st.S[ch][k * 4 + 0] = It[k * 4 + 0] * q0;
-        st.S[ch][k * 4 + 1] = It[k * 4 + 1] * q1;
-        st.S[ch][k * 4 + 2] = It[k * 4 + 2] * q2;
-        st.S[ch][k * 4 + 3] = It[k * 4 + 3] * q3;
-      }
-      if constexpr (INV) st.S[ch][0] += cinv_of(ch);
-      fold0(ch);
-      chain = zero_after(st.S[ch][15]);
-    }
-    double ew[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
-    return window_lnl<NCH, ZERO0, NW, TAILH, NG>(st, ew, cb, lane, tab);
+    stream_phase(std::integral_constant<int, 2>{});
+    return window_score();
   };
 
   // traverse_update_partials + initial score (optimize.cpp:15-42,111-113)
