@@ -116,8 +116,19 @@ struct LaneConst {
   double cN;   // Newton table coefficient: w_k * lr^slot (slot 0,1,2), 0 for slot 3
   double w;    // w_k
   int slot;
+  int npos;    // ZERO0: this lane's entry of the COMPACT Newton table [order][category][x = 1..3] (36
+               // doubles, read back as 18 aligned ds_read_b128); lanes of eigen index 0 / slot 3: a dump slot
   const double* e2t;  // LDS: 2^(j/64), j = 0..63 (exp_tab)
 };
+
+// 16-byte LDS reads of table entries: ds_read_b128 moves 256 B/clk/CU, the ds_read2_b64 the compiler
+// picks for unaligned pairs 128 (MI355X_MICROARCH.md, LDS table) -- and the tables are what keeps the
+// LDS busy in this kernel (36 wave-uniform doubles per Newton evaluation)
+__device__ __forceinline__ void lds_pair(const double* p, double& a, double& b) {
+  const double2 v = *reinterpret_cast<const double2*>(__builtin_assume_aligned(p, 16));
+  a = v.x;
+  b = v.y;
+}
 
 __device__ __forceinline__ void table_publish(double* tab, int lane, double v) {
   tab[lane] = v;
@@ -200,9 +211,11 @@ __device__ __forceinline__ double xhalf_max(double v) {
 template <class Model>
 __device__ __forceinline__ void cat_inner(const Model& m, const double (&F)[4], const double* e0,
                                           const double (&G)[4], const double* e1, double (&It)[4], int& mx) {
-  double av[4], bv[4], I[4];
+  double av[4], bv[4], I[4], ev0[4], ev1[4];
+  lds_pair(e0, ev0[0], ev0[1]); lds_pair(e0 + 2, ev0[2], ev0[3]);   // table rows are 32-byte aligned
+  lds_pair(e1, ev1[0], ev1[1]); lds_pair(e1 + 2, ev1[2], ev1[3]);
 #pragma unroll
-  for (int x = 0; x < 4; ++x) { av[x] = F[x] * e0[x]; bv[x] = G[x] * e1[x]; }
+  for (int x = 0; x < 4; ++x) { av[x] = F[x] * ev0[x]; bv[x] = G[x] * ev1[x]; }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     double a = m.U[i * 4] * av[0], b = m.U[i * 4] * bv[0];
@@ -231,9 +244,10 @@ __device__ __forceinline__ void cat_inner(const Model& m, const double (&F)[4], 
 template <class Model>
 __device__ __forceinline__ void cat_inner_pre(const Model& m, const double (&Ap)[4], const double (&G)[4],
                                               const double* e1, double (&It)[4], int& mx) {
-  double bv[4], I[4];
+  double bv[4], I[4], ev1[4];
+  lds_pair(e1, ev1[0], ev1[1]); lds_pair(e1 + 2, ev1[2], ev1[3]);
 #pragma unroll
-  for (int x = 0; x < 4; ++x) bv[x] = G[x] * e1[x];
+  for (int x = 0; x < 4; ++x) bv[x] = G[x] * ev1[x];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     double b = m.U[i * 4] * bv[0];
@@ -338,6 +352,38 @@ struct Comb {
   }
 };
 
+// half-chunk contraction of a Newton evaluation: this half's two categories (2 h, 2 h + 1) against
+// the table (ZERO0: compact layout, entries m * 12 + h * 6 + kk * 3 + x - 1, three aligned pairs per order)
+template <bool ZERO0>
+__device__ __forceinline__ void half_contract(const double (&S)[16], const double* tab, int lane, double& l0,
+                                              double& l1, double& l2) {
+  if constexpr (ZERO0) {
+    const double* th = tab + (lane >> 5) * 6;
+    double c[18];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) lds_pair(th + 12 * m + 2 * i, c[6 * m + 2 * i], c[6 * m + 2 * i + 1]);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int x = 1; x < 4; ++x) {
+        const double sv = S[kk * 4 + x];
+        l0 = fma(sv, c[kk * 3 + x - 1], l0);
+        l1 = fma(sv, c[6 + kk * 3 + x - 1], l1);
+        l2 = fma(sv, c[12 + kk * 3 + x - 1], l2);
+      }
+  } else {
+    const double* th = tab + ((lane >> 5) << 3);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      l0 = fma(S[i], th[i], l0);
+      l1 = fma(S[i], th[16 + i], l1);
+      l2 = fma(S[i], th[32 + i], l2);
+    }
+  }
+}
+
 // Newton tables for proposal t: e = w exp(lr t), e1 = w lr exp(lr t), e2 = w lr^2 exp(lr t).
 // ZERO0: eigenvalue 0 is exactly 0 (stationary mode) -> its e1/e2 columns vanish.
 // Then  f = sum_sites -l1/l0,  f' = sum_sites (l1/l0)^2 - l2/l0   (pll_compute_likelihood_
@@ -346,16 +392,33 @@ template <int NCH, bool ZERO0, int NW, bool TAILH = false, int NG = 1>
 __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* tab, int lane,
                                             const LaneConst& lc, Comb<NW, NG>& cb, double t, double& f,
                                             double& df) {
-  table_publish(tab, lane, TH_EXP(lc.lr * t) * lc.cN);
   double e[16], e1[16], e2[16];
-  if (TH_WAVES < 3 || NG > 1) {
+  if constexpr (ZERO0) {
+    // compact table: entry (order m, category k, eigen index x >= 1) at m * 12 + k * 3 + x - 1
+    table_publish(tab, lc.npos, TH_EXP(lc.lr * t) * lc.cN);
+    if (TH_WAVES < 3 || NG > 1) {
+      double c[36];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if (!(ZERO0 && (i & 3) == 0)) { e[i] = tab[i]; e1[i] = tab[16 + i]; e2[i] = tab[32 + i]; }
+      for (int i = 0; i < 18; ++i) lds_pair(tab + 2 * i, c[2 * i], c[2 * i + 1]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int x = 1; x < 4; ++x) {
+          e[k * 4 + x] = c[k * 3 + x - 1];
+          e1[k * 4 + x] = c[12 + k * 3 + x - 1];
+          e2[k * 4 + x] = c[24 + k * 3 + x - 1];
+        }
+    }
+  } else {
+    table_publish(tab, lane, TH_EXP(lc.lr * t) * lc.cN);
+    if (TH_WAVES < 3 || NG > 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { e[i] = tab[i]; e1[i] = tab[16 + i]; e2[i] = tab[32 + i]; }
     }
   }
   double fl = 0.0, dfl = 0.0;
 #if TH_WAVES >= 3
+  static_assert(!ZERO0 || TH_WAVES < 3, "the three-pass form reads the uncompacted table");
   if constexpr (NG == 1) {
     // three-waves-per-SIMD register budget: the contraction order by order (12 table entries live
     // instead of 36), partial sums of all chunks kept
@@ -410,16 +473,8 @@ __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* ta
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       if (TAILH && ch == NCH - 1) {
-        const double* th = tab + ((lane >> 5) << 3);
         double l0 = ZERO0 ? st.S[ch][0] : 0.0, l1 = 0.0, l2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if (!(ZERO0 && (i & 3) == 0)) {
-            l0 = fma(st.S[ch][i], th[i], l0);
-            l1 = fma(st.S[ch][i], th[16 + i], l1);
-            l2 = fma(st.S[ch][i], th[32 + i], l2);
-          }
-        }
+        half_contract<ZERO0>(st.S[ch], tab, lane, l0, l1, l2);
         lv[3 * ch] = xhalf_add(l0);
         lv[3 * ch + 1] = xhalf_add2(l1, l2);
         continue;
@@ -457,16 +512,8 @@ __device__ __forceinline__ void derivatives(const SiteState<NCH>& st, double* ta
     if (TAILH && ch == NCH - 1) {
       // half-chunk: 8 sumtable entries per lane against this half's table entries; l0 is needed
       // in both halves, l1 lands in the lower and l2 in the upper one
-      const double* th = tab + ((lane >> 5) << 3);
       double l0 = ZERO0 ? st.S[ch][0] : 0.0, l1 = 0.0, l2 = 0.0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (!(ZERO0 && (i & 3) == 0)) {
-          l0 = fma(st.S[ch][i], th[i], l0);
-          l1 = fma(st.S[ch][i], th[16 + i], l1);
-          l2 = fma(st.S[ch][i], th[32 + i], l2);
-        }
-      }
+      half_contract<ZERO0>(st.S[ch], tab, lane, l0, l1, l2);
       l0 = xhalf_add(l0);
       const double l12 = xhalf_add2(l1, l2);
       const double qv = -l12 * fast_rcp(l0);   // lower half: -l1 / l0 = d1;  upper half: -l2 / l0
@@ -508,9 +555,12 @@ __device__ __forceinline__ double window_lnl(const SiteState<NCH>& st, const dou
     double l0 = ZERO0 ? st.S[ch][0] : 0.0;
     if (TAILH && ch == NCH - 1) {   // half-chunk: this half's two categories, then both halves
       const double* ewh = tab + 32 + ((lane >> 5) << 3);
+      double eh[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lds_pair(ewh + 2 * i, eh[2 * i], eh[2 * i + 1]);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        if (!(ZERO0 && (i & 3) == 0)) l0 = fma(st.S[ch][i], ewh[i], l0);
+        if (!(ZERO0 && (i & 3) == 0)) l0 = fma(st.S[ch][i], eh[i], l0);
       l0 = xhalf_add(l0);
     } else {
 #pragma unroll
@@ -716,12 +766,13 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 #pragma unroll
         for (int x = 0; x < 4; ++x) It[x] = An[sl][x];
       } else if (MODE == 0) {
-        cat_inner(pm, An[sl], tb + k * 4 + tok, Bn[sl], tb + 16 + k * 4 + tok, It, mx);
+        cat_inner(pm, An[sl], tb + k * 4 + 2 * tok, Bn[sl], tb + 16 + k * 4 + 2 * tok, It, mx);   // (token in units of 16 bytes)
       } else {
         // this half's categories are 2 h, 2 h + 1 in a half-chunk
-        const double* ap = qa + st.code[ch] * 16 + ((halfc ? (int)half * 2 : 0) + k) * 4 + tok;
-        const double Ap[4] = {ap[0], ap[1], ap[2], ap[3]};
-        cat_inner_pre(pm, Ap, MODE == 1 ? Bn[sl] : An[sl], tb + 16 + k * 4 + tok, It, mx);
+        const double* ap = qa + st.code[ch] * 16 + ((halfc ? (int)half * 2 : 0) + k) * 4 + 2 * tok;
+        double Ap[4];
+        lds_pair(ap, Ap[0], Ap[1]); lds_pair(ap + 2, Ap[2], Ap[3]);
+        cat_inner_pre(pm, Ap, MODE == 1 ? Bn[sl] : An[sl], tb + 16 + k * 4 + 2 * tok, It, mx);
       }
 #pragma unroll
       for (int x = 0; x < 4; ++x)
@@ -767,7 +818,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
   auto window_score = [&]() -> double {
     double ew[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
+    for (int i = 0; i < 8; ++i) lds_pair(tab + 32 + 2 * i, ew[2 * i], ew[2 * i + 1]);
     return window_lnl<NCH, ZERO0, NW, TAILH, NG>(st, ew, cb, lane, tab);
   };
   auto score = [&](double td_, double tx_, double tp_) -> double {
@@ -825,7 +876,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
       table_publish(tab, lane, TH_EXP(lc.lr * tp) * (lc.slot == 2 ? lc.w : 1.0));
       double ew[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) ew[i] = tab[32 + i];
+      for (int i = 0; i < 8; ++i) lds_pair(tab + 32 + 2 * i, ew[2 * i], ew[2 * i + 1]);
       const double new_ll = -window_lnl<NCH, ZERO0, NW, TAILH, NG>(st, ew, cb, lane, tab);
       ++rounds;
       --smoothings;
@@ -893,11 +944,11 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
 template <int NCH, bool ZERO0, bool INV, int NW, bool LOCAL = false, bool TAILH = false, int NG = 1>
 __global__ void __launch_bounds__(64 * NW * NG, TH_WAVES) k_thorough_dna(const ThArgs a) {
   constexpr int NWV = NW * NG;     // waves of the workgroup: site blocks (NW) or category groups (NG)
-  __shared__ double tab[64 * NWV];  // broadcast table of each wave
+  __shared__ __attribute__((aligned(16))) double tab[64 * NWV];  // broadcast table of each wave
   __shared__ double qts[64];       // U^-1 image of the 16 query column codes
   __shared__ double red[2 * NW * 2];
   __shared__ double e2t[64];
-  __shared__ double qa[256 * NWV];  // per wave: (U (e o q_code))_i for 16 codes x 16 (category, state)
+  __shared__ __attribute__((aligned(16))) double qa[256 * NWV];  // per wave: (U (e o q_code))_i for 16 codes x 16 (category, state)
   __shared__ double xch[NG > 1 ? 2 * NG * Comb<NW, NG>::XCH_MAX * 64 : 1];
   const int lane = threadIdx.x & 63;
   Comb<NW, NG> cb{red, (int)(threadIdx.x >> 6), 0, xch, 0};
@@ -911,6 +962,9 @@ __global__ void __launch_bounds__(64 * NW * NG, TH_WAVES) k_thorough_dna(const T
     lc.lr = a.m.lam[lx] * a.m.rate[kg];
     lc.w = a.m.w[kg];
     lc.cN = lc.slot == 0 ? lc.w : (lc.slot == 1 ? lc.w * lc.lr : (lc.slot == 2 ? lc.w * lc.lr * lc.lr : 0.0));
+    // compact Newton table position; the 28 lanes without an entry (eigen index 0, slot 3) get the dump slots 36..63
+    const int dump = lc.slot == 3 ? 36 + (lane & 15) : 52 + lc.slot * 4 + lk;
+    lc.npos = (lc.slot < 3 && lx != 0) ? lc.slot * 12 + lk * 3 + lx - 1 : dump;
   }
   __syncthreads();
   const uint32_t x = blockIdx.x & 7;
