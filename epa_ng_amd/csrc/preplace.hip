@@ -451,6 +451,26 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
   if (lane == 0) keys[q] = (any_rare ? 2 * Wp : 0) + (begin & 1u) * Wp + begin;
 }
 
+// Walk of the (branch tile, group) work items by a persistent grid.  Workgroups are dealt to the
+// eight XCDs round robin (workgroup w runs on XCD w % 8, each with its own 4 MB L2), and the groups
+// are sorted by window start: neighbouring groups stage overlapping slices of the same branch rows
+// (a site lies in the slices of ~6 groups at cfg2).  XCD x therefore takes the CONTIGUOUS eighth
+// [x T / 8, (x + 1) T / 8) of the items in (tile, group) order and its workgroups stride through
+// it, so that at any time one L2 serves neighbouring groups of one tile instead of every eighth:
+// slice re-reads that reach the fabric 3.5 GB -> 1.5 GB per 100k-read launch (PMC, round 3).
+#ifndef PP_XCD
+#define PP_XCD 1
+#endif
+struct ItemWalk { uint32_t pos, end, step; };
+__device__ __forceinline__ ItemWalk item_walk(uint32_t total) {
+  if (PP_XCD && (gridDim.x & 7u) == 0) {
+    const uint32_t x = blockIdx.x & 7u, local = blockIdx.x >> 3;
+    const uint32_t lo = (uint32_t)((uint64_t)total * x / 8), hi = (uint32_t)((uint64_t)total * (x + 1) / 8);
+    return {lo + local, hi, gridDim.x >> 3};
+  }
+  return {blockIdx.x, total, gridDim.x};
+}
+
 // SPR: window starts of a group lie within SPR sites.  96 for large chunks (many reads per window
 // start: 1024 consecutive reads of the sorted order span few starts); 288 for small ones (the
 // reference's default --chunk-size 5000 puts ~2 reads on a start: a 96-site bucket holds ~180 reads,
@@ -465,13 +485,16 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     const uint32_t* __restrict__ status, double* __restrict__ lnl) {
   constexpr int TR2 = (CH + SPR) / 2;   // pair rows staged per (branch, chunk)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [TR2][PE] doubles, then accs
-  double* accs = reinterpret_cast<double*>(smem + (size_t)TR2 * PROWL);  // [NB2_ACC][GQ2] (ACC only)
+  double* accs = reinterpret_cast<double*>(smem + (size_t)TR2 * PROWL);  // [NB2_ACC][GQ2] / burst rows
   __shared__ uint32_t s_maxspan;
+  __shared__ uint32_t s_qi[GQ2];        // query of thread t (burst write-out), ~0 = nothing to write
   constexpr uint32_t NBP = ACC ? NB2_ACC : NB2;
+  constexpr uint32_t BSTR = GQ2 + 4;    // burst staging rows 4 doubles apart in the banks: conflict-free
   // persistent grid over (group, branch tile) items of class 0, see k_preplace
   const uint32_t ng = status[5], ntiles = (B + NBP - 1) / NBP;
   const int t = threadIdx.x;
-  for (uint32_t item = blockIdx.x; item < ng * ntiles; item += gridDim.x) {
+  const ItemWalk iw = item_walk(ng * ntiles);
+  for (uint32_t item = iw.pos; item < iw.end; item += iw.step) {
   const Group g = groups[item % ng];
   const uint32_t b0 = (item / ng) * NBP;
   const uint32_t nb = min(NBP, B - b0);
@@ -486,6 +509,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     if ((uint64_t)begin + span > W) span = 0;
   }
   if (t == 0) s_maxspan = 0;
+  s_qi[t] = (active && span > 0) ? qi : 0xffffffffu;
   __syncthreads();
   atomicMax(&s_maxspan, span);
   if (ACC) for (uint32_t j = 0; j < nb; ++j) accs[j * GQ2 + t] = 0.0;
@@ -525,45 +549,38 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     }
     const uint32_t row0 = gmin + cbase;  // alignment site of pair row 0 of the staged slice
     const uint32_t need = min((uint32_t)TR2, (gspread >> 1) + (min((uint32_t)CH, s_maxspan - cbase) + 1) / 2);
-    // The slice of branch j+1 is requested (into registers) before the gathers of branch j start
-    // and written to LDS after them: its HBM latency hides under the gather phase.
     const uint32_t rows = (row0 < W) ? min(need, (W - row0 + 1) / 2) : 0;
     const uint32_t n2 = rows * (PE / 2);
     constexpr int PF = (TR2 * (PE / 2) + GQ2 - 1) / GQ2;
-    double2 pf[PF];
-    auto request = [&](uint32_t j) {
+    auto request = [&](uint32_t j, double2 (&pfs)[PF]) {
       // pair row r = table row (row0 + 2r); the rows of one parity are contiguous in lookup2
       const double2* src = reinterpret_cast<const double2*>(
           lookup2 + (((size_t)(b0 + j) * 2 + (row0 & 1u)) * ((W + 1) / 2) + (row0 >> 1)) * PE);
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const uint32_t i = u * GQ2 + t;
-        pf[u] = make_double2(0.0, 0.0);
-        if (i < n2) pf[u] = src[i];
+        pfs[u] = make_double2(0.0, 0.0);
+        if (i < n2) pfs[u] = src[i];
       }
     };
-    request(0);
-    for (uint32_t j = 0; j < nb; ++j) {
-      __syncthreads();  // previous consumers of the tile are done
-      {
+    auto stage = [&](const double2 (&pfs)[PF], uint32_t boff) {
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-          const uint32_t i = u * GQ2 + t;   // double2 index in the compact [rows][PE / 2] slice
-          if (i < n2) {
-            if (PROWL == PROWB) {
-              reinterpret_cast<double2*>(smem)[i] = pf[u];
-            } else {                         // padded rows: odd rows are only 8-byte aligned
-              const uint32_t r = i / (PE / 2), c2 = i - r * (PE / 2);
-              double* dst = reinterpret_cast<double*>(smem + r * PROWL + c2 * 16);
-              dst[0] = pf[u].x;
-              dst[1] = pf[u].y;
-            }
+      for (int u = 0; u < PF; ++u) {
+        const uint32_t i = u * GQ2 + t;   // double2 index in the compact [rows][PE / 2] slice
+        if (i < n2) {
+          if (PROWL == PROWB) {
+            reinterpret_cast<double2*>(smem + boff)[i] = pfs[u];
+          } else {                         // padded rows: odd rows are only 8-byte aligned
+            const uint32_t r = i / (PE / 2), c2 = i - r * (PE / 2);
+            double* dst = reinterpret_cast<double*>(smem + boff + r * PROWL + c2 * 16);
+            dst[0] = pfs[u].x;
+            dst[1] = pfs[u].y;
           }
         }
       }
-      __syncthreads();
-      if (j + 1 < nb) request(j + 1);
-      __builtin_amdgcn_sched_barrier(0);
+    };
+    // the gathers of branch j from the slice staged at byte boff; the sum goes to the staging rows
+    auto gather = [&](uint32_t j, uint32_t boff) {
       if (mine) {
         double sum = ACC ? accs[j * GQ2 + t] : 0.0;
         // the offsets are invariant over the branches: without this hipcc hoists the 80 extracted
@@ -578,8 +595,8 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
 #pragma unroll
           for (int w = 0; w < WPB; ++w) {
             const uint32_t v = cw[bt * WPB + w];
-            rb[bt & 1][2 * w] = at(v & 0xffffu);
-            rb[bt & 1][2 * w + 1] = at(v >> 16);
+            rb[bt & 1][2 * w] = at((v & 0xffffu) + boff);
+            rb[bt & 1][2 * w + 1] = at((v >> 16) + boff);
           }
         };
         issue(0);
@@ -596,22 +613,50 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
           __builtin_amdgcn_sched_barrier(0);
         }
         if (c == tailchunk) {  // singles of the window tail, in order
-          sum += at(t0);
-          sum += at(t1);
-          sum += at(t2);
+          sum += at(t0 + boff);
+          sum += at(t1 + boff);
+          sum += at(t2 + boff);
         }
         if (ACC) {
           accs[j * GQ2 + t] = sum;
         } else {
-          // results leave in bursts of 8 consecutive branches (64 B per query, issued back to back
-          // so that L2 merges them into whole sectors): single 8-byte stores spread over the item
-          // were evicted sector by sector -- 1.76 GB written for a 0.41 GB table
-          accs[(j & 7u) * GQ2 + t] = sum;
-          if ((j & 7u) == 7u || j + 1 == nb) {
-            double* out = lnl + (size_t)qi * pitch + b0 + (j & ~7u);
-            for (uint32_t k = 0; k <= (j & 7u); ++k) out[k] = accs[k * GQ2 + t];
-          }
+          accs[(j & 7u) * BSTR + t] = sum;
         }
+      }
+    };
+    auto flush = [&](uint32_t j) {
+      if (!ACC && ((j & 7u) == 7u || j + 1 == nb)) {
+        // Results leave in bursts of 8 consecutive branches, 64 B per query, and the eight lanes
+        // l, l+1 .. l+7 write the eight doubles of ONE query: every store instruction hands the
+        // memory system whole 64-byte sectors (8 queries per wave and instruction).  History: single
+        // 8-byte stores spread over the item were evicted sector by sector (1.76 GB written for a
+        // 0.41 GB table); 8 stores per lane back to back, each lane its own sector, relied on L2
+        // merging them before eviction (1.19 GB for 0.83 GB; 2.15 GB under the XCD-contiguous walk).
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t lane = (uint32_t)t & 63u, wbase = (uint32_t)t & ~63u, col = lane & 7u;
+        const uint32_t ncol = (j & 7u) + 1u, bcol = b0 + (j & ~7u) + col;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+          const uint32_t tq = wbase + k * 8 + (lane >> 3);
+          const uint32_t q = s_qi[tq];
+          if (q != 0xffffffffu && col < ncol) lnl[(size_t)q * pitch + bcol] = accs[col * BSTR + tq];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    };
+    {
+      // The slice of branch j+1 is requested (into registers) before the gathers of branch j start
+      // and written to LDS after them: its HBM latency hides under the gather phase.
+      double2 pf[PF];
+      request(0, pf);
+      for (uint32_t j = 0; j < nb; ++j) {
+        __syncthreads();  // previous consumers of the tile are done
+        stage(pf, 0);
+        __syncthreads();
+        if (j + 1 < nb) request(j + 1, pf);
+        __builtin_amdgcn_sched_barrier(0);
+        gather(j, 0);
+        flush(j);
       }
     }
   }
@@ -682,7 +727,8 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
   const uint32_t ng = status[5], ntiles = (B + NBP - 1) / NBP;
   const int t = threadIdx.x;
   auto at = [&](uint32_t off) -> double { return *reinterpret_cast<const double*>(smem + off); };
-  for (uint32_t item = blockIdx.x; item < ng * ntiles; item += gridDim.x) {
+  const ItemWalk iw = item_walk(ng * ntiles);
+  for (uint32_t item = iw.pos; item < iw.end; item += iw.step) {
     const Group g = groups[item % ng];
     const uint32_t b0 = (item / ng) * NBP;
     const uint32_t nb = min(NBP, B - b0);
@@ -1199,7 +1245,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   // max_span: upper bound of the window spans when the caller knows it (0 = unknown)
   const bool acc = max_span == 0 || max_span > (uint32_t)CH || getenv("EPA_PREPLACE_ACC");
   const size_t lds = sizeof(double) * ((size_t)TROWS * ctx->ncols + (acc ? (size_t)NB * GQ : 0));
-  const size_t lds2 = (size_t)TROWS2 * PROWL + sizeof(double) * (acc ? NB2_ACC : NB2_BURST) * GQ2;  // accs / result staging
+  const size_t lds2 = (size_t)TROWS2 * PROWL + sizeof(double) * (acc ? NB2_ACC * GQ2 : NB2_BURST * (GQ2 + 4));  // accs / result staging
   const uint32_t ntiles2 = (ctx->B + (acc ? NB2_ACC : NB2) - 1) / (acc ? NB2_ACC : NB2);
   const dim3 grid2((uint32_t)std::min<uint64_t>((uint64_t)max_groups * ntiles2, (uint64_t)ctx->n_cu));  // 1 per CU
   // generic kernel: with the pair path on it only sees the few groups of queries with rare
@@ -1218,7 +1264,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
                        tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl);    \
   } while (0)
   if (pairs && wide) {
-    const size_t lds2w = (size_t)((CH + SPREAD_WIDE) / 2) * PROWL + sizeof(double) * NB2_BURST * GQ2;
+    const size_t lds2w = (size_t)((CH + SPREAD_WIDE) / 2) * PROWL + sizeof(double) * NB2_BURST * (GQ2 + 4);
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<false, SPREAD_WIDE>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2w));
     hipLaunchKernelGGL((k_preplace_pairs<false, SPREAD_WIDE>), grid2, dim3(GQ2), lds2w, ctx->stream, ctx->lookup2,
