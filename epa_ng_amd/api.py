@@ -358,10 +358,11 @@ class Evaluator:
     # ---- double-buffered chunk pipeline (epa_dev_chunk_stage / _launch / _finish): the upload of
     # chunk k+1 and the download of chunk k-1 overlap the kernels of chunk k
     def chunk_stage(self, slot, codes, win_begin, win_span):
-        """HOST arrays (numpy; codes may be Packed4) -> pinned buffer -> async H2D; returns at once"""
+        """HOST arrays (numpy; codes may be Packed4) -> pinned buffer -> async H2D; returns at once.
+        torch cuda tensors (all three) are read in place: keep them untouched until chunk_finish"""
         self._layout(codes)
         data = codes.data if isinstance(codes, Packed4) else codes
-        assert isinstance(data, np.ndarray) and isinstance(win_begin, np.ndarray)
+        assert isinstance(data, np.ndarray) == isinstance(win_begin, np.ndarray) == isinstance(win_span, np.ndarray)
         self._check(self.L.epa_dev_chunk_stage(self.h, slot, _ptr(codes), _ptr(win_begin), _ptr(win_span),
                                                len(win_begin)))
 

@@ -62,6 +62,39 @@ __global__ void __launch_bounds__(256) k_unpack4(const uint8_t* __restrict__ pac
   if (2 * p + 1 < stride) row[2 * p + 1] = b & 15u;
 }
 
+// Even row length: row q of the packed stream starts at byte q * stride / 2, the expansion is one
+// flat stream -- 4 packed bytes in, 8 codes out per thread, both coalesced (the byte-per-thread form
+// took 160 us for a 100k x 150 chunk, this one the time of moving 22 MB).
+__global__ void __launch_bounds__(256) k_unpack4_flat(const uint32_t* __restrict__ packed, uint2* __restrict__ codes,
+                                                      uint64_t n_bytes) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (4 * i >= n_bytes) return;
+  if (4 * i + 4 > n_bytes) {   // the last, partial word byte by byte: nothing beyond the arrays is touched
+    const uint8_t* pb = reinterpret_cast<const uint8_t*>(packed);
+    uint8_t* cb = reinterpret_cast<uint8_t*>(codes);
+    for (uint64_t k = 4 * i; k < n_bytes; ++k) { cb[2 * k] = pb[k] >> 4; cb[2 * k + 1] = pb[k] & 15u; }
+    return;
+  }
+  const uint32_t w = packed[i];
+  auto two = [](uint32_t b) { return (b >> 4) | ((b & 15u) << 8); };   // earlier site = high nibble
+  uint2 o;
+  o.x = two(w & 0xffu) | (two((w >> 8) & 0xffu) << 16);
+  o.y = two((w >> 16) & 0xffu) | (two(w >> 24) << 16);
+  codes[i] = o;
+}
+static void launch_unpack4(hipStream_t st, const uint8_t* d_packed, uint8_t* d_codes, uint32_t Q, uint32_t stride) {
+  const size_t pstride = ((size_t)stride + 1) / 2;
+  const uint64_t n = (uint64_t)Q * pstride;
+  if ((stride & 1u) == 0 && ((uintptr_t)d_packed & 3u) == 0 && ((uintptr_t)d_codes & 7u) == 0) {
+    const uint64_t nw = (n + 3) / 4;
+    hipLaunchKernelGGL(k_unpack4_flat, dim3((uint32_t)((nw + 255) / 256)), dim3(256), 0, st,
+                       (const uint32_t*)d_packed, (uint2*)d_codes, n);
+  } else {
+    hipLaunchKernelGGL(k_unpack4, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, d_packed, d_codes, Q,
+                       stride, (uint32_t)pstride);
+  }
+}
+
 const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_t Q) {
   const size_t stride = ctx->code_stride ? ctx->code_stride : ctx->W;
   if (!ctx->code_packed4) return (const uint8_t*)epa_to_device(ctx, 0, q_codes, (size_t)Q * stride);
@@ -69,9 +102,7 @@ const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_
   const uint8_t* d_packed = (const uint8_t*)epa_to_device(ctx, 10, q_codes, (size_t)Q * pstride);
   uint8_t* d = (uint8_t*)epa_scratch(ctx, 0, (size_t)Q * stride + 1024);
   if (!d_packed || !d) return nullptr;
-  const uint64_t n = (uint64_t)Q * pstride;
-  hipLaunchKernelGGL(k_unpack4, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_packed, d, Q,
-                     (uint32_t)stride, (uint32_t)pstride);
+  launch_unpack4(ctx->stream, d_packed, d, Q, (uint32_t)stride);
   return d;
 }
 
@@ -1404,6 +1435,18 @@ extern "C" int epa_dev_chunk_stage(epa_ctx* ctx, int slot, const uint8_t* q_code
   const size_t row = s->packed4 ? ((size_t)s->stride + 1) / 2 : s->stride;
   s->codes_bytes = ((size_t)Q * row + 255) & ~(size_t)255;
   const size_t total = s->codes_bytes + 2 * sizeof(uint32_t) * (size_t)Q;
+  const bool dev_in = epa_is_device_ptr(q_codes);
+  if (dev_in != epa_is_device_ptr(win_begin) || dev_in != epa_is_device_ptr(win_span))
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_stage: the three arrays must be all host or all device memory");
+  if (dev_in) {
+    // HBM-resident chunk: the slot reads the caller's arrays in place (no copy, no copy-stream
+    // work); they must stay untouched until chunk_finish and be complete on the context's stream
+    s->x_codes = q_codes; s->x_begin = win_begin; s->x_span = win_span;
+    s->Q = Q;
+    s->state = 1;
+    return EPA_OK;
+  }
+  s->x_codes = nullptr;
   rc = grow_pinned(ctx, &s->h_in, &s->h_in_sz, total);
   if (!rc) rc = grow_dev(ctx, (char**)&s->d_in, &s->d_in_sz, total + 1024);
   if (rc) return rc;
@@ -1468,21 +1511,18 @@ extern "C" int epa_dev_chunk_launch_begin(epa_ctx* ctx, int slot, uint32_t max_s
   // build; with device-resident results, the caller's reads of the result buffers).
   EPA_HIP(ctx, hipEventRecord(s->ev_base, ctx->stream));
   EPA_HIP(ctx, hipStreamWaitEvent(s->stream, s->ev_base, 0));
-  EPA_HIP(ctx, hipStreamWaitEvent(s->stream, s->ev_up, 0));
+  if (!s->x_codes) EPA_HIP(ctx, hipStreamWaitEvent(s->stream, s->ev_up, 0));
   SlotScope scope(ctx, s, slot);
   const char* d = (const char*)s->d_in;
-  const uint8_t* d_codes = (const uint8_t*)d;
-  const uint32_t* d_begin = (const uint32_t*)(d + s->codes_bytes);
-  const uint32_t* d_span = d_begin + Q;
+  const uint8_t* d_codes = s->x_codes ? s->x_codes : (const uint8_t*)d;
+  const uint32_t* d_begin = s->x_codes ? s->x_begin : (const uint32_t*)(d + s->codes_bytes);
+  const uint32_t* d_span = s->x_codes ? s->x_span : d_begin + Q;
   if (s->packed4) {
     size_t have = s->d_unpacked_sz;
     rc = grow_dev(ctx, &s->d_unpacked, &have, (size_t)Q * s->stride + 1024);
     s->d_unpacked_sz = have;
     if (rc) return rc;
-    const size_t pstride = ((size_t)s->stride + 1) / 2;
-    const uint64_t nb = (uint64_t)Q * pstride;
-    hipLaunchKernelGGL(k_unpack4, dim3((uint32_t)((nb + 255) / 256)), dim3(256), 0, ctx->stream, d_codes,
-                       s->d_unpacked, Q, s->stride, (uint32_t)pstride);
+    launch_unpack4(ctx->stream, d_codes, s->d_unpacked, Q, s->stride);
     d_codes = s->d_unpacked;
   }
   s->l_codes = d_codes; s->l_begin = d_begin; s->l_span = d_span;

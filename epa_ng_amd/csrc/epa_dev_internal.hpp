@@ -74,6 +74,9 @@ struct ChunkSlot {
   void* h_in = nullptr;       // pinned bounce buffer: codes | win_begin | win_span
   size_t h_in_sz = 0;
   void* d_in = nullptr;       // the same three arrays in HBM
+  const uint8_t* x_codes = nullptr;   // HBM-resident chunk staged in place (caller's arrays), else null
+  const uint32_t* x_begin = nullptr;
+  const uint32_t* x_span = nullptr;
   size_t d_in_sz = 0;
   uint8_t* d_unpacked = nullptr;  // one-byte codes when the chunk arrived in the 4-bit wire format
   size_t d_unpacked_sz = 0;

@@ -353,16 +353,21 @@ __global__ void __launch_bounds__(GQ, ACC ? 2 : 4) k_preplace(const double* __re
 // Site-pair fast path (DNA).
 // ---------------------------------------------------------------------------------------------
 constexpr int NSYM = 6;                 // A C G T N(or gap) none
-constexpr int PE = NSYM * NSYM;         // entries per pair row: e = sym(site) * 6 + sym(site + 1)
+constexpr int PE = NSYM * NSYM;         // entries per pair row, in pair_entry() order
 constexpr int PROWB = PE * 8;           // 288 bytes per pair row in HBM
-// Row stride of the staged slice in LDS.  With 288 B (36 doubles) row r starts on 8-byte bank 4 r mod
-// 16 (PMC round 2: 21 % of the LDS-active cycles were bank conflicts); 296 B (37 doubles) puts sixteen
-// consecutive rows on sixteen banks.  Measured round 3, same box, 100k-read launches: 1.295 / 1.353 ms
-// with 288, 1.297 / 1.353 ms with 296 -- the conflicts are not what bounds the kernel, so the
-// unpadded layout (and its 288-site wide variant for small chunks) stays; -DPROWL=296 rebuilds the other.
-#ifndef PROWL
-#define PROWL 288
-#endif
+// Entry order and LDS row stride are chosen for the LDS banks (64 dwords; a ds_read_b64 serves 32
+// lanes per cycle when their 8-byte words sit on different bank pairs or coincide).  32 neighbouring
+// queries of the sorted order start on one or two adjacent pair rows and, site pair by site pair, read
+// one of the 16 plain-nucleotide entries of "their" row.  Those 16 entries come FIRST in a row (128
+// contiguous bytes = 32 banks) and rows are ROWL_NARROW = 384 bytes apart in LDS (96 dwords = 32 mod
+// 64): the hot halves of adjacent rows cover all 64 banks once, the gathers of a lane group are
+// conflict-free.  exp/lds_gather.hip, 37 queries per start: 198 B/clk/CU against 143 for the old
+// e = s0 * 6 + s1 order at 288 bytes (row r on bank 8 r: every second symbol of adjacent rows collides),
+// which is why padding 288 -> 296 alone never helped.  Wide (small-chunk) and multi-chunk variants keep
+// 288-byte rows: their slices would not fit the 16-bit offsets / the LDS at 384, and their lane groups
+// span many rows anyway (12 queries per start: 125 vs 120 B/clk).
+constexpr int ROWL_NARROW = 384;
+constexpr int ROWL_PACKED = PROWB;
 constexpr int CP = CH / 2;              // pair slots per chunk
 constexpr int PW = CP / 2;              // packed words (2 x 16-bit LDS offsets) per chunk
 constexpr int TROWS2 = TROWS / 2;       // pair rows staged per (branch, chunk)
@@ -374,6 +379,18 @@ constexpr int NB2_ACC = 15;             // branches per work item when partial s
 constexpr int NB2_ACC_S = 14;           // the same for the 20-state site path (43 KB slice)
 constexpr int NB2_BURST = 8;            // single-chunk variants: result rows staged per 64-byte burst
 constexpr uint32_t ZERO_OFF = (PE - 1) * 8;  // (none, none) of the thread's own first row: exact +0.0
+
+// (symbol of site, symbol of site + 1) -> entry of the pair row: the 16 plain pairs first
+__device__ __forceinline__ uint32_t pair_entry(uint32_t s0, uint32_t s1) {
+  if (s0 < 4 && s1 < 4) return s0 * 4 + s1;
+  if (s0 < 4) return 16 + s0 * 2 + (s1 - 4);
+  return 24 + (s0 - 4) * NSYM + s1;      // (5, 5) = PE - 1
+}
+__device__ __forceinline__ void pair_symbols(uint32_t e, uint32_t& s0, uint32_t& s1) {
+  if (e < 16) { s0 = e >> 2; s1 = e & 3u; }
+  else if (e < 24) { s0 = (e - 16) >> 1; s1 = 4 + ((e - 16) & 1u); }
+  else { s0 = 4 + (e - 24) / NSYM; s1 = (e - 24) % NSYM; }
+}
 
 // state-set code (4-bit mask) -> symbol; 6 = any other ambiguity code (generic kernel)
 __device__ __forceinline__ uint32_t dna_sym(uint32_t code) {
@@ -390,7 +407,9 @@ __global__ void __launch_bounds__(256) k_build_lookup2(const double* __restrict_
   const uint32_t b = blockIdx.y;
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= W * PE) return;
-  const uint32_t s = i / PE, e = i - s * PE, i0 = e / NSYM, i1 = e - i0 * NSYM;
+  const uint32_t s = i / PE, e = i - s * PE;
+  uint32_t i0, i1;
+  pair_symbols(e, i0, i1);
   const uint32_t code[5] = {1, 2, 4, 8, 15};
   const double* T = lookup + (size_t)b * W * 16;
   const double v0 = i0 < 5 ? T[(size_t)s * 16 + code[i0]] : 0.0;
@@ -409,7 +428,7 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
                                                     const uint32_t* __restrict__ win_span, uint32_t Q,
                                                     uint32_t W, uint32_t cstride, uint32_t crel,
                                                     uint32_t span_bound, uint32_t Wp, uint32_t NP16,
-                                                    uint16_t* __restrict__ packed,
+                                                    uint32_t rowl, uint16_t* __restrict__ packed,
                                                     uint16_t* __restrict__ tails,
                                                     uint32_t* __restrict__ keys,
                                                     uint32_t* __restrict__ status) {
@@ -431,7 +450,7 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
     if (p < npairs) {
       const uint32_t s0 = dna_sym(c[2 * p]), s1 = dna_sym(c[2 * p + 1]);
       rare |= (s0 > 4) | (s1 > 4);
-      v = (p % CP) * PROWL + (min(s0, 5u) * NSYM + min(s1, 5u)) * 8;
+      v = (p % CP) * rowl + pair_entry(min(s0, 5u), min(s1, 5u)) * 8;
     }
     packed[(size_t)q * NP16 + p] = (uint16_t)v;
   }
@@ -442,8 +461,8 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
       rare |= sy > 4;
       sy = min(sy, 5u);
       const uint32_t kt = npairs % CP;  // row of the first tail site inside its chunk (even)
-      const uint32_t e = lane == 1 ? 5 * NSYM + sy : sy * NSYM + 5;
-      v = (kt + (lane == 2 ? 1u : 0u)) * PROWL + e * 8;
+      const uint32_t e = lane == 1 ? pair_entry(5, sy) : pair_entry(sy, 5);
+      v = (kt + (lane == 2 ? 1u : 0u)) * rowl + e * 8;
     }
     tails[(size_t)q * 4 + lane] = (uint16_t)v;
   }
@@ -475,8 +494,8 @@ __device__ __forceinline__ ItemWalk item_walk(uint32_t total) {
 // start: 1024 consecutive reads of the sorted order span few starts); 288 for small ones (the
 // reference's default --chunk-size 5000 puts ~2 reads on a start: a 96-site bucket holds ~180 reads,
 // a workgroup's 1024 lanes would be 18 % full) -- the 16-bit LDS offsets still fit:
-// (272 / 2 + 79) * 296 + 35 * 8 < 65536 (LDS rows are PROWL = 296 bytes apart).
-template <bool ACC, int SPR = SPREAD>
+// (288 / 2 + 79) * 288 + 35 * 8 < 65536.  ROWL: byte stride of the staged pair rows in LDS (see above).
+template <bool ACC, int SPR, int ROWL>
 __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     const double* __restrict__ lookup2, const uint16_t* __restrict__ packed,
     const uint16_t* __restrict__ tails, const uint32_t* __restrict__ win_begin,
@@ -485,7 +504,8 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     const uint32_t* __restrict__ status, double* __restrict__ lnl) {
   constexpr int TR2 = (CH + SPR) / 2;   // pair rows staged per (branch, chunk)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [TR2][PE] doubles, then accs
-  double* accs = reinterpret_cast<double*>(smem + (size_t)TR2 * PROWL);  // [NB2_ACC][GQ2] / burst rows
+  static_assert(ROWL % 16 == 0 && ROWL >= PROWB && ((TR2 - 1) * ROWL + PROWB) < 65536, "16-bit LDS offsets");
+  double* accs = reinterpret_cast<double*>(smem + (size_t)TR2 * ROWL);  // [NB2_ACC][GQ2] / burst rows
   __shared__ uint32_t s_maxspan;
   __shared__ uint32_t s_qi[GQ2];        // query of thread t (burst write-out), ~0 = nothing to write
   constexpr uint32_t NBP = ACC ? NB2_ACC : NB2;
@@ -517,7 +537,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
   // all members share the parity of their window start: rel is even, pair rows line up
   const uint32_t gmin = win_begin[perm[g.start]];
   const uint32_t gspread = win_begin[perm[g.start + g.count - 1]] - gmin;  // < SPREAD
-  const uint32_t rowoff = ((begin - gmin) >> 1) * PROWL;
+  const uint32_t rowoff = ((begin - gmin) >> 1) * ROWL;
   const uint32_t rowoff2 = rowoff | (rowoff << 16);
   const uint32_t nchunks = ACC ? (s_maxspan + CH - 1) / CH : 1;
   uint32_t t0 = 0, t1 = 0, t2 = 0, tailchunk = 0xffffffffu;
@@ -568,13 +588,11 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
       for (int u = 0; u < PF; ++u) {
         const uint32_t i = u * GQ2 + t;   // double2 index in the compact [rows][PE / 2] slice
         if (i < n2) {
-          if (PROWL == PROWB) {
+          if (ROWL == PROWB) {
             reinterpret_cast<double2*>(smem + boff)[i] = pfs[u];
-          } else {                         // padded rows: odd rows are only 8-byte aligned
+          } else {                         // padded rows
             const uint32_t r = i / (PE / 2), c2 = i - r * (PE / 2);
-            double* dst = reinterpret_cast<double*>(smem + boff + r * PROWL + c2 * 16);
-            dst[0] = pfs[u].x;
-            dst[1] = pfs[u].y;
+            *reinterpret_cast<double2*>(smem + boff + r * ROWL + c2 * 16) = pfs[u];
           }
         }
       }
@@ -1211,9 +1229,14 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   hipLaunchKernelGGL(k_iota, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, iota, Q);
   int key_bits = 1;
   while (key_bits < 32 && (1ull << key_bits) < (uint64_t)n_blocks * Wp) ++key_bits;
+  // wide slices for the pair path when a chunk puts few reads on a window start (see k_preplace_pairs)
+  const bool acc = max_span == 0 || max_span > (uint32_t)CH || getenv("EPA_PREPLACE_ACC");
+  static const bool narrow_only = getenv("EPA_PREPLACE_NARROW") != nullptr;
+  const bool wide = pairs && !acc && !narrow_only && (uint64_t)Q * SPREAD < (uint64_t)1400 * ctx->W;   // < ~700 reads per 96-site bucket and parity
+  const uint32_t rowl = (wide || acc) ? ROWL_PACKED : ROWL_NARROW;  // LDS row stride the 16-bit offsets are built for
   if (pairs) {
     hipLaunchKernelGGL(k_pack_pairs, dim3((Q + 3) / 4), dim3(256), 0, ctx->stream, d_codes, d_begin,
-                       d_span, Q, ctx->W, cstride, crel, span_bound, Wp, NP16, packed, tails, keys, status);
+                       d_span, Q, ctx->W, cstride, crel, span_bound, Wp, NP16, rowl, packed, tails, keys, status);
     EPA_HIP(ctx, rocprim::radix_sort_pairs<epa_radix_cfg>(temp, temp_bytes, keys, sorted_keys, iota, perm, Q, 0,
                                            key_bits, ctx->stream));
   } else if (sites) {
@@ -1231,21 +1254,16 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     EPA_HIP(ctx, rocprim::radix_sort_pairs<epa_radix_cfg>(temp, temp_bytes, d_begin, sorted_keys, iota, perm, Q, 0, wbits,
                                            ctx->stream));
   }
-  // wide slices for the pair path when a chunk puts few reads on a window start (see k_preplace_pairs)
-  const bool acc_early = max_span == 0 || max_span > (uint32_t)CH || getenv("EPA_PREPLACE_ACC");
-  static const bool narrow_only = getenv("EPA_PREPLACE_NARROW") != nullptr;
-  const bool wide = pairs && !acc_early && !narrow_only && (uint64_t)Q * SPREAD < (uint64_t)1400 * ctx->W;   // < ~700 reads per 96-site bucket and parity
-  constexpr int SPREAD_WIDE = PROWL == 288 ? 288 : 272;   // 16-bit LDS offsets: ((CH + SPREAD_WIDE) / 2 - 1) * PROWL + 35 * 8 < 65536
+  constexpr int SPREAD_WIDE = 288;
   hipLaunchKernelGGL(k_make_groups, dim3(1), dim3(256),
                      sizeof(uint32_t) * (2 * (n_blocks + 1) + 4 * (size_t)max_runs + 2), ctx->stream,
                      sorted_keys, Q, pairs ? Wp : 0xffffffffu, n_blocks, class_blocks, gq0, gq1,
                      (uint32_t)(wide ? SPREAD_WIDE : SPREAD), max_runs, groups, max_groups, status);
   // persistent grids: every resident workgroup slot of the device, work items strided over them
   const uint32_t ntiles = (ctx->B + NB - 1) / NB;
-  // max_span: upper bound of the window spans when the caller knows it (0 = unknown)
-  const bool acc = max_span == 0 || max_span > (uint32_t)CH || getenv("EPA_PREPLACE_ACC");
+  // max_span: upper bound of the window spans when the caller knows it (0 = unknown) -> acc, above
   const size_t lds = sizeof(double) * ((size_t)TROWS * ctx->ncols + (acc ? (size_t)NB * GQ : 0));
-  const size_t lds2 = (size_t)TROWS2 * PROWL + sizeof(double) * (acc ? NB2_ACC * GQ2 : NB2_BURST * (GQ2 + 4));  // accs / result staging
+  const size_t lds2 = (size_t)TROWS2 * rowl + sizeof(double) * (acc ? NB2_ACC * GQ2 : NB2_BURST * (GQ2 + 4));  // accs / result staging
   const uint32_t ntiles2 = (ctx->B + (acc ? NB2_ACC : NB2) - 1) / (acc ? NB2_ACC : NB2);
   const dim3 grid2((uint32_t)std::min<uint64_t>((uint64_t)max_groups * ntiles2, (uint64_t)ctx->n_cu));  // 1 per CU
   // generic kernel: with the pair path on it only sees the few groups of queries with rare
@@ -1256,20 +1274,19 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   const size_t codes_bytes = (size_t)Q * cstride;
   const uint32_t want_cls = pairs ? 1u : 0u;
   epa_timer_start(ctx, ctx->t_preplace);
-#define PRE2(A)                                                                                      \
+#define PRE2(A, SP, RL, LDSB)                                                                        \
   do {                                                                                               \
-    EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<A>,                               \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));        \
-    hipLaunchKernelGGL((k_preplace_pairs<A>), grid2, dim3(GQ2), lds2, ctx->stream, ctx->lookup2, packed, \
+    EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<A, SP, RL>,                       \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB)));      \
+    hipLaunchKernelGGL((k_preplace_pairs<A, SP, RL>), grid2, dim3(GQ2), (LDSB), ctx->stream, ctx->lookup2, packed, \
                        tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl);    \
   } while (0)
   if (pairs && wide) {
-    const size_t lds2w = (size_t)((CH + SPREAD_WIDE) / 2) * PROWL + sizeof(double) * NB2_BURST * (GQ2 + 4);
-    EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<false, SPREAD_WIDE>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2w));
-    hipLaunchKernelGGL((k_preplace_pairs<false, SPREAD_WIDE>), grid2, dim3(GQ2), lds2w, ctx->stream, ctx->lookup2,
-                       packed, tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl);
-  } else if (pairs) { if (acc) PRE2(true); else PRE2(false); }
+    const size_t lds2w = (size_t)((CH + SPREAD_WIDE) / 2) * ROWL_PACKED + sizeof(double) * NB2_BURST * (GQ2 + 4);
+    PRE2(false, SPREAD_WIDE, ROWL_PACKED, lds2w);
+  } else if (pairs) {
+    if (acc) PRE2(true, SPREAD, ROWL_PACKED, lds2); else PRE2(false, SPREAD, ROWL_NARROW, lds2);
+  }
 #undef PRE2
   if (sites) {
     const bool acc_s = max_span == 0 || max_span > (uint32_t)CHS || getenv("EPA_PREPLACE_ACC");

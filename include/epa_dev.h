@@ -312,7 +312,9 @@ int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* wi
  * run on a copy stream while the kernels of chunk k run.  Two slots (0, 1), each walks
  *     stage -> launch -> finish -> stage -> ...
  *   stage   copies the caller's HOST arrays (layout / packing as set for the context) into the
- *           slot's pinned buffer and starts the H2D transfer; returns at once.
+ *           slot's pinned buffer and starts the H2D transfer; returns at once.  DEVICE arrays (all
+ *           three) are read in place instead: no copy; they must be complete on the context's
+ *           stream at launch and stay untouched until finish.
  *   launch  preplace -> heuristic -> thorough on the compute stream as soon as the upload has
  *           landed; blocks only until the candidate count is known (it sizes the thorough launch),
  *           then queues the thorough kernels and the D2H of pairs / results and returns.

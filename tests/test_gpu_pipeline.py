@@ -910,6 +910,57 @@ def test_staged_chunk_pipeline_equals_place_chunk(packed):
     assert np.array_equal(d_res[:n, 0].cpu().numpy(), expect[2][1]["lnl"])
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_staged_chunks_in_hbm_and_two_half_launch_order(packed):
+    """chunk_stage of DEVICE arrays reads them in place (no copy), and the two-half loop bench.py runs
+    -- launch_begin(k); finish(k-1); stage(k+1); launch_end(k) -- returns, chunk for chunk, the bits
+    of epa_dev_place_chunk, for host chunks (even row length: the flat 4-bit expansion; odd: byte by
+    byte) and for HBM-resident ones; mixing host and device arrays in one stage call is an error"""
+    import torch
+    w = synth.dna_workload(48, 640, 1500, 150, (71, 72, 73))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    Q = 300
+    cap = Q * 64
+    dev = torch.device("cuda", 0)
+    for odd in (False, True):
+        chunks = []
+        for c in range(5):
+            codes, wb, ws = epa.encode_queries(4, w["reads"][c * Q:(c + 1) * Q], compact=True)
+            if odd:                                   # rows of 151 codes: one trailing gap column
+                codes = np.concatenate([codes, np.full((len(codes), 1), 15, np.uint8)], axis=1)
+                codes = np.ascontiguousarray(codes)
+            chunks.append((codes, wb, ws))
+        expect = [ev.place_chunk(*ch, max_span=150) for ch in chunks]
+        if packed:
+            host = [(epa.pack_codes_4bit(c), b, s) for c, b, s in chunks]
+            hbm = [(epa.Packed4(torch.from_numpy(p.data).to(dev), p.stride), torch.from_numpy(b.view(np.int32)).to(dev),
+                    torch.from_numpy(s.view(np.int32)).to(dev)) for p, b, s in host]
+        else:
+            host = chunks
+            hbm = [(torch.from_numpy(c).to(dev), torch.from_numpy(b.view(np.int32)).to(dev),
+                    torch.from_numpy(s.view(np.int32)).to(dev)) for c, b, s in chunks]
+        for src in (host, hbm):
+            got = []
+            ev.chunk_stage(0, *src[0])
+            for k in range(len(src)):
+                ev.chunk_launch_begin(k & 1, max_span=150, max_pairs=cap)
+                if k:
+                    got.append(ev.chunk_finish((k - 1) & 1))
+                if k + 1 < len(src):
+                    ev.chunk_stage((k + 1) & 1, *src[k + 1])
+                ev.chunk_launch_end(k & 1)
+            got.append(ev.chunk_finish((len(src) - 1) & 1))
+            for (p, r), (ep, er) in zip(got, expect):
+                assert np.array_equal(p, ep) and np.array_equal(r, er)
+    with pytest.raises(AssertionError):
+        ev.chunk_stage(0, hbm[0][0], chunks[0][1], chunks[0][2])
+    with pytest.raises(epa.EpaError):                 # straight at the C-ABI: device codes, host windows
+        ev._check(ev.L.epa_dev_chunk_stage(ev.h, 0, hbm[0][0].data.data_ptr() if packed else hbm[0][0].data_ptr(),
+                                           chunks[0][1].ctypes.data, chunks[0][2].ctypes.data, Q))
+
+
 def test_baseball_heuristic_counts_follow_the_reference_arithmetic():
     """baseball_heuristic (src/core/heuristics.hpp:74-117): hits = branches within 3.0 lnL of the
     best, then std::min(max_pitches - hits, max_strikes) more in size_t arithmetic -- 6 more when
