@@ -373,7 +373,7 @@ constexpr int PW = CP / 2;              // packed words (2 x 16-bit LDS offsets)
 constexpr int TROWS2 = TROWS / 2;       // pair rows staged per (branch, chunk)
 constexpr int GQ2 = 1024;               // queries (threads) per group of the pair path: one
                                         // workgroup per CU, the staged slice is shared by 1024 queries
-constexpr int NB2 = 32;                 // branches per item of the fast paths (single-chunk variant)
+                                        // branches per item of the single-chunk fast paths: choose_tile()
 constexpr int NB2_ACC = 15;             // branches per work item when partial sums live in LDS (multi-chunk
                                         // windows): 15 x 1024 doubles + the 36 KB slice fill the CU's 160 KB
 constexpr int NB2_ACC_S = 14;           // the same for the 20-state site path (43 KB slice)
@@ -490,6 +490,23 @@ __device__ __forceinline__ ItemWalk item_walk(uint32_t total) {
   return {blockIdx.x, total, gridDim.x};
 }
 
+// Branches per work item of the single-chunk fast paths (ng groups x ceil(B / n) items on nwg
+// persistent workgroups): the multiple of 8 (whole result bursts) in 16 .. 96 with the smallest
+// rounds x (branches + per-item setup).  Per item a workgroup fetches its queries' offsets (160 B per
+// query) and runs a chain of dependent loads before the first slice is staged, ~3 branch times: at
+// cfg2 (98 groups, 1021 branches, 256 workgroups) 13 tiles of 80 are 5 rounds = 415 branch times
+// where 32 tiles of 32 were 13 rounds = 455, and the offsets are read 13 times instead of 32; a
+// 5000-read chunk (10 groups) gets 43 tiles of 24 instead of 1.25 rounds of 32.
+__device__ __forceinline__ uint32_t choose_tile(uint32_t ng, uint32_t B, uint32_t nwg) {
+  uint32_t best = 32, best_cost = 0xffffffffu;
+  for (uint32_t n = 16; n <= 96; n += 8) {
+    const uint32_t items = ng * ((B + n - 1) / n);
+    const uint32_t cost = ((items + nwg - 1) / nwg) * (n + 3);
+    if (cost <= best_cost) { best_cost = cost; best = n; }
+  }
+  return best;
+}
+
 // SPR: window starts of a group lie within SPR sites.  96 for large chunks (many reads per window
 // start: 1024 consecutive reads of the sorted order span few starts); 288 for small ones (the
 // reference's default --chunk-size 5000 puts ~2 reads on a start: a 96-site bucket holds ~180 reads,
@@ -508,10 +525,11 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
   double* accs = reinterpret_cast<double*>(smem + (size_t)TR2 * ROWL);  // [NB2_ACC][GQ2] / burst rows
   __shared__ uint32_t s_maxspan;
   __shared__ uint32_t s_qi[GQ2];        // query of thread t (burst write-out), ~0 = nothing to write
-  constexpr uint32_t NBP = ACC ? NB2_ACC : NB2;
   constexpr uint32_t BSTR = GQ2 + 4;    // burst staging rows 4 doubles apart in the banks: conflict-free
   // persistent grid over (group, branch tile) items of class 0, see k_preplace
-  const uint32_t ng = status[5], ntiles = (B + NBP - 1) / NBP;
+  const uint32_t ng = status[5];
+  const uint32_t NBP = ACC ? NB2_ACC : choose_tile(ng, B, gridDim.x);
+  const uint32_t ntiles = (B + NBP - 1) / NBP;
   const int t = threadIdx.x;
   const ItemWalk iw = item_walk(ng * ntiles);
   for (uint32_t item = iw.pos; item < iw.end; item += iw.step) {
@@ -739,10 +757,13 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
     const uint32_t* __restrict__ status, double* __restrict__ lnl) {
   constexpr uint32_t ROWB = NCOLS * 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [TROWS_S][NCOLS] doubles, then accs
-  double* accs = reinterpret_cast<double*>(smem + (size_t)TROWS_S * ROWB);  // [NB2_ACC][GQ2] (ACC only)
+  double* accs = reinterpret_cast<double*>(smem + (size_t)TROWS_S * ROWB);  // [NB2_ACC][GQ2] / burst rows
   __shared__ uint32_t s_maxspan;
-  constexpr uint32_t NBP = ACC ? NB2_ACC_S : NB2;
-  const uint32_t ng = status[5], ntiles = (B + NBP - 1) / NBP;
+  __shared__ uint32_t s_qi[GQ2];        // query of thread t (burst write-out), ~0 = nothing to write
+  constexpr uint32_t BSTR = GQ2 + 4;
+  const uint32_t ng = status[5];
+  const uint32_t NBP = ACC ? NB2_ACC_S : choose_tile(ng, B, gridDim.x);
+  const uint32_t ntiles = (B + NBP - 1) / NBP;
   const int t = threadIdx.x;
   auto at = [&](uint32_t off) -> double { return *reinterpret_cast<const double*>(smem + off); };
   const ItemWalk iw = item_walk(ng * ntiles);
@@ -761,6 +782,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
       if ((uint64_t)begin + span > W) span = 0;
     }
     if (t == 0) s_maxspan = 0;
+    s_qi[t] = (active && span > 0) ? qi : 0xffffffffu;
     __syncthreads();
     atomicMax(&s_maxspan, span);
     if (ACC) for (uint32_t j = 0; j < nb; ++j) accs[j * GQ2 + t] = 0.0;
@@ -864,15 +886,21 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
           if (ACC) {
             accs[j * GQ2 + t] = sum;
           } else {
-            // results leave in bursts of 8 consecutive branches (64 B per query, issued back to back
-            // so that L2 merges them into whole sectors): single 8-byte stores spread over the item
-            // were evicted sector by sector -- 1.76 GB written for a 0.41 GB table
-            accs[(j & 7u) * GQ2 + t] = sum;
-            if ((j & 7u) == 7u || j + 1 == nb) {
-              double* out = lnl + (size_t)qi * pitch + b0 + (j & ~7u);
-              for (uint32_t k = 0; k <= (j & 7u); ++k) out[k] = accs[k * GQ2 + t];
-            }
+            accs[(j & 7u) * BSTR + t] = sum;
           }
+        }
+        if (!ACC && ((j & 7u) == 7u || j + 1 == nb)) {
+          // bursts of 8 branches, eight lanes per query: whole 64-byte sectors (see k_preplace_pairs)
+          __builtin_amdgcn_wave_barrier();
+          const uint32_t lane = (uint32_t)t & 63u, wbase = (uint32_t)t & ~63u, col = lane & 7u;
+          const uint32_t ncol = (j & 7u) + 1u, bcol = b0 + (j & ~7u) + col;
+#pragma unroll
+          for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t tq = wbase + k * 8 + (lane >> 3);
+            const uint32_t q = s_qi[tq];
+            if (q != 0xffffffffu && col < ncol) lnl[(size_t)q * pitch + bcol] = accs[col * BSTR + tq];
+          }
+          __builtin_amdgcn_wave_barrier();
         }
       }
     }
@@ -1264,7 +1292,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   // max_span: upper bound of the window spans when the caller knows it (0 = unknown) -> acc, above
   const size_t lds = sizeof(double) * ((size_t)TROWS * ctx->ncols + (acc ? (size_t)NB * GQ : 0));
   const size_t lds2 = (size_t)TROWS2 * rowl + sizeof(double) * (acc ? NB2_ACC * GQ2 : NB2_BURST * (GQ2 + 4));  // accs / result staging
-  const uint32_t ntiles2 = (ctx->B + (acc ? NB2_ACC : NB2) - 1) / (acc ? NB2_ACC : NB2);
+  const uint32_t ntiles2 = (ctx->B + (acc ? NB2_ACC : 16) - 1) / (acc ? NB2_ACC : 16);   // single chunk: choose_tile, >= 16
   const dim3 grid2((uint32_t)std::min<uint64_t>((uint64_t)max_groups * ntiles2, (uint64_t)ctx->n_cu));  // 1 per CU
   // generic kernel: with the pair path on it only sees the few groups of queries with rare
   // ambiguity codes -> persistent grid; as the only kernel (20 states) one workgroup per item,
@@ -1290,8 +1318,8 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
 #undef PRE2
   if (sites) {
     const bool acc_s = max_span == 0 || max_span > (uint32_t)CHS || getenv("EPA_PREPLACE_ACC");
-    const size_t lds_s = (size_t)TROWS_S * 24 * 8 + sizeof(double) * (acc_s ? NB2_ACC_S : NB2_BURST) * GQ2;  // accs / result staging
-    const uint32_t ntiles_s = (ctx->B + (acc_s ? NB2_ACC_S : NB2) - 1) / (acc_s ? NB2_ACC_S : NB2);
+    const size_t lds_s = (size_t)TROWS_S * 24 * 8 + sizeof(double) * (acc_s ? NB2_ACC_S * GQ2 : NB2_BURST * (GQ2 + 4));  // accs / result staging
+    const uint32_t ntiles_s = (ctx->B + (acc_s ? NB2_ACC_S : 16) - 1) / (acc_s ? NB2_ACC_S : 16);
     const dim3 grid_s((uint32_t)std::min<uint64_t>((uint64_t)max_groups * ntiles_s, (uint64_t)ctx->n_cu));
 #define PRES(A)                                                                                      \
   do {                                                                                               \
