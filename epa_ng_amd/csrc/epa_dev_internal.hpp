@@ -64,6 +64,8 @@ struct SelectPending {
   const uint32_t* d_span = nullptr;
   unsigned long long *stage = nullptr, *keys_a = nullptr, *keys_b = nullptr;
   uint32_t *counts = nullptr, *offsets = nullptr;
+  uint32_t *bitmap = nullptr, *boffs = nullptr;   // bitmap form of the selection (preplace.hip, SelOut)
+  uint32_t wpr = 0;
   void* temp = nullptr;
   size_t sort_bytes = 0;
   uint32_t* rb = nullptr;   // host read-back block, 64 words

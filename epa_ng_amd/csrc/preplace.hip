@@ -1004,6 +1004,30 @@ __device__ __forceinline__ double wave_add(double v) {
 //   2 baseball  every branch within 3.0 lnL of the best ("strike box"), plus min(40 - hits, 6)
 //               more -- 6 when more than 40 were hit: the reference's unsigned wrap-around
 //               (src/core/heuristics.hpp:70-117; quirk D7: clamped at B)
+// Where a selected (query, branch) goes.  Bitmap form (the usual one): bit q of row b of a
+// [B][ceil(Q / 32)] bitmap plus a per-branch counter -- the candidate list in the reference's Work
+// order (branch-major, queries ascending: src/core/Work.hpp:21-113) is then one scan over the B
+// counters and one pass over the bitmap (k_emit_pairs), no per-query staging rows, no compaction, no
+// device sort.  Staging form (bitmap over 64 MB): key (branch << 32 | query) in stage[q][0..cap).
+struct SelOut {
+  unsigned long long* stage;
+  uint32_t cap;
+  uint32_t* bitmap;
+  uint32_t* bcount;
+  uint32_t wpr;     // bitmap words per branch row
+  __device__ __forceinline__ void put(uint32_t q, uint32_t bi, uint32_t taken, uint32_t* status) const {
+    if (bitmap) {
+      atomicOr(&bitmap[(size_t)bi * wpr + (q >> 5)], 1u << (q & 31u));
+      atomicAdd(&bcount[bi], 1u);
+    } else if (taken < cap) {
+      stage[(size_t)q * cap + taken] = ((unsigned long long)bi << 32) | q;
+    } else {
+      atomicMax(&status[2], taken + 1);  // staging row too short: caller retries wider
+    }
+  }
+  __device__ __forceinline__ uint32_t count(uint32_t taken) const { return bitmap ? taken : min(taken, cap); }
+};
+
 struct SelRule {
   int mode;
   double thr;
@@ -1034,8 +1058,7 @@ struct SelRule {
 
 template <int NR>
 __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, uint32_t Q, uint32_t B, uint32_t pitch,
-                                                double threshold, int mode, uint32_t limit, uint32_t cap,
-                                                unsigned long long* __restrict__ stage,
+                                                double threshold, int mode, uint32_t limit, SelOut so,
                                                 uint32_t* __restrict__ counts,
                                                 uint32_t* __restrict__ status) {
   const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1059,7 +1082,6 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
   tot = epa_wave::wave_sum(tot);
   SelRule rule(mode, threshold, limit);
   uint32_t taken = 0;
-  unsigned long long* out = stage + (size_t)q * cap;
   while (rule.more(taken, B)) {
     double lbest = -INFINITY;
     uint32_t lbi = 0xffffffffu;
@@ -1074,13 +1096,10 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
 #pragma unroll
     for (int r = 0; r < NR; ++r)
       if ((uint32_t)(r * 64 + lane) == bi) v[r] = -INFINITY;
-    if (lane == 0) {
-      if (taken < cap) out[taken] = ((unsigned long long)bi << 32) | q;
-      else atomicMax(&status[2], taken + 1);  // staging row too short: caller retries wider
-    }
+    if (lane == 0) so.put(q, bi, taken, status);
     ++taken;
   }
-  if (lane == 0) counts[q] = min(taken, cap);
+  if (lane == 0) counts[q] = so.count(taken);
 }
 
 // Same selection, workgroup per query (4 waves): the row of up to 256 x NRT branches lives in the
@@ -1089,8 +1108,7 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
 // through LDS.  Used for 4096 < B <= 16384.
 template <int NRT>
 __global__ void __launch_bounds__(256) k_select_wg(const double* __restrict__ lnl, uint32_t Q, uint32_t B, uint32_t pitch,
-                                                   double threshold, int mode, uint32_t limit, uint32_t cap,
-                                                   unsigned long long* __restrict__ stage,
+                                                   double threshold, int mode, uint32_t limit, SelOut so,
                                                    uint32_t* __restrict__ counts,
                                                    uint32_t* __restrict__ status) {
   __shared__ double s_val[2][4];
@@ -1126,7 +1144,6 @@ __global__ void __launch_bounds__(256) k_select_wg(const double* __restrict__ ln
   ph ^= 1;
   SelRule rule(mode, threshold, limit);
   uint32_t taken = 0;
-  unsigned long long* out = stage + (size_t)q * cap;
   while (rule.more(taken, B)) {
     double best = -INFINITY;
     uint32_t bi = 0xffffffffu;
@@ -1155,13 +1172,10 @@ __global__ void __launch_bounds__(256) k_select_wg(const double* __restrict__ ln
 #pragma unroll
     for (int r = 0; r < NRT; ++r)
       if ((uint32_t)(r * 256) + t == bi) v[r] = -INFINITY;
-    if (t == 0) {
-      if (taken < cap) out[taken] = ((unsigned long long)bi << 32) | q;
-      else atomicMax(&status[2], taken + 1);
-    }
+    if (t == 0) so.put(q, bi, taken, status);
     ++taken;
   }
-  if (t == 0) counts[q] = min(taken, cap);
+  if (t == 0) counts[q] = so.count(taken);
 }
 
 // Same selection for references with more than 16384 branches: the row does not fit the register
@@ -1170,8 +1184,7 @@ __global__ void __launch_bounds__(256) k_select_wg(const double* __restrict__ ln
 // (element i lives in lane i % 64, bit i / 64; up to 64 x 64 x NW branches).
 template <int NW>
 __global__ void __launch_bounds__(256) k_select_big(const double* __restrict__ lnl, uint32_t Q, uint32_t B, uint32_t pitch,
-                                                    double threshold, int mode, uint32_t limit, uint32_t cap,
-                                                    unsigned long long* __restrict__ stage,
+                                                    double threshold, int mode, uint32_t limit, SelOut so,
                                                     uint32_t* __restrict__ counts,
                                                     uint32_t* __restrict__ status) {
   const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1189,7 +1202,6 @@ __global__ void __launch_bounds__(256) k_select_big(const double* __restrict__ l
   tot = wave_add(tot);
   SelRule rule(mode, threshold, limit);
   uint32_t taken = 0;
-  unsigned long long* out = stage + (size_t)q * cap;
   while (rule.more(taken, B)) {
     double best = -INFINITY;
     uint32_t bi = 0xffffffffu;
@@ -1212,13 +1224,10 @@ __global__ void __launch_bounds__(256) k_select_big(const double* __restrict__ l
       for (int w = 0; w < NW; ++w)
         if ((uint32_t)w == (r >> 6)) takenmask[w] |= 1ull << (r & 63);
     }
-    if (lane == 0) {
-      if (taken < cap) out[taken] = ((unsigned long long)bi << 32) | q;
-      else atomicMax(&status[2], taken + 1);
-    }
+    if (lane == 0) so.put(q, bi, taken, status);
     ++taken;
   }
-  if (lane == 0) counts[q] = min(taken, cap);
+  if (lane == 0) counts[q] = so.count(taken);
 }
 
 // span-class histogram of the selected pairs: sum of the per-query candidate counts by the class
@@ -1259,6 +1268,49 @@ __global__ void __launch_bounds__(256) k_compact(const unsigned long long* __res
   if (q >= Q) return;
   const uint32_t n = counts[q], o = offsets[q];
   for (uint32_t i = lane; i < n; i += 64) keys[o + i] = stage[(size_t)q * cap + i];
+}
+
+// Bitmap form of the selection: workgroup b walks row b of the bitmap in chunks of 256 words and
+// writes the set bits -- queries ascending -- as pairs behind boffs[b] (exclusive scan of the per-
+// branch counters): the candidate list in (branch, query) order.
+__global__ void __launch_bounds__(256) k_emit_pairs(const uint32_t* __restrict__ bitmap, uint32_t wpr,
+                                                    const uint32_t* __restrict__ boffs,
+                                                    epa_pair* __restrict__ pairs) {
+  __shared__ uint32_t wsum[4];
+  const uint32_t b = blockIdx.x, t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+  uint32_t base = boffs[b];
+  const uint32_t end = boffs[b + 1];
+  if (base == end) return;
+  const uint32_t* row = bitmap + (size_t)b * wpr;
+  for (uint32_t w0 = 0; w0 < wpr && base < end; w0 += 256) {
+    const uint32_t wi = w0 + t;
+    uint32_t bits = wi < wpr ? row[wi] : 0u;
+    const uint32_t c = (uint32_t)__popc(bits);
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(inc, o);
+      if ((int)lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) {
+      if (w < wv) before += wsum[w];
+      total += wsum[w];
+    }
+    uint32_t o = base + before + inc - c;
+    while (bits) {
+      const uint32_t k = (uint32_t)__ffs((int)bits) - 1u;
+      bits &= bits - 1u;
+      pairs[o].branch_id = b;
+      pairs[o].seq_id = wi * 32u + k;
+      ++o;
+    }
+    base += total;
+    __syncthreads();
+  }
 }
 
 __global__ void k_keys_to_pairs(const unsigned long long* __restrict__ keys, uint64_t n,
@@ -1463,6 +1515,47 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
   const size_t worst = std::min<uint64_t>(max_pairs, (uint64_t)Q * cap);
   (void)rocprim::radix_sort_keys<epa_radix_cfg>(nullptr, sort_bytes, (unsigned long long*)nullptr,
                                  (unsigned long long*)nullptr, worst, 0, 64, ctx->stream);
+  // Bitmap form (SelOut): [status 512 B | branch counters B+1 | bitmap B x wpr | counts Q+1]
+  const uint32_t wpr = (Q + 31) / 32;
+  static const bool force_sort = getenv("EPA_SELECT_SORT") != nullptr;
+  const bool bm = !force_sort && (size_t)B * wpr * sizeof(uint32_t) <= ((size_t)64 << 20);
+  sp->bitmap = nullptr;
+  if (bm) {
+    const size_t cb = align256(sizeof(uint32_t) * ((size_t)B + 1));
+    const size_t mb = align256(sizeof(uint32_t) * (size_t)B * wpr);
+    const size_t qb2 = align256(sizeof(uint32_t) * (Q + 1));
+    char* base = (char*)epa_scratch(ctx, 7, 512 + cb + mb + qb2);
+    if (!base) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(select scratch)");
+    uint32_t* status = reinterpret_cast<uint32_t*>(base);
+    uint32_t* bcount = reinterpret_cast<uint32_t*>(base + 512);
+    uint32_t* bitmap = reinterpret_cast<uint32_t*>(base + 512 + cb);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(base + 512 + cb + mb);
+    sp->bitmap = bitmap; sp->boffs = bcount; sp->wpr = wpr;
+    sp->counts = counts; sp->offsets = nullptr;
+    sp->d_lnl = d_lnl; sp->Q = Q; sp->threshold = threshold; sp->d_pairs = d_pairs; sp->max_pairs = max_pairs;
+    sp->d_span = d_span; sp->cap = cap; sp->rb = rb;
+    EPA_HIP(ctx, hipMemsetAsync(base, 0, 512 + cb + mb, ctx->stream));   // status, counters, bitmap: one fill
+    epa_timer_start(ctx, ctx->t_select);
+    const SelOut so{nullptr, 0u, bitmap, bcount, wpr};
+    const dim3 grid((Q + 3) / 4);
+    const int nr = (int)((B + 63) / 64);
+#define SEL(N) hipLaunchKernelGGL(k_select<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status)
+    if (nr <= 2) SEL(2); else if (nr <= 4) SEL(4); else if (nr <= 8) SEL(8); else if (nr <= 16) SEL(16);
+    else if (nr <= 32) SEL(32); else if (nr <= 64) SEL(64);
+    else if (nr <= 128) hipLaunchKernelGGL(k_select_wg<32>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status);
+    else if (nr <= 256) hipLaunchKernelGGL(k_select_wg<64>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status);
+    else hipLaunchKernelGGL(k_select_big<16>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status);
+#undef SEL
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, bcount, B + 1);   // bcount[B] = total
+    if (d_span)
+      hipLaunchKernelGGL(k_class_hist, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, counts, d_span, Q,
+                         ctx->s, status + 8);
+    hipLaunchKernelGGL(k_pack_readback, dim3(1), dim3(64), 0, ctx->stream, status, bcount + B,
+                       (const uint32_t*)ctx->d_status, status + 64);
+    EPA_HIP(ctx, hipMemcpyAsync(rb, status + 64, sizeof(uint32_t) * 36, hipMemcpyDeviceToHost, ctx->stream));
+    sp->have_status = ctx->d_status != nullptr;
+    return EPA_OK;
+  }
   // scratch 7: [status 512 B | counts Q+1 | offsets Q+1 | stage Q*cap | keys_a worst | keys_b worst | temp]
   // status words [0, 8 + EPA_N_CLS): selection status + class histogram; [64, 128): the packed read-back block
   const size_t qb = align256(sizeof(uint32_t) * (Q + 1));
@@ -1488,13 +1581,13 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
   epa_timer_start(ctx, ctx->t_select);
   const dim3 grid((Q + 3) / 4);
   const int nr = (int)((B + 63) / 64);
-  unsigned long long* stage = sp->stage;
-#define SEL(N) hipLaunchKernelGGL(k_select<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, cap, stage, counts, status)
-#define SELBIG(N) hipLaunchKernelGGL(k_select_big<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, cap, stage, counts, status)
+  const SelOut so{sp->stage, cap, nullptr, nullptr, 0u};
+#define SEL(N) hipLaunchKernelGGL(k_select<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status)
+#define SELBIG(N) hipLaunchKernelGGL(k_select_big<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status)
   if (nr <= 2) SEL(2); else if (nr <= 4) SEL(4); else if (nr <= 8) SEL(8); else if (nr <= 16) SEL(16);
   else if (nr <= 32) SEL(32); else if (nr <= 64) SEL(64);
-  else if (nr <= 128) hipLaunchKernelGGL(k_select_wg<32>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, cap, stage, counts, status);
-  else if (nr <= 256) hipLaunchKernelGGL(k_select_wg<64>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, cap, stage, counts, status);
+  else if (nr <= 128) hipLaunchKernelGGL(k_select_wg<32>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status);
+  else if (nr <= 256) hipLaunchKernelGGL(k_select_wg<64>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status);
   else SELBIG(16);
 #undef SELBIG
 #undef SEL
@@ -1518,7 +1611,7 @@ int launch_select_end(epa_ctx* ctx, SelectPending* sp, uint64_t* n_pairs) {
     EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t total = sp->rb[0];
     const uint32_t* hst = sp->rb + 1;
-    if (hst[2]) {  // some query selected more candidates than the staging row holds: widen, redo
+    if (hst[2] && !sp->bitmap) {  // some query selected more candidates than the staging row holds: widen, redo
       if (sp->cap >= B) return epa_fail(ctx, EPA_ERR_HIP, "select_candidates: staging overflow");
       ctx->select_cap = std::min<uint32_t>(B, std::max(sp->cap * 4, hst[2]));
       uint32_t* rb = sp->rb;
@@ -1529,7 +1622,9 @@ int launch_select_end(epa_ctx* ctx, SelectPending* sp, uint64_t* n_pairs) {
     if (total > sp->max_pairs)
       return epa_fail(ctx, EPA_ERR_PAIR_OVERFLOW,
                       "select_candidates: " + std::to_string(total) + " candidates exceed max_pairs");
-    if (total) {
+    if (total && sp->bitmap) {
+      hipLaunchKernelGGL(k_emit_pairs, dim3(B), dim3(256), 0, ctx->stream, sp->bitmap, sp->wpr, sp->boffs, sp->d_pairs);
+    } else if (total) {
       const dim3 grid((Q + 3) / 4);
       hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, ctx->stream, sp->stage, sp->counts, sp->offsets, Q, sp->cap,
                          sp->keys_a);
