@@ -78,11 +78,18 @@ __global__ void k_iota(uint32_t* v, uint32_t n) {
 }
 
 // Counting sort of the queries by their grouping key (the fast paths; K = key space, a few thousand
-// values): the pack kernels count every key and keep each query's arrival rank, one workgroup turns
+// values): a kernel counts every key and keeps each query's arrival rank, one workgroup turns
 // the counts into offsets, a scatter writes (sorted_keys, perm).  Three short kernels instead of the
 // ten launches of a two-pass device radix sort with its histogram fills (~75 us per chunk, the same for
 // 5 000 reads as for 100 000).  The order of equal keys is arrival order: which lane of a group a
 // query lands on varies from run to run, its sums do not.
+// one thread per query: its key's count, the old value = the query's rank among equal keys (in the
+// pack kernels, one returning atomic per WAVE, the same 100k atomics cost 50 us instead of 5)
+__global__ void __launch_bounds__(256) k_count_keys(const uint32_t* __restrict__ keys, uint32_t Q,
+                                                    uint32_t* __restrict__ cnt, uint32_t* __restrict__ rank) {
+  const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q < Q) rank[q] = atomicAdd(&cnt[keys[q]], 1u);
+}
 __global__ void __launch_bounds__(1024) k_scan_counts(uint32_t* __restrict__ cnt, uint32_t K) {
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t carry_s;
@@ -485,9 +492,7 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
                                                     uint32_t span_bound, uint32_t Wp, uint32_t NP16,
                                                     uint32_t rowl, uint16_t* __restrict__ packed,
                                                     uint16_t* __restrict__ tails,
-                                                    uint32_t* __restrict__ keys,
-                                                    uint32_t* __restrict__ cnt, uint32_t K,
-                                                    uint32_t* __restrict__ rank,
+                                                    uint32_t* __restrict__ keys, uint32_t K,
                                                     uint32_t* __restrict__ status) {
   const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63;
@@ -527,7 +532,6 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
   if (lane == 0) {   // an invalid window start (flagged above) must not leave the key space
     const uint32_t key = min((any_rare ? 2 * Wp : 0) + (begin & 1u) * Wp + min(begin, Wp - 1), K - 1);
     keys[q] = key;
-    rank[q] = atomicAdd(&cnt[key], 1u);
   }
 }
 
@@ -782,9 +786,7 @@ __global__ void __launch_bounds__(256) k_pack_sites(const uint8_t* __restrict__ 
                                                     uint32_t span_bound, uint32_t NP16,
                                                     uint16_t* __restrict__ packed,
                                                     uint16_t* __restrict__ tails,
-                                                    uint32_t* __restrict__ keys,
-                                                    uint32_t* __restrict__ cnt, uint32_t K,
-                                                    uint32_t* __restrict__ rank,
+                                                    uint32_t* __restrict__ keys, uint32_t K,
                                                     uint32_t* __restrict__ status) {
   const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
   const uint32_t lane = threadIdx.x & 63;
@@ -811,7 +813,6 @@ __global__ void __launch_bounds__(256) k_pack_sites(const uint8_t* __restrict__ 
   if (lane == 0) {
     const uint32_t key = min(begin, K - 1);
     keys[q] = key;
-    rank[q] = atomicAdd(&cnt[key], 1u);
   }
 }
 
@@ -1384,14 +1385,13 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   const uint32_t rowl = (wide || acc) ? ROWL_PACKED : ROWL_NARROW;  // LDS row stride the 16-bit offsets are built for
   if (pairs) {
     hipLaunchKernelGGL(k_pack_pairs, dim3((Q + 3) / 4), dim3(256), 0, ctx->stream, d_codes, d_begin,
-                       d_span, Q, ctx->W, cstride, crel, span_bound, Wp, NP16, rowl, packed, tails, keys, key_cnt, K,
-                       iota, status);
+                       d_span, Q, ctx->W, cstride, crel, span_bound, Wp, NP16, rowl, packed, tails, keys, K, status);
   } else if (sites) {
     hipLaunchKernelGGL(k_pack_sites<24>, dim3((Q + 3) / 4), dim3(256), 0, ctx->stream, d_codes, d_begin,
-                       d_span, Q, ctx->W, cstride, crel, span_bound, NP16, packed, tails, keys, key_cnt, K, iota,
-                       status);
+                       d_span, Q, ctx->W, cstride, crel, span_bound, NP16, packed, tails, keys, K, status);
   }
   if (pairs || sites) {
+    hipLaunchKernelGGL(k_count_keys, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, keys, Q, key_cnt, iota);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, key_cnt, K);
     hipLaunchKernelGGL(k_scatter_sorted, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, keys, iota, key_cnt, Q,
                        sorted_keys, perm);
