@@ -51,7 +51,7 @@ def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--warmup", type=int, default=5)   # the first launches run ~20 % slower (clocks, TLB): profiles/r3 timeline
     p.add_argument("--chunk", type=int, default=100000,
                    help="reads per step (EPA-ng --chunk-size; default = the whole cfg2 query set)")
     p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
@@ -227,85 +227,91 @@ def main():
     rows_cap = min(cap, 4 * max(Q, 1))
     exch = parallel.AsyncResultGather(dist, rows_cap, dev) if world > 1 else None
 
-    def step_resident(i, record):
-        dc, dwb, dws = dev_chunks[i % n_chunks]
-        # one fused call = the reference's chunk body: place() -> apply_heuristic() -> place_thorough()
-        n = ev.place_chunk(dc, dwb, dws, Q=Q, threshold=0.99999, max_span=a.read_len, max_pairs=cap,
-                           pairs_out=d_pairs, results_out=d_res) if Q else 0
-        if world > 1:
-            # the path's only exchange: every rank's candidate placements -> rank 0 (RCCL over
-            # xGMI; the reference gathers jplace byte ranges, src/io/jplace_writer.hpp:117-129).
-            # Posted asynchronously: it overlaps the next chunk's kernels (parallel.py).
-            exch.post(d_pairs, d_res, n)
-        if record and Q:
-            th_ms.append(ev.kernel_ms("thorough")); pre_ms.append(ev.kernel_ms("preplace"))
-            sel_ms.append(ev.kernel_ms("select"))
-            th_pairs.append(n); th_rounds.append(ev.last_stats["rounds"])
-            th_evals.append(ev.last_stats["newton_evals"])
-        return n
-
-    fin_resident = (lambda: exch.finish()) if world > 1 else (lambda: None)
-    elapsed = timed(step_resident, fin_resident, "resident")
-
-    # ---------------- loop 2: PCIe inside the step, overlapped on the copy stream
-    exch2 = parallel.AsyncResultGather(dist, rows_cap, dev, host_copy=True) if world > 1 else None
-    state = {"staged": None, "inflight": None, "bytes_up": 0, "bytes_down": 0,
-             "t_stage": 0.0, "t_launch": 0.0, "t_end": 0.0, "t_finish": 0.0, "timed": False}
+    # Both loops run the library's two-slot chunk pipeline in the same host order,
+    #     launch_begin(i); finish(i-1); stage(i+1); launch_end(i)
+    # (begin queues preplacement + selection and returns; the previous chunk is retired and the next
+    # one staged while they run; end waits for the candidate count and queues the Newton kernels).
+    # Loop 1 stages HBM-resident chunks (read in place, results stay in HBM: the contract's `value`),
+    # loop 2 host chunks (H2D of the 4-bit codes + D2H of pairs / results inside the clock).  A
+    # plain place_chunk() per step measures the same kernels plus one exposed host round trip between
+    # steps (exp/pcie_probe.py: 6.90 vs 6.84 ms per step).
     bufs = [(d_pairs, d_res), (torch.empty_like(d_pairs), torch.empty_like(d_res))]
 
-    def stage(i):
-        _, hb, hs, wire = host_chunks[i % n_chunks]
-        t = time.perf_counter()
-        ev.chunk_stage(i & 1, wire, hb, hs)                  # host -> pinned -> async H2D (copy stream)
-        state["t_stage"] += (time.perf_counter() - t) if i > a.warmup else 0.0   # timed steps only
-        state["staged"] = i
-        state["bytes_up"] += (wire.data if isinstance(wire, epa.Packed4) else wire).nbytes + 8 * Q
+    def make_loop(resident, gather):
+        st = {"staged": None, "inflight": None, "rec": False, "bytes_up": 0, "bytes_down": 0,
+              "t_stage": 0.0, "t_launch": 0.0, "t_end": 0.0, "t_finish": 0.0, "timed": False}
 
-    def retire(slot):
-        t = time.perf_counter()
-        if world > 1:
-            n = ev.chunk_finish_device(slot)
-            exch2.post(bufs[slot][0], bufs[slot][1], n)     # gather to rank 0, which copies it to the host
-        else:
-            p, r = ev.chunk_finish(slot, copy=False)        # views of the slot's pinned host buffer
-            n = len(p)
-        state["t_finish"] += (time.perf_counter() - t) if state["timed"] else 0.0
-        state["bytes_down"] += n * 32
-        state["inflight"] = None
+        def stage(i):
+            t = time.perf_counter()
+            if resident:
+                dc, dwb, dws = dev_chunks[i % n_chunks]
+                ev.chunk_stage(i & 1, dc, dwb, dws)              # HBM-resident: read in place, no copy
+            else:
+                _, hb, hs, wire = host_chunks[i % n_chunks]
+                ev.chunk_stage(i & 1, wire, hb, hs)              # host -> pinned -> async H2D (copy stream)
+                st["bytes_up"] += (wire.data if isinstance(wire, epa.Packed4) else wire).nbytes + 8 * Q
+            st["t_stage"] += (time.perf_counter() - t) if i > a.warmup else 0.0   # timed steps only
+            st["staged"] = i
 
-    def step_pcie(i, record):
-        if not Q:
+        def retire(slot):
+            t = time.perf_counter()
+            if resident or world > 1:
+                n = ev.chunk_finish_device(slot)
+                if world > 1:
+                    # the path's only exchange: every rank's candidate placements -> rank 0 (RCCL over
+                    # xGMI; the reference gathers jplace byte ranges, src/io/jplace_writer.hpp:117-129).
+                    # Posted asynchronously: it overlaps the next chunk's kernels (parallel.py).
+                    gather.post(bufs[slot][0], bufs[slot][1], n)
+            else:
+                p, r = ev.chunk_finish(slot, copy=False)        # views of the slot's pinned host buffer
+                n = len(p)
+            st["t_finish"] += (time.perf_counter() - t) if st["timed"] else 0.0
+            st["bytes_down"] += n * 32
+            if st["rec"]:                                        # the retired chunk's Newton kernel
+                th_ms.append(ev.kernel_ms("thorough")); th_pairs.append(n)
+                th_rounds.append(ev.last_stats["rounds"]); th_evals.append(ev.last_stats["newton_evals"])
+            st["inflight"] = None
+
+        def step(i, record):
+            if not Q:
+                if world > 1:
+                    gather.post(d_pairs, d_res, 0)
+                return
+            slot = i & 1
+            if st["staged"] != i:                                # first step of a loop: nothing prefetched
+                stage(i)
+            kw = dict(pairs_out=bufs[slot][0], results_out=bufs[slot][1], keep_on_device=True) if (resident or world > 1) else {}
+            t = time.perf_counter()
+            ev.chunk_launch_begin(slot, threshold=0.99999, max_span=a.read_len, max_pairs=cap, **kw)
+            st["t_launch"] += (time.perf_counter() - t) if i >= a.warmup else 0.0
+            if st["inflight"] is not None:                       # previous chunk: D2H / gather behind its Newton kernel
+                retire(st["inflight"])
+            st["timed"] = i > a.warmup
+            if i + 1 < n_steps and i + 1 != a.warmup:            # next chunk under this one's kernels
+                stage(i + 1)                                     # (never across the warmup / timed boundary)
+            t = time.perf_counter()
+            ev.chunk_launch_end(slot)
+            st["t_end"] += (time.perf_counter() - t) if i >= a.warmup else 0.0
+            if record and resident:                              # this chunk's preplacement + selection are complete
+                pre_ms.append(ev.kernel_ms("preplace")); sel_ms.append(ev.kernel_ms("select"))
+            st["rec"] = bool(record and resident)
+            st["inflight"] = slot
+
+        def finish():
+            if st["inflight"] is not None:
+                retire(st["inflight"])
+            st["rec"] = False
             if world > 1:
-                exch2.post(d_pairs, d_res, 0)
-            return
-        slot = i & 1
-        if state["staged"] != i:                             # first step of a loop: nothing prefetched
-            stage(i)
-        kw = dict(pairs_out=bufs[slot][0], results_out=bufs[slot][1], keep_on_device=True) if world > 1 else {}
-        # The order of the calls is the library's launch in two halves: begin(i) queues unpack +
-        # preplacement + selection and returns at once; the previous chunk is retired and the next
-        # one uploaded while they run; end(i) waits for the candidate count and queues the Newton
-        # kernels + the result D2H.  (launch(i) whole, then retire / stage: 7.29 against 6.92 ms per
-        # step on one box -- exp/pcie_probe.py.)
-        t = time.perf_counter()
-        ev.chunk_launch_begin(slot, threshold=0.99999, max_span=a.read_len, max_pairs=cap, **kw)
-        state["t_launch"] += (time.perf_counter() - t) if i >= a.warmup else 0.0
-        if state["inflight"] is not None:                    # previous chunk: D2H behind its Newton kernel
-            retire(state["inflight"])
-        state["timed"] = i > a.warmup
-        if i + 1 < n_steps and i + 1 != a.warmup:            # upload of the next chunk under this one's kernels
-            stage(i + 1)                                     # (never across the warmup / timed boundary)
-        t = time.perf_counter()
-        ev.chunk_launch_end(slot)
-        state["t_end"] += (time.perf_counter() - t) if i >= a.warmup else 0.0
-        state["inflight"] = slot
+                gather.finish()
 
-    def finish_pcie():
-        if state["inflight"] is not None:
-            retire(state["inflight"])
-        if world > 1:
-            exch2.finish()
+        return st, step, finish
 
+    _, step_resident, fin_resident = make_loop(True, exch)
+    elapsed = timed(step_resident, fin_resident, "resident")
+
+    # ---------------- loop 2: PCIe inside the step, overlapped on the copy streams
+    exch2 = parallel.AsyncResultGather(dist, rows_cap, dev, host_copy=True) if world > 1 else None
+    state, step_pcie, finish_pcie = make_loop(False, exch2)
     elapsed_pcie = timed(step_pcie, finish_pcie, "pcie")
 
     # ---------------- the fixed-size job of BASELINE configs[3] (cfg4: 10^7 reads) on these N GPUs:

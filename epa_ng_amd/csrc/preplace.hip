@@ -494,42 +494,45 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
                                                     uint16_t* __restrict__ tails,
                                                     uint32_t* __restrict__ keys, uint32_t K,
                                                     uint32_t* __restrict__ status) {
-  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const uint32_t lane = threadIdx.x & 63;
-  if (q >= Q) return;
-  const uint32_t begin = win_begin[q];
-  uint32_t span = win_span[q];
+  // sixteen lanes per query, four queries per wave: the kernel is a chain of three dependent memory
+  // round trips (window, codes, store) with little work between them -- a wave per query was 100k
+  // waves of it, 65 us per 100k reads
+  const uint32_t q = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + ((threadIdx.x >> 4) & 3u);
+  const uint32_t l16 = threadIdx.x & 15, grp = (threadIdx.x >> 4) & 3u;
+  const bool live = q < Q;
+  const uint32_t begin = live ? win_begin[q] : 0u;
+  uint32_t span = live ? win_span[q] : 0u;
   // a window longer than the caller's max_span (or than a compact row) is an input error: the
   // kernel variant and the packed rows were sized by it
   const uint32_t cmax = min(span_bound, crel ? cstride : 0xffffffffu);
-  if (lane == 0) validate_window(q, begin, span, W, cmax, status);
+  if (live && l16 == 0) validate_window(q, begin, span, W, cmax, status);
   if ((uint64_t)begin + span > W || span > cmax) span = 0;  // invalid window (flagged above)
-  const uint8_t* c = codes + (size_t)q * cstride + (crel ? 0u : begin);
+  const uint8_t* c = codes + (size_t)(live ? q : 0u) * cstride + (crel ? 0u : begin);
   const uint32_t nfull = span >> 2, ntail = span & 3, npairs = 2 * nfull;
   bool rare = false;
-  for (uint32_t p = lane; p < NP16; p += 64) {
+  for (uint32_t p = l16; p < NP16; p += 16) {
     uint32_t v = ZERO_OFF;
     if (p < npairs) {
       const uint32_t s0 = dna_sym(c[2 * p]), s1 = dna_sym(c[2 * p + 1]);
       rare |= (s0 > 4) | (s1 > 4);
       v = (p % CP) * rowl + pair_entry(min(s0, 5u), min(s1, 5u)) * 8;
     }
-    packed[(size_t)q * NP16 + p] = (uint16_t)v;
+    if (live) packed[(size_t)q * NP16 + p] = (uint16_t)v;
   }
-  if (lane < 4) {
+  if (l16 < 4) {
     uint32_t v = ZERO_OFF;
-    if (lane < ntail) {
-      uint32_t sy = dna_sym(c[4 * nfull + lane]);
+    if (l16 < ntail) {
+      uint32_t sy = dna_sym(c[4 * nfull + l16]);
       rare |= sy > 4;
       sy = min(sy, 5u);
       const uint32_t kt = npairs % CP;  // row of the first tail site inside its chunk (even)
-      const uint32_t e = lane == 1 ? pair_entry(5, sy) : pair_entry(sy, 5);
-      v = (kt + (lane == 2 ? 1u : 0u)) * rowl + e * 8;
+      const uint32_t e = l16 == 1 ? pair_entry(5, sy) : pair_entry(sy, 5);
+      v = (kt + (l16 == 2 ? 1u : 0u)) * rowl + e * 8;
     }
-    tails[(size_t)q * 4 + lane] = (uint16_t)v;
+    if (live) tails[(size_t)q * 4 + l16] = (uint16_t)v;
   }
-  const bool any_rare = __ballot(rare) != 0ull;
-  if (lane == 0) {   // an invalid window start (flagged above) must not leave the key space
+  const bool any_rare = ((__ballot(rare) >> (16 * grp)) & 0xffffull) != 0ull;
+  if (live && l16 == 0) {   // an invalid window start (flagged above) must not leave the key space
     const uint32_t key = min((any_rare ? 2 * Wp : 0) + (begin & 1u) * Wp + min(begin, Wp - 1), K - 1);
     keys[q] = key;
   }
@@ -1384,7 +1387,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   const bool wide = pairs && !acc && !narrow_only && (uint64_t)Q * SPREAD < (uint64_t)1400 * ctx->W;   // < ~700 reads per 96-site bucket and parity
   const uint32_t rowl = (wide || acc) ? ROWL_PACKED : ROWL_NARROW;  // LDS row stride the 16-bit offsets are built for
   if (pairs) {
-    hipLaunchKernelGGL(k_pack_pairs, dim3((Q + 3) / 4), dim3(256), 0, ctx->stream, d_codes, d_begin,
+    hipLaunchKernelGGL(k_pack_pairs, dim3((Q + 15) / 16), dim3(256), 0, ctx->stream, d_codes, d_begin,
                        d_span, Q, ctx->W, cstride, crel, span_bound, Wp, NP16, rowl, packed, tails, keys, K, status);
   } else if (sites) {
     hipLaunchKernelGGL(k_pack_sites<24>, dim3((Q + 3) / 4), dim3(256), 0, ctx->stream, d_codes, d_begin,
