@@ -1384,7 +1384,7 @@ extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const u
 // ---------------------------------------------------------------------------------------------
 static int slot_of(epa_ctx* ctx, int slot, ChunkSlot** out) {
   if (!ctx) return EPA_ERR_INVALID_ARG;
-  if (slot < 0 || slot > 1) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk pipeline: slot must be 0 or 1");
+  if (slot < 0 || slot >= epa_ctx::N_SLOTS) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk pipeline: slot must be 0 .. 5");
   ChunkSlot& s = ctx->slots[slot];
   if (!ctx->copy_stream) EPA_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
   if (!ctx->down_stream) EPA_HIP(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));

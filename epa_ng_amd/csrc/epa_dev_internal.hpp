@@ -149,10 +149,12 @@ struct epa_ctx {
   std::vector<double> h_blen;
 
   // per-call scratch (grown on demand)
-  // Three banks: 0 = the direct entry points (caller's stream), 1 / 2 = the two slots of the chunk
-  // pipeline, whose kernels run concurrently on their own streams and therefore share no scratch.
+  // Banks: 0 = the direct entry points (caller's stream), 1 .. N_SLOTS = the slots of the chunk
+  // pipeline, whose kernels run concurrently on their own streams and therefore share no scratch
+  // (allocated on first use: a two-slot caller pays for two).
   static constexpr int N_SCRATCH = 11;
-  static constexpr int N_BANKS = 3;
+  static constexpr int N_SLOTS = 6;
+  static constexpr int N_BANKS = 1 + N_SLOTS;
   int bank = 0;
   void* scratch[N_BANKS * N_SCRATCH] = {};
   size_t scratch_sz[N_BANKS * N_SCRATCH] = {};
@@ -173,7 +175,7 @@ struct epa_ctx {
   // non-blocking copy streams of the chunk pipeline: uploads and downloads each have their own, so
   // the H2D of chunk k+1 is not queued behind the D2H of chunk k (which waits for k's kernels)
   hipStream_t copy_stream = nullptr, down_stream = nullptr;
-  ChunkSlot slots[2];
+  ChunkSlot slots[N_SLOTS];
 
   EvTimer t_lookup, t_preplace, t_thorough, t_select;
   epa_thorough_stats last_stats{};

@@ -309,7 +309,8 @@ int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* wi
  * The same chunk body as a double-buffered pipeline, the device-side counterpart of the
  * reference's read-ahead of the next chunk (src/seq/MSA_Stream.cpp:79-82, the prefetch in
  * src/core/place.cpp:190-215): the query upload of chunk k+1 and the result download of chunk k-1
- * run on a copy stream while the kernels of chunk k run.  Two slots (0, 1), each walks
+ * run on a copy stream while the kernels of chunk k run.  Slots 0 .. 5 (the loops below use two; a
+ * caller of many small chunks keeps more in flight, see launch_begin), each walks
  *     stage -> launch -> finish -> stage -> ...
  *   stage   copies the caller's HOST arrays (layout / packing as set for the context) into the
  *           slot's pinned buffer and starts the H2D transfer; returns at once.  DEVICE arrays (all
@@ -328,8 +329,12 @@ int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* wi
  *           for the candidate count (normally long there by then) and queues the rest.  Each slot
  *           has its own stream and scratch, so chunk k + 1's begin-half overlaps chunk k's Newton
  *           kernel on the device:
- *               stage(0, c0); begin(0);
- *               for k: { stage((k+1)&1, c[k+1]); begin((k+1)&1); end(k&1); finish((k-1)&1) ... }
+ *               for k in 0..2: { stage(k, c[k]); begin(k); }
+ *               for k: { end(k%5); if (k >= 2) finish((k-2)%5); stage((k+3)%5, c[k+3]); begin((k+3)%5); }
+ *           (five slots: chunk k's Newton kernel is queued while chunk k-1's still runs and fills
+ *           its tail wave by wave -- what small chunks need: 6.6 -> 8.3 M placements/s at 5000 reads
+ *           per chunk against the two-slot order; bench.py's chunk5000 leg).  For large chunks two
+ *           slots do: begin(k&1); finish((k-1)&1); stage((k+1)&1); end(k&1).
  * A typical loop:  stage(0, c0); for k: { launch(k&1); finish((k-1)&1); stage((k+1)&1, c[k+1]); }
  * Candidate overflow (EPA_ERR_PAIR_OVERFLOW from launch, as epa_dev_place_chunk) leaves the slot
  * staged: launch again with a larger max_pairs.

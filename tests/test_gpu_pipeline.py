@@ -961,6 +961,41 @@ def test_staged_chunks_in_hbm_and_two_half_launch_order(packed):
                                            chunks[0][1].ctypes.data, chunks[0][2].ctypes.data, Q))
 
 
+def test_five_slot_order_for_small_chunks():
+    """the order bench.py's chunk5000 leg runs -- three chunks begun ahead on five slots, a chunk's
+    Newton kernel queued while the previous chunk's still runs -- returns, chunk for chunk, the bits of
+    epa_dev_place_chunk; slots beyond 5 are an error"""
+    w = synth.dna_workload(40, 600, 1800, 150, (81, 82, 83))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    Q, S, A = 150, 5, 3
+    chunks = []
+    for c in range(12):
+        codes, wb, ws = epa.encode_queries(4, w["reads"][c * Q:(c + 1) * Q], compact=True)
+        chunks.append((epa.pack_codes_4bit(codes), wb, ws))
+    expect = [ev.place_chunk(*ch, max_span=150) for ch in chunks]
+    kw = dict(threshold=0.99999, max_span=150, max_pairs=Q * 64)
+    n = len(chunks)
+    got = [None] * n
+    for k in range(A):
+        ev.chunk_stage(k % S, *chunks[k])
+        ev.chunk_launch_begin(k % S, **kw)
+    for k in range(n):
+        ev.chunk_launch_end(k % S)
+        if k >= 2:
+            got[k - 2] = ev.chunk_finish((k - 2) % S)
+        if k + A < n:
+            ev.chunk_stage((k + A) % S, *chunks[k + A])
+            ev.chunk_launch_begin((k + A) % S, **kw)
+    for k in range(n - 2, n):
+        got[k] = ev.chunk_finish(k % S)
+    for (p, r), (ep, er) in zip(got, expect):
+        assert np.array_equal(p, ep) and np.array_equal(r, er)
+    with pytest.raises(epa.EpaError):
+        ev.chunk_stage(6, *chunks[0])
+
+
 def test_baseball_heuristic_counts_follow_the_reference_arithmetic():
     """baseball_heuristic (src/core/heuristics.hpp:74-117): hits = branches within 3.0 lnL of the
     best, then std::min(max_pitches - hits, max_strikes) more in size_t arithmetic -- 6 more when
