@@ -12,6 +12,8 @@ from epa_ng_amd import hostlib, synth
 from golden_util import GOLDEN, load_case
 from oracle_lib import Oracle
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -994,6 +996,38 @@ def test_five_slot_order_for_small_chunks():
         assert np.array_equal(p, ep) and np.array_equal(r, er)
     with pytest.raises(epa.EpaError):
         ev.chunk_stage(6, *chunks[0])
+
+
+def test_selection_bitmap_and_sorted_staging_paths_agree(tmp_path):
+    """the candidate list comes from a [B][Q] bitmap (default) or, for bitmaps over 64 MB, from
+    staging rows + compaction + a stable device sort (EPA_SELECT_SORT forces that path): same pairs
+    in the same (branch, query) order, same results, for the three selection rules"""
+    import subprocess, sys
+    script = tmp_path / "sel.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import epa_ng_amd as epa\n"
+        "from epa_ng_amd import hostlib, synth\n"
+        "w = synth.dna_workload(96, 400, 700, 120, (91, 92, 93))\n"
+        "ref = hostlib.Reference(w['newick'], w['labels'], w['seqs'], states=4, subst=w['subst'], freqs=w['freqs'], rates=w['rates'])\n"
+        "ev = ref.evaluator()\n"
+        "codes, wb, ws = epa.encode_queries(4, w['reads'], compact=True)\n"
+        "out = {}\n"
+        "for mode, param in (('dynamic', 0.0), ('fixed', 0.05), ('baseball', 0.0)):\n"
+        "    ev.set_heuristic(mode, param)\n"
+        "    p, r = ev.place_chunk(codes, wb, ws, max_span=120, max_pairs=len(wb) * ref.B)\n"
+        "    out[mode + '_p'] = p; out[mode + '_r'] = r\n"
+        "np.savez(sys.argv[1], **out)\n" % (REPO, os.path.join(REPO, "tests")))
+    outs = []
+    for env_extra, name in (({}, "bitmap.npz"), ({"EPA_SELECT_SORT": "1"}, "sorted.npz")):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, str(script), str(tmp_path / name)], capture_output=True, text=True,
+                           timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(np.load(tmp_path / name))
+    for k in outs[0].files:
+        assert len(outs[0][k]) > 0 and np.array_equal(outs[0][k], outs[1][k]), k
 
 
 def test_baseball_heuristic_counts_follow_the_reference_arithmetic():
