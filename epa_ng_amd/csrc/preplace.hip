@@ -5,17 +5,16 @@
 //     lnl[q][b] = sum_{site in window(q)} T[b][site][code(q, site)]
 // with the reference's association order ((a0+a1)+(a2+a3) per group of 4, then singles).
 //
-// Pipeline (all on the stream, nothing is read back):
-//   1. queries are radix-sorted by window start (rocprim), k_make_groups cuts the sorted list into
-//      groups of <= 256 queries whose starts fall into one SPREAD-site bucket;
-//   2. k_preplace: workgroup = one query group x one tile of NB branches.  Per (branch,
-//      160-site chunk) the 256-row x ncols slice of T the whole group can touch is staged through
-//      LDS once (coalesced 16 B/lane loads), then every thread gathers its own query's values
-//      with ds_read_b64.  Query codes sit in registers as packed byte offsets, partial sums in
-//      LDS, so HBM sees T-slices in (L2/MALL resident: T is 196 MB at cfg2), codes in and the
-//      Q x B table out.  For the 16-column DNA table the LDS columns are XOR-swizzled by the row
-//      ((row >> 1) & 15): DNA reads use 4 of 16 columns, which would pile a half-wave onto 8 of
-//      the 32 8-byte bank slots.
+// Pipeline (all on the stream; the host reads back one 36-word block: candidate total + status):
+//   1. queries are sorted by window start -- the fast paths by a counting sort over (class, start
+//      parity, start) (k_count_keys / k_scan_counts / k_scatter_sorted), the generic path by a device
+//      radix sort -- and k_make_groups cuts the sorted list into groups whose starts fall into one
+//      SPREAD-site bucket (<= 1024 queries on the fast paths, <= 256 on the generic one);
+//   2. k_preplace (generic): workgroup = one query group x one tile of NB branches.  Per (branch,
+//      160-site chunk) the slice of T the whole group can touch is staged through LDS once
+//      (coalesced 16 B/lane loads), then every thread gathers its own query's values with
+//      ds_read_b64.  Query codes sit in registers as packed byte offsets, partial sums in LDS.  For
+//      the 16-column DNA table the LDS columns are XOR-swizzled by the row ((row >> 1) & 15).
 //   2b. DNA fast path (k_preplace_pairs): queries whose windows hold only A/C/G/T/N-or-gap use a
 //      second table T2[b][s][36] = T[b][s][c0] + T[b][s+1][c1] over {A,C,G,T,N,none}^2: one
 //      ds_read_b64 per TWO sites, and the value is exactly the (a0 + a1) the reference forms
@@ -23,11 +22,15 @@
 //      the generic path.  Queries are additionally split by window-start parity (a group stages
 //      only the pair rows of its own parity) and their per-pair LDS offsets are precomputed once
 //      per chunk of queries (k_pack_pairs); queries with other ambiguity codes take the generic
-//      kernel.
-//   3. k_select (dynamic heuristic) works on the table in HBM: one wave per query, the row lives
-//      in registers, candidates go to a per-query staging row; an exclusive scan of the counts
-//      gives every query its output offset (no atomics on a shared counter, deterministic
-//      order); the keys (branch << 32 | query) are radix-sorted into Work's branch-major order.
+//      kernel.  Persistent grid, XCD-contiguous walk of the (tile, group) items (item_walk),
+//      branches per item chosen per launch (choose_tile), pair rows in LDS-bank order
+//      (pair_entry, ROWL_NARROW), results written as whole 64-byte sectors.
+//   2c. 20-state fast path (k_preplace_sites): the same machinery over the ordinary [W][24] table.
+//   3. k_select (the three selection rules) works on the table in HBM: one wave per query, the row
+//      lives in registers; a selected (query, branch) is one bit of a [B][Q] bitmap + a per-branch
+//      counter, the candidate list in Work's branch-major order is one scan over the counters and
+//      one pass over the bitmap (k_emit_pairs).  Bitmaps over 64 MB: per-query staging rows, an
+//      exclusive scan of the counts, compaction and a stable radix sort on the branch bits.
 #include "epa_dev_internal.hpp"
 #include "wave_util.hpp"
 
