@@ -1428,7 +1428,7 @@ extern "C" int epa_dev_chunk_stage(epa_ctx* ctx, int slot, const uint8_t* q_code
   int rc = slot_of(ctx, slot, &s);
   if (rc) return rc;
   if (!q_codes || !win_begin || !win_span || Q == 0) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_stage: null / empty chunk");
-  if (s->state == 2) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_stage: the slot has an unfinished launch");
+  if (s->state == 2 || s->state == 3) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_stage: the slot has an unfinished launch");
   EPA_HIP(ctx, hipSetDevice(ctx->device));
   s->stride = ctx->code_stride ? ctx->code_stride : ctx->W;
   s->packed4 = ctx->code_packed4;

@@ -983,6 +983,8 @@ def test_five_slot_order_for_small_chunks():
     for k in range(A):
         ev.chunk_stage(k % S, *chunks[k])
         ev.chunk_launch_begin(k % S, **kw)
+    with pytest.raises(epa.EpaError):
+        ev.chunk_stage(0, *chunks[0])            # begun, not ended: the slot is busy
     for k in range(n):
         ev.chunk_launch_end(k % S)
         if k >= 2:
