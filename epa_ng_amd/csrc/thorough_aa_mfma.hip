@@ -313,15 +313,25 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
             double ya[NTS], yb[NTS];
 #pragma unroll
             for (int rt = 0; rt < NTS; ++rt) { ya[rt] = 0.0; yb[rt] = 0.0; }
-#pragma unroll
-            for (int p = 0; p < 13; ++p) {
+            // the tile pair of step p + 1 is requested before the MFMAs of step p are issued: with one
+            // register pair the read could only be issued once its predecessor had been consumed, and
+            // every group of MFMAs waited for a full LDS round trip
+            {
               double u0, u1;
-              lds_tiles(sh.Ua, p, ao, u0, u1);
-              ya[(2 * p) % NTS] = mfma4(u0, Av[(2 * p) / NTS], ya[(2 * p) % NTS]);
-              yb[(2 * p) % NTS] = mfma4(u0, Bv[(2 * p) / NTS], yb[(2 * p) % NTS]);
-              if (p < 12) {
-                ya[(2 * p + 1) % NTS] = mfma4(u1, Av[(2 * p + 1) / NTS], ya[(2 * p + 1) % NTS]);
-                yb[(2 * p + 1) % NTS] = mfma4(u1, Bv[(2 * p + 1) / NTS], yb[(2 * p + 1) % NTS]);
+              lds_tiles(sh.Ua, 0, ao, u0, u1);
+#pragma unroll
+              for (int p = 0; p < 13; ++p) {
+                double n0 = 0.0, n1 = 0.0;
+                if (p < 12) lds_tiles(sh.Ua, p + 1, ao, n0, n1);
+                __builtin_amdgcn_sched_barrier(0);
+                ya[(2 * p) % NTS] = mfma4(u0, Av[(2 * p) / NTS], ya[(2 * p) % NTS]);
+                yb[(2 * p) % NTS] = mfma4(u0, Bv[(2 * p) / NTS], yb[(2 * p) % NTS]);
+                if (p < 12) {
+                  ya[(2 * p + 1) % NTS] = mfma4(u1, Av[(2 * p + 1) / NTS], ya[(2 * p + 1) % NTS]);
+                  yb[(2 * p + 1) % NTS] = mfma4(u1, Bv[(2 * p + 1) / NTS], yb[(2 * p + 1) % NTS]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                u0 = n0; u1 = n1;
               }
             }
             double Iv[NTS];
@@ -331,12 +341,19 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
               mx = fmax(mx, Iv[rt]);
               It[rt] = 0.0;
             }
-#pragma unroll
-            for (int p = 0; p < 13; ++p) {
+            {
               double u0, u1;
-              lds_tiles(sh.Uia, p, ao, u0, u1);
-              It[(2 * p) % NTS] = mfma4(u0, Iv[(2 * p) / NTS], It[(2 * p) % NTS]);
-              if (p < 12) It[(2 * p + 1) % NTS] = mfma4(u1, Iv[(2 * p + 1) / NTS], It[(2 * p + 1) % NTS]);
+              lds_tiles(sh.Uia, 0, ao, u0, u1);
+#pragma unroll
+              for (int p = 0; p < 13; ++p) {
+                double n0 = 0.0, n1 = 0.0;
+                if (p < 12) lds_tiles(sh.Uia, p + 1, ao, n0, n1);
+                __builtin_amdgcn_sched_barrier(0);
+                It[(2 * p) % NTS] = mfma4(u0, Iv[(2 * p) / NTS], It[(2 * p) % NTS]);
+                if (p < 12) It[(2 * p + 1) % NTS] = mfma4(u1, Iv[(2 * p + 1) / NTS], It[(2 * p + 1) % NTS]);
+                __builtin_amdgcn_sched_barrier(0);
+                u0 = n0; u1 = n1;
+              }
             }
           }
           double e2[NTS];
@@ -398,23 +415,26 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
       __syncthreads();
       const int row = lane & 3;
       double fl = 0.0, dfl = 0.0;
+      // the B operands (this lane's five table entries of each category) are the same for every tile:
+      // read once per evaluation; row 3 reads the zero table: no per-value select
+      double av[4][NTS];
+      {
+        const int zt = zero_after(t);
+#pragma unroll
+        for (int cat = 0; cat < 4; ++cat) lds5(&sh.tab[row][(cat * 4 + kq) * 6 + zt], av[cat]);
+      }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if (!tile_on[j]) continue;
-        double acc0 = 0.0, acc1 = 0.0;   // two chains: categories 0,1 and 2,3
-        const int zt = zero_after(fl);
+        // four independent accumulation chains (one per category), issued round robin: a chain's next
+        // MFMA never waits for its predecessor's result (two chains of ten back to back did)
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int cat = 0; cat < 4; ++cat) {
-          double av[NTS];
-          lds5(&sh.tab[row][(cat * 4 + kq) * 6 + zt], av);   // row 3 reads the zero table: no per-value select
+        for (int tt = 0; tt < NTS; ++tt)
 #pragma unroll
-          for (int tt = 0; tt < NTS; ++tt) {
-            if (cat < 2) acc0 = mfma4(Sm[j][cat][tt], av[tt], acc0);
-            else acc1 = mfma4(Sm[j][cat][tt], av[tt], acc1);
-          }
-        }
+          for (int cat = 0; cat < 4; ++cat) acc[cat] = mfma4(Sm[j][cat][tt], av[cat][tt], acc[cat]);
         // lane (i = lane / 16, block, r): l_r of site 4 block + i of the tile
-        const double lr = acc0 + acc1;
+        const double lr = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         const double l0 = lr, l1 = quad_bcast<1>(lr), l2 = quad_bcast<2>(lr);
         const uint32_t dsite = 16u * (uint32_t)(wv + NW * j) + (uint32_t)(((lane >> 2) & 3) * 4 + kq);
         if (row == 0 && dsite < n) {
