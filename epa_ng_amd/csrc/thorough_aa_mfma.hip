@@ -335,15 +335,17 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
               }
             }
             double Iv[NTS];
-#pragma unroll
-            for (int rt = 0; rt < NTS; ++rt) {
-              Iv[rt] = ya[rt] * yb[rt];
-              mx = fmax(mx, Iv[rt]);
-              It[rt] = 0.0;
-            }
             {
+              // the first U^-1 tile pair is requested before the element-wise product it will meet
               double u0, u1;
               lds_tiles(sh.Uia, 0, ao, u0, u1);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int rt = 0; rt < NTS; ++rt) {
+                Iv[rt] = ya[rt] * yb[rt];
+                mx = fmax(mx, Iv[rt]);
+                It[rt] = 0.0;
+              }
 #pragma unroll
               for (int p = 0; p < 13; ++p) {
                 double n0 = 0.0, n1 = 0.0;
