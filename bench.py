@@ -66,6 +66,8 @@ def parse():
     p.add_argument("--read-len", type=int, default=150)
     p.add_argument("--cpu-sample", type=int, default=20000, help="reads timed on the CPU baseline")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--parity-sample", type=int, default=0,
+                   help="with --no-cpu-baseline: still check this many reads of step 0 against the oracle (untimed)")
     p.add_argument("--no-extras", action="store_true",
                    help="skip the secondary measurements (chunk-5000 rate, reference-binary hook)")
     p.add_argument("--workload", choices=["dna", "aa"], default="dna",
@@ -420,13 +422,13 @@ def main():
     # ---------------- CPU baseline: the oracle's OpenMP restatement on a bounded sample
     cpu = None
     parity = None
-    if not a.no_cpu_baseline and world == 1:   # rank 0 at N=1 only (bench contract)
+    if (not a.no_cpu_baseline or a.parity_sample > 0) and world == 1:   # rank 0 at N=1 only (bench contract)
         # the oracle's OpenMP threads = the CPUs this process may really use (a container can see
         # 256 CPUs and be limited to 16 by its cgroup quota: oversubscribing would slow the baseline)
         eff = hostlib.configure_threads()
         import oracle_lib
         from oracle_lib import Oracle
-        ns = min(a.cpu_sample, Q)
+        ns = min(a.parity_sample if a.no_cpu_baseline else a.cpu_sample, Q)
         hc, hb, hs, _ = host_chunks[a.warmup % n_chunks]
         sample = synth.compact_to_ascii(hc[:ns], hb[:ns], hs[:ns], W, states)
         codes, wb, ws = epa.encode_queries(states, sample)
@@ -435,30 +437,40 @@ def main():
         res_gpu = ev.thorough(prs, codes, wb, ws)
         # timed leg: the oracle's source built with full optimisation for THIS host CPU
         # (oracle_lib.FAST_CFLAGS); parity leg: the strict build (-O2, no FMA contraction), untimed
-        of = Oracle(newick, labels, seqs, states, subst, freqs, rates, fast=True)
-        of.preplace(sample[:8])                     # builds the per-branch lookups (one-off)
-        c0 = time.perf_counter()
-        of.preplace(sample)
-        of.thorough(prs["branch_id"], prs["seq_id"], sample)
-        cpu_t = time.perf_counter() - c0
-        cores = min(eff, of.L.orc_max_threads())
-        del of
+        if not a.no_cpu_baseline:
+            of = Oracle(newick, labels, seqs, states, subst, freqs, rates, fast=True)
+            of.preplace(sample[:8])                     # builds the per-branch lookups (one-off)
+            c0 = time.perf_counter()
+            of.preplace(sample)
+            of.thorough(prs["branch_id"], prs["seq_id"], sample)
+            cpu_t = time.perf_counter() - c0
+            cores = min(eff, of.L.orc_max_threads())
+            del of
         o = Oracle(newick, labels, seqs, states, subst, freqs, rates)
         s0 = time.perf_counter()
         lnl_cpu = o.preplace(sample)
         tl, tp, td = o.thorough(prs["branch_id"], prs["seq_id"], sample)
         strict_t = time.perf_counter() - s0         # includes the strict build's lookup construction
         sc_at = o.score_at(prs["branch_id"], prs["seq_id"], sample, res_gpu["pendant_length"], res_gpu["distal_length"])
-        cpu = {"value": round(ns / cpu_t, 2), "unit": "placements/s", "cores": cores, "kind": "port",
-               "cflags": oracle_lib.FAST_CFLAGS,
-               "sample": "%d reads of step 0 through the oracle's OpenMP preplace (B=%d) + thorough "
-                         "(%d pairs), lookups prebuilt" % (ns, B, len(prs)),
-               "strict_build_seconds_same_sample": round(strict_t, 2)}
+        if not a.no_cpu_baseline:
+            cpu = {"value": round(ns / cpu_t, 2), "unit": "placements/s", "cores": cores, "kind": "port",
+                   "cflags": oracle_lib.FAST_CFLAGS,
+                   "sample": "%d reads of step 0 through the oracle's OpenMP preplace (B=%d) + thorough "
+                             "(%d pairs), lookups prebuilt" % (ns, B, len(prs)),
+                   "strict_build_seconds_same_sample": round(strict_t, 2)}
+        # the optimiser-path rule of the parity sweep (tests/sweep_util.py) on this sample: pairs whose
+        # lengths differ from the oracle's own must be reproduced by a rounded sibling of the oracle
+        import sweep_util
+        flat = sweep_util.lengths_differ(res_gpu["pendant_length"], res_gpu["distal_length"], tp, td)
+        rep = sweep_util.reproduce_flat_pairs(o, sample, prs["branch_id"], prs["seq_id"], res_gpu, flat)
         parity = {"preplace_max_abs_dlnl": float(np.max(np.abs(lnl_gpu - lnl_cpu))),
                   "thorough_max_abs_dlnl": float(np.max(np.abs(res_gpu["lnl"] - tl))),
                   "evaluator_max_abs_dlnl_at_device_lengths": float(np.max(np.abs(res_gpu["lnl"] - sc_at))),
-                  "pairs_checked": int(len(prs))}
-        if not a.no_extras:
+                  "pairs_checked": int(len(prs)), "reads_checked": int(ns),
+                  "flat_pairs": rep["flat_pairs"], "flat_reproduced": rep["flat_reproduced"],
+                  "max_variant": rep["max_amplitude_log2_ulp"], "flat_decisions": rep["decisions"],
+                  "max_variant_unit": "log2 ulp of the rounding sibling needed (0 with no flat pair)"}
+        if not a.no_extras and not a.no_cpu_baseline:
             # the reference's own executable, if the box happens to have one (it never did so far)
             nref = min(ns, 2000)
             best = {}
@@ -521,15 +533,18 @@ def main():
         # measurement by the same script in its own process, so that the driver's line carries it too
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "aa", "--tips", "2000", "--width", "500",
-                                "--read-len", "100", "--chunk", "10000", "--steps", "6", "--warmup", "2",
-                                "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600)
+                                "--read-len", "100", "--chunk", "50000", "--steps", "6", "--warmup", "2", "--pool", "3",
+                                "--no-cpu-baseline", "--parity-sample", "400", "--no-extras"],
+                               capture_output=True, text=True, timeout=900)
             aj = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
             extras["cfg3_aa"] = {"value": aj["value"], "unit": aj["unit"], "ms_per_step": aj["ms_per_step"],
                                  "workload": aj["config"]["workload"], "reads_per_step": aj["config"]["reads_per_step_per_gpu"],
                                  "kernel_ms_per_step": aj["config"]["kernel_ms_per_step"],
                                  "pcie_inclusive": aj["pcie_inclusive"]["value"],
                                  "roofline": {k: aj["roofline"][k] for k in ("bound", "kernel", "achieved", "frac", "achieved_algorithmic",
-                                                                            "frac_algorithmic", "pairs_per_launch", "ms_per_launch")}}
+                                                                            "frac_algorithmic", "pairs_per_launch", "ms_per_launch",
+                                                                            "traffic", "traffic_source")},
+                                 "parity": aj.get("parity")}
         except Exception as e:  # noqa: BLE001  (a secondary measurement must never take the bench line down)
             extras["cfg3_aa"] = {"status": "failed: %r" % (e,)}
 

@@ -1773,6 +1773,16 @@ extern "C" int epa_dev_place_all(epa_ctx* ctx, const uint8_t* q_codes, const uin
   return EPA_OK;
 }
 
+extern "C" int epa_dev_mem_info(epa_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes) {
+  if (!ctx) return EPA_ERR_INVALID_ARG;
+  EPA_HIP(ctx, hipSetDevice(ctx->device));
+  size_t fr = 0, tot = 0;
+  EPA_HIP(ctx, hipMemGetInfo(&fr, &tot));
+  if (free_bytes) *free_bytes = fr;
+  if (total_bytes) *total_bytes = tot;
+  return EPA_OK;
+}
+
 extern "C" double epa_dev_last_kernel_ms(const epa_ctx* ctx, const char* which) {
   if (!ctx || !which) return -1.0;
   const EvTimer* t = nullptr;

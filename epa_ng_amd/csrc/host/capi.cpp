@@ -216,7 +216,7 @@ int epa_host_place_file(void* h, const char* query_file, const char* outdir, uin
   return guarded([&] {
     Ref* r = static_cast<Ref*>(h);
     Options o = r->opt;
-    if (chunk_size) { o.chunk_size = chunk_size; o.device_min_chunk = 0; }   // the harness asks for exact chunks
+    if (chunk_size) { o.chunk_size = chunk_size; o.chunk_size_given = true; o.device_min_chunk = 0; }   // the harness asks for exact chunks
     o.prescoring = prescoring != 0;
     if (prescoring_threshold > 0) o.prescoring_threshold = prescoring_threshold;
     o.premasking = premasking != 0;

@@ -42,6 +42,9 @@ struct Options {  // defaults: src/util/Options.hpp:13-34
   // at least this many sequences per device chunk, whatever smaller value was asked for (0: never
   // more than chunk_size)
   unsigned int device_min_chunk = 40000;
+  // an explicit --chunk-size is the user's memory knob and is honoured as given: the floor above
+  // applies to the DEFAULT chunk size only (or when --device-min-chunk itself is given)
+  bool chunk_size_given = false, device_min_chunk_given = false;
   unsigned int num_threads = 0;
   bool premasking = true;
   bool baseball = false;

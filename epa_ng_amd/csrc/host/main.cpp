@@ -67,8 +67,8 @@ int main(int argc, char** argv) {
     else if (a == "--filter-min") opt.filter_min = (unsigned)std::stoul(need(i));
     else if (a == "--filter-max") opt.filter_max = (unsigned)std::stoul(need(i));
     else if (a == "--precision") opt.precision = (unsigned)std::stoul(need(i));
-    else if (a == "--chunk-size") opt.chunk_size = (unsigned)std::stoul(need(i));
-    else if (a == "--device-min-chunk") opt.device_min_chunk = (unsigned)std::stoul(need(i));
+    else if (a == "--chunk-size") { opt.chunk_size = (unsigned)std::stoul(need(i)); opt.chunk_size_given = true; }
+    else if (a == "--device-min-chunk") { opt.device_min_chunk = (unsigned)std::stoul(need(i)); opt.device_min_chunk_given = true; }
     else if (a == "--no-pre-mask") opt.premasking = false;
     else if (a == "--raxml-blo") opt.sliding_blo = false;   // src/main.cpp:239-242
     else if (a == "--rate-scalers") {                       // src/main.cpp:248-250,399-407

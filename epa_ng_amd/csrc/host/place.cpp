@@ -554,6 +554,23 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
     }
   };
 
+  // Reads per device chunk.  The device_min_chunk floor lifts the DEFAULT chunk size only: an explicit
+  // --chunk-size is the user's memory knob (src/main.cpp:234-238) and is honoured as given unless
+  // --device-min-chunk is given as well.  Either way the chunk is clamped to what the smallest device
+  // has room for: two pipeline slots x Q x pitch(B) x 8 bytes of preplacement table (+ a quarter for
+  // codes, bitmap, candidates) within half of its free memory.
+  size_t device_chunk = options.chunk_size;
+  if (!options.chunk_size_given || options.device_min_chunk_given)
+    device_chunk = std::max<size_t>(device_chunk, options.device_min_chunk);
+  {
+    const size_t pitch = (tree.num_branches() * 8 + 63) / 64 * 64;
+    for (auto& d : devs) {
+      uint64_t fr = 0, tot = 0;
+      if (epa_dev_mem_info(d->ctx(), &fr, &tot) != EPA_OK) continue;
+      const size_t room = (size_t)(fr / 2) / (pitch * 2 * 5 / 4);
+      if (room < device_chunk) device_chunk = std::max<size_t>(std::min<size_t>(options.chunk_size, device_chunk), std::max<size_t>(room, 1));
+    }
+  }
   std::thread stager([&] {
     try {
       Fasta_Stream reader(query_file);
@@ -563,7 +580,7 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
         const auto r0 = clk::now();
         // one-line records of a mapped file are encoded straight from the mapping (no sequence strings)
         std::vector<const char*> rows;
-        const size_t per_chunk = std::max<size_t>(options.chunk_size, options.device_min_chunk);
+        const size_t per_chunk = device_chunk;
         if (!premask) reader.read_next_views(s.chunk, rows, tree.num_sites(), per_chunk);
         if (rows.empty()) reader.read_next(s.chunk, per_chunk);
         const double rd = std::chrono::duration<double>(clk::now() - r0).count();
@@ -667,6 +684,17 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
         have_prev = true;
         slot ^= 1;
       }
+    } catch (const std::exception& e) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!failure) {
+        const std::string what = e.what();
+        if (what.find("hipMalloc") != std::string::npos)   // the chunk did not fit: name the knobs
+          failure = std::make_exception_ptr(std::runtime_error{what + " (device chunks of " + std::to_string(device_chunk) +
+                    " queries; lower --chunk-size, and pass --device-min-chunk 0 if it was raised)"});
+        else failure = std::current_exception();
+      }
+      cv_put.notify_all();
+      cv_get.notify_all();
     } catch (...) {
       std::lock_guard<std::mutex> lk(mu);
       if (!failure) failure = std::current_exception();

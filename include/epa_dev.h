@@ -369,6 +369,11 @@ int epa_dev_place_all(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_
                       epa_result* results, double* lwr, uint32_t* counts,
                       epa_thorough_stats* stats);
 
+/* free / total bytes of the context's device (hipMemGetInfo): the chunk loop sizes its device chunks
+ * against it -- a chunk of Q queries keeps 2 pipeline slots x Q x pitch(B) x 8 bytes of preplacement
+ * table live (`--chunk-size` is the user's memory knob, src/main.cpp:234-238). */
+int epa_dev_mem_info(epa_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
+
 /* duration in milliseconds of the last launch of the named kernel family on ctx's stream,
  * measured with HIP events ("preplace", "thorough", "lookup", "select"); < 0 if never run. */
 double epa_dev_last_kernel_ms(const epa_ctx* ctx, const char* which);

@@ -46,3 +46,103 @@ def make_case(seed):
 def lengths_differ(p_a, d_a, p_b, d_b):
     """the sweep's 'flat-optimum pair' predicate: optimised lengths differ by more than 1e-6"""
     return (np.abs(p_a - p_b) > 1e-6 * np.maximum(1.0, p_b)) | (np.abs(d_a - d_b) > 1e-6)
+
+
+# ---- the optimiser-path rule for pairs whose lengths differ from the oracle's ("flat pairs")
+# A faithfully rounded sibling of the oracle (orc_model.rounding_variant) must reach the device's
+# lengths.  Round 4: the amplitude schedule stops at 2^8 ulp (5.7e-14 relative: the largest any of the
+# ~3.3 million pairs of the hand runs ever needed) -- a pair that needs more FAILS; the decision at
+# which the sibling leaves the oracle's own path is located in the two traces (orc_trace_pair) and
+# must be one of the solver's three rounding-level decisions.
+ROUNDING_AMPLITUDES = (0, 2, 4, 6, 8)          # log2 ulp
+ROUNDING_VARIANTS = [v | z | (a << 16) for a in ROUNDING_AMPLITUDES for v in range(1, 17) for z in (0x800, 0, 0x1000)]
+DECISIONS = ("newton_branch", "newton_termination", "round_decision")
+
+
+def _close(a, b):
+    return abs(a - b) <= 1e-6 * max(abs(a), abs(b)) + 1e-12
+
+
+def first_divergence(ra, rb):
+    """Where two traces of ONE pair (rows {1|2, t, f, f'} per derivative evaluation, {3, new, old,
+    reverted} per round) part, and which decision of optimize.cpp:120-240 / minimize_newton that is:
+      newton_branch       same evaluation count so far, the next abscissa differs: the sign of f or f'
+                          (bracket update, bisection instead of a Newton step) fell the other way
+      newton_termination  one solve stopped (|dx| < tol, |f| < tol with f' > 0, x == x') where the
+                          other evaluated once more
+      round_decision      the end-of-round score: the revert test new - old > new 1e-14 or the
+                          0.1-lnL stop fell the other way
+    Returns (row index, decision) or (None, None) when the traces agree."""
+    n = min(len(ra), len(rb))
+    for i in range(n):
+        a, b = ra[i], rb[i]
+        if a[0] != b[0]:
+            return i, ("round_decision" if 3.0 in (a[0], b[0]) and i > 0 and ra[i - 1][0] == 3.0 else "newton_termination")
+        if a[0] == 3.0:
+            if a[3] != b[3]:
+                return i, "round_decision"
+            continue      # the values of a score may differ at rounding level: not a decision by itself
+        if not _close(a[1], b[1]):
+            return i, "newton_branch"
+    if len(ra) != len(rb):
+        last = (ra if len(ra) < len(rb) else rb)[n - 1]
+        return n, ("round_decision" if last[0] == 3.0 else "newton_termination")
+    return None, None
+
+
+def reproduce_flat_pairs(o, reads, pb, ps, res, flat, lnl_tol=1e-6, classify=True):
+    """For every pair of `flat` (device lengths differ from the oracle's own): find the smallest rounding
+    variant of the oracle that lands on the device's lengths, check the device's lnL against that sibling
+    and name the decision at which the sibling leaves the oracle's path.  Returns a dict:
+      flat_pairs, flat_reproduced, max_amplitude_log2_ulp (of the variants needed), stationary_mode
+      (pairs that needed the stationary eigenvalue taken as 0 / sign-flipped), decisions {name: count},
+      unreproduced [(branch, read)]"""
+    idx = np.nonzero(flat)[0]
+    left = np.ones(len(idx), bool)
+    needed = np.zeros(len(idx), np.int64)
+    for v in ROUNDING_VARIANTS:
+        if not left.any():
+            break
+        o.set_rounding_variant(v)
+        k = idx[left]
+        l2, p2, d2 = o.thorough(pb[k], ps[k], reads)
+        hit = ~lengths_differ(p2, d2, res["pendant_length"][k], res["distal_length"][k])
+        bad = np.abs(l2[hit] - res["lnl"][k][hit]) > lnl_tol
+        assert not bad.any(), ("device lnL differs from the sibling that reaches its lengths", hex(v))
+        w = np.nonzero(left)[0][hit]
+        needed[w] = v
+        left[w] = False
+    decisions = {}
+    if classify:
+        for j in np.nonzero(~left)[0]:
+            b, q = int(pb[idx[j]]), int(ps[idx[j]])
+            o.set_rounding_variant(0)
+            ra = o.trace_pair(b, reads[q])[0]
+            o.set_rounding_variant(int(needed[j]))
+            rb = o.trace_pair(b, reads[q])[0]
+            at, dec = first_divergence(ra, rb)
+            assert dec in DECISIONS, ("sibling and oracle agree on the whole trace, yet end at different lengths", b, q)
+            # up to the parting point the two runs are the same computation to rounding level
+            for i in range(at):
+                assert _close(ra[i][1], rb[i][1]), (b, q, i)
+            decisions[dec] = decisions.get(dec, 0) + 1
+    o.set_rounding_variant(0)
+    ok = needed[~left]
+    return {"flat_pairs": int(len(idx)), "flat_reproduced": int((~left).sum()),
+            "max_amplitude_log2_ulp": int((ok >> 16).max()) if len(ok) else 0,
+            "stationary_mode": int(((ok & 0x1800) != 0).sum()) if len(ok) else 0,
+            "decisions": decisions,
+            "unreproduced": [(int(pb[i]), int(ps[i])) for i in idx[left]]}
+
+
+# Bounds of the sweep.  A configuration drawn by make_case() outside OUTLIER_BOUNDS may have at most
+# FLAT_MAX_FRACTION of its pairs off the oracle's path and each of them within FLAT_LNL_TOL of the
+# oracle's own optimum (measured over seeds 0..179: <= 0.35 % and <= 4.4e-6, profiles/r3_sweep.log).
+# The named configurations (saturated pendant lengths, 1- to 3-site reads: the stationary eigenvalue's
+# residue decides a bisection, see DESIGN.md section 2) carry their own measured bounds: (flat pairs,
+# |dlnL|) of profiles/r3_sweep.log with a margin of 2 x + 2 pairs, 1.5 x lnL.
+FLAT_MAX_FRACTION = 0.01
+FLAT_LNL_TOL = 1e-4
+OUTLIER_BOUNDS = {231: (4, 0.41), 1070: (8, 1.15), 1457: (18, 6e-3), 1671: (20, 0.86), 1882: (24, 3.9),
+                  2233: (48, 1e-4), 2297: (4, 0.041), 2409: (4, 3.0), 2623: (710, 4.5e-4), 2692: (10, 3.0),
+                  2695: (4, 3.1), 2869: (6, 5.8e-3)}

@@ -257,3 +257,40 @@ def test_oracle_disagrees_with_itself_on_the_known_bimodal_seeds():
             if fl.any():
                 worst = max(worst, float(np.abs(l2 - tl)[fl].max()))
         assert abs(worst - gap) < 0.01, (seed, worst)
+
+
+def test_flat_pair_rule_names_the_decision_where_a_sibling_leaves_the_oracles_path():
+    """The optimiser-path rule of the GPU sweep (sweep_util.reproduce_flat_pairs) exercised on CPU with a
+    rounded sibling of the oracle standing in for the device: on the bimodal seeds every pair whose
+    lengths differ is reproduced with amplitude 0 (the stationary-eigenvalue variant), the two traces
+    agree up to a point and part at one of the solver's three decisions; and a "device" that no sibling
+    reproduces (lengths moved by hand) is reported as unreproduced."""
+    import sweep_util as su
+    for seed in (1070, 2692):
+        c, o, pb, ps = _sweep_oracle(seed)
+        tl, tp, td = o.thorough(pb, ps, c["reads"])
+        o.set_rounding_variant(0x801)
+        l2, p2, d2 = o.thorough(pb, ps, c["reads"])
+        o.set_rounding_variant(0)
+        res = {"lnl": l2, "pendant_length": p2, "distal_length": d2}
+        flat = su.lengths_differ(p2, d2, tp, td)
+        assert flat.any()
+        rep = su.reproduce_flat_pairs(o, c["reads"], pb, ps, res, flat)
+        assert rep["flat_reproduced"] == rep["flat_pairs"] == int(flat.sum()) and not rep["unreproduced"]
+        assert rep["max_amplitude_log2_ulp"] == 0 and rep["stationary_mode"] == rep["flat_pairs"]
+        assert sum(rep["decisions"].values()) == rep["flat_pairs"] and set(rep["decisions"]) <= set(su.DECISIONS)
+        # a result nobody computes: not reproduced
+        k = int(np.nonzero(flat)[0][0])
+        bad = {"lnl": l2.copy(), "pendant_length": p2.copy(), "distal_length": d2.copy()}
+        bad["pendant_length"][k] *= 1.37
+        only = np.zeros(len(pb), bool)
+        only[k] = True
+        rep = su.reproduce_flat_pairs(o, c["reads"], pb, ps, bad, only)
+        assert rep["unreproduced"] == [(int(pb[k]), int(ps[k]))]
+    # trace comparison on hand-made rows
+    a = [(1, 0.1, 2.0, 5.0), (1, 0.5, -1e-18, 3.0), (1, 0.7, 0.1, 3.0), (3, 10.0, 11.0, 0.0)]
+    assert su.first_divergence(a, a) == (None, None)
+    assert su.first_divergence(a, a[:2] + [(1, 0.3, 0.1, 3.0)] + a[3:]) == (2, "newton_branch")
+    assert su.first_divergence(a, a[:2] + a[3:]) == (2, "newton_termination")
+    assert su.first_divergence(a, a[:3] + [(3, 10.0, 11.0, 1.0)]) == (3, "round_decision")
+    assert su.first_divergence(a, a + [(1, 0.1, 2.0, 5.0)]) == (4, "round_decision")
