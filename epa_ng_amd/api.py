@@ -16,11 +16,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEV_SO = os.environ.get("EPA_DEV_SO", os.path.join(HERE, "libepa_dev.so"))
 
 __all__ = ["EpaError", "dev_lib", "device_count", "encode_queries", "Evaluator", "PAIR_DTYPE",
-           "RESULT_DTYPE", "DEV_SO", "Packed4", "pack_codes_4bit", "unpack_codes_4bit"]
+           "RESULT_DTYPE", "ROW_DTYPE", "DEV_SO", "Packed4", "pack_codes_4bit", "unpack_codes_4bit", "Comm",
+           "comm_unique_id"]
 
 PAIR_DTYPE = np.dtype([("branch_id", np.uint32), ("seq_id", np.uint32)])
 RESULT_DTYPE = np.dtype([("lnl", np.float64), ("pendant_length", np.float64),
                          ("distal_length", np.float64)])
+
+# one gathered row of the multi-GPU exchange (include/epa_dev.h: epa_row; seq_id is global)
+ROW_DTYPE = np.dtype([("branch_id", np.uint32), ("seq_id", np.uint32), ("lnl", np.float64),
+                      ("pendant_length", np.float64), ("distal_length", np.float64)])
 
 
 class EpaError(RuntimeError):
@@ -112,6 +117,20 @@ def dev_lib():
                                         C.c_uint32, C.c_double, C.c_int, C.c_uint32, C.c_uint32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(_Stats)]
+        L.epa_comm_get_unique_id.argtypes = [C.c_void_p]
+        L.epa_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_int,
+                                      C.POINTER(C.c_void_p)]
+        L.epa_comm_destroy.argtypes = [C.c_void_p]
+        L.epa_comm_destroy.restype = None
+        L.epa_dev_gather_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64,
+                                             C.c_uint32, C.POINTER(C.c_uint64)]
+        L.epa_dev_gather_slot.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.epa_comm_collect.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
+                                       C.POINTER(C.c_uint64)]
+        L.epa_comm_flush.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+        L.epa_comm_carried_rows.argtypes = [C.c_void_p]
+        L.epa_comm_carried_rows.restype = C.c_uint64
+        L.epa_dev_mem_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.epa_dev_last_kernel_ms.restype = C.c_double
         L.epa_dev_last_kernel_ms.argtypes = [C.c_void_p, C.c_char_p]
         _LIB = L
@@ -446,3 +465,81 @@ class Evaluator:
 
     def kernel_ms(self, which):
         return self.L.epa_dev_last_kernel_ms(self.h, which.encode())
+
+
+def comm_unique_id():
+    """rank 0: the 128 bytes every rank passes to Comm() (hand them over out of band)"""
+    L = dev_lib()
+    buf = C.create_string_buffer(128)
+    rc = L.epa_comm_get_unique_id(buf)
+    if rc:
+        raise EpaError(rc, (L.epa_dev_last_error(None) or b"").decode())
+    return buf.raw
+
+
+class Comm:
+    """The product library's RCCL gather of (pair, result) rows to rank 0 (include/epa_dev.h, epa_comm_*;
+    epa_ng_amd/csrc/comm.hip).  One per process / Evaluator."""
+
+    def __init__(self, ev, unique_id, rank, world, rows_cap, depth=2):
+        self.ev, self.L, self.rank, self.world, self.rows_cap, self.depth = ev, ev.L, rank, world, rows_cap, depth
+        h = C.c_void_p()
+        ev._check(self.L.epa_comm_create(ev.h, unique_id, rank, world, rows_cap, depth, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.epa_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def post(self, pairs, results, n, seq_offset=0):
+        """pairs / results: DEVICE buffers (torch tensors or raw pointers) of >= n rows -> ticket"""
+        t = C.c_uint64(0)
+        self.ev._check(self.L.epa_dev_gather_results(self.ev.h, self.h, _ptr(pairs), _ptr(results), n, seq_offset,
+                                                     C.byref(t)))
+        return t.value
+
+    def post_slot(self, slot, seq_offset=0):
+        """a chunk slot launched with keep_on_device=True, after chunk_launch_end -> ticket"""
+        t = C.c_uint64(0)
+        self.ev._check(self.L.epa_dev_gather_slot(self.ev.h, self.h, slot, seq_offset, C.byref(t)))
+        return t.value
+
+    def collect(self, ticket):
+        """rank 0: list (one ROW_DTYPE array per rank) of gather `ticket`"""
+        import ctypes
+        ptrs = (C.c_void_p * self.world)()
+        cnt = (C.c_uint32 * self.world)()
+        pend = (C.c_uint64 * self.world)()
+        self.ev._check(self.L.epa_comm_collect(self.h, ticket, ptrs, cnt, pend))
+        self.last_pending = [int(x) for x in pend]
+        out = []
+        for r in range(self.world):
+            if cnt[r] == 0:
+                out.append(np.zeros(0, ROW_DTYPE))
+                continue
+            raw = np.ctypeslib.as_array(ctypes.cast(ptrs[r], C.POINTER(C.c_uint8)), (32 * cnt[r],))
+            out.append(raw.view(ROW_DTYPE).copy())
+        return out
+
+    def flush(self, on_ticket=None):
+        """collective: drains carried rows with extra gathers (rounds of <= depth, agreed on by an all-reduce
+        each); on_ticket(t) is called for every extra gather as soon as it may be collected (rank 0 must
+        collect inside it).  -> list of the extra tickets"""
+        out = []
+        while True:
+            first, n = C.c_uint64(0), C.c_uint32(0)
+            self.ev._check(self.L.epa_comm_flush(self.ev.h, self.h, C.byref(first), C.byref(n)))
+            if n.value == 0:
+                return out
+            for t in range(first.value, first.value + n.value):
+                out.append(t)
+                if on_ticket is not None:
+                    on_ticket(t)
+
+    @property
+    def carried_rows(self):
+        return int(self.L.epa_comm_carried_rows(self.h))

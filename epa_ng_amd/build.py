@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-DEV_SOURCES = ["epa_dev.hip", "preplace.hip", "thorough_dna.hip", "thorough_aa.hip", "thorough_aa_mfma.hip", "thorough_generic.hip"]
+DEV_SOURCES = ["epa_dev.hip", "preplace.hip", "thorough_dna.hip", "thorough_aa.hip", "thorough_aa_mfma.hip", "thorough_generic.hip", "comm.hip"]
 DEV_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
              "-I", CSRC, "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
 
@@ -49,7 +49,7 @@ def build_dev(force=False, verbose=False):
     return out
 
 
-HOST_SOURCES = ["model.cpp", "aa_models.cpp", "parse_model.cpp", "tree.cpp", "place.cpp", "io.cpp", "capi.cpp"]
+HOST_SOURCES = ["model.cpp", "aa_models.cpp", "parse_model.cpp", "tree.cpp", "place.cpp", "place_ranks.cpp", "io.cpp", "capi.cpp"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-fopenmp", "-Wall", "-Wextra", "-Wno-unused-parameter",
               "-I", os.path.join(ROOT, "include")]
 

@@ -428,4 +428,11 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
                      const std::string& outdir, const Options& options, const std::string& invocation,
                      const std::vector<int>& devices);
 
+// one process per GPU: rank's contiguous slice of the query file on `device`, results gathered to rank 0
+// over the product library's RCCL gather (place_ranks.cpp; src/net/epa_mpi_util.cpp:10-30)
+std::pair<size_t, size_t> local_seq_package(size_t num_sequences, int rank, int world);
+Run_Stats simple_mpi_ranks(const Tree& tree, const std::string& query_file, const MSA_Info& msa_info,
+                           const std::string& outdir, const Options& options, const std::string& invocation,
+                           int device, int rank, int world, const std::string& comm_file);
+
 }  // namespace epa

@@ -36,7 +36,10 @@ static void usage() {
       "  --preserve-rooting on|off  rooted reference tree: report on the rooted tree (default on)\n"
       "  -T,--threads N        upper limit on the host threads (parsing, encoding, LWR / filter, jplace text)\n"
       "  --device N            GPU ordinal (default 0)\n"
-      "  --devices a,b,..      place on several GPUs of the node (chunks are dealt to them in turn)\n";
+      "  --devices a,b,..      place on several GPUs of the node (chunks are dealt to them in turn)\n"
+      "  --rank R --world N --comm-file F   one process per GPU: rank R places its contiguous slice of the\n"
+      "                        queries, results are gathered to rank 0 over RCCL; rank 0 leaves the RCCL id in F\n"
+      "                        (defaults: RANK / WORLD_SIZE / LOCAL_RANK / EPA_COMM_FILE of the environment)\n";
 }
 
 int main(int argc, char** argv) {
@@ -46,7 +49,17 @@ int main(int argc, char** argv) {
   std::string tree_file, ref_file, query_file, outdir = "./", model_desc = "GTR+G";
   Options opt;
   int device = 0;
+  bool device_given = false;
   std::vector<int> devices;
+  // one process per GPU (place_ranks.cpp): --rank / --world / --comm-file, or what torchrun / mpirun export
+  auto env_int = [](const char* a, const char* b, int dflt) {
+    const char* v = std::getenv(a);
+    if (!v && b) v = std::getenv(b);
+    return v ? std::atoi(v) : dflt;
+  };
+  int rank = env_int("EPA_RANK", "RANK", 0), world = env_int("EPA_WORLD", "WORLD_SIZE", 1);
+  const int local_rank = env_int("EPA_LOCAL_RANK", "LOCAL_RANK", rank);
+  std::string comm_file = std::getenv("EPA_COMM_FILE") ? std::getenv("EPA_COMM_FILE") : "";
   auto need = [&](int& i) -> std::string {
     if (i + 1 >= argc) { std::cerr << "missing value for " << argv[i] << "\n"; std::exit(1); }
     return argv[++i];
@@ -88,12 +101,15 @@ int main(int argc, char** argv) {
       opt.num_threads = (unsigned)std::stoul(need(i));
       set_host_thread_limit((int)opt.num_threads);   // caps the OpenMP host stages; the placement itself runs on the GPU
     }
-    else if (a == "--device") device = std::stoi(need(i));
+    else if (a == "--device") { device = std::stoi(need(i)); device_given = true; }
     else if (a == "--devices") {
       std::stringstream ls(need(i));
       std::string tok;
       while (std::getline(ls, tok, ',')) if (!tok.empty()) devices.push_back(std::stoi(tok));
     }
+    else if (a == "--rank") rank = std::stoi(need(i));
+    else if (a == "--world") world = std::stoi(need(i));
+    else if (a == "--comm-file") comm_file = need(i);
     else if (a == "--redo" || a == "--verbose") {}
     else if (a == "-h" || a == "--help") { usage(); return 0; }
     else { std::cerr << "option " << a << " is outside the placement hot path of this build\n"; return 1; }
@@ -133,7 +149,14 @@ int main(int argc, char** argv) {
                 << std::endl;
     const double secs_tree = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_tree).count();
     if (devices.empty()) devices.push_back(device);
-    const Run_Stats st = simple_mpi(tree, query_file, qry_info, outdir, opt, invocation, devices);
+    const bool rank_mode = world > 1 || !comm_file.empty();   // a 1-rank communicator is legal (tests, 1-GPU nodes)
+    const Run_Stats st = rank_mode
+        ? simple_mpi_ranks(tree, query_file, qry_info, outdir, opt, invocation, device_given ? device : local_rank, rank, world, comm_file)
+        : simple_mpi(tree, query_file, qry_info, outdir, opt, invocation, devices);
+    if (rank_mode && rank != 0) {
+      std::cout << "rank " << rank << " of " << world << ": " << st.queries << " sequences placed" << std::endl;
+      return 0;
+    }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
     std::cout << "Reference tree log-likelihood: " << st.ref_tree_logl << "\n";
     std::cout << st.queries << " Sequences done! (" << st.pairs << " thorough pairs)\n"

@@ -369,6 +369,51 @@ int epa_dev_place_all(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_
                       epa_result* results, double* lwr, uint32_t* counts,
                       epa_thorough_stats* stats);
 
+/*
+ * Multi-GPU: one process per GPU.  Queries are split into contiguous per-rank slices without any
+ * exchange (src/net/epa_mpi_util.cpp:10-30, local_seq_package); the path's ONLY collective is the
+ * gather of every chunk's (pair, result) rows to rank 0, which writes the jplace
+ * (src/io/jplace_writer.hpp:117-129 gathers the ranks' text with MPI_Gatherv; here the 32-byte numeric
+ * rows travel over RCCL: point-to-point xGMI links into the root, one group per chunk).
+ *   epa_comm_get_unique_id  rank 0: 128 bytes to hand to the other ranks out of band (a file, an
+ *                           environment variable, MPI_Bcast -- whatever launched the processes)
+ *   epa_comm_create         collective (ncclCommInitRank).  rows_cap: rows per rank and gather (size it
+ *                           from the expected candidates per chunk, e.g. 4 x reads); depth: send /
+ *                           receive slots used round robin (2: gather k travels while chunk k + 1 runs)
+ *   epa_dev_gather_results  collective, asynchronous, every rank once per chunk in the same order:
+ *                           packs n rows (DEVICE pairs / results, complete on the context's stream;
+ *                           sequence ids + seq_offset = global ids) and posts the fixed-size exchange on
+ *                           the communicator's own stream.  Never blocks the host; rows beyond rows_cap
+ *                           are carried into the rank's next gather.  *ticket names the gather.
+ *   epa_dev_gather_slot     the same for a chunk slot launched with EPA_CHUNK_NO_D2H (after launch_end)
+ *   epa_comm_collect        rank 0: waits for gather `ticket`, copies its VALID rows to pinned host
+ *                           memory and hands out one row block and count per rank; the blocks stay
+ *                           valid until gather ticket + depth is posted.  pending[r] (optional): rows rank
+ *                           r still carried after this gather -- 0 means every row it has posted so far
+ *                           has arrived (a chunk's rows are branch-major: a query is complete only then)
+ *   epa_comm_flush          collective, at the end, REPEATED until it reports *n_extra == 0: agrees (one
+ *                           all-reduce) on whether any rank still carries rows and posts up to `depth` extra
+ *                           gathers (tickets *first .. *first + *n_extra - 1) that drain them; rank 0
+ *                           collects those before the next call
+ * RCCL is loaded at run time (dlopen; EPA_RCCL_LIB overrides the name): EPA_ERR_UNSUPPORTED without it.
+ */
+#define EPA_COMM_ID_BYTES 128
+typedef struct epa_comm epa_comm;
+typedef struct {
+  uint32_t branch_id, seq_id;   /* seq_id is GLOBAL (rank's offset added) */
+  double lnl, pendant_length, distal_length;
+} epa_row;
+int epa_comm_get_unique_id(void* id128);
+int epa_comm_create(epa_ctx* ctx, const void* id128, int rank, int world, uint32_t rows_cap, int depth,
+                    epa_comm** out);
+void epa_comm_destroy(epa_comm* comm);
+int epa_dev_gather_results(epa_ctx* ctx, epa_comm* comm, const epa_pair* d_pairs, const epa_result* d_results,
+                           uint64_t n, uint32_t seq_offset, uint64_t* ticket);
+int epa_dev_gather_slot(epa_ctx* ctx, epa_comm* comm, int slot, uint32_t seq_offset, uint64_t* ticket);
+int epa_comm_collect(epa_comm* comm, uint64_t ticket, const epa_row** rows, uint32_t* counts, uint64_t* pending);
+int epa_comm_flush(epa_ctx* ctx, epa_comm* comm, uint64_t* first_extra_ticket, uint32_t* n_extra);
+uint64_t epa_comm_carried_rows(const epa_comm* comm);
+
 /* free / total bytes of the context's device (hipMemGetInfo): the chunk loop sizes its device chunks
  * against it -- a chunk of Q queries keeps 2 pipeline slots x Q x pitch(B) x 8 bytes of preplacement
  * table live (`--chunk-size` is the user's memory knob, src/main.cpp:234-238). */

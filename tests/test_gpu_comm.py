@@ -1,0 +1,251 @@
+"""The product library's RCCL gather (include/epa_dev.h epa_comm_*, epa_ng_amd/csrc/comm.hip): the
+exchange that replaces src/net/epa_mpi_util.cpp:10-30 + src/io/jplace_writer.hpp:117-129 for the
+one-process-per-GPU mode.  On the 1-GPU box: a 1-rank communicator, once with rank 0's rows taken the
+local way and once sent to itself through ncclSend / ncclRecv (EPA_COMM_SELF_SEND), carry path and flush
+included; wherever >= 2 GPUs are visible: one process per GPU over the C-ABI and the CLI's --rank mode."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import epa_ng_amd as epa
+from epa_ng_amd import hostlib, synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _workload():
+    w = synth.dna_workload(48, 600, 1200, 150, (71, 72, 73))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    return w, ref
+
+
+def _rows_of(pairs, res, seq_offset):
+    rows = np.zeros(len(pairs), epa.ROW_DTYPE)
+    rows["branch_id"] = pairs["branch_id"]
+    rows["seq_id"] = pairs["seq_id"] + seq_offset
+    for k in ("lnl", "pendant_length", "distal_length"):
+        rows[k] = res[k]
+    return rows
+
+
+@pytest.mark.parametrize("self_send", [False, True])
+def test_one_rank_gather_with_carry_and_flush(self_send, monkeypatch):
+    """Three chunks through the staged pipeline with the results kept in HBM, each posted to the gather
+    (epa_dev_gather_slot / epa_dev_gather_results); rows_cap is smaller than a chunk's candidate count,
+    so every post carries rows into the next one and flush() drains the rest.  What rank 0 collects,
+    in ticket order, is exactly the chunks' (pair, result) rows with global sequence ids."""
+    import torch
+    if self_send:
+        monkeypatch.setenv("EPA_COMM_SELF_SEND", "1")
+    else:
+        monkeypatch.delenv("EPA_COMM_SELF_SEND", raising=False)
+    w, ref = _workload()
+    ev = ref.evaluator()
+    Q = 400
+    chunks = [epa.encode_queries(4, w["reads"][c * Q:(c + 1) * Q], compact=True) for c in range(3)]
+    expect = [ev.place_chunk(*ch, max_span=150) for ch in chunks]
+    n_exp = [len(p) for p, _ in expect]
+    cap = Q * 64
+    rows_cap = max(n_exp) * 2 // 3            # forces the carry path
+    comm = epa.Comm(ev, epa.comm_unique_id(), 0, 1, rows_cap, depth=2)
+    dev = torch.device("cuda", 0)
+    bufs = [(torch.zeros((cap, 2), dtype=torch.int32, device=dev), torch.zeros((cap, 3), dtype=torch.float64, device=dev))
+            for _ in range(2)]
+    got, tickets = [], []
+    for k, ch in enumerate(chunks):
+        ev.chunk_stage(k & 1, *ch)
+        ev.chunk_launch(k & 1, max_span=150, max_pairs=cap, pairs_out=bufs[k & 1][0], results_out=bufs[k & 1][1],
+                        keep_on_device=True)
+        if k == 1:   # the explicit-buffer entry point
+            n = ev.chunk_finish_device(k & 1)
+            tickets.append(comm.post(bufs[k & 1][0], bufs[k & 1][1], n, seq_offset=1000 * k))
+        else:        # straight from the slot, no host wait for the kernels
+            tickets.append(comm.post_slot(k & 1, seq_offset=1000 * k))
+            ev.chunk_finish_device(k & 1)
+        if k >= 1:   # collect within `depth` posts
+            got.append(comm.collect(tickets[k - 1])[0])
+    got.append(comm.collect(tickets[-1])[0])
+    extra = comm.flush(on_ticket=lambda t: got.append(comm.collect(t)[0]))
+    assert len(extra) >= 1 and comm.carried_rows > 0
+    assert all(len(g) <= rows_cap for g in got)
+    allrows = np.concatenate(got)
+    want = np.concatenate([_rows_of(p, r, 1000 * k) for k, (p, r) in enumerate(expect)])
+    assert len(allrows) == len(want)
+    assert np.array_equal(allrows, want)
+    with pytest.raises(epa.EpaError):
+        comm.collect(tickets[0])              # that gather's slot has been reused
+    comm.close()
+
+
+def test_gather_argument_errors():
+    w, ref = _workload()
+    ev = ref.evaluator()
+    uid = epa.comm_unique_id()
+    with pytest.raises(epa.EpaError):
+        epa.Comm(ev, uid, 1, 1, 100)          # rank outside the world
+    with pytest.raises(epa.EpaError):
+        epa.Comm(ev, uid, 0, 1, 0)            # no rows
+    comm = epa.Comm(ev, uid, 0, 1, 100)
+    host_pairs = np.zeros(4, epa.PAIR_DTYPE)
+    host_res = np.zeros(4, epa.RESULT_DTYPE)
+    with pytest.raises(epa.EpaError):
+        comm.post(host_pairs, host_res, 4)    # host memory: the gather reads device buffers
+    with pytest.raises(epa.EpaError):
+        comm.post_slot(0)                     # nothing launched on the slot
+    comm.close()
+
+
+WORKER = r"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.environ["EPA_ROOT"]); sys.path.insert(0, os.path.join(os.environ["EPA_ROOT"], "tests"))
+import torch
+import epa_ng_amd as epa
+from epa_ng_amd import hostlib, synth, parallel
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+idf = os.environ["EPA_COMM_FILE"]
+w = synth.dna_workload(48, 600, 1200, 150, (71, 72, 73))
+ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"], freqs=w["freqs"], rates=w["rates"])
+ev = ref.evaluator(device=rank)
+if rank == 0:
+    uid = epa.comm_unique_id()
+    open(idf + ".tmp", "wb").write(uid); os.replace(idf + ".tmp", idf)
+else:
+    t0 = time.time()
+    while not os.path.exists(idf):
+        assert time.time() - t0 < 120
+        time.sleep(0.05)
+    uid = open(idf, "rb").read()
+off, cnt = parallel.local_seq_package(len(w["reads"]), rank, world)
+Q = 200
+comm = epa.Comm(ev, uid, rank, world, rows_cap=Q * 8, depth=2)
+dev = torch.device("cuda", rank)
+cap = Q * 64
+bufs = [(torch.zeros((cap, 2), dtype=torch.int32, device=dev), torch.zeros((cap, 3), dtype=torch.float64, device=dev)) for _ in range(2)]
+nchunks = -(-(-(-len(w["reads"]) // world)) // Q)       # the same number of posts on every rank (collective)
+tickets, got = [], []
+for k in range(nchunks):
+    lo = off + k * Q
+    reads = w["reads"][lo:min(off + cnt, lo + Q)]
+    if reads:
+        ev.chunk_stage(k & 1, *epa.encode_queries(4, reads, compact=True))
+        ev.chunk_launch(k & 1, max_span=150, max_pairs=cap, pairs_out=bufs[k & 1][0], results_out=bufs[k & 1][1], keep_on_device=True)
+        tickets.append(comm.post_slot(k & 1, seq_offset=lo))
+        ev.chunk_finish_device(k & 1)
+    else:
+        tickets.append(comm.post(None, None, 0))
+    if rank == 0 and k >= 1:
+        got += comm.collect(tickets[k - 1])
+if rank == 0:
+    got += comm.collect(tickets[-1])
+comm.flush(on_ticket=(lambda t: got.extend(comm.collect(t))) if rank == 0 else None)
+if rank == 0:
+    rows = np.concatenate(got)
+    rows = rows[np.lexsort((rows["branch_id"], rows["seq_id"]))]
+    np.save(os.environ["EPA_COMM_OUT"], rows)
+    print("COMM_GATHER_OK world=%d rows=%d" % (world, len(rows)))
+comm.close()
+"""
+
+
+def test_gather_one_process_per_gpu(tmp_path):
+    """world = every visible GPU (>= 2): the contiguous query slices of local_seq_package, one process and
+    epa_ctx per GPU, every chunk's rows gathered to rank 0 over RCCL through the C-ABI -- and rank 0 holds
+    the rows of a single-process run over all reads."""
+    n = min(8, epa.device_count())
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL wants one device per rank)")
+    script = tmp_path / "comm_worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "rows.npy"
+    env = dict(os.environ, EPA_ROOT=ROOT, WORLD_SIZE=str(n), EPA_COMM_FILE=str(tmp_path / "uid"), EPA_COMM_OUT=str(out),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(n)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "COMM_GATHER_OK world=%d" % n in outs[0][0]
+    rows = np.load(out)
+    w, ref = _workload()
+    ev = ref.evaluator()
+    pairs, res = ev.place_chunk(*epa.encode_queries(4, w["reads"], compact=True), max_span=150)
+    want = _rows_of(pairs, res, 0)
+    want = want[np.lexsort((want["branch_id"], want["seq_id"]))]
+    assert np.array_equal(rows, want)
+
+
+def _cli_case(tmp_path, nreads=900):
+    import json
+    w = synth.dna_workload(30, 400, nreads, 100, (121, 122, 123))
+    tre, aln, qf = tmp_path / "r.tre", tmp_path / "r.fasta", tmp_path / "q.fasta"
+    tre.write_text(w["newick"] + "\n")
+    with open(aln, "w") as f:
+        for l, s in zip(w["labels"], w["seqs"]):
+            f.write(">%s\n%s\n" % (l, s))
+    with open(qf, "w") as f:
+        for i, s in enumerate(w["reads"]):
+            f.write(">q%d\n%s\n" % (i, s))
+    model = "GTR{%s}+FU{%s}+G4{0.478218}" % ("/".join(map(repr, w["subst"])), "/".join(map(repr, w["freqs"])))
+    base = [hostlib.cli_exe(), "-t", str(tre), "-s", str(aln), "-q", str(qf), "-m", model, "--chunk-size", "100"]
+
+    def load(od):
+        jp = json.load(open(od / "epa_result.jplace"))
+        jp.pop("metadata", None)
+        return jp
+    return base, load
+
+
+@pytest.mark.parametrize("rows_per_read,self_send", [(8, False), (1, True)])
+def test_cli_rank_mode_one_rank_same_jplace(tmp_path, rows_per_read, self_send):
+    """epa-ng-amd --rank 0 --world 1 --comm-file F: the one-process-per-GPU chunk loop (place_ranks.cpp) with a
+    1-rank communicator -- results stay in HBM, every chunk's rows go through epa_dev_gather_slot /
+    epa_comm_collect (rows_per_read = 1: smaller than a chunk's candidate count, so the carry path and the
+    flush rounds run; self_send: rank 0's rows travel through ncclSend / ncclRecv) -- writes the jplace of
+    the threaded chunk loop."""
+    base, load = _cli_case(tmp_path)
+    ref_dir = tmp_path / "out_threads"
+    ref_dir.mkdir()
+    r = subprocess.run(base + ["-w", str(ref_dir)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    od = tmp_path / "out_rank"
+    od.mkdir()
+    env = dict(os.environ, EPA_COMM_ROWS_PER_READ=str(rows_per_read))
+    if self_send:
+        env["EPA_COMM_SELF_SEND"] = "1"
+    r = subprocess.run(base + ["-w", str(od), "--rank", "0", "--world", "1", "--comm-file", str(tmp_path / "uid")],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    a, b = load(ref_dir), load(od)
+    assert len(b["placements"]) == 900
+    assert a == b
+
+
+def test_cli_one_process_per_gpu_same_jplace(tmp_path):
+    """one epa-ng-amd process per visible GPU (>= 2), RCCL gather to rank 0: the jplace of the 1-process run
+    (pquery order: by rank slice = file order)."""
+    n = min(8, epa.device_count())
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL wants one device per rank)")
+    base, load = _cli_case(tmp_path)
+    ref_dir = tmp_path / "out_threads"
+    ref_dir.mkdir()
+    r = subprocess.run(base + ["-w", str(ref_dir)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    od = tmp_path / "out_ranks"
+    od.mkdir()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen(base + ["-w", str(od), "--rank", str(k), "--world", str(n), "--device", str(k),
+                                      "--comm-file", str(tmp_path / "uid")], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for k in range(n)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    a, b = load(ref_dir), load(od)
+    key = lambda p: p["n"][0]
+    assert sorted(a["placements"], key=key) == sorted(b["placements"], key=key)
+    assert a["tree"] == b["tree"]
