@@ -1285,9 +1285,20 @@ static int chunk_body_begin(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t
   double* d_lnl = (double*)epa_scratch(ctx, 3, sizeof(double) * (size_t)Q * pitch);
   if (!d_lnl) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(chunk table)");
   ctx->lnl_pitch = pitch;
+  // per-(query, 64-branch segment) maxima of the table: a by-product of the preplacement fast paths that lets
+  // the dynamic rule read only the segments near a row's maximum (preplace.hip: seg_key, k_select_seg)
+  const uint32_t nseg = (ctx->B + 63) / 64;
+  ctx->segmax = nullptr;
+  if (nseg <= 64 && ctx->heur_mode == 0) {
+    ctx->segp = (nseg + 7u) & ~7u;
+    ctx->segmax = (unsigned long long*)epa_scratch(ctx, 10, sizeof(unsigned long long) * (size_t)Q * ctx->segp);
+    if (!ctx->segmax) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(segment maxima)");
+    EPA_HIP(ctx, hipMemsetAsync(ctx->segmax, 0, sizeof(unsigned long long) * (size_t)Q * ctx->segp, ctx->stream));
+  }
   int rc = launch_preplace(ctx, d_codes, d_begin, d_span, Q, d_lnl, max_span);
   if (!rc) rc = launch_select_begin(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, d_span, rb, sp);
   ctx->lnl_pitch = 0;
+  ctx->segmax = nullptr;
   return rc;
 }
 

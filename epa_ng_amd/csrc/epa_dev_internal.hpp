@@ -168,6 +168,10 @@ struct epa_ctx {
   uint32_t* th_ctr = nullptr;  // work counters of the thorough kernel (one per XCD slice): 256 B per bank,
                                // [0, 64) the counters, [128, 256) the fused chunk's statistics
   uint32_t lnl_pitch = 0;  // row pitch (doubles) of the table handed to launch_preplace / launch_select; 0 = B
+  // fused chunk body only: [Q][segp] order-preserving keys of the per-segment maxima of the table rows
+  // (written by the preplacement fast paths, read by k_select_seg; preplace.hip), or null
+  unsigned long long* segmax = nullptr;
+  uint32_t segp = 0;
   bool code_packed4 = false;  // q_codes arrive in the 4-bit wire format (epa_dev_set_query_packing)
   int heur_mode = 0;        // EPA_HEUR_* (epa_dev_set_heuristic)
   double heur_param = 0.0;  // fixed: fraction of the branches

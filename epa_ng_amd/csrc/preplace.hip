@@ -551,6 +551,33 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
 #ifndef PP_XCD
 #define PP_XCD 1
 #endif
+// ---- per-(query, 64-branch segment) maxima of the preplacement table, written by the single-chunk fast
+// paths as a by-product (one fmax per branch, one atomic per segment and work item) and read by the
+// candidate selection (k_select_seg): a query's candidates and every term that can move its LWR
+// denominator lie in the one or two segments whose maximum is within a few dozen lnL units of the row
+// maximum (cfg2: 1.5 of 16 segments on average), so the selection reads 128 bytes of maxima + those
+// segments instead of the whole 8 KB row.  Stored as order-preserving 64-bit keys (atomicMax on unsigned
+// integers), 0 = nothing written (a query served by another kernel: the selection then reads its row).
+__device__ __forceinline__ unsigned long long seg_key(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double seg_val(unsigned long long k) {
+  const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)u);
+}
+struct SegTrack {   // running maximum of the current segment of one query
+  double m = -INFINITY;
+  __device__ __forceinline__ void add(unsigned long long* __restrict__ segmax, uint32_t segp, uint32_t qi, uint32_t b,
+                                      bool last, double v) {
+    m = fmax(m, v);
+    if ((b & 63u) == 63u || last) {
+      atomicMax(&segmax[(size_t)qi * segp + (b >> 6)], seg_key(m));
+      m = -INFINITY;
+    }
+  }
+};
+
 struct ItemWalk { uint32_t pos, end, step; };
 __device__ __forceinline__ ItemWalk item_walk(uint32_t total) {
   if (PP_XCD && (gridDim.x & 7u) == 0) {
@@ -583,19 +610,38 @@ __device__ __forceinline__ uint32_t choose_tile(uint32_t ng, uint32_t B, uint32_
 // reference's default --chunk-size 5000 puts ~2 reads on a start: a 96-site bucket holds ~180 reads,
 // a workgroup's 1024 lanes would be 18 % full) -- the 16-bit LDS offsets still fit:
 // (288 / 2 + 79) * 288 + 35 * 8 < 65536.  ROWL: byte stride of the staged pair rows in LDS (see above).
-template <bool ACC, int SPR, int ROWL>
+// DB (single-chunk narrow variant): the slices of consecutive branches alternate between two LDS buffers
+// and a branch costs ONE workgroup barrier.  In-kernel cycle counters of the single-buffer loop (cfg2,
+// per branch and wave): 2900 clocks in the gathers, 1200 waiting at the barrier for the slowest wave
+// (the LDS serves the 16 waves unevenly), 670 in staging + its barrier, 450 in the result write-out --
+// all three with the LDS gather path idle.  Here a wave that has finished its gathers of branch j stages
+// its part of slice j + 1 into the other buffer and writes its results out while the slower waves still
+// gather.  Buffer B starts at the fixed offset DB_OFF (a compile-time immediate of its ds_reads); the
+// burst staging rows follow its db_rows rows; the query ids of the write-out come from the wave's own
+// lanes (no s_qi array): 160 KB hold it for windows up to 158 sites.
+// (the batch structure was once pinned with sched_barriers; with two-word batches the compiler's own
+// schedule is as good or better: -DPP_SCHED_PIN restores them for an A/B)
+#ifdef PP_SCHED_PIN
+#define PP_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PP_SCHED_BARRIER()
+#endif
+template <bool ACC, int SPR, int ROWL, bool DB = false>
 __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     const double* __restrict__ lookup2, const uint16_t* __restrict__ packed,
     const uint16_t* __restrict__ tails, const uint32_t* __restrict__ win_begin,
     const uint32_t* __restrict__ win_span, const uint32_t* __restrict__ perm,
     const Group* __restrict__ groups, uint32_t W, uint32_t B, uint32_t pitch, uint32_t NP16,
-    const uint32_t* __restrict__ status, double* __restrict__ lnl) {
+    const uint32_t* __restrict__ status, double* __restrict__ lnl, uint32_t db_rows,
+    unsigned long long* __restrict__ segmax, uint32_t segp) {
   constexpr int TR2 = (CH + SPR) / 2;   // pair rows staged per (branch, chunk)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [TR2][PE] doubles, then accs
   static_assert(ROWL % 16 == 0 && ROWL >= PROWB && ((TR2 - 1) * ROWL + PROWB) < 65536, "16-bit LDS offsets");
-  double* accs = reinterpret_cast<double*>(smem + (size_t)TR2 * ROWL);  // [NB2_ACC][GQ2] / burst rows
+  static_assert(!DB || !ACC, "double-buffered slices: single-chunk variant only");
+  constexpr uint32_t DB_OFF = (uint32_t)TR2 * ROWL;   // byte offset of the second slice buffer
+  double* accs = reinterpret_cast<double*>(smem + (DB ? DB_OFF + (size_t)db_rows * ROWL : (size_t)TR2 * ROWL));  // [NB2_ACC][GQ2] / burst rows
   __shared__ uint32_t s_maxspan;
-  __shared__ uint32_t s_qi[GQ2];        // query of thread t (burst write-out), ~0 = nothing to write
+  __shared__ uint32_t s_qi[DB ? 1 : GQ2];   // query of thread t (burst write-out), ~0 = nothing to write
   constexpr uint32_t BSTR = GQ2 + 4;    // burst staging rows 4 doubles apart in the banks: conflict-free
   // persistent grid over (group, branch tile) items of class 0, see k_preplace
   const uint32_t ng = status[5];
@@ -603,7 +649,21 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
   const uint32_t ntiles = (B + NBP - 1) / NBP;
   const int t = threadIdx.x;
   const ItemWalk iw = item_walk(ng * ntiles);
+#ifdef PP_PROFILE
+  // in-kernel cycle accounting (s_memtime): per wave and branch, the sections between the stamps
+  unsigned long long pp_t[6], pp_sum[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long pp_item_t0 = 0, pp_setup = 0;
+  const unsigned long long pp_k0 = __builtin_readcyclecounter();
+#define PP_STAMP(i) pp_t[i] = __builtin_readcyclecounter()
+#define PP_ACCUM() do { for (int s_ = 0; s_ < 5; ++s_) pp_sum[s_] += pp_t[s_ + 1] - pp_t[s_]; pp_sum[5] += 1; if (j == 0) pp_setup += pp_t[0] - pp_item_t0; } while (0)
+#else
+#define PP_STAMP(i)
+#define PP_ACCUM()
+#endif
   for (uint32_t item = iw.pos; item < iw.end; item += iw.step) {
+#ifdef PP_PROFILE
+  pp_item_t0 = __builtin_readcyclecounter();
+#endif
   const Group g = groups[item % ng];
   const uint32_t b0 = (item / ng) * NBP;
   const uint32_t nb = min(NBP, B - b0);
@@ -618,9 +678,15 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     if ((uint64_t)begin + span > W) span = 0;
   }
   if (t == 0) s_maxspan = 0;
-  s_qi[t] = (active && span > 0) ? qi : 0xffffffffu;
+  const uint32_t my_q = (active && span > 0) ? qi : 0xffffffffu;
+  if (!DB) s_qi[t] = my_q;
   __syncthreads();
-  atomicMax(&s_maxspan, span);
+  {   // one LDS atomic per wave, not per thread (1024 atomics on one word cost ~16k cycles per item)
+    uint32_t m = span;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    if ((t & 63) == 0) atomicMax(&s_maxspan, m);
+  }
   if (ACC) for (uint32_t j = 0; j < nb; ++j) accs[j * GQ2 + t] = 0.0;
   __syncthreads();
   // all members share the parity of their window start: rel is even, pair rows line up
@@ -636,6 +702,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     tailchunk = ((span >> 2) * 2) / CP;
   }
   auto at = [&](uint32_t off) -> double { return *reinterpret_cast<const double*>(smem + off); };
+  SegTrack seg;
 
   for (uint32_t c = 0; c < nchunks; ++c) {
     const uint32_t cbase = c * CH;
@@ -696,7 +763,10 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
         for (int i = 0; i < PW; ++i) asm volatile("" : "+v"(cw[i]));
         // Software pipeline as in k_preplace: batch k+1 (4 words = 8 ds_read_b64) is issued
         // before batch k is summed.  Slots past the window read an exact +0.0.
-        constexpr int WPB = 4, NBATCH = PW / WPB;
+#ifndef PP_WPB
+#define PP_WPB 2   // round 4 A/B, ms per 100k-read launch: 1 -> 0.91, 2 -> 0.905 - 0.914, 4 -> 0.93 - 0.95, 5 -> 0.95, 8 -> 1.35
+#endif
+        constexpr int WPB = PP_WPB, NBATCH = PW / WPB;
         double rb[2][WPB * 2];
         auto issue = [&](int bt) {
 #pragma unroll
@@ -707,17 +777,17 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
           }
         };
         issue(0);
-        __builtin_amdgcn_sched_barrier(0);
+        PP_SCHED_BARRIER();
 #pragma unroll
         for (int bt = 0; bt < NBATCH; ++bt) {
           if (bt + 1 < NBATCH) issue(bt + 1);
-          __builtin_amdgcn_sched_barrier(0);
+          PP_SCHED_BARRIER();
 #pragma unroll
           for (int w = 0; w < WPB; ++w) {
             const double s1 = rb[bt & 1][2 * w] + rb[bt & 1][2 * w + 1];  // (a0+a1) + (a2+a3)
             sum += s1;
           }
-          __builtin_amdgcn_sched_barrier(0);
+          PP_SCHED_BARRIER();
         }
         if (c == tailchunk) {  // singles of the window tail, in order
           sum += at(t0 + boff);
@@ -728,6 +798,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
           accs[j * GQ2 + t] = sum;
         } else {
           accs[(j & 7u) * BSTR + t] = sum;
+          if (segmax) seg.add(segmax, segp, qi, b0 + j, j + 1 == nb, sum);
         }
       }
     };
@@ -740,30 +811,71 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
         // 0.41 GB table); 8 stores per lane back to back, each lane its own sector, relied on L2
         // merging them before eviction (1.19 GB for 0.83 GB; 2.15 GB under the XCD-contiguous walk).
         __builtin_amdgcn_wave_barrier();
-        const uint32_t lane = (uint32_t)t & 63u, wbase = (uint32_t)t & ~63u, col = lane & 7u;
-        const uint32_t ncol = (j & 7u) + 1u, bcol = b0 + (j & ~7u) + col;
+        // four lanes per query, 16 bytes (two branches) per lane: a store instruction still hands over whole
+        // 64-byte sectors (16 queries per wave and instruction) with half as many instructions as 8-byte
+        // stores -- the write-out is store-issue bound (in-kernel cycle counters: 3.7k cycles per burst)
+        const uint32_t lane = (uint32_t)t & 63u, wbase = (uint32_t)t & ~63u, c4 = lane & 3u;
+        const uint32_t ncol = (j & 7u) + 1u, bcol = b0 + (j & ~7u) + 2u * c4;
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) {
-          const uint32_t tq = wbase + k * 8 + (lane >> 3);
-          const uint32_t q = s_qi[tq];
-          if (q != 0xffffffffu && col < ncol) lnl[(size_t)q * pitch + bcol] = accs[col * BSTR + tq];
+        for (uint32_t k = 0; k < 4; ++k) {
+          const uint32_t tq = wbase + k * 16 + (lane >> 2);
+          const uint32_t q = DB ? (uint32_t)__shfl((int)my_q, (int)(k * 16 + (lane >> 2))) : s_qi[tq];
+          if (q != 0xffffffffu && 2u * c4 < ncol) {
+            const double a0 = accs[(2u * c4) * BSTR + tq];
+            double* dst = lnl + (size_t)q * pitch + bcol;
+            if (2u * c4 + 1u < ncol) *reinterpret_cast<double2*>(dst) = make_double2(a0, accs[(2u * c4 + 1u) * BSTR + tq]);
+            else *dst = a0;
+          }
         }
         __builtin_amdgcn_wave_barrier();
       }
     };
-    {
+    if constexpr (DB) {
+      double2 pf[PF];
+      request(0, pf);
+      __syncthreads();                      // both buffers are free (the previous item's consumers are done)
+      stage(pf, 0);
+      if (nb > 1) request(1, pf);
+      __syncthreads();
+      for (uint32_t j = 0; j < nb; j += 2) {
+        PP_STAMP(0);
+        PP_STAMP(1);
+        gather(j, 0);
+        PP_STAMP(2);
+        if (j + 1 < nb) { stage(pf, DB_OFF); if (j + 2 < nb) request(j + 2, pf); }   // buffer B: last read by branch j - 1
+        PP_STAMP(3);
+        flush(j);
+        PP_STAMP(4);
+        __syncthreads();
+        PP_STAMP(5);
+        PP_ACCUM();
+        if (j + 1 < nb) {
+          gather(j + 1, DB_OFF);
+          if (j + 2 < nb) { stage(pf, 0); if (j + 3 < nb) request(j + 3, pf); }      // buffer A: last read by branch j
+          flush(j + 1);
+          __syncthreads();
+        }
+      }
+    } else {
       // The slice of branch j+1 is requested (into registers) before the gathers of branch j start
       // and written to LDS after them: its HBM latency hides under the gather phase.
       double2 pf[PF];
       request(0, pf);
       for (uint32_t j = 0; j < nb; ++j) {
+        PP_STAMP(0);
         __syncthreads();  // previous consumers of the tile are done
+        PP_STAMP(1);
         stage(pf, 0);
+        PP_STAMP(2);
         __syncthreads();
+        PP_STAMP(3);
         if (j + 1 < nb) request(j + 1, pf);
-        __builtin_amdgcn_sched_barrier(0);
+        PP_SCHED_BARRIER();
         gather(j, 0);
+        PP_STAMP(4);
         flush(j);
+        PP_STAMP(5);
+        PP_ACCUM();
       }
     }
   }
@@ -772,6 +884,15 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     for (uint32_t j = 0; j < nb; ++j) out[j] = accs[j * GQ2 + t];
   }
   }  // work items
+#ifdef PP_PROFILE
+  if ((threadIdx.x & 63) == 0) {
+    uint32_t* st = const_cast<uint32_t*>(status) + 40;
+    for (int s_ = 0; s_ < 6; ++s_) atomicAdd(&st[s_], (uint32_t)(s_ < 5 ? pp_sum[s_] >> 10 : pp_sum[s_]));
+    atomicAdd(&st[6], (uint32_t)(pp_setup >> 10));
+    atomicAdd(&st[7], (uint32_t)((__builtin_readcyclecounter() - pp_k0) >> 10));
+    atomicAdd(&st[8], 1u);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -828,7 +949,8 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
     const uint16_t* __restrict__ tails, const uint32_t* __restrict__ win_begin,
     const uint32_t* __restrict__ win_span, const uint32_t* __restrict__ perm,
     const Group* __restrict__ groups, uint32_t W, uint32_t B, uint32_t pitch, uint32_t NP16,
-    const uint32_t* __restrict__ status, double* __restrict__ lnl) {
+    const uint32_t* __restrict__ status, double* __restrict__ lnl,
+    unsigned long long* __restrict__ segmax, uint32_t segp) {
   constexpr uint32_t ROWB = NCOLS * 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [TROWS_S][NCOLS] doubles, then accs
   double* accs = reinterpret_cast<double*>(smem + (size_t)TROWS_S * ROWB);  // [NB2_ACC][GQ2] / burst rows
@@ -846,6 +968,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
     const uint32_t b0 = (item / ng) * NBP;
     const uint32_t nb = min(NBP, B - b0);
     __syncthreads();  // the previous item's readers of s_maxspan / accs / the tile are done
+    SegTrack seg;
     if (g.count == 0) continue;
     const bool active = t < (int)g.count;
     uint32_t qi = 0, begin = 0, span = 0;
@@ -858,7 +981,12 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
     if (t == 0) s_maxspan = 0;
     s_qi[t] = (active && span > 0) ? qi : 0xffffffffu;
     __syncthreads();
-    atomicMax(&s_maxspan, span);
+    {   // one LDS atomic per wave, not per thread
+      uint32_t m = span;
+#pragma unroll
+      for (int off = 32; off; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+      if ((t & 63) == 0) atomicMax(&s_maxspan, m);
+    }
     if (ACC) for (uint32_t j = 0; j < nb; ++j) accs[j * GQ2 + t] = 0.0;
     __syncthreads();
     const uint32_t gmin = win_begin[perm[g.start]];
@@ -961,6 +1089,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
             accs[j * GQ2 + t] = sum;
           } else {
             accs[(j & 7u) * BSTR + t] = sum;
+            if (segmax) seg.add(segmax, segp, qi, b0 + j, j + 1 == nb, sum);
           }
         }
         if (!ACC && ((j & 7u) == 7u || j + 1 == nb)) {
@@ -1042,7 +1171,10 @@ struct SelRule {
   double sum = 0.0;
   uint32_t hits = 0;
   bool striking = true;
-  __device__ __forceinline__ SelRule(int m, double t, uint32_t l) : mode(m), thr(t), limit(l) {}
+  const double* e2t = nullptr;   // LDS table of exp_tab (wave_util.hpp), or null: library exp
+  __device__ __forceinline__ SelRule(int m, double t, uint32_t l, const double* tab = nullptr) : mode(m), thr(t), limit(l), e2t(tab) {}
+  // exp(x), x <= 0; far below the underflow threshold either way once x < -800
+  __device__ __forceinline__ double ex(double x) const { return e2t ? epa_wave::exp_tab(fmax(x, -800.0), e2t) : exp(x); }
   __device__ __forceinline__ bool more(uint32_t taken, uint32_t B) const {
     if (mode == 0) return taken < B && sum < thr;
     if (mode == 1) return taken < limit;
@@ -1050,7 +1182,7 @@ struct SelRule {
   }
   // the next best value: take it?  (wave / workgroup uniform)
   __device__ __forceinline__ bool accept(double best, double mx, double tot, uint32_t taken) {
-    if (mode == 0) { sum += exp(best - mx) / tot; return true; }
+    if (mode == 0) { sum += ex(best - mx) / tot; return true; }
     if (mode == 1) return true;
     if (striking) {
       if (!(best < mx - 3.0)) { ++hits; return true; }
@@ -1083,11 +1215,12 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
   // wave reductions on the DPP ladder (no LDS round trips: the extraction loop below was 18
   // ds_bpermute per candidate), results wave-uniform
   mx = epa_wave::wave_max_d(mx);
+  // (the table-driven exp_tab instead of the library exp: 0.283 -> 0.296 ms, the kernel is not bound by them)
+  SelRule rule(mode, threshold, limit);
   double tot = 0.0;
 #pragma unroll
   for (int r = 0; r < NR; ++r) tot += exp(v[r] - mx);  // exp(-inf) == 0 for the padding
   tot = epa_wave::wave_sum(tot);
-  SelRule rule(mode, threshold, limit);
   uint32_t taken = 0;
   while (rule.more(taken, B)) {
     double lbest = -INFINITY;
@@ -1105,6 +1238,104 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
       if ((uint32_t)(r * 64 + lane) == bi) v[r] = -INFINITY;
     if (lane == 0) so.put(q, bi, taken, status);
     ++taken;
+  }
+  if (lane == 0) counts[q] = so.count(taken);
+}
+
+// The dynamic rule from the per-segment maxima the preplacement left behind (seg_key above): wave per query,
+// lane = 64-branch segment.  With tot >= 1 (the maximum itself) a candidate has lnL >= mx + log((1 - thr) / B)
+// -- everything below sums to less than 1 - thr -- and a term below mx - (log B + 38) is less than 2^-54 / B of
+// tot: all B of them together cannot move its double.  So only the segments whose maximum lies inside those
+// bands are read: 1.5 of 16 on average at cfg2 (tests/...) -- 0.13 GB instead of the 0.82 GB row
+// read per 100k-read chunk.  Up to NRN candidate segments are held in registers; more (or a row without
+// published maxima: its query went through another preplacement kernel) are streamed per extraction.
+template <int NRN>
+__global__ void __launch_bounds__(256) k_select_seg(const double* __restrict__ lnl, const unsigned long long* __restrict__ segmax,
+                                                    uint32_t segp, uint32_t Q, uint32_t B, uint32_t pitch, double threshold,
+                                                    SelOut so, uint32_t* __restrict__ counts, uint32_t* __restrict__ status) {
+  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t lane = threadIdx.x & 63;
+  if (q >= Q) return;
+  const uint32_t nseg = (B + 63) >> 6;   // <= 64
+  const double* src = lnl + (size_t)q * pitch;
+  auto value = [&](uint32_t s) -> double {   // this lane's element of segment s (-inf past the row)
+    const uint32_t i = s * 64 + lane;
+    return i < B ? src[i] : -INFINITY;
+  };
+  const unsigned long long key = lane < nseg ? segmax[(size_t)q * segp + lane] : ~0ull;
+  double m = -INFINITY;
+  if (__ballot(key == 0ull) == 0ull) {
+    if (lane < nseg) m = seg_val(key);
+  } else {   // no maxima for this row: build them from the row itself
+    for (uint32_t s = 0; s < nseg; ++s) {
+      const double xm = epa_wave::wave_max_d(value(s));
+      if (lane == s) m = xm;
+    }
+  }
+  const double mx = epa_wave::wave_max_d(m);
+  const double band_x = 1.0 - log((1.0 - threshold) / (double)B);
+  const double band_t = fmax(band_x, log((double)B) + 38.0);
+  const unsigned long long mask_t = __ballot(m >= mx - band_t), mask_x = __ballot(m >= mx - band_x);
+  double tot = 0.0;
+  for (unsigned long long mm = mask_t; mm; mm &= mm - 1) tot += exp(value((uint32_t)__builtin_ctzll(mm)) - mx);
+  tot = epa_wave::wave_sum(tot);
+  SelRule rule(0, threshold, 0u);
+  uint32_t taken = 0;
+  if (__popcll(mask_x) <= NRN) {
+    double v[NRN];
+    uint32_t base[NRN];
+    unsigned long long mm = mask_x;
+#pragma unroll
+    for (int r = 0; r < NRN; ++r) {
+      if (mm) {
+        const uint32_t s = (uint32_t)__builtin_ctzll(mm);
+        mm &= mm - 1;
+        base[r] = s * 64;
+        v[r] = value(s);
+      } else {
+        base[r] = 0;
+        v[r] = -INFINITY;
+      }
+    }
+    while (rule.more(taken, B)) {
+      double lbest = -INFINITY;
+      uint32_t lbi = 0xffffffffu;
+#pragma unroll
+      for (int r = 0; r < NRN; ++r)   // segments ascend with r: the first maximum has the lowest branch id
+        if (v[r] > lbest) { lbest = v[r]; lbi = base[r] + lane; }
+      const double best = epa_wave::wave_max_d(lbest);
+      const uint32_t bi = epa_wave::wave_min_u((lbest == best && lbest > -INFINITY) ? lbi : 0xffffffffu);
+      if (bi == 0xffffffffu) break;
+      if (!rule.accept(best, mx, tot, taken)) break;
+#pragma unroll
+      for (int r = 0; r < NRN; ++r)
+        if (base[r] + lane == bi) v[r] = -INFINITY;
+      if (lane == 0) so.put(q, bi, taken, status);
+      ++taken;
+    }
+  } else {
+    // many candidate segments: every extraction streams them again and takes the next element in
+    // (lnL descending, branch ascending) order after the previous one
+    double pbest = INFINITY;
+    uint32_t pbi = 0;
+    while (rule.more(taken, B)) {
+      double lbest = -INFINITY;
+      uint32_t lbi = 0xffffffffu;
+      for (unsigned long long mm = mask_x; mm; mm &= mm - 1) {
+        const uint32_t s = (uint32_t)__builtin_ctzll(mm), i = s * 64 + lane;
+        const double x = value(s);
+        const bool after = x < pbest || (x == pbest && i > pbi);
+        if (after && x > lbest) { lbest = x; lbi = i; }
+      }
+      const double best = epa_wave::wave_max_d(lbest);
+      const uint32_t bi = epa_wave::wave_min_u((lbest == best && lbest > -INFINITY) ? lbi : 0xffffffffu);
+      if (bi == 0xffffffffu) break;
+      if (!rule.accept(best, mx, tot, taken)) break;
+      pbest = best;
+      pbi = bi;
+      if (lane == 0) so.put(q, bi, taken, status);
+      ++taken;
+    }
   }
   if (lane == 0) counts[q] = so.count(taken);
 }
@@ -1345,6 +1576,8 @@ int launch_build_lookup2(epa_ctx* ctx) {
 int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin,
                     const uint32_t* d_span, uint32_t Q, double* d_lnl, uint32_t max_span) {
   const uint32_t pitch = ctx->lnl_pitch ? ctx->lnl_pitch : ctx->B;  // row pitch of d_lnl in doubles
+  unsigned long long* const segmax = ctx->segmax;   // per-(query, 64-branch segment) maxima wanted by the fused chunk body, or null
+  const uint32_t segp = ctx->segp;
   const bool pairs = ctx->s == 4 && ctx->lookup2 && !getenv("EPA_PREPLACE_GENERIC");
   const bool sites = ctx->s == 20 && ctx->ncols == 24 && !getenv("EPA_PREPLACE_GENERIC");
   const uint32_t crel = ctx->code_stride ? 1u : 0u, cstride = crel ? ctx->code_stride : ctx->W;
@@ -1435,15 +1668,38 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<A, SP, RL>,                       \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB)));      \
     hipLaunchKernelGGL((k_preplace_pairs<A, SP, RL>), grid2, dim3(GQ2), (LDSB), ctx->stream, ctx->lookup2, packed, \
-                       tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl);    \
+                       tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl, 0u, (A) ? nullptr : segmax, segp);    \
   } while (0)
   if (pairs && wide) {
     const size_t lds2w = (size_t)((CH + SPREAD_WIDE) / 2) * ROWL_PACKED + sizeof(double) * NB2_BURST * (GQ2 + 4);
     PRE2(false, SPREAD_WIDE, ROWL_PACKED, lds2w);
   } else if (pairs) {
-    if (acc) PRE2(true, SPREAD, ROWL_PACKED, lds2); else PRE2(false, SPREAD, ROWL_NARROW, lds2);
+    // single-chunk narrow variant: double-buffered slices when both buffers + the burst rows fit the LDS
+    const uint32_t db_rows = SPREAD / 2 + (std::min<uint32_t>(span_bound, CH) + 1) / 2;
+    const size_t lds_db = (size_t)TROWS2 * ROWL_NARROW + (size_t)db_rows * ROWL_NARROW + sizeof(double) * NB2_BURST * (GQ2 + 4);
+    // measured (round 4, same box): 0.966 ms double-buffered against 0.930 ms single-buffered per 100k-read launch --
+    // the gather phase is bound by the LDS itself, overlapping staging / write-out with it buys nothing: opt-in only
+    static const bool db_off = getenv("EPA_PREPLACE_DB") == nullptr;
+    if (acc) PRE2(true, SPREAD, ROWL_PACKED, lds2);
+    else if (!db_off && lds_db + 64 <= 163840) {
+      EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<false, SPREAD, ROWL_NARROW, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_db));
+      hipLaunchKernelGGL((k_preplace_pairs<false, SPREAD, ROWL_NARROW, true>), grid2, dim3(GQ2), lds_db, ctx->stream, ctx->lookup2,
+                         packed, tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl, db_rows, segmax, segp);
+    } else PRE2(false, SPREAD, ROWL_NARROW, lds2);
   }
 #undef PRE2
+#ifdef PP_PROFILE
+  if (pairs && getenv("EPA_PP_PROFILE")) {
+    uint32_t h[64];
+    EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    EPA_HIP(ctx, hipMemcpy(h, status, 256, hipMemcpyDeviceToHost));
+    const double nb_ = h[45] ? (double)h[45] : 1.0, nw_ = h[48] ? (double)h[48] : 1.0;
+    fprintf(stderr, "PP_PROFILE waves %u branch-iterations/wave %.1f | clk per branch and wave: wait-barrier1 %.0f stage %.0f barrier2 %.0f request+gather %.0f flush %.0f | "
+            "item setup clk/wave %.0f | kernel clk/wave %.0f\n", h[48], nb_ / nw_, 1024.0 * h[40] / nb_, 1024.0 * h[41] / nb_, 1024.0 * h[42] / nb_,
+            1024.0 * h[43] / nb_, 1024.0 * h[44] / nb_, 1024.0 * h[46] / nw_, 1024.0 * h[47] / nw_);
+  }
+#endif
   if (sites) {
     const bool acc_s = max_span == 0 || max_span > (uint32_t)CHS || getenv("EPA_PREPLACE_ACC");
     const size_t lds_s = (size_t)TROWS_S * 24 * 8 + sizeof(double) * (acc_s ? NB2_ACC_S * GQ2 : NB2_BURST * (GQ2 + 4));  // accs / result staging
@@ -1454,7 +1710,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_sites<24, A>,                           \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));       \
     hipLaunchKernelGGL((k_preplace_sites<24, A>), grid_s, dim3(GQ2), lds_s, ctx->stream, ctx->lookup, \
-                       packed, tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl); \
+                       packed, tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl, (A) ? nullptr : segmax, segp); \
   } while (0)
     if (acc_s) PRES(true); else PRES(false);
 #undef PRES
@@ -1546,7 +1802,10 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
     const dim3 grid((Q + 3) / 4);
     const int nr = (int)((B + 63) / 64);
 #define SEL(N) hipLaunchKernelGGL(k_select<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status)
-    if (nr <= 2) SEL(2); else if (nr <= 4) SEL(4); else if (nr <= 8) SEL(8); else if (nr <= 16) SEL(16);
+    static const bool seg_off = getenv("EPA_SELECT_FULL_ROWS") != nullptr;
+    if (ctx->segmax && !seg_off && mode == 0 && threshold < 1.0 && nr <= 64)
+      hipLaunchKernelGGL(k_select_seg<8>, grid, dim3(256), 0, ctx->stream, d_lnl, ctx->segmax, ctx->segp, Q, B, pitch, threshold, so, counts, status);
+    else if (nr <= 2) SEL(2); else if (nr <= 4) SEL(4); else if (nr <= 8) SEL(8); else if (nr <= 16) SEL(16);
     else if (nr <= 32) SEL(32); else if (nr <= 64) SEL(64);
     else if (nr <= 128) hipLaunchKernelGGL(k_select_wg<32>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status);
     else if (nr <= 256) hipLaunchKernelGGL(k_select_wg<64>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status);
