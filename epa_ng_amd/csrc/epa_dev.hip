@@ -533,9 +533,12 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   // unpadded model, and k_thorough_dna serves them with one wave per group of four.
   int c = (c_in == 1 || c_in == 2) ? 4 : c_in;
   if (s == 4 && c_in >= 3 && (c_in & 3) && !getenv("EPA_NO_CAT_PAD")) c = (c_in + 3) & ~3;
+  // 20 states: 3 -> 4, 5 .. 7 -> 8 (k_thorough_aa_mfma serves 4 and 8 categories; more go to the general kernel)
+  if (s == 20 && (c_in == 3 || (c_in >= 5 && c_in <= 7)) && !getenv("EPA_NO_CAT_PAD")) c = (c_in + 3) & ~3;
   if (c_in != c && (d->flags & EPA_FLAG_RATE_SCALERS) && !tree)
     return epa_fail(ctx, EPA_ERR_UNSUPPORTED,
-                    "per-rate scaler arrays of a 1- or 2-category model: use epa_dev_create_from_tree");
+                    "per-rate scaler arrays of a model whose categories are replicated / padded to a multiple of four "
+                    "(1, 2, 3, 5 .. 7, 9 ..): use epa_dev_create_from_tree");
   ctx->c_in = c_in;
   if (!d->sites || !d->branches) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "empty reference");
   const double pinv = d->prop_invar;
@@ -629,7 +632,8 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   const bool tuned_local = (s == 4 && ctx->dna_zero0 && !(pinv > 0.0)) || s == 20;
   // (more than 4 categories: tuned for nucleotide models, sliding rule, zero eigenvalue -- the class
   // launcher of thorough_dna.hip sends what it does not serve to the general kernel itself)
-  const bool tuned_cats = c == 4 || (dna_groups && ctx->blo.sliding && ctx->dna_zero0 && !getenv("EPA_NO_CAT_GROUPS"));
+  const bool tuned_cats = c == 4 || (dna_groups && ctx->blo.sliding && ctx->dna_zero0 && !getenv("EPA_NO_CAT_GROUPS")) ||
+                          (s == 20 && c == 8 && !getenv("EPA_NO_CAT_GROUPS"));   // k_thorough_aa_mfma<.., NC = 8>
   ctx->generic_thorough = !tuned_cats || (!ctx->blo.sliding && !tuned_local) || ctx->blo.newton_variant != 0 ||
                           getenv("EPA_TH_GENERIC") != nullptr;   // (diagnostic switch: measure the general kernel)
 

@@ -67,7 +67,10 @@ struct ThArgsAM {
 // LDS is read with ds_read_b128 wherever two neighbouring doubles go to the same lane: 256 B/clk from
 // one wave per SIMD, where the 8-byte reads need four waves per SIMD for half of that -- and this
 // kernel runs at two.
-constexpr int TAB_STRIDE = 104;   // doubles per table; = 64 B mod 256 B: the three Newton rows hit different banks
+// doubles per table: NC * 4 * 6 entries + 8 of padding = 64 B mod 256 B for NC = 4 and 8: the three Newton rows
+// hit different banks
+template <int NC> constexpr int tab_stride() { return NC * 24 + 8; }
+template <int NC>
 struct SharedM {
   // A-operand tiles of U in the order the products use them, q = 5 t + rt, two tiles interleaved:
   // Ua[((q / 2) * 16 + k * 4 + i) * 2 + q % 2] = U[4 rt + i][4 t + k]
@@ -75,11 +78,19 @@ struct SharedM {
   double Uia[13 * 32];             // the same of U^-1
   // wave-uniform exp tables, entry (category c, eigen index 4 t + kq) at [(c * 4 + kq) * 6 + t]:
   // the five values a lane needs are consecutive (the sixth is padding)
-  double tab[4][TAB_STRIDE];       // [3]: zeros -- the B operand's fourth column in a Newton evaluation
+  double tab[4][tab_stride<NC>()];  // [3]: zeros -- the B operand's fourth column in a Newton evaluation
   double bc[24];                   // cross-wave sums: f [0..8), f' [8..16), lnL [16..24)
   uint32_t next_pair;              // work-queue hand-out of the workgroup
   double e2t[64];                  // 2^(j/64): table of exp_tab (wave_util.hpp)
 };
+// the per-wave partial sums of a workgroup in a fixed order (4 waves: (b0 + b1) + (b2 + b3), as ever)
+template <int NW>
+__device__ __forceinline__ double sum_waves(const double* b) {
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per pair");
+  const double lo = (b[0] + b[1]) + (b[2] + b[3]);
+  if constexpr (NW == 4) return lo;
+  else return lo + ((b[4] + b[5]) + (b[6] + b[7]));
+}
 
 
 // 0 that the optimiser cannot see through, ordered after `v`: added to an LDS index it keeps the
@@ -152,10 +163,14 @@ __device__ __forceinline__ double rows_max(double v) {
   return fmax(a, b);
 }
 
-template <int NT, bool LOCAL = false>
-__global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
-  constexpr int NW = 4, NTHR = 64 * NW;
-  __shared__ alignas(16) SharedM sh;
+// NC: rate categories (4, or 8 = two groups of four: +G8, +R5 .. +R8 padded with weight-0 copies; the
+// sumtable of a tile is NC x 5 registers, so NT x NC <= 16 to stay near the register budget);
+// NW: waves per pair (4, or 8 for windows of up to 8 x NT x 16 sites: one workgroup of 512 threads per CU)
+template <int NT, bool LOCAL = false, int NC = 4, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(const ThArgsAM a) {
+  constexpr int NTHR = 64 * NW;
+  constexpr int CS = NC * S;          // component rows of a reference vector
+  __shared__ alignas(16) SharedM<NC> sh;
   const ModelDev* __restrict__ m = a.m;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int kq = lane >> 4;            // component residue of this lane (state 4 t + kq of vector register t)
@@ -168,15 +183,23 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     sh.Uia[dst] = m->Ui[(4 * rt + i) * S + 4 * t + kk];
   }
   if (tid < 64) sh.e2t[tid] = exp2((double)tid * 0.015625);
-  for (int i = tid; i < TAB_STRIDE; i += NTHR) sh.tab[3][i] = 0.0;
-  // per-thread table constants: thread t < 240 owns (slot = t / 80, kx = t % 80)
-  const int tslot = tid / 80, tkx = tid % 80;
-  const int tpos = ((tkx / S) * 4 + (tkx % S) % 4) * 6 + (tkx % S) / 4;
-  double t_lr = 0.0, t_w = 0.0, t_c = 0.0;
-  if (tid < 240) {
-    t_lr = m->lam[tkx % S] * m->rate[tkx / S];
-    t_w = m->w[tkx / S];
-    t_c = tslot == 0 ? t_w : (tslot == 1 ? t_w * t_lr : t_w * t_lr * t_lr);
+  for (int i = tid; i < tab_stride<NC>(); i += NTHR) sh.tab[3][i] = 0.0;
+  // per-thread table constants: entry e = tid + i NTHR < 3 CS is (slot = e / CS, kx = e % CS)
+  constexpr int NENT = 3 * CS, NE = (NENT + NTHR - 1) / NTHR;
+  int tslot[NE], tpos[NE];
+  double t_lr[NE], t_w[NE], t_c[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = tid + i * NTHR;
+    const int kx = e % CS;
+    tslot[i] = e / CS;
+    tpos[i] = ((kx / S) * 4 + (kx % S) % 4) * 6 + (kx % S) / 4;
+    t_lr[i] = 0.0; t_w[i] = 0.0; t_c[i] = 0.0;
+    if (e < NENT) {
+      t_lr[i] = m->lam[kx % S] * m->rate[kx / S];
+      t_w[i] = m->w[kx / S];
+      t_c[i] = tslot[i] == 0 ? t_w[i] : (tslot[i] == 1 ? t_w[i] * t_lr[i] : t_w[i] * t_lr[i] * t_lr[i]);
+    }
   }
   __syncthreads();
 
@@ -210,8 +233,8 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     const uint32_t b = pr.branch_id, q = pr.seq_id;
     const uint32_t begin = a.win_begin[q], n = a.win_span[q];
     const size_t cW = a.W;
-    const double* Xt = a.refT + (size_t)(2 * b) * 80 * cW + begin;       // proximal
-    const double* Dt = a.refT + (size_t)(2 * b + 1) * 80 * cW + begin;   // distal
+    const double* Xt = a.refT + (size_t)(2 * b) * CS * cW + begin;       // proximal
+    const double* Dt = a.refT + (size_t)(2 * b + 1) * CS * cW + begin;   // distal
     const uint32_t* scp = a.scSum + (size_t)b * cW + begin;
     const uint8_t* qc = a.codes + (size_t)q * a.cstride + (a.crel ? 0u : begin);
     const double orig = a.blen[b];
@@ -222,7 +245,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     uint32_t sscl[NT], lo[NT];      // site of this lane in tile j, clamped for the loads; kq W + site
     bool valid[NT], tile_on[NT];
     double qv[NT][NTS];             // query tip vector in the eigenbasis, vector layout
-    double Sm[NT][4][NTS];          // sumtable of the branch being optimised: [tile][category][reg]
+    double Sm[NT][NC][NTS];         // sumtable of the branch being optimised: [tile][category][reg]
     bool resc_keep[NT];             // LOCAL: rescale flag of the last inner vector toward the query
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -239,11 +262,13 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     // (no barrier in front: whatever ran before ended with a workgroup barrier behind its last
     // table read -- the phases and the Newton evaluations below keep that invariant)
     auto publish = [&](double t0, double t1, double t2) {
-      if (tid < 240) {
-        const double t = tslot == 0 ? t0 : (tslot == 1 ? t1 : t2);
-        const double e = exp_tab(t_lr * t, sh.e2t);
-        sh.tab[tslot][tpos] = tslot == 2 ? e * t_w : e;
-      }
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+        if (tid + i * NTHR < NENT) {
+          const double t = tslot[i] == 0 ? t0 : (tslot[i] == 1 ? t1 : t2);
+          const double e = exp_tab(t_lr[i] * t, sh.e2t);
+          sh.tab[tslot[i]][tpos[i]] = tslot[i] == 2 ? e * t_w[i] : e;
+        }
       __syncthreads();
     };
 
@@ -255,7 +280,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
       const bool side = mode == 1 || mode == 3;   // sumtable of a side branch: no window lnL
       double mant = 1.0;
       int ex = 0;
-      const double* I0 = a.refI + (size_t)b * 80 * cW + begin;
+      const double* I0 = a.refI + (size_t)b * CS * cW + begin;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if (!tile_on[j]) continue;   // wave-uniform
@@ -282,7 +307,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
         };
         fetch(0, zero_after(mant));
 #pragma unroll
-        for (int cat = 0; cat < 4; ++cat) {
+        for (int cat = 0; cat < NC; ++cat) {
           __builtin_amdgcn_sched_barrier(0);
           // ordering token of this category's matrix-tile / table reads: behind the arrival of its
           // operands (requested a category ago).  Without it the loop-invariant tile reads are
@@ -294,7 +319,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
           if (mode == 2) {
 #pragma unroll
             for (int t = 0; t < NTS; ++t) It[t] = Bn[t];
-            if (cat < 3) fetch(cat + 1, zt);
+            if (cat < NC - 1) fetch(cat + 1, zt);
           } else {
             double Av[NTS], Bv[NTS];
             {
@@ -308,7 +333,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
                 Bv[t] = Bn[t] * e1[t];
               }
             }
-            if (cat < 3) fetch(cat + 1, zt);
+            if (cat < NC - 1) fetch(cat + 1, zt);
             // a = U (e0 o A), b = U (e1 o B): one read of a U tile pair feeds four MFMAs
             double ya[NTS], yb[NTS];
 #pragma unroll
@@ -375,7 +400,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
           if (__any(resc)) {
             const double mult = resc ? 0x1p+256 : 1.0;
 #pragma unroll
-            for (int cat = 0; cat < 4; ++cat)
+            for (int cat = 0; cat < NC; ++cat)
 #pragma unroll
               for (int t = 0; t < NTS; ++t) Sm[j][cat][t] *= mult;
             l0 *= mult;
@@ -402,7 +427,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
         const double tot = wave_sum(log(mant) + (double)ex * LOG_2);
         if (lane == 0) sh.bc[16 + wv] = tot;
         __syncthreads();   // also: every wave is past its last table read
-        lnl_out = (sh.bc[16] + sh.bc[17]) + (sh.bc[18] + sh.bc[19]);
+        lnl_out = sum_waves<NW>(sh.bc + 16);
       } else {
         __syncthreads();   // every wave is past its last table read
       }
@@ -413,17 +438,19 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
     // column 3 zeros); D puts l_0, l_1, l_2 of a site in lanes 0, 1, 2 of one quad
     uint32_t evals = 0;
     auto derivatives = [&](double t, double& f, double& df) {
-      if (tid < 240) sh.tab[tslot][tpos] = exp_tab(t_lr * t, sh.e2t) * t_c;
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+        if (tid + i * NTHR < NENT) sh.tab[tslot[i]][tpos[i]] = exp_tab(t_lr[i] * t, sh.e2t) * t_c[i];
       __syncthreads();
       const int row = lane & 3;
       double fl = 0.0, dfl = 0.0;
       // the B operands (this lane's five table entries of each category) are the same for every tile:
       // read once per evaluation; row 3 reads the zero table: no per-value select
-      double av[4][NTS];
+      double av[NC][NTS];
       {
         const int zt = zero_after(t);
 #pragma unroll
-        for (int cat = 0; cat < 4; ++cat) lds5(&sh.tab[row][(cat * 4 + kq) * 6 + zt], av[cat]);
+        for (int cat = 0; cat < NC; ++cat) lds5(&sh.tab[row][(cat * 4 + kq) * 6 + zt], av[cat]);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -434,7 +461,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
 #pragma unroll
         for (int tt = 0; tt < NTS; ++tt)
 #pragma unroll
-          for (int cat = 0; cat < 4; ++cat) acc[cat] = mfma4(Sm[j][cat][tt], av[cat][tt], acc[cat]);
+          for (int cat = 0; cat < NC; ++cat) acc[cat & 3] = mfma4(Sm[j][cat][tt], av[cat][tt], acc[cat & 3]);
         // lane (i = lane / 16, block, r): l_r of site 4 block + i of the tile
         const double lr = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         const double l0 = lr, l1 = quad_bcast<1>(lr), l2 = quad_bcast<2>(lr);
@@ -450,8 +477,8 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
       wave_sum2(fl, dfl, ft, dft);
       if (lane == 0) { sh.bc[wv] = ft; sh.bc[8 + wv] = dft; }
       __syncthreads();   // also: every wave is past its table reads
-      f = (sh.bc[0] + sh.bc[1]) + (sh.bc[2] + sh.bc[3]);
-      df = (sh.bc[8] + sh.bc[9]) + (sh.bc[10] + sh.bc[11]);
+      f = sum_waves<NW>(sh.bc);
+      df = sum_waves<NW>(sh.bc + 8);
       ++evals;
     };
 
@@ -498,7 +525,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
         double l0 = 0.0;
         const int zt = zero_after(mant);
 #pragma unroll
-        for (int cat = 0; cat < 4; ++cat) {
+        for (int cat = 0; cat < NC; ++cat) {
           double e2[NTS];
           lds5(&sh.tab[2][(cat * 4 + kq) * 6 + zt], e2);
 #pragma unroll
@@ -514,7 +541,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
       const double tot = wave_sum(log(mant) + (double)ex * LOG_2);
       if (lane == 0) sh.bc[16 + wv] = tot;
       __syncthreads();   // also: every wave is past its last table read
-      lnl_out = (sh.bc[16] + sh.bc[17]) + (sh.bc[18] + sh.bc[19]);
+      lnl_out = sum_waves<NW>(sh.bc + 16);
     };
 
     double lnl_now = 0.0;
@@ -635,7 +662,7 @@ __global__ void __launch_bounds__(256, 2) k_thorough_aa_mfma(const ThArgsAM a) {
 
 }  // namespace
 
-// windows up to 64 * NT sites (NT = 1, 2, 3); the caller routes longer windows to k_thorough_aa
+// windows up to 384 sites (4 rate categories) / 256 sites (8); the caller routes longer windows elsewhere
 int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_order, uint64_t n_pairs,
                             const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span,
                             uint32_t max_span, epa_result* d_out, unsigned long long* d_stats) {
@@ -660,32 +687,45 @@ int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_
   a.stats = d_stats;
   a.n_pairs = n_pairs;
   a.W = ctx->W;
-  // 2 resident workgroups per CU, grid oversubscribed so that the dispatcher balances the cost
-  // spread of the pairs (as k_thorough_aa)
+  // (an LDS cache of the pair's reference windows was measured and dropped: a third fewer HBM reads,
+  // 1 - 6 % slower -- profiles/r2_aa_mfma_ab.txt)
+  const uint32_t tiles = (max_span + 15) / 16;
+  const int nc = ctx->c;
+  if (!(nc == 4 || nc == 8)) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "thorough_aa_mfma: 4 or 8 rate categories");
+  if (tiles > (nc == 4 ? 24u : 16u))
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "thorough_aa_mfma: window longer than 384 (4 categories) / 256 (8) sites");
+  // waves per pair: 4 (two workgroups per CU) or 8 (one); tiles per wave NT
+  const int nw = nc == 4 ? (tiles <= 12 ? 4 : 8) : (tiles <= 4 ? 4 : 8);
+  const uint32_t wg_per_cu = nw == 4 ? 2u : 1u;
+  // resident workgroups + a work counter per XCD slice (EPA_TH_QUEUE=0: an oversubscribed static grid,
+  // the dispatcher balances the cost spread of the pairs)
   uint32_t per_slot = 16;
   if (const char* e = getenv("EPA_TH_WAVES_PER_SLOT")) per_slot = (uint32_t)std::max(1, atoi(e));
-  uint32_t nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * 2 * per_slot);
-  // resident workgroups + a work counter per XCD slice (EPA_TH_QUEUE=0: the oversubscribed static grid)
+  uint32_t nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * wg_per_cu * per_slot);
   a.qctr = nullptr;
   if (!(getenv("EPA_TH_QUEUE") && atoi(getenv("EPA_TH_QUEUE")) == 0) && ctx->th_ctr) {
     EPA_HIP(ctx, hipMemsetAsync(epa_th_ctr(ctx), 0, 64, ctx->stream));
     a.qctr = epa_th_ctr(ctx);
-    nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * 2);
+    nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * wg_per_cu);
   }
   nwg = (nwg + 7) / 8 * 8;
-  if (max_span > 192) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "thorough_aa_mfma: window longer than 192 sites");
-  // (an LDS cache of the pair's reference windows was measured and dropped: a third fewer HBM reads,
-  // 1 - 6 % slower -- profiles/r2_aa_mfma_ab.txt)
-  const uint32_t tiles = (max_span + 15) / 16;
-  if (!ctx->blo.sliding) {   // --raxml-blo
-    if (tiles <= 4) hipLaunchKernelGGL((k_thorough_aa_mfma<1, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
-    else if (tiles <= 8) hipLaunchKernelGGL((k_thorough_aa_mfma<2, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((k_thorough_aa_mfma<3, true>), dim3(nwg), dim3(256), 0, ctx->stream, a);
+#define AAM(NT_, NC_, NW_)                                                                                        \
+  do {                                                                                                            \
+    if (!ctx->blo.sliding) hipLaunchKernelGGL((k_thorough_aa_mfma<NT_, true, NC_, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
+    else hipLaunchKernelGGL((k_thorough_aa_mfma<NT_, false, NC_, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a);                 \
+  } while (0)
+  if (nc == 4) {
+    if (tiles <= 4) AAM(1, 4, 4);
+    else if (tiles <= 8) AAM(2, 4, 4);
+    else if (tiles <= 12) AAM(3, 4, 4);
+    else if (tiles <= 16) AAM(2, 4, 8);
+    else AAM(3, 4, 8);
   } else {
-    if (tiles <= 4) hipLaunchKernelGGL((k_thorough_aa_mfma<1>), dim3(nwg), dim3(256), 0, ctx->stream, a);
-    else if (tiles <= 8) hipLaunchKernelGGL((k_thorough_aa_mfma<2>), dim3(nwg), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((k_thorough_aa_mfma<3>), dim3(nwg), dim3(256), 0, ctx->stream, a);
+    if (tiles <= 4) AAM(1, 8, 4);
+    else if (tiles <= 8) AAM(1, 8, 8);
+    else AAM(2, 8, 8);
   }
+#undef AAM
   EPA_HIP(ctx, hipGetLastError());
   return EPA_OK;
 }

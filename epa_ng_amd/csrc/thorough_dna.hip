@@ -1579,7 +1579,7 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
   if (n_pairs > 0xffffffffull) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "thorough: more than 2^32 pairs per call");
   // any category count, Newton variants, --raxml-blo outside the tuned instantiation (20 states, +I,
   // windows beyond the multi-wave classes)
-  if (ctx->generic_thorough || (!ctx->blo.sliding && max_span > (ctx->s == 4 ? 1536u : 192u))) {
+  if (ctx->generic_thorough || (!ctx->blo.sliding && ctx->s == 4 && max_span > 1536u)) {
     ctx->cls_hist_pairs = 0;
     return launch_thorough_generic(ctx, d_pairs, n_pairs, d_codes, d_begin, d_span, max_span, d_out, d_stats);
   }
@@ -1645,17 +1645,21 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
     const uint32_t* ord = order ? order + off : nullptr;
     off += hist[c];
     if (ctx->s == 20) {
-      // windows up to 192 sites: matrix-core kernel (sumtable in registers); longer ones, or all of
-      // them with EPA_AA_VALU=1 (A/B switch), the lane = site VALU kernel
+      // matrix-core kernel (sumtable in registers): windows up to 384 sites with 4 rate categories, up to 256
+      // with 8 (+G8, +R5 ..); longer ones, or all of them with EPA_AA_VALU=1 (A/B switch, 4 categories), the
+      // lane = site VALU kernel / the general kernel
       static const uint32_t aa_bound[4] = {64, 128, 192, 0xffffffffu};
       static const bool aa_valu = getenv("EPA_AA_VALU") != nullptr;
       const uint32_t bound = std::min(max_span, aa_bound[c < 4 ? c : 3]);
+      const uint32_t mfma_max = ctx->c == 4 ? 384u : 256u;
       // (the VALU kernel has no --raxml-blo instantiation: the A/B switch applies to the sliding rule only)
-      if (c < 3 && (!aa_valu || !ctx->blo.sliding))
+      if (bound <= mfma_max && (!aa_valu || !ctx->blo.sliding || ctx->c != 4))
         rc = launch_thorough_aa_mfma(ctx, d_pairs, ord, hist[c], d_codes, d_begin, d_span, bound, d_out, d_stats);
-      else
+      else if (ctx->c == 4 && ctx->blo.sliding)
         rc = launch_thorough_aa(ctx, d_pairs, ord, hist[c], d_codes, d_begin, d_span, bound,
                                 bound <= EPA_AA_LDS_MAX_SPAN, d_out, d_stats);
+      else
+        rc = launch_thorough_generic(ctx, d_pairs, hist[c], d_codes, d_begin, d_span, bound, d_out, d_stats, ord);
       continue;
     }
     ThArgs a;

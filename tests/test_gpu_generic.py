@@ -104,6 +104,50 @@ def test_category_group_kernel_equals_general_kernel(cats, pinv, monkeypatch):
     assert st["rounds"] == o.last_stats["rounds"]
 
 
+@pytest.mark.parametrize("cats,pinv,blo", [(4, 0.0, "sliding"), (5, 0.0, "sliding"), (8, 0.0, "sliding"), (8, 0.2, "sliding"),
+                                           (8, 0.0, "raxml"), (4, 0.0, "raxml")])
+def test_aa_matrix_core_kernel_8_categories_and_long_windows(cats, pinv, blo, monkeypatch):
+    """20-state models on k_thorough_aa_mfma beyond {4 categories, 192 sites}: 8 categories (+G8; +R5 padded
+    with weight-0 copies of its last category) as NC = 8 instantiations, windows of up to 384 (4 categories)
+    / 256 (8) residues on 8-wave workgroups; longer ones in the same chunk go to the lane = site / general
+    kernel.  EPA_TH_GENERIC=1 sends the same context shape to k_thorough_generic: same pairs, lnL and lengths
+    to 1e-9, identical round / Newton-evaluation counters; and the oracle on the mixed chunk."""
+    rng = np.random.RandomState(700 + cats)
+    rates = np.sort(rng.gamma(0.6, 1.5, cats)) + 1e-3
+    weights = rng.dirichlet(np.full(cats, 3.0))
+    rates = rates / np.sum(rates * weights)
+    subst, freqs = synth.aa_model(9)
+    root = synth.random_tree(24, 90 + cats)
+    labels, seqs = synth.simulate_msa(root, 420, subst, freqs, synth.gamma_rates(0.7), 91)
+    nw = synth.newick(root)
+    reads = []
+    for k, rl in enumerate((30, 64, 65, 100, 128, 129, 192, 193, 250, 256, 257, 300, 384, 385, 410)):
+        r, _ = synth.make_reads(seqs, 2, rl, 0.05, 160 + k, states=20)
+        reads += list(r)
+    kw = dict(raxml_blo=True) if blo == "raxml" else {}
+    ref = hostlib.Reference(nw, labels, seqs, states=20, subst=subst, freqs=freqs, rates=rates, weights=weights, pinv=pinv)
+    codes, wb, ws = epa.encode_queries(20, reads, compact=True)
+    pairs = all_pairs(ref.B, len(reads))[::2].copy()
+    ev = ref.evaluator(**kw)
+    res = ev.thorough(pairs, codes, wb, ws)
+    st = dict(ev.last_stats)
+    monkeypatch.setenv("EPA_TH_GENERIC", "1")
+    evg = ref.evaluator(**kw)
+    resg = evg.thorough(pairs, codes, wb, ws)
+    monkeypatch.delenv("EPA_TH_GENERIC")
+    assert np.max(np.abs(res["lnl"] - resg["lnl"])) < 1e-9
+    assert np.max(np.abs(res["pendant_length"] - resg["pendant_length"])) < 1e-9
+    assert np.max(np.abs(res["distal_length"] - resg["distal_length"])) < 1e-9
+    assert st["rounds"] == evg.last_stats["rounds"] and st["newton_evals"] == evg.last_stats["newton_evals"]
+    o = Oracle(nw, labels, seqs, 20, subst, freqs, rates, weights=weights, pinv=pinv)
+    if blo == "raxml":
+        o.set_raxml_blo(True)
+    tl, tp, td = o.thorough(pairs["branch_id"], pairs["seq_id"], reads)
+    assert np.max(np.abs(res["lnl"] - tl)) < LNL_TOL
+    assert np.max(np.abs(res["distal_length"] - td)) < 1e-6
+    assert st["rounds"] == o.last_stats["rounds"]
+
+
 @pytest.mark.parametrize("states", [4, 20])
 def test_per_rate_scalers_equal_per_site_scalers_on_ordinary_data(states):
     """where nothing underflows the two scaling schemes give the same numbers (the device in
