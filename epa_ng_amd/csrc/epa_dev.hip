@@ -512,7 +512,8 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
   }
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
-  EvTimer* ts[4] = {&ctx->t_lookup, &ctx->t_preplace, &ctx->t_thorough, &ctx->t_select};
+  std::vector<EvTimer*> ts = {&ctx->t_lookup};
+  for (auto& bk : ctx->t_bank) for (auto& t : bk) ts.push_back(&t);
   for (auto* t : ts) { if (t->a) (void)hipEventDestroy(t->a); if (t->b) (void)hipEventDestroy(t->b); }
   delete ctx;
 }
@@ -535,10 +536,12 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   if (s == 4 && c_in >= 3 && (c_in & 3) && !getenv("EPA_NO_CAT_PAD")) c = (c_in + 3) & ~3;
   // 20 states: 3 -> 4, 5 .. 7 -> 8 (k_thorough_aa_mfma serves 4 and 8 categories; more go to the general kernel)
   if (s == 20 && (c_in == 3 || (c_in >= 5 && c_in <= 7)) && !getenv("EPA_NO_CAT_PAD")) c = (c_in + 3) & ~3;
+  // per-rate scaler rows from the caller ([W][c_in]) cannot be padded here: such a context keeps its category
+  // count and runs on the general kernel (as before the category groups existed)
+  if (c_in >= 3 && c != c_in && (d->flags & EPA_FLAG_RATE_SCALERS) && !tree) c = c_in;
   if (c_in != c && (d->flags & EPA_FLAG_RATE_SCALERS) && !tree)
     return epa_fail(ctx, EPA_ERR_UNSUPPORTED,
-                    "per-rate scaler arrays of a model whose categories are replicated / padded to a multiple of four "
-                    "(1, 2, 3, 5 .. 7, 9 ..): use epa_dev_create_from_tree");
+                    "per-rate scaler arrays of a 1- or 2-category model (replicated to four): use epa_dev_create_from_tree");
   ctx->c_in = c_in;
   if (!d->sites || !d->branches) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "empty reference");
   const double pinv = d->prop_invar;
@@ -1559,11 +1562,20 @@ extern "C" int epa_dev_chunk_launch_end(epa_ctx* ctx, int slot) {
   epa_pair* d_pairs = s->l_pairs;
   epa_result* d_results = s->l_res;
   SlotScope scope(ctx, s, slot);
-  s->state = 1;        // candidate overflow etc.: the slot stays staged
   rc = chunk_body_end(ctx, &s->sel, s->l_codes, s->l_begin, s->l_span, s->l_max_span, d_pairs, d_results, s->d_stats, &n);
-  if (rc) return rc;
+  // Candidate overflow and the window-validation errors are found before any thorough kernel is queued: the
+  // slot stays staged (launch again with a larger max_pairs).  Any other failure may leave kernels of this
+  // chunk in flight on the slot's stream: wait for them and free the slot, so that it cannot be re-staged or
+  // re-launched (its result buffers re-allocated) under running kernels.
+  auto abandon = [&](int code) {
+    (void)hipStreamSynchronize(s->stream);
+    s->state = 0;
+    return code;
+  };
+  if (rc == EPA_ERR_PAIR_OVERFLOW || rc == EPA_ERR_QUERY_ALL_GAP || rc == EPA_ERR_QUERY_WIDTH) { s->state = 1; return rc; }
+  if (rc) return abandon(rc);
   s->n = n;
-  EPA_HIP(ctx, hipEventRecord(s->ev_done, ctx->stream));
+  if (hipEventRecord(s->ev_done, ctx->stream) != hipSuccess) return abandon(epa_fail(ctx, EPA_ERR_HIP, "hipEventRecord(chunk done)"));
   EPA_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, s->ev_done, 0));
   if (s->l_flags & EPA_CHUNK_NO_D2H) {
     s->out_pairs = d_pairs;
@@ -1573,7 +1585,7 @@ extern "C" int epa_dev_chunk_launch_end(epa_ctx* ctx, int slot) {
   } else {
     const size_t off_r = (sizeof(epa_pair) * n + 255) & ~(size_t)255;
     rc = grow_pinned(ctx, &s->h_out, &s->h_out_sz, off_r + sizeof(epa_result) * n);
-    if (rc) return rc;
+    if (rc) return abandon(rc);
     if (n) {
       EPA_HIP(ctx, hipMemcpyAsync(s->h_out, d_pairs, sizeof(epa_pair) * n, hipMemcpyDeviceToHost, ctx->down_stream));
       EPA_HIP(ctx, hipMemcpyAsync((char*)s->h_out + off_r, d_results, sizeof(epa_result) * n, hipMemcpyDeviceToHost,
@@ -1801,10 +1813,10 @@ extern "C" int epa_dev_mem_info(epa_ctx* ctx, uint64_t* free_bytes, uint64_t* to
 extern "C" double epa_dev_last_kernel_ms(const epa_ctx* ctx, const char* which) {
   if (!ctx || !which) return -1.0;
   const EvTimer* t = nullptr;
-  if (!strcmp(which, "preplace")) t = &ctx->t_preplace;
-  else if (!strcmp(which, "thorough")) t = &ctx->t_thorough;
+  if (!strcmp(which, "preplace")) t = &ctx->t_bank[ctx->t_last[epa_ctx::T_PREPLACE]][epa_ctx::T_PREPLACE];
+  else if (!strcmp(which, "thorough")) t = &ctx->t_bank[ctx->t_last[epa_ctx::T_THOROUGH]][epa_ctx::T_THOROUGH];
   else if (!strcmp(which, "lookup")) t = &ctx->t_lookup;
-  else if (!strcmp(which, "select")) t = &ctx->t_select;
+  else if (!strcmp(which, "select")) t = &ctx->t_bank[ctx->t_last[epa_ctx::T_SELECT]][epa_ctx::T_SELECT];
   if (!t || !t->valid) return -1.0;
   if (hipEventSynchronize(t->b) != hipSuccess) return -1.0;
   float ms = -1.f;

@@ -70,6 +70,9 @@ struct SelectPending {
   size_t sort_bytes = 0;
   uint32_t* rb = nullptr;   // host read-back block, 64 words
   bool have_status = false;
+  bool rerun = false;
+  const uint32_t* pre_status = nullptr;   // window-validation words of THIS chunk's preplacement (ctx->d_status may belong
+                                          // to another pipeline slot by the time a widened re-run packs the read-back)
 };
 
 struct ChunkSlot {
@@ -181,7 +184,13 @@ struct epa_ctx {
   hipStream_t copy_stream = nullptr, down_stream = nullptr;
   ChunkSlot slots[N_SLOTS];
 
-  EvTimer t_lookup, t_preplace, t_thorough, t_select;
+  // kernel-family timers (epa_dev_last_kernel_ms): one set per scratch bank -- the pipeline slots run
+  // concurrently on their own streams, a single set would have its start event re-recorded by slot k + 1
+  // before slot k records its stop; t_last = the bank whose timer was stopped last
+  enum { T_PREPLACE = 0, T_THOROUGH = 1, T_SELECT = 2 };
+  EvTimer t_lookup;
+  EvTimer t_bank[N_BANKS][3];
+  int t_last[3] = {0, 0, 0};
   epa_thorough_stats last_stats{};
 };
 
@@ -198,6 +207,8 @@ const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_
 const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_t Q);
 void epa_timer_start(epa_ctx* ctx, EvTimer& t);
 void epa_timer_stop(epa_ctx* ctx, EvTimer& t);
+// the current bank's timer of a kernel family (epa_ctx::T_*)
+inline EvTimer& epa_t(epa_ctx* ctx, int which) { ctx->t_last[which] = ctx->bank; return ctx->t_bank[ctx->bank][which]; }
 
 #define EPA_HIP(ctx, call)                                                               \
   do {                                                                                    \
@@ -240,7 +251,7 @@ int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_
 int launch_thorough_generic(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
                             const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
                             epa_result* d_out, unsigned long long* d_stats,
-                            const uint32_t* d_order = nullptr);
+                            const uint32_t* d_order = nullptr, bool caller_times = false);   // caller_times: a per-class launch inside launch_thorough's timed region
 int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_order, uint64_t n_pairs,
                             const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span,
                             uint32_t max_span, epa_result* d_out, unsigned long long* d_stats);

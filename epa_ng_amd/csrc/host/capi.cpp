@@ -191,6 +191,10 @@ int epa_host_dev_create_opts(void* h, int device, int aa_x_as_n, int device_prec
     d.ref.blo_min_branch = blo_min_branch;
     rc = epa_dev_create_from_tree(&d, device, out);
   } else {
+    if (flags & EPA_FLAG_RATE_SCALERS) {   // as Device_Evaluator: the host CLV path keeps per-site scalers only
+      g_err = "per-rate scalers need the device-side reference precompute (the host CLV path keeps per-site scalers)";
+      return EPA_ERR_UNSUPPORTED;
+    }
     epa_ref_desc d;
     std::vector<const double*> pc, dc;
     std::vector<const uint32_t*> ps, ds;

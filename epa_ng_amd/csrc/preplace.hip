@@ -1662,7 +1662,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
                         : max_groups * ntiles);
   const size_t codes_bytes = (size_t)Q * cstride;
   const uint32_t want_cls = pairs ? 1u : 0u;
-  epa_timer_start(ctx, ctx->t_preplace);
+  epa_timer_start(ctx, epa_t(ctx, epa_ctx::T_PREPLACE));
 #define PRE2(A, SP, RL, LDSB)                                                                        \
   do {                                                                                               \
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<A, SP, RL>,                       \
@@ -1714,7 +1714,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   } while (0)
     if (acc_s) PRES(true); else PRES(false);
 #undef PRES
-    epa_timer_stop(ctx, ctx->t_preplace);
+    epa_timer_stop(ctx, epa_t(ctx, epa_ctx::T_PREPLACE));
     EPA_HIP(ctx, hipGetLastError());
     return EPA_OK;
   }
@@ -1728,7 +1728,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   if (ctx->ncols == 16) { if (acc) PRE(16, true); else PRE(16, false); }
   else { if (acc) PRE(24, true); else PRE(24, false); }
 #undef PRE
-  epa_timer_stop(ctx, ctx->t_preplace);
+  epa_timer_stop(ctx, epa_t(ctx, epa_ctx::T_PREPLACE));
   EPA_HIP(ctx, hipGetLastError());
   return EPA_OK;
 }
@@ -1758,6 +1758,7 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
   ctx->cls_hist_pairs = 0;
   const uint32_t B = ctx->B;
   const uint32_t pitch = ctx->lnl_pitch ? ctx->lnl_pitch : B;  // row pitch of d_lnl in doubles
+  if (!sp->rerun) sp->pre_status = (const uint32_t*)ctx->d_status;
   if (B > 64 * 64 * 16)
     return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "select_candidates: more than 65536 branches");
   // selection rule of the context (epa_dev_set_heuristic); fixed: ceil(x * B) best, at least... none:
@@ -1797,7 +1798,7 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
     sp->d_lnl = d_lnl; sp->Q = Q; sp->threshold = threshold; sp->d_pairs = d_pairs; sp->max_pairs = max_pairs;
     sp->d_span = d_span; sp->cap = cap; sp->rb = rb;
     EPA_HIP(ctx, hipMemsetAsync(base, 0, 512 + cb + mb, ctx->stream));   // status, counters, bitmap: one fill
-    epa_timer_start(ctx, ctx->t_select);
+    epa_timer_start(ctx, epa_t(ctx, epa_ctx::T_SELECT));
     const SelOut so{nullptr, 0u, bitmap, bcount, wpr};
     const dim3 grid((Q + 3) / 4);
     const int nr = (int)((B + 63) / 64);
@@ -1816,9 +1817,9 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
       hipLaunchKernelGGL(k_class_hist, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, counts, d_span, Q,
                          ctx->s, status + 8);
     hipLaunchKernelGGL(k_pack_readback, dim3(1), dim3(64), 0, ctx->stream, status, bcount + B,
-                       (const uint32_t*)ctx->d_status, status + 64);
+                       sp->pre_status, status + 64);
     EPA_HIP(ctx, hipMemcpyAsync(rb, status + 64, sizeof(uint32_t) * 36, hipMemcpyDeviceToHost, ctx->stream));
-    sp->have_status = ctx->d_status != nullptr;
+    sp->have_status = sp->pre_status != nullptr;
     return EPA_OK;
   }
   // scratch 7: [status 512 B | counts Q+1 | offsets Q+1 | stage Q*cap | keys_a worst | keys_b worst | temp]
@@ -1843,7 +1844,7 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
   // status words and the trailing count in one fill: counts[Q] sits in the same allocation
   EPA_HIP(ctx, hipMemsetAsync(status, 0, 512, ctx->stream));
   EPA_HIP(ctx, hipMemsetAsync(counts + Q, 0, sizeof(uint32_t), ctx->stream));
-  epa_timer_start(ctx, ctx->t_select);
+  epa_timer_start(ctx, epa_t(ctx, epa_ctx::T_SELECT));
   const dim3 grid((Q + 3) / 4);
   const int nr = (int)((B + 63) / 64);
   const SelOut so{sp->stage, cap, nullptr, nullptr, 0u};
@@ -1864,9 +1865,9 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
   // rb: [0] total, [1 .. 8 + EPA_N_CLS] status words + class histogram, [32 .. 35] window validation:
   // packed on the device so that ONE small copy brings everything the host waits for
   hipLaunchKernelGGL(k_pack_readback, dim3(1), dim3(64), 0, ctx->stream, status, offsets + Q,
-                     (const uint32_t*)ctx->d_status, status + 64);
+                     sp->pre_status, status + 64);
   EPA_HIP(ctx, hipMemcpyAsync(rb, status + 64, sizeof(uint32_t) * 36, hipMemcpyDeviceToHost, ctx->stream));
-  sp->have_status = ctx->d_status != nullptr;
+  sp->have_status = sp->pre_status != nullptr;
   return EPA_OK;
 }
 
@@ -1880,7 +1881,9 @@ int launch_select_end(epa_ctx* ctx, SelectPending* sp, uint64_t* n_pairs) {
       if (sp->cap >= B) return epa_fail(ctx, EPA_ERR_HIP, "select_candidates: staging overflow");
       ctx->select_cap = std::min<uint32_t>(B, std::max(sp->cap * 4, hst[2]));
       uint32_t* rb = sp->rb;
+      sp->rerun = true;    // keeps this chunk's preplacement status pointer
       int rc = launch_select_begin(ctx, sp->d_lnl, Q, sp->threshold, sp->d_pairs, sp->max_pairs, sp->d_span, rb, sp);
+      sp->rerun = false;
       if (rc) return rc;
       continue;
     }
@@ -1904,7 +1907,7 @@ int launch_select_end(epa_ctx* ctx, SelectPending* sp, uint64_t* n_pairs) {
       hipLaunchKernelGGL(k_keys_to_pairs, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, sp->keys_b,
                          (uint64_t)total, sp->d_pairs);
     }
-    epa_timer_stop(ctx, ctx->t_select);
+    epa_timer_stop(ctx, epa_t(ctx, epa_ctx::T_SELECT));
     EPA_HIP(ctx, hipGetLastError());
     *n_pairs = total;
     if (sp->d_span) {

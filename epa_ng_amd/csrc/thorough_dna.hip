@@ -1525,7 +1525,7 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
     if (!ok) {
       a.Wpad = (std::max(max_span, 1u) + 63) / 64 * 64;
       return launch_thorough_generic(ctx, a.pairs, n_pairs, a.codes, a.win_begin, a.win_span, max_span, a.out,
-                                     a.stats, a.order ? a.order : nullptr);
+                                     a.stats, a.order ? a.order : nullptr, true);
     }
     const int nch = cls == 0 ? 1 : (cls == 1 || cls == 10) ? 2 : 3;
     uint64_t want = (uint64_t)256 * 8 * per_slot / (uint64_t)ctx->dna.ng;
@@ -1635,7 +1635,7 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
                                            ctx->stream));
     order = d_order;
   }
-  epa_timer_start(ctx, ctx->t_thorough);
+  epa_timer_start(ctx, epa_t(ctx, epa_ctx::T_THOROUGH));
   int rc = EPA_OK;
   uint64_t off = 0;
   // window bound of a class (slab sizing of the 20-state LDS kernel, the long-window kernel)
@@ -1659,7 +1659,7 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
         rc = launch_thorough_aa(ctx, d_pairs, ord, hist[c], d_codes, d_begin, d_span, bound,
                                 bound <= EPA_AA_LDS_MAX_SPAN, d_out, d_stats);
       else
-        rc = launch_thorough_generic(ctx, d_pairs, hist[c], d_codes, d_begin, d_span, bound, d_out, d_stats, ord);
+        rc = launch_thorough_generic(ctx, d_pairs, hist[c], d_codes, d_begin, d_span, bound, d_out, d_stats, ord, true);
       continue;
     }
     ThArgs a;
@@ -1690,7 +1690,7 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
     a.Wpad = 0;
     rc = launch_thorough_dna_class(ctx, a, c, std::min(max_span, dna_bound[c]));
   }
-  epa_timer_stop(ctx, ctx->t_thorough);
+  epa_timer_stop(ctx, epa_t(ctx, epa_ctx::T_THOROUGH));
   if (rc) return rc;
   EPA_HIP(ctx, hipGetLastError());
   return EPA_OK;

@@ -358,7 +358,7 @@ __global__ void __launch_bounds__(64) k_thorough_generic(const ThArgsG a) {
 
 int launch_thorough_generic(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
                             const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
-                            epa_result* d_out, unsigned long long* d_stats, const uint32_t* d_order) {
+                            epa_result* d_out, unsigned long long* d_stats, const uint32_t* d_order, bool caller_times) {
   ThArgsG a;
   a.m = ctx->dmodel;
   a.blo = ctx->blo;
@@ -383,10 +383,11 @@ int launch_thorough_generic(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pa
   const size_t per = (size_t)(ctx->c * ctx->s + 1) * a.Wpad;
   a.slab = (double*)epa_scratch(ctx, 7, sizeof(double) * per * grid);
   if (!a.slab) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(generic sumtable scratch)");
-  if (!d_order) epa_timer_start(ctx, ctx->t_thorough);   // a per-class launch is timed by its caller
+  const bool timed = !d_order && !caller_times;   // a per-class launch is timed by its caller
+  if (timed) epa_timer_start(ctx, epa_t(ctx, epa_ctx::T_THOROUGH));
   if (ctx->s == 4) hipLaunchKernelGGL(k_thorough_generic<4>, dim3(grid), dim3(64), 0, ctx->stream, a);
   else hipLaunchKernelGGL(k_thorough_generic<20>, dim3(grid), dim3(64), 0, ctx->stream, a);
-  if (!d_order) epa_timer_stop(ctx, ctx->t_thorough);
+  if (timed) epa_timer_stop(ctx, epa_t(ctx, epa_ctx::T_THOROUGH));
   EPA_HIP(ctx, hipGetLastError());
   return EPA_OK;
 }
