@@ -442,7 +442,7 @@ def main():
             of.preplace(sample[:8])                     # builds the per-branch lookups (one-off)
             c0 = time.perf_counter()
             of.preplace(sample)
-            of.thorough(prs["branch_id"], prs["seq_id"], sample)
+            tl_fast = of.thorough(prs["branch_id"], prs["seq_id"], sample)[0]
             cpu_t = time.perf_counter() - c0
             cores = min(eff, of.L.orc_max_threads())
             del of
@@ -457,7 +457,11 @@ def main():
                    "cflags": oracle_lib.FAST_CFLAGS,
                    "sample": "%d reads of step 0 through the oracle's OpenMP preplace (B=%d) + thorough "
                              "(%d pairs), lookups prebuilt" % (ns, B, len(prs)),
-                   "strict_build_seconds_same_sample": round(strict_t, 2)}
+                   "strict_build_seconds_same_sample": round(strict_t, 2),
+                   "kernels": "4-state x 4-category loops in libpll's AVX2 shape (states of a site = one vector, transposed "
+                              "matrices, omp simd; oracle/epa_oracle.c ORC_FAST_KERNELS); the preplacement gathers are "
+                              "scalar as in src/core/Lookup_Store.hpp:110-141",
+                   "fast_vs_strict_max_abs_dlnl": float(np.max(np.abs(tl_fast - tl)))}
         # the optimiser-path rule of the parity sweep (tests/sweep_util.py) on this sample: pairs whose
         # lengths differ from the oracle's own must be reproduced by a rounded sibling of the oracle
         import sweep_util

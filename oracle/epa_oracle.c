@@ -530,12 +530,142 @@ static inline double side_term(const orc_side* sd, const double* Prow, int s, si
   return acc;
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * ORC_FAST_KERNELS (the timed `cpu_baseline` build of bench.py only; the parity build never defines it):
+ * the four hot loops specialised for 4 states x 4 rate categories, per-site scalers, no +I, written the
+ * way libpll's AVX / AVX2 kernels are -- the 4 states of a (site, category) are one vector, a
+ * matrix-vector product is four broadcast-multiply-adds over it, matrices are kept transposed for that --
+ * with fixed trip counts and `omp simd` so that -O3 -march=native turns them into vector code.  Same
+ * algorithm and data layout as the generic loops below them; sums are associated per state instead of
+ * per row, so results agree with the parity build to rounding (bench.py checks 1e-6 on the sample).
+ * ---------------------------------------------------------------------------------------- */
+#ifdef ORC_FAST_KERNELS
+static inline int orc_fast_ok(const orc_model* m) {
+  return m->s == 4 && m->c == 4 && !m->rate_scalers && !m->rounding_variant && m->pinv == 0.0;
+}
+typedef struct { double v[4]; } orc_v4;
+static inline orc_v4 side_vec(const orc_side* sd, size_t site, int k) {
+  orc_v4 x;
+  if (sd->clv) {
+    const double* p = sd->clv + (site * 4 + k) * 4;
+#pragma omp simd
+    for (int j = 0; j < 4; ++j) x.v[j] = p[j];
+  } else {
+    const uint32_t mk = sd->tipmask[site];
+#pragma omp simd
+    for (int j = 0; j < 4; ++j) x.v[j] = (double)((mk >> j) & 1u);
+  }
+  return x;
+}
+/* y[i] = sum_j MT[j][i] x[j]  (MT = the matrix transposed: four broadcast FMAs over a 4-vector) */
+static inline orc_v4 matvec_t(const double* MT, orc_v4 x) {
+  orc_v4 y;
+#pragma omp simd
+  for (int i = 0; i < 4; ++i) y.v[i] = MT[i] * x.v[0];
+  for (int j = 1; j < 4; ++j) {
+#pragma omp simd
+    for (int i = 0; i < 4; ++i) y.v[i] += MT[j * 4 + i] * x.v[j];
+  }
+  return y;
+}
+static inline void transpose_p(const double* P, double* PT) {   /* P[k][i][j] -> PT[k][j][i] */
+  for (int k = 0; k < 4; ++k)
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) PT[(k * 4 + j) * 4 + i] = P[(k * 4 + i) * 4 + j];
+}
+static void update_partial_fast(const orc_side* l, const double* Pl, const orc_side* r, const double* Pr,
+                                double* parent, uint32_t* parent_sc, size_t b, size_t n) {
+  const double thr = orc_scale_threshold(), fac = orc_scale_factor();
+  double PlT[64], PrT[64];
+  transpose_p(Pl, PlT);
+  transpose_p(Pr, PrT);
+  for (size_t site = b; site < b + n; ++site) {
+    double* p = parent + site * 16;
+    double mx = 0.0;
+    for (int k = 0; k < 4; ++k) {
+      const orc_v4 ta = matvec_t(PlT + k * 16, side_vec(l, site, k)), tb = matvec_t(PrT + k * 16, side_vec(r, site, k));
+#pragma omp simd reduction(max : mx)
+      for (int i = 0; i < 4; ++i) {
+        const double v = ta.v[i] * tb.v[i];
+        p[k * 4 + i] = v;
+        mx = v > mx ? v : mx;
+      }
+    }
+    uint32_t sc = (l->scaler ? l->scaler[site] : 0) + (r->scaler ? r->scaler[site] : 0);
+    if (mx < thr) {
+#pragma omp simd
+      for (int x = 0; x < 16; ++x) p[x] *= fac;
+      sc += 1;
+    }
+    parent_sc[site] = sc;
+  }
+}
+static double edge_lnl_fast(const orc_model* m, const orc_side* par, const orc_side* ch, const double* P,
+                            double* persite, size_t b, size_t n) {
+  const double log_thr = log(orc_scale_threshold());
+  double PT[64], logl = 0.0;
+  transpose_p(P, PT);
+  for (size_t site = b; site < b + n; ++site) {
+    double terma = 0.0;
+    for (int k = 0; k < 4; ++k) {
+      const orc_v4 tb = matvec_t(PT + k * 16, side_vec(ch, site, k)), pv = side_vec(par, site, k);
+      double acc = 0.0;
+#pragma omp simd reduction(+ : acc)
+      for (int i = 0; i < 4; ++i) acc += pv.v[i] * m->freqs[i] * tb.v[i];
+      terma += acc * m->weights[k];
+    }
+    const uint32_t sc = (par->scaler ? par->scaler[site] : 0) + (ch->scaler ? ch->scaler[site] : 0);
+    double site_lk = log(terma);
+    if (sc) site_lk += sc * log_thr;
+    if (persite) persite[site] = site_lk;
+    logl += site_lk;
+  }
+  return logl;
+}
+static void update_sumtable_fast(const orc_model* m, const orc_side* A, const orc_side* Bs, double* S, size_t b, size_t n) {
+  double piU[16], UiT[16];   /* piU[i][j] = pi_i U[i][j];  UiT[i][j] = Uinv[j][i] */
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) { piU[i * 4 + j] = m->freqs[i] * m->u[i * 4 + j]; UiT[i * 4 + j] = m->uinv[j * 4 + i]; }
+  for (size_t site = b; site < b + n; ++site)
+    for (int k = 0; k < 4; ++k) {
+      const orc_v4 lt = matvec_t(piU, side_vec(A, site, k)), rt = matvec_t(UiT, side_vec(Bs, site, k));
+      double* o = S + ((site - b) * 4 + k) * 4;
+#pragma omp simd
+      for (int j = 0; j < 4; ++j) o[j] = lt.v[j] * rt.v[j];
+    }
+}
+static void lk_derivatives_fast(const orc_model* m, const double* S, size_t n, double t, double* d1, double* d2) {
+  double d0[16], dg1[16], dg2[16];   /* weights folded in */
+  for (int k = 0; k < 4; ++k)
+    for (int j = 0; j < 4; ++j) {
+      const double lr = m->evals[j] * m->rates[k], e0 = exp(lr * t) * m->weights[k];
+      d0[k * 4 + j] = e0; dg1[k * 4 + j] = lr * e0; dg2[k * 4 + j] = lr * lr * e0;
+    }
+  double f = 0.0, df = 0.0;
+  for (size_t x = 0; x < n; ++x) {
+    const double* sm = S + x * 16;
+    double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+#pragma omp simd reduction(+ : l0, l1, l2)
+    for (int j = 0; j < 16; ++j) { l0 += sm[j] * d0[j]; l1 += sm[j] * dg1[j]; l2 += sm[j] * dg2[j]; }
+    const double dv1 = -l1 / l0;
+    f += dv1;
+    df += dv1 * dv1 - l2 / l0;
+  }
+  *d1 = f;
+  *d2 = df;
+}
+#endif /* ORC_FAST_KERNELS */
+
 /* restates pll_update_partials for one op over sites [b, b+n)
  * (call sites src/tree/Tiny_Tree.cpp:112,203; src/core/pll/optimize.cpp:41,173,217;
  *  src/core/pll/epa_pll_util.cpp:105).  Per-site scaling: all c*s entries < 2^-256. */
 static void update_partial(const orc_model* m, const orc_side* l, const double* Pl,
                            const orc_side* r, const double* Pr, double* parent,
                            uint32_t* parent_sc, size_t b, size_t n) {
+#ifdef ORC_FAST_KERNELS
+  if (orc_fast_ok(m)) { update_partial_fast(l, Pl, r, Pr, parent, parent_sc, b, n); return; }
+#endif
   const int s = m->s, c = m->c;
   const double thr = orc_scale_threshold(), fac = orc_scale_factor();
   for (size_t site = b; site < b + n; ++site) {
@@ -590,6 +720,9 @@ static uint32_t rate_alignment(const orc_model* m, const orc_side* a, const orc_
 static double edge_lnl(const orc_model* m, const orc_side* par, const orc_side* ch,
                        const double* P, const int8_t* invariant, double* persite, size_t b,
                        size_t n) {
+#ifdef ORC_FAST_KERNELS
+  if (orc_fast_ok(m)) return edge_lnl_fast(m, par, ch, P, persite, b, n);
+#endif
   const int s = m->s, c = m->c;
   const double log_thr = log(orc_scale_threshold());
   double logl = 0.0;
@@ -631,6 +764,9 @@ static double edge_lnl(const orc_model* m, const orc_side* par, const orc_side* 
  * S[site][k][j] = (sum_i pi_i A_i U[i][j]) * (sum_m Uinv[j][m] B_m) */
 static void update_sumtable(const orc_model* m, const orc_side* A, const orc_side* Bs, double* S,
                             size_t b, size_t n) {
+#ifdef ORC_FAST_KERNELS
+  if (orc_fast_ok(m)) { update_sumtable_fast(m, A, Bs, S, b, n); return; }
+#endif
   const int s = m->s, c = m->c;
   for (size_t site = b; site < b + n; ++site) {
     double rfac[ORC_MAX_C];
@@ -661,6 +797,9 @@ static void update_sumtable(const orc_model* m, const orc_side* A, const orc_sid
  * src/core/pll/optimize.cpp:44-49): first/second derivative of -lnL w.r.t. t */
 static void lk_derivatives(const orc_model* m, const double* S, size_t n, double t,
                            const int8_t* invariant, size_t b, double* d1, double* d2) {
+#ifdef ORC_FAST_KERNELS
+  if (orc_fast_ok(m)) { lk_derivatives_fast(m, S, n, t, d1, d2); return; }
+#endif
   const int s = m->s, c = m->c;
   double dg[ORC_MAX_C * ORC_MAX_S * 3];
   /* rounding variants with bit 11 / bit 12 set: the eigenvalue of the stationary mode -- 0 in exact

@@ -14,7 +14,8 @@ _LIBS = {}
 # flags of the second build of the SAME source that bench.py times as `cpu_baseline` (the strict
 # build stays the parity checker): full optimisation for the host CPU the bench runs on.  Built on
 # that box (-march=native code must not travel between machines), so it is never shipped.
-FAST_CFLAGS = "-O3 -march=native -funroll-loops -ffp-contract=fast -fno-math-errno -std=gnu99 -fPIC -fopenmp"
+FAST_CFLAGS = ("-O3 -march=native -funroll-loops -ffp-contract=fast -fno-math-errno -std=gnu99 -fPIC -fopenmp "
+               "-DORC_FAST_KERNELS")   # + the vector-shaped 4-state x 4-category loops (oracle/epa_oracle.c)
 
 
 def build(force=False):
