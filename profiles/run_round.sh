@@ -21,7 +21,7 @@ bash profiles/run_pmc.sh ${tag} \
   "FETCH_SIZE TCC_HIT_sum" "WRITE_SIZE TCC_MISS_sum" > gpurun_out/${tag}_pmc_summary.txt 2>&1
 grep -A22 "== k_thorough" gpurun_out/${tag}_pmc_summary.txt | head -30
 # 20-state workload (BASELINE.json configs[2] shape): bench line, kernel trace, counters of the matrix-core kernel
-AA="--workload aa --tips 2000 --width 500 --read-len 100 --chunk 10000"
+AA="--workload aa --tips 2000 --width 500 --read-len 100 --chunk 50000 --pool 3"   # BASELINE configs[2] at its own size (round 4; rounds 1-3: 10000)
 python bench.py $AA > gpurun_out/${tag}_aa_bench.json 2> gpurun_out/${tag}_aa_bench.err
 tail -1 gpurun_out/${tag}_aa_bench.json | cut -c1-300
 cd /tmp
