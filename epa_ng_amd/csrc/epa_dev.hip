@@ -591,7 +591,7 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
       for (int i = 0; i < s; ++i) std::swap(m.U[i * s], m.U[i * s + imax]);
       for (int j = 0; j < s; ++j) std::swap(m.Ui[j], m.Ui[imax * s + j]);
     }
-    ctx->dna_zero0 = fabs(m.lam[0]) <= 1e-9 * amax;
+    ctx->dna_zero0 = fabs(m.lam[0]) <= 1e-9 * amax && !(d->flags & EPA_FLAG_KEEP_EIGENVALUES);
     if (ctx->dna_zero0) m.lam[0] = 0.0;
     if (pinv > 0.0 && !ctx->dna_zero0)
       return epa_fail(ctx, EPA_ERR_UNSUPPORTED, "+I needs a rate matrix with a zero eigenvalue (any proper GTR)");
@@ -638,6 +638,7 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   const bool tuned_cats = c == 4 || (dna_groups && ctx->blo.sliding && ctx->dna_zero0 && !getenv("EPA_NO_CAT_GROUPS")) ||
                           (s == 20 && c == 8 && !getenv("EPA_NO_CAT_GROUPS"));   // k_thorough_aa_mfma<.., NC = 8>
   ctx->generic_thorough = !tuned_cats || (!ctx->blo.sliding && !tuned_local) || ctx->blo.newton_variant != 0 ||
+                          (d->flags & EPA_FLAG_KEEP_EIGENVALUES) != 0 ||   // every term as libpll: the general kernel
                           getenv("EPA_TH_GENERIC") != nullptr;   // (diagnostic switch: measure the general kernel)
 
   EPA_HIP(ctx, hipMalloc(&ctx->dmodel, sizeof(ModelDev)));

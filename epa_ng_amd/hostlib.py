@@ -193,16 +193,17 @@ class Reference:
                 "dist_scaler": view(p[4], C.c_uint32, (self.W,)), "length": ln.value}
 
     def evaluator(self, device=0, aa_x_as_n=False, device_precompute=True, rate_scalers=False,
-                  raxml_blo=False, newton_variant=0, blo_min_branch=0.0):
+                  raxml_blo=False, newton_variant=0, blo_min_branch=0.0, keep_eigenvalues=False):
         """reference -> GPU -> api.Evaluator (epa_ctx created by the C++ host).  By default the
         tree and the tip sequences are sent and all directional CLVs are computed on the device;
         device_precompute=False uploads the host-computed CLVs instead.  rate_scalers: per-rate
         numerical scaling (EPA_FLAG_RATE_SCALERS); raxml_blo: --raxml-blo (EPA_FLAG_RAXML_BLO);
         newton_variant: bit 0 EPA_FLAG_NEWTON_SLOW_BISECT, bit 1 EPA_FLAG_NEWTON_STRICT_DF;
-        blo_min_branch: PLLMOD_OPT_MIN_BRANCH_LEN (0 = default 1e-4)."""
+        blo_min_branch: PLLMOD_OPT_MIN_BRANCH_LEN (0 = default 1e-4); keep_eigenvalues:
+        EPA_FLAG_KEEP_EIGENVALUES (the stationary eigenvalue is not snapped to 0)."""
         h = C.c_void_p()
         flags = ((0x2 if rate_scalers else 0) | (0x4 if raxml_blo else 0) | (0x8 if newton_variant & 1 else 0) |
-                 (0x10 if newton_variant & 2 else 0))
+                 (0x10 if newton_variant & 2 else 0) | (0x20 if keep_eigenvalues else 0))
         rc = host_lib().epa_host_dev_create_opts(self.h, device, int(aa_x_as_n), int(device_precompute),
                                                  flags, float(blo_min_branch), C.byref(h))
         if rc:

@@ -59,6 +59,13 @@ typedef enum {
  * they change): */
 #define EPA_FLAG_NEWTON_SLOW_BISECT 0x8u  /* also bisect when |2 f| > |dx_old f'| (Numerical Recipes rtsafe) */
 #define EPA_FLAG_NEWTON_STRICT_DF 0x10u   /* first convergence test needs f' > 0 instead of f' >= 0          */
+#define EPA_FLAG_KEEP_EIGENVALUES 0x20u   /* use the caller's eigenvalues verbatim: by default the stationary one
+                                          * (a few 1e-17 of either sign out of libpll's eigen-solver, 0 in exact
+                                          * arithmetic) is set to exactly 0 and the kernels drop its derivative terms.
+                                          * With this flag nothing is snapped and the general kernel evaluates every
+                                          * term as libpll does: the switch to A/B the snap against a real libpll
+                                          * build (at saturated lengths the residue's sign decides a bisection,
+                                          * DESIGN section 2).  Not available with prop_invar > 0. */
 #define EPA_FLAG_RATE_SCALERS 0x2u /* PLL_ATTRIB_RATE_SCALERS: every rate category is rescaled on its *
                                     * own (src/tree/tiny_util.cpp:37-44; the reference turns it on    *
                                     * above 2000 tips, src/io/file_io.cpp:211-214, or with            *

@@ -276,3 +276,29 @@ def test_recollected_optimiser_constants_are_runtime_parameters(states, cats):
         else:
             moved += int((np.abs(res["lnl"] - base["lnl"]) > 1e-6).sum())
     assert moved > 0      # the switches are not no-ops
+
+
+@pytest.mark.parametrize("states", [4, 20])
+def test_keep_eigenvalues_switch_runs_every_term_and_agrees_on_ordinary_data(states):
+    """EPA_FLAG_KEEP_EIGENVALUES: the stationary eigenvalue out of the eigen-solver (1e-17-ish) is used verbatim on
+    the general kernel instead of being set to exactly 0 -- the switch a maintainer with a real libpll build
+    needs to A/B the snap.  On ordinary data (no saturated lengths) both contexts and the oracle agree."""
+    subst, freqs = (synth.CFG2_SUBST, synth.CFG2_FREQS) if states == 4 else synth.aa_model(5)
+    root = synth.random_tree(40, 77)
+    rates = synth.gamma_rates(0.6)
+    labels, seqs = synth.simulate_msa(root, 300, subst, freqs, rates, 78)
+    nw = synth.newick(root)
+    reads, _ = synth.make_reads(seqs, 32, 120 if states == 4 else 80, 0.04, 79, states=states)
+    ref = hostlib.Reference(nw, labels, seqs, states=states, subst=subst, freqs=freqs, rates=rates)
+    o = Oracle(nw, labels, seqs, states, subst, freqs, rates)
+    ev_keep = ref.evaluator(keep_eigenvalues=True)
+    ev_snap = ref.evaluator()
+    _, pairs, res_keep = check_against_oracle(ev_keep, o, reads, states)
+    codes, wb, ws = epa.encode_queries(states, reads, compact=True)
+    res_snap = ev_snap.thorough(pairs, codes, wb, ws)
+    assert np.max(np.abs(res_keep["lnl"] - res_snap["lnl"])) < 1e-8
+    assert np.max(np.abs(res_keep["pendant_length"] - res_snap["pendant_length"])) < 1e-8
+    # +I needs the exact zero mode: refused, not silently snapped
+    refi = hostlib.Reference(nw, labels, seqs, states=states, subst=subst, freqs=freqs, rates=rates, pinv=0.2)
+    with pytest.raises(Exception):
+        refi.evaluator(keep_eigenvalues=True)
