@@ -1825,7 +1825,7 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
     const dim3 grid((Q + 3) / 4);
     const int nr = (int)((B + 63) / 64);
 #define SEL(N) hipLaunchKernelGGL(k_select<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status)
-    static const bool seg_off = getenv("EPA_SELECT_FULL_ROWS") != nullptr;
+    const bool seg_off = getenv("EPA_SELECT_FULL_ROWS") != nullptr;   // A/B and test switch: the full-row kernels
     if (ctx->segmax && !seg_off && mode == 0 && threshold < 1.0 && nr <= 64)
       hipLaunchKernelGGL(k_select_seg<8>, grid, dim3(256), 0, ctx->stream, d_lnl, ctx->segmax, ctx->segp, Q, B, pitch, threshold, so, counts, status);
     else if (nr <= 2) SEL(2); else if (nr <= 4) SEL(4); else if (nr <= 8) SEL(8); else if (nr <= 16) SEL(16);

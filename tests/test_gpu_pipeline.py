@@ -1032,6 +1032,46 @@ def test_selection_bitmap_and_sorted_staging_paths_agree(tmp_path):
         assert len(outs[0][k]) > 0 and np.array_equal(outs[0][k], outs[1][k]), k
 
 
+@pytest.mark.parametrize("states,tips,width,rl", [(4, 300, 900, 150), (20, 700, 260, 90), (4, 9, 200, 60)])
+def test_selection_from_segment_maxima_equals_full_row_selection(states, tips, width, rl, monkeypatch):
+    """The fused chunk body selects the dynamic rule's candidates from the per-(query, 64-branch segment) maxima the
+    preplacement leaves behind (k_select_seg: only the segments near a row's maximum are read);
+    EPA_SELECT_FULL_ROWS=1 sends the same chunk through the full-row kernel.  Same pairs in the same order, same
+    results -- for a tree of 10 segments, one of 22 (20 states), one of a single partial segment, thresholds from
+    lax to 1 - 1e-9, and reads with rare ambiguity codes (their rows have no maxima: rebuilt from the row)."""
+    if states == 4:
+        w = synth.dna_workload(tips, width, 600, rl, (131, 132, 133))
+        reads = list(w["reads"])
+        for i in range(0, len(reads), 17):     # rare codes: the generic preplacement kernel, no segment maxima
+            r = list(reads[i])
+            k = next(j for j, ch in enumerate(r) if ch != "-")
+            r[k + 3] = "R"
+            reads[i] = "".join(r)
+    else:
+        w = synth.aa_workload(tips, width, 300, rl, (134, 135, 136)) if hasattr(synth, "aa_workload") else None
+        if w is None:
+            subst, freqs = synth.aa_model(7)
+            root = synth.random_tree(tips, 134)
+            rates = synth.gamma_rates(0.6)
+            labels, seqs = synth.simulate_msa(root, width, subst, freqs, rates, 135)
+            rd, _ = synth.make_reads(seqs, 300, rl, 0.04, 136, states=20)
+            w = dict(newick=synth.newick(root), labels=labels, seqs=seqs, subst=subst, freqs=freqs, rates=rates, reads=rd)
+        reads = list(w["reads"])
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=states, subst=w["subst"], freqs=w["freqs"],
+                            rates=w["rates"])
+    ev = ref.evaluator()
+    codes, wb, ws = epa.encode_queries(states, reads, compact=True)
+    for thr in (0.9, 0.99999, 1.0 - 1e-9):
+        monkeypatch.delenv("EPA_SELECT_FULL_ROWS", raising=False)
+        p_seg, r_seg = ev.place_chunk(codes, wb, ws, threshold=thr)
+        monkeypatch.setenv("EPA_SELECT_FULL_ROWS", "1")
+        p_full, r_full = ev.place_chunk(codes, wb, ws, threshold=thr)
+        monkeypatch.delenv("EPA_SELECT_FULL_ROWS")
+        assert np.array_equal(p_seg, p_full), thr
+        assert np.array_equal(r_seg["lnl"], r_full["lnl"])
+    assert len(p_seg) >= len(reads)
+
+
 def test_baseball_heuristic_counts_follow_the_reference_arithmetic():
     """baseball_heuristic (src/core/heuristics.hpp:74-117): hits = branches within 3.0 lnL of the
     best, then std::min(max_pitches - hits, max_strikes) more in size_t arithmetic -- 6 more when
