@@ -466,7 +466,8 @@ def main():
         # lengths differ from the oracle's own must be reproduced by a rounded sibling of the oracle
         import sweep_util
         flat = sweep_util.lengths_differ(res_gpu["pendant_length"], res_gpu["distal_length"], tp, td)
-        rep = sweep_util.reproduce_flat_pairs(o, sample, prs["branch_id"], prs["seq_id"], res_gpu, flat)
+        rep = sweep_util.reproduce_flat_pairs(o, sample, prs["branch_id"], prs["seq_id"], res_gpu, flat,
+                                              dl=np.abs(res_gpu["lnl"] - tl))
         parity = {"preplace_max_abs_dlnl": float(np.max(np.abs(lnl_gpu - lnl_cpu))),
                   "thorough_max_abs_dlnl": float(np.max(np.abs(res_gpu["lnl"] - tl))),
                   "evaluator_max_abs_dlnl_at_device_lengths": float(np.max(np.abs(res_gpu["lnl"] - sc_at))),

@@ -265,7 +265,8 @@ def test_thorough_long_windows_hbm_slab():
 #         of the sumtable / derivative dot products moved by at most 2^8 ulp = 5.7e-14 relative, the
 #         stationary eigenvalue -- 1e-17 instead of 0 out of any eigen-solver -- taken as 0 or with
 #         the other sign), and the device's lnL then equals that sibling's to 1e-6; a pair that no
-#         sibling of amplitude <= 2^8 reproduces FAILS;
+#         sibling of amplitude <= 2^8 reproduces FAILS -- unless its lnL equals the oracle's own to 1e-6
+#         (flat in a length, not another optimum): such a pair may need up to 2^12 (sweep_util);
 #      b. the point where that sibling's trace leaves the oracle's (orc_trace_pair) is one of the
 #         solver's three decisions -- Newton branch (sign of f / f'), Newton termination (|dx| < tol),
 #         end-of-round decision (revert test, 0.1-lnL stop) -- and the traces agree up to there;
@@ -308,7 +309,7 @@ def check_sweep_case(seed):
     # 3. flat pairs: bounded (c), reproduced by a sibling of amplitude <= 2^8 (a), at a named decision (b)
     nflat, dflat = int(flat.sum()), float(dl[flat].max()) if flat.any() else 0.0
     max_flat, max_dlnl = su.OUTLIER_BOUNDS.get(seed, (int(su.FLAT_MAX_FRACTION * len(pairs)), su.FLAT_LNL_TOL))
-    rep = su.reproduce_flat_pairs(o, reads, pb, ps, res, flat, LNL_TOL)
+    rep = su.reproduce_flat_pairs(o, reads, pb, ps, res, flat, LNL_TOL, dl=dl)
     if os.environ.get("EPA_SWEEP_LOG"):   # one line per configuration of a full run
         with open(os.environ["EPA_SWEEP_LOG"], "a") as f:
             f.write("%d states=%d tips=%d W=%d rl=%d pinv=%g alpha=%g pairs=%d evaluator_max_dlnl=%.3g flat=%d "
@@ -320,6 +321,8 @@ def check_sweep_case(seed):
                        ",".join("%s:%d" % kv for kv in sorted(rep["decisions"].items())) or "-",
                        ev.last_stats["rounds"], rounds_orc))
     assert not rep["unreproduced"], (seed, rep["unreproduced"])
+    if os.environ.get("EPA_SWEEP_NO_BOUNDS"):   # hand runs over NEW random seeds: bimodal configurations are logged, not failed
+        return
     assert nflat <= max_flat, (seed, nflat, max_flat)
     assert dflat <= max_dlnl, (seed, dflat, max_dlnl)
 
