@@ -513,35 +513,28 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
   const uint8_t* c = codes + (size_t)(live ? q : 0u) * cstride + (crel ? 0u : begin);
   const uint32_t nfull = span >> 2, ntail = span & 3, npairs = 2 * nfull;
   bool rare = false;
-  // four pairs (eight codes) per lane and step: one 8-byte load, one 8-byte store (the kernel was bound by
-  // the issue of its one- and two-byte accesses: 65 us per 100k reads).  NP16 is a multiple of CP = 80.
-  for (uint32_t p4 = l16; 4 * p4 < NP16; p4 += 16) {
-    const uint32_t p0 = 4 * p4;
-    uint8_t cc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (2 * p0 + 8 <= span) {
-      const uint2 w = *reinterpret_cast<const uint2*>(__builtin_assume_aligned(c + 2 * p0, 1));
-      __builtin_memcpy(cc, &w, 8);
-    } else {
-      for (uint32_t k = 0; k < 8; ++k)
-        if (2 * p0 + k < span) cc[k] = c[2 * p0 + k];
-    }
-    uint16_t vv[4];
+  // a chunk of CP = 80 pair slots at a time: its ten code loads per lane are issued together, then the offsets
+  // are formed and stored (NP16 is a multiple of CP).  Round 4, traced us per 100k reads: one loop of dependent
+  // load / store pairs 78, this form 74, four pairs per lane with an unaligned 8-byte load and an 8-byte store 96,
+  // byte loads + 8-byte store 88: neither the load nor the store width is what it waits for.
+  for (uint32_t pb = 0; pb < NP16; pb += CP) {
+    uint32_t c0[CP / 16], c1[CP / 16];
 #pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-      const uint32_t p = p0 + k;
+    for (int i = 0; i < CP / 16; ++i) {
+      const uint32_t p = pb + (uint32_t)i * 16 + l16;
+      c0[i] = p < npairs ? c[2 * p] : 0u;
+      c1[i] = p < npairs ? c[2 * p + 1] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < CP / 16; ++i) {
+      const uint32_t p = pb + (uint32_t)i * 16 + l16;
       uint32_t v = ZERO_OFF;
       if (p < npairs) {
-        const uint32_t s0 = dna_sym(cc[2 * k]), s1 = dna_sym(cc[2 * k + 1]);
+        const uint32_t s0 = dna_sym(c0[i]), s1 = dna_sym(c1[i]);
         rare |= (s0 > 4) | (s1 > 4);
         v = (p % CP) * rowl + pair_entry(min(s0, 5u), min(s1, 5u)) * 8;
       }
-      vv[k] = (uint16_t)v;
-    }
-    if (live) {
-      uint2 o;
-      o.x = (uint32_t)vv[0] | ((uint32_t)vv[1] << 16);
-      o.y = (uint32_t)vv[2] | ((uint32_t)vv[3] << 16);
-      *reinterpret_cast<uint2*>(packed + (size_t)q * NP16 + p0) = o;
+      if (live) packed[(size_t)q * NP16 + p] = (uint16_t)v;
     }
   }
   if (l16 < 4) {
