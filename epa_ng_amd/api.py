@@ -225,7 +225,8 @@ class Evaluator:
 
     def __init__(self, states, rates, weights, eigenvals, u, uinv, freqs, branch_length,
                  prox_clv, dist_clv, prox_scaler=None, dist_scaler=None, dist_tip=None,
-                 tipmap=None, device=0, aa_x_as_n=False, pinv=0.0, invariant_state=None):
+                 tipmap=None, device=0, aa_x_as_n=False, pinv=0.0, invariant_state=None, flags=0):
+        """flags: EPA_FLAG_* of include/epa_dev.h (0x2 = per-rate scalers: the scaler rows are then uint32 [W][c])"""
         L = dev_lib()
         B = len(branch_length)
         self.B, self.s, self.c = B, states, len(rates)
@@ -275,6 +276,7 @@ class Evaluator:
         if tm is not None:
             d.tipmap, d.tipmap_size = tm.ctypes.data, len(tm)
         d.aa_x_as_n = int(aa_x_as_n)
+        d.flags = int(flags)
         h = C.c_void_p()
         rc = L.epa_dev_create(C.byref(d), device, C.byref(h))
         if rc:

@@ -302,3 +302,36 @@ def test_keep_eigenvalues_switch_runs_every_term_and_agrees_on_ordinary_data(sta
     refi = hostlib.Reference(nw, labels, seqs, states=states, subst=subst, freqs=freqs, rates=rates, pinv=0.2)
     with pytest.raises(Exception):
         refi.evaluator(keep_eigenvalues=True)
+
+
+@pytest.mark.parametrize("states,cats", [(4, 4), (4, 5), (4, 8), (20, 4), (20, 6)])
+def test_descriptor_path_with_caller_supplied_per_rate_scaler_rows(states, cats):
+    """epa_dev_create (the binding of INTEGRATION.md: libpll's CLVs and scale buffers handed over as they are) with
+    EPA_FLAG_RATE_SCALERS: scaler rows are uint32 [W][c] per branch side (PLL_ATTRIB_RATE_SCALERS,
+    src/tree/tiny_util.cpp:37-44).  Producer: the oracle in per-rate mode on a deep tree (non-zero, category-
+    dependent counts).  The device transposes the rows, aligns every category to the site's minimum once per
+    branch side (k_add_scaler, k_align_rates) and must reproduce the oracle's tree lnL, preplacement and thorough
+    results -- with 4 categories on the tuned kernels, with 5 / 6 / 8 on the general kernel (caller rows are
+    not padded)."""
+    rng = np.random.RandomState(900 + cats)
+    rates = np.sort(rng.gamma(0.5, 1.5, cats)) + 1e-3
+    weights = np.full(cats, 1.0 / cats)
+    rates = rates / np.sum(rates * weights)
+    subst, freqs = (synth.CFG2_SUBST, synth.CFG2_FREQS) if states == 4 else synth.aa_model(4)
+    root = synth.random_tree(260, 33 + cats, mean_bl=0.5, lo=0.05, hi=3.0)
+    labels, seqs = synth.simulate_msa(root, 90, subst, freqs, synth.gamma_rates(0.4), 34)
+    nw = synth.newick(root)
+    reads, _ = synth.make_reads(seqs, 16, 60, 0.05, 35, states=states)
+    o = Oracle(nw, labels, seqs, states, subst, freqs, rates, weights=weights, rate_scalers=True)
+    ev_, u, ui = o.eigen()
+    pc, ps, dc, ds, bl = [], [], [], [], []
+    for b in range(o.B):
+        cp, sp, cd, sd = o.branch_sides(b)
+        pc.append(cp); ps.append(sp); dc.append(cd); ds.append(sd)
+        bl.append(o.branch_info(b)[0])
+    assert max(int(x.max()) for x in ps) > 0                       # the tree is deep enough to rescale
+    assert any(len(set(x.reshape(-1, cats)[w])) > 1 for x in ps for w in range(0, 90, 7))   # ... differently per category
+    ev = epa.Evaluator(states, rates, weights, ev_, u, ui, freqs, bl, pc, dc, ps, ds, flags=0x2)
+    for b in (0, o.B // 2, o.B - 1):
+        assert abs(ev.tree_logl(b) - o.tree_lnl(b)) < 1e-7 * abs(o.tree_lnl(b))
+    check_against_oracle(ev, o, reads, states)
