@@ -586,6 +586,9 @@ def main():
                                              "thorough": round(float(np.mean(th_ms)), 3)}},
            "pcie_inclusive": pcie, "strong_cfg4": strong,
            "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
+           # rank 0's view of the result gather: rows per rank and gather, rows that took the carry path (0 expected)
+           "gather": ({"rows_cap": rows_cap, "carried_rows_rank0": int(exch.carried_rows + exch2.carried_rows)}
+                      if world > 1 else None),
            "per_rank_ms_per_step": [round(x / a.steps * 1e3, 3) for x in rank_elapsed["resident"]],
            "roofline": roof, "roofline_preplace": roof_pre, "cpu_baseline": cpu, "parity": parity}
     out.update(extras)

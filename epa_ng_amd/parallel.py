@@ -140,7 +140,11 @@ class AsyncResultGather:
             w.wait()                                   # the SIDE stream waits for the gather, not the compute stream
             for rk, r in enumerate(self.recv[slot]):
                 self.host_cnt[slot, rk].copy_(r[self.rows_cap], non_blocking=True)
-            self.side.synchronize()                    # a gather posted `depth` chunks ago: long complete
+            # wait for exactly these copies (an event, not the stream: nothing queued on the side stream later --
+            # the previous slot's row copies -- is waited for); the gather was posted `depth` chunks ago
+            ev = t.cuda.Event()
+            ev.record(self.side)
+            ev.synchronize()
             cnt = [int(v) for v in self.host_cnt[slot, :, 0].tolist()]
             if self.host is not None:
                 for rk, (r, k) in enumerate(zip(self.recv[slot], cnt)):
