@@ -232,6 +232,13 @@ int epa_host_place_file(void* h, const char* query_file, const char* outdir, uin
 
 // host-side set operations exposed for unit tests with literal vectors
 // (the reference's test/src/set_manipulators.cpp:340-443)
+// the C++ chunk loop's query slice of a rank (place_ranks.cpp; src/net/epa_mpi_util.cpp:10-30)
+void epa_host_local_seq_package(uint64_t num_sequences, int rank, int world, uint64_t* offset, uint64_t* count) {
+  const auto p = epa::local_seq_package((size_t)num_sequences, rank, world);
+  *offset = p.first;
+  *count = p.second;
+}
+
 int epa_host_filter(const double* lwr, uint32_t n, double thresh, int acc, uint32_t mn, uint32_t mx,
                     uint32_t* kept_branch_ids, uint32_t* n_kept) {
   return guarded([&] {

@@ -105,6 +105,25 @@ def test_local_seq_package_matches_reference_formula():
             assert all(c <= part for _, c in slices)
 
 
+def test_cpp_local_seq_package_equals_the_harness_formula():
+    """the slice the one-process-per-GPU chunk loop of the product takes (epa_ng_amd/csrc/host/place_ranks.cpp) is the
+    one the Python harness takes: both restate src/net/epa_mpi_util.cpp:10-30"""
+    import ctypes as C
+    from epa_ng_amd import hostlib, parallel
+    L = hostlib.host_lib()
+    L.epa_host_local_seq_package.argtypes = [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.epa_host_local_seq_package.restype = None
+    for n in (0, 1, 7, 8, 9, 100, 1000003, 10 ** 7):
+        for world in (1, 2, 3, 8):
+            tot = 0
+            for r in range(world):
+                o, c = C.c_uint64(), C.c_uint64()
+                L.epa_host_local_seq_package(n, r, world, C.byref(o), C.byref(c))
+                assert (o.value, c.value) == parallel.local_seq_package(n, r, world)
+                tot += c.value
+            assert tot == n
+
+
 def test_two_rank_gloo_gather(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
