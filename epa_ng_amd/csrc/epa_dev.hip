@@ -1286,7 +1286,8 @@ extern "C" int epa_dev_select_candidates(epa_ctx* ctx, const double* lnl, uint32
 // the thorough launches.  rb: 64-word host block (pinned in the chunk pipeline).
 static int chunk_body_begin(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span,
                             uint32_t Q, uint32_t max_span, double threshold, epa_pair* d_pairs,
-                            uint64_t max_pairs, uint32_t* rb, SelectPending* sp) {
+                            uint64_t max_pairs, uint32_t* rb, SelectPending* sp, epa_result* d_res = nullptr,
+                            unsigned long long* d_stats = nullptr) {
   // internal table: rows padded to whole 64-byte sectors (the preplacement kernels write 8
   // consecutive branches per burst; with rows of B doubles every burst straddled two sectors)
   const uint32_t pitch = (ctx->B + 7u) & ~7u;
@@ -1307,6 +1308,27 @@ static int chunk_body_begin(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t
   if (!rc) rc = launch_select_begin(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, d_span, rb, sp);
   ctx->lnl_pitch = 0;
   ctx->segmax = nullptr;
+  // One read length (the windows can only be of max_span's class): pair list and Newton kernel can be queued right
+  // here, guarded on the device by the same read-back block the host will look at in chunk_body_end -- no host round
+  // trip between the selection and the thorough kernel.  OPT-IN (EPA_QUEUED_THOROUGH=1):
+  // measured (profiles/r4_queued_thorough.txt) it buys nothing -- a chunk's preplacement and its Newton kernel each
+  // need whole CUs, so they serialise on the device whichever is queued first -- and with HIP's default four
+  // hardware queues the early Newton kernel blocks the other slots' chains that share its queue (8.5 -> 7.7 M/s).
+  if (!rc && d_res && d_stats && sp->d_rb && sp->bitmap && max_pairs <= 0xffffffffull) {
+    const bool off = getenv("EPA_QUEUED_THOROUGH") == nullptr;
+    const int cls = epa_span_class(ctx->s, max_span);
+    const bool eligible = !off && ctx->s == 4 && !ctx->generic_thorough && ctx->dna.ng == 1 && epa_th_ctr(ctx) &&
+                          (cls <= 2 || cls == 10 || cls == 11);
+    if (eligible) {
+      rc = launch_select_emit(ctx, sp);
+      if (!rc) EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, ctx->stream));
+      if (!rc) {
+        const int q = launch_thorough_queued(ctx, d_pairs, sp->d_rb, max_pairs, d_codes, d_begin, d_span, max_span, d_res, d_stats);
+        if (q == -2) return EPA_ERR_HIP;
+        sp->queued_cls = q;
+      }
+    }
+  }
   return rc;
 }
 
@@ -1322,6 +1344,9 @@ static int chunk_body_end(epa_ctx* ctx, SelectPending* sp, const uint8_t* d_code
   rc = select_check_status(ctx, sp);
   if (rc) return rc;
   *n_out = n;
+  // the queued launch ran iff all n pairs are of its class (no overflow / window error: checked above) -- the test
+  // k_thorough_dna applied to the same block
+  if (sp->queued_cls >= 0 && sp->rb[9 + sp->queued_cls] == (uint32_t)n) { ctx->cls_hist_pairs = 0; return EPA_OK; }
   EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, ctx->stream));
   if (n == 0) return EPA_OK;
   return launch_thorough(ctx, d_pairs, n, d_codes, d_begin, d_span, max_span, d_res, d_stats);
@@ -1332,7 +1357,7 @@ static int chunk_body(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_be
                       uint64_t max_pairs, unsigned long long* d_stats, uint64_t* n_out) {
   uint32_t rb[64] = {};
   SelectPending sp;
-  int rc = chunk_body_begin(ctx, d_codes, d_begin, d_span, Q, max_span, threshold, d_pairs, max_pairs, rb, &sp);
+  int rc = chunk_body_begin(ctx, d_codes, d_begin, d_span, Q, max_span, threshold, d_pairs, max_pairs, rb, &sp, d_res, d_stats);
   if (rc) return rc;
   return chunk_body_end(ctx, &sp, d_codes, d_begin, d_span, max_span, d_pairs, d_res, d_stats, n_out);
 }
@@ -1546,7 +1571,8 @@ extern "C" int epa_dev_chunk_launch_begin(epa_ctx* ctx, int slot, uint32_t max_s
   }
   s->l_codes = d_codes; s->l_begin = d_begin; s->l_span = d_span;
   s->l_pairs = d_pairs; s->l_res = d_results; s->l_max_span = max_span; s->l_flags = flags;
-  rc = chunk_body_begin(ctx, d_codes, d_begin, d_span, Q, max_span, threshold, d_pairs, max_pairs, s->h_sel, &s->sel);
+  rc = chunk_body_begin(ctx, d_codes, d_begin, d_span, Q, max_span, threshold, d_pairs, max_pairs, s->h_sel, &s->sel,
+                        d_results, s->d_stats);
   if (rc) return rc;   // the slot stays staged
   s->state = 3;
   return EPA_OK;

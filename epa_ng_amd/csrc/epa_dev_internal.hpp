@@ -71,6 +71,10 @@ struct SelectPending {
   uint32_t* rb = nullptr;   // host read-back block, 64 words
   bool have_status = false;
   bool rerun = false;
+  hipEvent_t ev_rb = nullptr;      // recorded behind the read-back copy: launch_select_end waits for this, not for the stream
+  const uint32_t* d_rb = nullptr;  // the packed read-back block on the device (bitmap form)
+  bool emitted = false;            // k_emit_pairs (guarded by the total) is already queued behind the read-back
+  int queued_cls = -1;             // >= 0: a thorough launch for this span class is queued too (launch_thorough_queued)
   const uint32_t* pre_status = nullptr;   // window-validation words of THIS chunk's preplacement (ctx->d_status may belong
                                           // to another pipeline slot by the time a widened re-run packs the read-back)
 };
@@ -190,6 +194,7 @@ struct epa_ctx {
   enum { T_PREPLACE = 0, T_THOROUGH = 1, T_SELECT = 2 };
   EvTimer t_lookup;
   EvTimer t_bank[N_BANKS][3];
+  hipEvent_t ev_rb[N_BANKS] = {};   // per bank: behind the selection's read-back copy (SelectPending::ev_rb)
   int t_last[3] = {0, 0, 0};
   epa_thorough_stats last_stats{};
 };
@@ -245,6 +250,10 @@ int preplace_check_status(epa_ctx* ctx);
 int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
                     const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
                     epa_result* d_out, unsigned long long* d_stats);
+int launch_thorough_queued(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_spec, uint64_t max_pairs,
+                           const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
+                           epa_result* d_out, unsigned long long* d_stats);
+int launch_select_emit(epa_ctx* ctx, SelectPending* sp);   // queues the guarded k_emit_pairs behind launch_select_begin
 int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_order, uint64_t n_pairs,
                        const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span,
                        uint32_t max_span, bool want_lds, epa_result* d_out, unsigned long long* d_stats);

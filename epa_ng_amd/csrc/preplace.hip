@@ -1528,9 +1528,10 @@ __global__ void __launch_bounds__(256) k_compact(const unsigned long long* __res
 // branch counters): the candidate list in (branch, query) order.
 __global__ void __launch_bounds__(256) k_emit_pairs(const uint32_t* __restrict__ bitmap, uint32_t wpr,
                                                     const uint32_t* __restrict__ boffs,
-                                                    epa_pair* __restrict__ pairs) {
+                                                    epa_pair* __restrict__ pairs, uint32_t nb, uint32_t max_pairs) {
   __shared__ uint32_t wsum[4];
   const uint32_t b = blockIdx.x, t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+  if (boffs[nb] > max_pairs) return;   // queued ahead of the host's overflow check (launch_select_emit): the list would not fit
   uint32_t base = boffs[b];
   const uint32_t end = boffs[b + 1];
   if (base == end) return;
@@ -1835,8 +1836,15 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
                        sp->pre_status, status + 64);
     EPA_HIP(ctx, hipMemcpyAsync(rb, status + 64, sizeof(uint32_t) * 36, hipMemcpyDeviceToHost, ctx->stream));
     sp->have_status = sp->pre_status != nullptr;
+    if (!ctx->ev_rb[ctx->bank]) EPA_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_rb[ctx->bank], hipEventDisableTiming));
+    EPA_HIP(ctx, hipEventRecord(ctx->ev_rb[ctx->bank], ctx->stream));
+    sp->ev_rb = ctx->ev_rb[ctx->bank];
+    sp->d_rb = status + 64;
+    sp->emitted = false;
+    sp->queued_cls = -1;
     return EPA_OK;
   }
+  sp->ev_rb = nullptr; sp->d_rb = nullptr; sp->emitted = false; sp->queued_cls = -1;
   // scratch 7: [status 512 B | counts Q+1 | offsets Q+1 | stage Q*cap | keys_a worst | keys_b worst | temp]
   // status words [0, 8 + EPA_N_CLS): selection status + class histogram; [64, 128): the packed read-back block
   const size_t qb = align256(sizeof(uint32_t) * (Q + 1));
@@ -1886,10 +1894,24 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
   return EPA_OK;
 }
 
+// Bitmap form: the pair list written behind the read-back without waiting for the host (the kernel itself refuses a
+// list that would not fit); the selection's timer stops here.
+int launch_select_emit(epa_ctx* ctx, SelectPending* sp) {
+  if (!sp->bitmap || !sp->d_rb || sp->emitted) return EPA_OK;
+  hipLaunchKernelGGL(k_emit_pairs, dim3(ctx->B), dim3(256), 0, ctx->stream, sp->bitmap, sp->wpr, sp->boffs, sp->d_pairs, ctx->B,
+                     (uint32_t)std::min<uint64_t>(sp->max_pairs, 0xffffffffu));
+  epa_timer_stop(ctx, epa_t(ctx, epa_ctx::T_SELECT));
+  EPA_HIP(ctx, hipGetLastError());
+  sp->emitted = true;
+  return EPA_OK;
+}
+
 int launch_select_end(epa_ctx* ctx, SelectPending* sp, uint64_t* n_pairs) {
   const uint32_t B = ctx->B, Q = sp->Q;
   for (;;) {
-    EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // everything up to the read-back copy; kernels queued behind it (launch_select_emit, launch_thorough_queued) run on
+    if (sp->ev_rb) EPA_HIP(ctx, hipEventSynchronize(sp->ev_rb));
+    else EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t total = sp->rb[0];
     const uint32_t* hst = sp->rb + 1;
     if (hst[2] && !sp->bitmap) {  // some query selected more candidates than the staging row holds: widen, redo
@@ -1906,7 +1928,9 @@ int launch_select_end(epa_ctx* ctx, SelectPending* sp, uint64_t* n_pairs) {
       return epa_fail(ctx, EPA_ERR_PAIR_OVERFLOW,
                       "select_candidates: " + std::to_string(total) + " candidates exceed max_pairs");
     if (total && sp->bitmap) {
-      hipLaunchKernelGGL(k_emit_pairs, dim3(B), dim3(256), 0, ctx->stream, sp->bitmap, sp->wpr, sp->boffs, sp->d_pairs);
+      if (!sp->emitted)
+        hipLaunchKernelGGL(k_emit_pairs, dim3(B), dim3(256), 0, ctx->stream, sp->bitmap, sp->wpr, sp->boffs, sp->d_pairs, B,
+                           (uint32_t)std::min<uint64_t>(sp->max_pairs, 0xffffffffu));
     } else if (total) {
       const dim3 grid((Q + 3) / 4);
       hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, ctx->stream, sp->stage, sp->counts, sp->offsets, Q, sp->cap,
@@ -1922,7 +1946,7 @@ int launch_select_end(epa_ctx* ctx, SelectPending* sp, uint64_t* n_pairs) {
       hipLaunchKernelGGL(k_keys_to_pairs, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, sp->keys_b,
                          (uint64_t)total, sp->d_pairs);
     }
-    epa_timer_stop(ctx, epa_t(ctx, epa_ctx::T_SELECT));
+    if (!sp->emitted) epa_timer_stop(ctx, epa_t(ctx, epa_ctx::T_SELECT));   // (else stopped behind the queued k_emit_pairs)
     EPA_HIP(ctx, hipGetLastError());
     *n_pairs = total;
     if (sp->d_span) {

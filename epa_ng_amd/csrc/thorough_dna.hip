@@ -71,6 +71,12 @@ struct ThArgs {
   uint64_t n_pairs;
   uint32_t W;
   uint32_t Wpad;
+  // queued launch (launch_thorough_queued): the pair count is not known on the host yet.  spec = the selection's
+  // packed read-back block ON THE DEVICE (k_pack_readback: [0] total, [9 + c] pairs of span class c, [32], [33]
+  // window-validation errors); the kernel runs only if the host, once it has read the same block, will find
+  // that this launch was the right one (launch_select_end / chunk_body_end apply the same test), else it exits
+  const uint32_t* spec;
+  uint32_t spec_cls, spec_max;
 };
 
 using namespace epa_wave;
@@ -1193,15 +1199,26 @@ __global__ void __launch_bounds__(64 * NW * NG, TH_WAVES) k_thorough_dna(const T
   __syncthreads();
   const uint32_t x = blockIdx.x & 7;
   const uint32_t w = blockIdx.x >> 3, stride = gridDim.x >> 3;
-  const uint64_t per = (a.n_pairs + 7) / 8;
+  uint64_t n_pairs = a.n_pairs;
+  if constexpr (NW == 1 && NG == 1) {
+    if (a.spec) {   // queued launch: count and validity come from the selection's read-back block
+      const uint32_t n = a.spec[0];
+      if (n > a.spec_max || a.spec[9 + a.spec_cls] != n || a.spec[32] || a.spec[33]) return;
+      n_pairs = n;
+    }
+  }
+  const uint64_t per = (n_pairs + 7) / 8;
   const uint64_t lo = (uint64_t)x * per;
-  const uint64_t hi = lo + per < a.n_pairs ? lo + per : a.n_pairs;
+  const uint64_t hi = lo + per < n_pairs ? lo + per : n_pairs;
   uint32_t wstat[3] = {0, 0, 0};
   if constexpr (NW == 1 && NG == 1) {
     // resident waves fetch the next pair of their XCD slice from a counter: no relaunches, no
     // tail of unlucky waves.  The next index is requested before the current pair is processed.
     // (The single-wave classes are always launched with the counters; one loop, not two copies of
     // the pair body: the second copy cost 16 spilled registers in the dominant instantiation.)
+    // (Measured and dropped, round 4: waves that find their slice exhausted fetching from the next XCD's slice in
+    // short launches -- 13k pairs, six per resident wave: 0.563 -> 0.655 ms per 5000-read chunk; the stolen pairs'
+    // reference rows are in another XCD's L2.)
     uint32_t* ctr = a.qctr + x;
     const uint32_t cnt = (uint32_t)(hi > lo ? hi - lo : 0);
     uint32_t nxt = 0;
@@ -1486,6 +1503,7 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
   // / 64 -> 6.64 / 6.66 / 6.50 / 6.58 ms; one pair per wave: 10.2 ms).  EPA_TH_WAVES_PER_SLOT overrides.
   uint32_t per_slot = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(8, n_pairs / (2048 * 4)));
   if (const char* e = getenv("EPA_TH_WAVES_PER_SLOT")) per_slot = (uint32_t)std::max(1, atoi(e));
+  static const uint64_t th_grid_waves = getenv("EPA_TH_GRID_WAVES") ? (uint64_t)std::max(8, atoi(getenv("EPA_TH_GRID_WAVES"))) : 0;   // experiment: resident waves of the single-wave classes
   // class -> (wavefronts per pair NW, 64-site chunks per wavefront NCH): windows up to 192 sites
   // are one wave's job; longer ones are spread over 2 / 4 / 8 waves of a workgroup, each keeping
   // its part of the sumtable in registers (NCH stays <= 3: the kernel's register budget)
@@ -1498,7 +1516,7 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
     if ((NW_) == 1) {                                                                              \
       EPA_HIP(ctx, hipMemsetAsync(epa_th_ctr(ctx), 0, 64, ctx->stream));                               \
       a.qctr = epa_th_ctr(ctx);                                                                        \
-      want = 1024 * TH_WAVES;                                                                                 \
+      want = th_grid_waves ? th_grid_waves : 1024 * TH_WAVES;                                                   \
     }                                                                                              \
     if (want > n_pairs) want = n_pairs;                                                            \
     const uint32_t nwg = (uint32_t)((want + 7) / 8 * 8);                                           \
@@ -1571,6 +1589,69 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
   }
 #undef LAUNCH
   return EPA_OK;
+}
+
+static ThArgs dna_args(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* ord, const uint8_t* d_codes,
+                       const uint32_t* d_begin, const uint32_t* d_span, epa_result* d_out, unsigned long long* d_stats) {
+  ThArgs a;
+  a.m = ctx->dna;
+  a.blo = ctx->blo;
+  a.refT = ctx->refT;
+  // filled by k_build_lookup; until then every pair computes its own starting vector
+  a.refI = ctx->lookup_built ? ctx->refI : nullptr;
+  a.resc0 = ctx->resc0;
+  a.cinv = ctx->cinv;
+  a.inv_w0 = ctx->inv_w0;
+  a.scSum = ctx->scSum;
+  a.blen = ctx->blen;
+  a.qt = ctx->dmodel->qt;
+  a.pairs = d_pairs;
+  a.order = ord;
+  a.codes = d_codes;
+  a.crel = ctx->code_stride ? 1u : 0u;
+  a.cstride = a.crel ? ctx->code_stride : ctx->W;
+  a.win_begin = d_begin;
+  a.win_span = d_span;
+  a.out = d_out;
+  a.stats = d_stats;
+  a.sscratch = nullptr;
+  a.qctr = nullptr;
+  a.n_pairs = 0;
+  a.W = ctx->W;
+  a.Wpad = 0;
+  a.spec = nullptr;
+  a.spec_cls = 0;
+  a.spec_max = 0;
+  return a;
+}
+
+// The thorough launch of a fused chunk body queued BEHIND the selection, before the host has seen the candidate
+// count (what place_thorough() starts from, src/core/place.cpp:97-171, decided on the device): possible when the
+// chunk's windows can only be of ONE span class that a single-wave instantiation serves -- the class of max_span,
+// i.e. reads of one length, the BASELINE workloads -- because then the launch needs no class partition and the
+// resident grid is the same for every pair count.  The kernel takes the count from d_spec and exits at once when
+// the block says that this was not the right launch (pairs of another class, candidate overflow, a window error);
+// the host applies the same test to its copy of the block and queues the ordinary launches in that case.
+// Returns the class (>= 0) when queued, -1 when the configuration is not eligible.
+int launch_thorough_queued(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_spec, uint64_t max_pairs,
+                           const uint8_t* d_codes, const uint32_t* d_begin, const uint32_t* d_span, uint32_t max_span,
+                           epa_result* d_out, unsigned long long* d_stats) {
+  if (ctx->s != 4 || ctx->generic_thorough || ctx->dna.ng != 1 || !epa_th_ctr(ctx) || !d_span || !d_spec) return -1;
+  if (max_pairs > 0xffffffffull) return -1;
+  const int cls = epa_span_class(4, max_span);
+  if (!(cls <= 2 || cls == 10 || cls == 11)) return -1;   // single-wave classes (resident waves + work counters)
+  static const uint32_t bound[12] = {64, 128, 192, 0, 0, 0, 0, 0, 0, 0, 96, 160};
+  ThArgs a = dna_args(ctx, d_pairs, nullptr, d_codes, d_begin, d_span, d_out, d_stats);
+  a.n_pairs = 0xffffffffull;   // sizes the (full resident) grid only
+  a.spec = d_spec;
+  a.spec_cls = (uint32_t)cls;
+  a.spec_max = (uint32_t)max_pairs;
+  epa_timer_start(ctx, epa_t(ctx, epa_ctx::T_THOROUGH));
+  const int rc = launch_thorough_dna_class(ctx, a, cls, std::min(max_span, bound[cls]));
+  epa_timer_stop(ctx, epa_t(ctx, epa_ctx::T_THOROUGH));
+  if (rc) return -2;
+  if (hipGetLastError() != hipSuccess) { (void)epa_fail(ctx, EPA_ERR_HIP, "queued thorough launch"); return -2; }
+  return cls;
 }
 
 int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, const uint8_t* d_codes,
@@ -1662,32 +1743,8 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
         rc = launch_thorough_generic(ctx, d_pairs, hist[c], d_codes, d_begin, d_span, bound, d_out, d_stats, ord, true);
       continue;
     }
-    ThArgs a;
-    a.m = ctx->dna;
-    a.blo = ctx->blo;
-    a.refT = ctx->refT;
-    // filled by k_build_lookup; until then every pair computes its own starting vector
-    a.refI = ctx->lookup_built ? ctx->refI : nullptr;
-    a.resc0 = ctx->resc0;
-  a.cinv = ctx->cinv;
-  a.inv_w0 = ctx->inv_w0;
-    a.scSum = ctx->scSum;
-    a.blen = ctx->blen;
-    a.qt = ctx->dmodel->qt;
-    a.pairs = d_pairs;
-    a.order = ord;
-    a.codes = d_codes;
-    a.crel = ctx->code_stride ? 1u : 0u;
-    a.cstride = a.crel ? ctx->code_stride : ctx->W;
-    a.win_begin = d_begin;
-    a.win_span = d_span;
-    a.out = d_out;
-    a.stats = d_stats;
-    a.sscratch = nullptr;
-    a.qctr = nullptr;
+    ThArgs a = dna_args(ctx, d_pairs, ord, d_codes, d_begin, d_span, d_out, d_stats);
     a.n_pairs = hist[c];
-    a.W = ctx->W;
-    a.Wpad = 0;
     rc = launch_thorough_dna_class(ctx, a, c, std::min(max_span, dna_bound[c]));
   }
   epa_timer_stop(ctx, epa_t(ctx, epa_ctx::T_THOROUGH));

@@ -1000,6 +1000,71 @@ def test_five_slot_order_for_small_chunks():
         ev.chunk_stage(6, *chunks[0])
 
 
+def test_queued_thorough_launch_equals_host_launched(monkeypatch):
+    """EPA_QUEUED_THOROUGH=1 (opt-in): the pair list and the Newton kernel are queued behind the selection before the
+    host has seen the candidate count, guarded on the device by the read-back block the host checks afterwards
+    (launch_thorough_queued).  Same bits as the host-launched order -- for a chunk of one read length (the queued
+    kernel runs), for mixed read lengths (the queued kernel must exit, the ordinary per-class launches run), through
+    the fused call and the five-slot staged order; a candidate overflow is still reported and still recoverable."""
+    w = synth.dna_workload(40, 600, 1500, 150, (181, 182, 183))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    one_len = list(w["reads"][:900])
+    mixed = []
+    for i, r in enumerate(w["reads"][900:1500]):     # shorten every third read to 70 sites: span classes 11 and 10
+        if i % 3 == 0:
+            k = [j for j, ch in enumerate(r) if ch != "-"]
+            r = "".join(ch if (j <= k[69] or ch == "-") else "-" for j, ch in enumerate(r)) if len(k) > 70 else r
+        mixed.append(r)
+    for reads in (one_len, mixed):
+        codes, wb, ws = epa.encode_queries(4, reads, compact=True)
+        monkeypatch.delenv("EPA_QUEUED_THOROUGH", raising=False)
+        p0, r0 = ev.place_chunk(codes, wb, ws, max_span=150)
+        st0 = dict(ev.last_stats)
+        monkeypatch.setenv("EPA_QUEUED_THOROUGH", "1")
+        p1, r1 = ev.place_chunk(codes, wb, ws, max_span=150)
+        st1 = dict(ev.last_stats)
+        assert len(p0) > len(reads) and np.array_equal(p0, p1) and np.array_equal(r0, r1)
+        assert st0 == st1
+        # staged order, three chunks begun ahead
+        Q, S, A = 150, 5, 3
+        chunks = []
+        for c in range(len(reads) // Q):
+            cc, cb, cs = epa.encode_queries(4, reads[c * Q:(c + 1) * Q], compact=True)
+            chunks.append((epa.pack_codes_4bit(cc), cb, cs))
+        monkeypatch.delenv("EPA_QUEUED_THOROUGH")
+        expect = [ev.place_chunk(*ch, max_span=150) for ch in chunks]
+        monkeypatch.setenv("EPA_QUEUED_THOROUGH", "1")
+        kw = dict(threshold=0.99999, max_span=150, max_pairs=Q * 64)
+        n = len(chunks)
+        got = [None] * n
+        for k in range(min(A, n)):
+            ev.chunk_stage(k % S, *chunks[k])
+            ev.chunk_launch_begin(k % S, **kw)
+        for k in range(n):
+            ev.chunk_launch_end(k % S)
+            if k >= 2:
+                got[k - 2] = ev.chunk_finish((k - 2) % S)
+            if k + A < n:
+                ev.chunk_stage((k + A) % S, *chunks[k + A])
+                ev.chunk_launch_begin((k + A) % S, **kw)
+        for k in range(max(0, n - 2), n):
+            got[k] = ev.chunk_finish(k % S)
+        for (p, r), (ep, er) in zip(got, expect):
+            assert np.array_equal(p, ep) and np.array_equal(r, er)
+        # overflow: reported by launch_end, the slot stays staged, a larger max_pairs succeeds
+        ev.chunk_stage(0, *chunks[0])
+        ev.chunk_launch_begin(0, threshold=0.99999, max_span=150, max_pairs=8)
+        with pytest.raises(epa.EpaError):
+            ev.chunk_launch_end(0)
+        ev.chunk_launch_begin(0, **kw)
+        ev.chunk_launch_end(0)
+        p, r = ev.chunk_finish(0)
+        assert np.array_equal(p, expect[0][0]) and np.array_equal(r, expect[0][1])
+        monkeypatch.delenv("EPA_QUEUED_THOROUGH")
+
+
 def test_selection_bitmap_and_sorted_staging_paths_agree(tmp_path):
     """the candidate list comes from a [B][Q] bitmap (default) or, for bitmaps over 64 MB, from
     staging rows + compaction + a stable device sort (EPA_SELECT_SORT forces that path): same pairs
