@@ -106,6 +106,38 @@ const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_
   return d;
 }
 
+// The eight XCDs of one device do not run the Newton kernel equally fast (a few per cent, stable from launch to
+// launch, different from box to box): a launch that stamped its XCDs' drain times (ThArgs::xstamp) moves the shares of
+// the next ones half way toward share_x ~ pairs_x / time_x.  Short launches (start-up and the last pairs dominate)
+// and implausible stamps are ignored; a share stays within 0.85 .. 1.15 of an eighth.  EPA_TH_XCD_BALANCE=0: off.
+void epa_xcd_feedback(epa_ctx* ctx, uint64_t n_pairs, const unsigned long long* hst) {
+  static const bool off = getenv("EPA_TH_XCD_BALANCE") && atoi(getenv("EPA_TH_XCD_BALANCE")) == 0;
+  if (off || n_pairs < 65536 || hst[7] == 0) return;
+  double sp[8], tot = 0.0;
+  for (int x = 0; x < 8; ++x) {
+    if (hst[8 + x] <= hst[7]) return;
+    const double t = (double)(hst[8 + x] - hst[7]);               // 10 ns ticks
+    const double share = (double)(ctx->xcd_cum[x + 1] - ctx->xcd_cum[x]) / (double)(1u << 20);
+    if (t < 1e4 || t > 1e9) return;                                // < 0.1 ms or > 10 s: not a launch worth learning from
+    sp[x] = share / t;
+    tot += sp[x];
+  }
+  double norm = 0.0;
+  for (int x = 0; x < 8; ++x) {
+    double w = 0.5 * ctx->xcd_w[x] + 0.5 * sp[x] / tot;
+    w = std::min(0.125 * 1.15, std::max(0.125 * 0.85, w));
+    ctx->xcd_w[x] = w;
+    norm += w;
+  }
+  double c = 0.0;
+  for (int x = 0; x < 8; ++x) {
+    ctx->xcd_w[x] /= norm;
+    ctx->xcd_cum[x] = (uint32_t)std::llround(c * (double)(1u << 20));
+    c += ctx->xcd_w[x];
+  }
+  ctx->xcd_cum[8] = 1u << 20;
+}
+
 void epa_timer_start(epa_ctx* ctx, EvTimer& t) {
   if (!t.a) { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
   (void)hipEventRecord(t.a, ctx->stream);
@@ -1237,13 +1269,14 @@ extern "C" int epa_dev_thorough(epa_ctx* ctx, const epa_pair* pairs, uint64_t n_
   EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, ctx->stream));
   rc = launch_thorough(ctx, d_pairs, n_pairs, d_codes, d_begin, d_span, max_span, d_out, d_stats);
   if (rc) return rc;
-  unsigned long long hst[8];
+  unsigned long long hst[16];
   if (!out_dev)
     EPA_HIP(ctx, hipMemcpyAsync(out, d_out, sizeof(epa_result) * n_pairs, hipMemcpyDeviceToHost,
                                 ctx->stream));
   if (!out_dev || stats) {
-    EPA_HIP(ctx, hipMemcpyAsync(hst, d_stats, 64, hipMemcpyDeviceToHost, ctx->stream));
+    EPA_HIP(ctx, hipMemcpyAsync(hst, d_stats, 128, hipMemcpyDeviceToHost, ctx->stream));
     EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    epa_xcd_feedback(ctx, n_pairs, hst);
     ctx->last_stats.pairs = n_pairs;
     ctx->last_stats.rounds = hst[0];
     ctx->last_stats.newton_evals = hst[1];
@@ -1363,6 +1396,7 @@ static int chunk_body(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_be
 }
 
 static int chunk_stats(epa_ctx* ctx, uint64_t n, const unsigned long long* hst, epa_thorough_stats* stats) {
+  epa_xcd_feedback(ctx, n, hst);
   ctx->last_stats.pairs = n;
   ctx->last_stats.rounds = hst[0];
   ctx->last_stats.newton_evals = hst[1];
@@ -1413,12 +1447,12 @@ extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const u
   if (rc) return rc;
   *n_pairs = n;
   if (n == 0) return EPA_OK;
-  unsigned long long hst[8];
+  unsigned long long hst[16];
   if (!pairs_dev)
     EPA_HIP(ctx, hipMemcpyAsync(pairs, d_pairs, sizeof(epa_pair) * n, hipMemcpyDeviceToHost, ctx->stream));
   if (!res_dev)
     EPA_HIP(ctx, hipMemcpyAsync(results, d_res, sizeof(epa_result) * n, hipMemcpyDeviceToHost, ctx->stream));
-  EPA_HIP(ctx, hipMemcpyAsync(hst, d_stats, 64, hipMemcpyDeviceToHost, ctx->stream));
+  EPA_HIP(ctx, hipMemcpyAsync(hst, d_stats, 128, hipMemcpyDeviceToHost, ctx->stream));
   EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return chunk_stats(ctx, n, hst, stats);
 }
@@ -1438,7 +1472,7 @@ static int slot_of(epa_ctx* ctx, int slot, ChunkSlot** out) {
     EPA_HIP(ctx, hipEventCreateWithFlags(&s.ev_down, hipEventDisableTiming));
     EPA_HIP(ctx, hipEventCreateWithFlags(&s.ev_base, hipEventDisableTiming));
     EPA_HIP(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    EPA_HIP(ctx, hipHostMalloc((void**)&s.h_stats, 64, hipHostMallocDefault));
+    EPA_HIP(ctx, hipHostMalloc((void**)&s.h_stats, 128, hipHostMallocDefault));
     EPA_HIP(ctx, hipHostMalloc((void**)&s.h_sel, 256, hipHostMallocDefault));
     EPA_HIP(ctx, hipMalloc((void**)&s.d_stats, 128));
   }
@@ -1621,7 +1655,7 @@ extern "C" int epa_dev_chunk_launch_end(epa_ctx* ctx, int slot) {
     s->out_pairs = (const epa_pair*)s->h_out;
     s->out_res = (const epa_result*)((char*)s->h_out + off_r);
   }
-  EPA_HIP(ctx, hipMemcpyAsync(s->h_stats, s->d_stats, 64, hipMemcpyDeviceToHost, ctx->down_stream));
+  EPA_HIP(ctx, hipMemcpyAsync(s->h_stats, s->d_stats, 128, hipMemcpyDeviceToHost, ctx->down_stream));
   EPA_HIP(ctx, hipEventRecord(s->ev_down, ctx->down_stream));
   s->state = 2;
   return EPA_OK;

@@ -97,7 +97,7 @@ struct ChunkSlot {
   size_t cap = 0;
   void* h_out = nullptr;      // pinned: pairs | results
   size_t h_out_sz = 0;
-  unsigned long long* h_stats = nullptr;  // pinned, 8 words
+  unsigned long long* h_stats = nullptr;  // pinned, 16 words
   unsigned long long* d_stats = nullptr;  // 16 words in HBM
   hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_down = nullptr, ev_base = nullptr;
   hipStream_t stream = nullptr;  // the slot's own compute stream: the kernels of the two chunks in flight overlap
@@ -194,6 +194,10 @@ struct epa_ctx {
   enum { T_PREPLACE = 0, T_THOROUGH = 1, T_SELECT = 2 };
   EvTimer t_lookup;
   EvTimer t_bank[N_BANKS][3];
+  // shares of the branch-sorted pair list the eight XCDs take in the single-wave Newton launches (cumulative, 20-bit
+  // fixed point; thorough_dna.hip ThArgs::xcum), adapted to the speeds the XCDs showed: epa_xcd_feedback
+  uint32_t xcd_cum[9] = {0u, 1u << 17, 2u << 17, 3u << 17, 4u << 17, 5u << 17, 6u << 17, 7u << 17, 1u << 20};
+  double xcd_w[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
   hipEvent_t ev_rb[N_BANKS] = {};   // per bank: behind the selection's read-back copy (SelectPending::ev_rb)
   int t_last[3] = {0, 0, 0};
   epa_thorough_stats last_stats{};
@@ -210,6 +214,8 @@ const void* epa_to_device(epa_ctx* ctx, int slot, const void* p, size_t bytes);
 const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_t Q);
 // query code rows -> device in the one-byte layout the kernels read (unpacks the 4-bit wire format)
 const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_t Q);
+// hst: the 16 statistics words of a thorough launch ([7] start, [8 + x] last exit of XCD x: ThArgs::xstamp)
+void epa_xcd_feedback(epa_ctx* ctx, uint64_t n_pairs, const unsigned long long* hst);
 void epa_timer_start(epa_ctx* ctx, EvTimer& t);
 void epa_timer_stop(epa_ctx* ctx, EvTimer& t);
 // the current bank's timer of a kernel family (epa_ctx::T_*)

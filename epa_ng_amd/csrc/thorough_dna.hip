@@ -41,6 +41,8 @@ using epa_radix_cfg = rocprim::radix_sort_config<rocprim::default_config, rocpri
                                                  rocprim::default_config, 0>;
 
 #include <algorithm>
+#include <vector>
+#include <cstdio>
 #include <type_traits>
 #include <cstdlib>
 
@@ -77,6 +79,13 @@ struct ThArgs {
   // that this launch was the right one (launch_select_end / chunk_body_end apply the same test), else it exits
   const uint32_t* spec;
   uint32_t spec_cls, spec_max;
+  // single-wave classes: XCD x takes the pairs [n * xcum[x], n * xcum[x + 1]) >> 20 of the branch-sorted list.  The
+  // shares follow the speed each XCD showed in the context's previous launches (epa_xcd_feedback): in-kernel stamps
+  // showed the eight equal slices of a 262k-pair launch draining up to 250 us apart, the same XCDs early / late from
+  // launch to launch and other ones on another box.  xstamp != 0: the launch records stats[7] = start and
+  // stats[8 + x] = the last exit of XCD x's waves (s_memrealtime, 100 MHz) for that feedback.
+  uint32_t xcum[9];
+  uint32_t xstamp;
 };
 
 using namespace epa_wave;
@@ -1208,8 +1217,13 @@ __global__ void __launch_bounds__(64 * NW * NG, TH_WAVES) k_thorough_dna(const T
     }
   }
   const uint64_t per = (n_pairs + 7) / 8;
-  const uint64_t lo = (uint64_t)x * per;
-  const uint64_t hi = lo + per < n_pairs ? lo + per : n_pairs;
+  uint64_t lo = (uint64_t)x * per;
+  uint64_t hi = lo + per < n_pairs ? lo + per : n_pairs;
+  if constexpr (NW == 1 && NG == 1) {
+    lo = (n_pairs * a.xcum[x]) >> 20;
+    hi = (n_pairs * a.xcum[x + 1]) >> 20;
+    if (a.xstamp && blockIdx.x == 0 && threadIdx.x == 0) a.stats[7] = __builtin_amdgcn_s_memrealtime();
+  }
   uint32_t wstat[3] = {0, 0, 0};
   if constexpr (NW == 1 && NG == 1) {
     // resident waves fetch the next pair of their XCD slice from a counter: no relaunches, no
@@ -1219,9 +1233,19 @@ __global__ void __launch_bounds__(64 * NW * NG, TH_WAVES) k_thorough_dna(const T
     // (Measured and dropped, round 4: waves that find their slice exhausted fetching from the next XCD's slice in
     // short launches -- 13k pairs, six per resident wave: 0.563 -> 0.655 ms per 5000-read chunk; the stolen pairs'
     // reference rows are in another XCD's L2.)
+    // (Measured and dropped, round 4: XCD x working through eight interleaved blocks of the list instead of one
+    // contiguous eighth -- 5.19 - 5.22 ms per launch either way.  In-kernel stamps (-DTH_TIMING) show the slices
+    // draining up to 250 us apart in a 5.5 ms launch, but the SAME XCDs are early / late for both block layouts and
+    // other ones on another box: the XCDs differ in speed by a few per cent, the slices do not differ in cost.)
     uint32_t* ctr = a.qctr + x;
     const uint32_t cnt = (uint32_t)(hi > lo ? hi - lo : 0);
     uint32_t nxt = 0;
+#ifdef TH_TIMING
+    unsigned long long* tlog = reinterpret_cast<unsigned long long*>(a.sscratch) + (size_t)blockIdx.x * 8;
+    unsigned long long t_first = 0, t_second = 0;
+    uint32_t npr = 0;
+    if (lane == 0) tlog[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (lane == 0) nxt = atomicAdd(ctr, 1u);
     nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
     while (nxt < cnt) {
@@ -1230,7 +1254,15 @@ __global__ void __launch_bounds__(64 * NW * NG, TH_WAVES) k_thorough_dna(const T
       if (lane == 0) f = atomicAdd(ctr, 1u);
       process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH, NG>(a, lo + cur, lane, tab + cb.wv * 64, qts, qa + cb.wv * (16 * QA_STRIDE + (TH_MFMA_LDS_T ? 256 : 0)), lc, cb, wstat);
       nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
+#ifdef TH_TIMING
+      ++npr;
+      if (npr == 1) t_first = __builtin_amdgcn_s_memrealtime();
+      if (npr == 2) t_second = __builtin_amdgcn_s_memrealtime();
+#endif
     }
+#ifdef TH_TIMING
+    if (lane == 0) { tlog[1] = t_first; tlog[2] = t_second; tlog[3] = __builtin_amdgcn_s_memrealtime(); tlog[4] = npr; }
+#endif
   } else {
     for (uint64_t p = lo + w; p < hi; p += stride)
       process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH, NG>(a, p, lane, tab + cb.wv * 64, qts, qa + cb.wv * (16 * QA_STRIDE + (TH_MFMA_LDS_T ? 256 : 0)), lc, cb, wstat);
@@ -1239,6 +1271,9 @@ __global__ void __launch_bounds__(64 * NW * NG, TH_WAVES) k_thorough_dna(const T
     atomicAdd(&a.stats[0], (unsigned long long)wstat[0]);
     atomicAdd(&a.stats[1], (unsigned long long)wstat[1]);
     atomicAdd(&a.stats[2], (unsigned long long)wstat[2]);
+    if constexpr (NW == 1 && NG == 1) {
+      if (a.xstamp) atomicMax(&a.stats[8 + x], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
   }
 }
 
@@ -1509,11 +1544,19 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
   // its part of the sumtable in registers (NCH stays <= 3: the kernel's register budget)
   // single-wave classes: resident waves + a work counter per XCD slice (round 1: the oversubscribed
   // static grid instead cost 262k pairs 6.56 vs 6.47 ms)
+#ifdef TH_TIMING
+#define TH_TIMING_ALLOC a.sscratch = (double*)epa_scratch(ctx, 9, 2048 * 64); (void)hipMemsetAsync(a.sscratch, 0, 2048 * 64, ctx->stream);
+#define TH_TIMING_DUMP th_timing_dump(ctx, a.sscratch);
+#else
+#define TH_TIMING_ALLOC
+#define TH_TIMING_DUMP
+#endif
 #define LAUNCH(N, NW_)                                                                            \
   do {                                                                                            \
     uint64_t want = (uint64_t)256 * 8 * per_slot / (NW_);                                          \
     a.qctr = nullptr;                                                                              \
     if ((NW_) == 1) {                                                                              \
+      TH_TIMING_ALLOC                                                                              \
       EPA_HIP(ctx, hipMemsetAsync(epa_th_ctr(ctx), 0, 64, ctx->stream));                               \
       a.qctr = epa_th_ctr(ctx);                                                                        \
       want = th_grid_waves ? th_grid_waves : 1024 * TH_WAVES;                                                   \
@@ -1588,6 +1631,38 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
     }
   }
 #undef LAUNCH
+#ifdef TH_TIMING
+  if (a.sscratch && (cls <= 2 || cls == 10 || cls == 11)) {
+    std::vector<unsigned long long> h(2048 * 8);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpy(h.data(), a.sscratch, 2048 * 64, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int w = 0; w < 2048; ++w) if (h[w * 8]) { t0 = std::min(t0, h[w * 8]); t1 = std::max(t1, h[w * 8 + 3]); }
+    std::vector<double> st, fp, sp, ex, np_;
+    for (int w = 0; w < 2048; ++w) {
+      if (!h[w * 8]) continue;
+      st.push_back((h[w * 8] - t0) * 0.01);
+      if (h[w * 8 + 1]) fp.push_back((h[w * 8 + 1] - h[w * 8]) * 0.01);
+      if (h[w * 8 + 2]) sp.push_back((h[w * 8 + 2] - h[w * 8 + 1]) * 0.01);
+      ex.push_back((h[w * 8 + 3] - t0) * 0.01);
+      np_.push_back((double)h[w * 8 + 4]);
+    }
+    for (int x = 0; x < 8; ++x) {
+      double e0 = 1e30, e1 = 0, fsum = 0; unsigned long long np2 = 0; int nw = 0;
+      for (int w = x; w < 2048; w += 8) {
+        if (!h[w * 8]) continue;
+        const double e = (h[w * 8 + 3] - t0) * 0.01;
+        e0 = std::min(e0, e); e1 = std::max(e1, e); np2 += h[w * 8 + 4]; ++nw;
+        if (h[w * 8 + 1]) fsum += (h[w * 8 + 1] - h[w * 8]) * 0.01;
+      }
+      fprintf(stderr, "  x %d: waves %d pairs %llu exit %.1f .. %.1f us, mean first pair %.1f\n", x, nw, np2, e0, e1, nw ? fsum / nw : 0.0);
+    }
+    auto pct = [](std::vector<double>& v, double p) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; };
+    fprintf(stderr, "TH_TIMING n_pairs %llu: span %.1f us | wave start p50 %.1f p99 %.1f max %.1f | first pair p50 %.1f p90 %.1f max %.1f | second pair p50 %.1f p90 %.1f | exit p1 %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f | pairs/wave p50 %.0f max %.0f\n",
+            (unsigned long long)a.n_pairs, (t1 - t0) * 0.01, pct(st, 0.5), pct(st, 0.99), pct(st, 1.0), pct(fp, 0.5), pct(fp, 0.9), pct(fp, 1.0), pct(sp, 0.5), pct(sp, 0.9),
+            pct(ex, 0.01), pct(ex, 0.1), pct(ex, 0.5), pct(ex, 0.9), pct(ex, 1.0), pct(np_, 0.5), pct(np_, 1.0));
+  }
+#endif
   return EPA_OK;
 }
 
@@ -1622,6 +1697,8 @@ static ThArgs dna_args(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* or
   a.spec = nullptr;
   a.spec_cls = 0;
   a.spec_max = 0;
+  for (int i = 0; i < 9; ++i) a.xcum[i] = ctx->xcd_cum[i];
+  a.xstamp = 0;
   return a;
 }
 
@@ -1646,6 +1723,7 @@ int launch_thorough_queued(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t
   a.spec = d_spec;
   a.spec_cls = (uint32_t)cls;
   a.spec_max = (uint32_t)max_pairs;
+  a.xstamp = 1u;
   epa_timer_start(ctx, epa_t(ctx, epa_ctx::T_THOROUGH));
   const int rc = launch_thorough_dna_class(ctx, a, cls, std::min(max_span, bound[cls]));
   epa_timer_stop(ctx, epa_t(ctx, epa_ctx::T_THOROUGH));
@@ -1745,6 +1823,7 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
     }
     ThArgs a = dna_args(ctx, d_pairs, ord, d_codes, d_begin, d_span, d_out, d_stats);
     a.n_pairs = hist[c];
+    a.xstamp = (present == 1 && ctx->dna.ng == 1 && (c <= 2 || c == 10 || c == 11)) ? 1u : 0u;
     rc = launch_thorough_dna_class(ctx, a, c, std::min(max_span, dna_bound[c]));
   }
   epa_timer_stop(ctx, epa_t(ctx, epa_ctx::T_THOROUGH));

@@ -284,8 +284,11 @@ def test_full_size_cfg2_properties():
     lw = np.exp(lnl - lnl.max(1, keepdims=True))
     lw /= lw.sum(1, keepdims=True)
     assert np.allclose(lw.sum(1), 1.0)
-    p2, r2 = ev.place_chunk(codes, wb, ws, max_span=150)
-    assert np.array_equal(p2, pairs) and np.array_equal(r2["lnl"], res["lnl"])
+    # repeats: every launch of this size moves the XCDs' shares of the pair list toward the speeds the previous one
+    # measured (epa_xcd_feedback) -- which wave places a pair must not show in any bit of the results
+    for _ in range(3):
+        p2, r2 = ev.place_chunk(codes, wb, ws, max_span=150)
+        assert np.array_equal(p2, pairs) and np.array_equal(r2, res)
 
 
 @pytest.mark.parametrize("states", [4, 20])
