@@ -108,17 +108,17 @@ const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_
 
 // The eight XCDs of one device do not run the Newton kernel equally fast (a few per cent, stable from launch to
 // launch, different from box to box): a launch that stamped its XCDs' drain times (ThArgs::xstamp) moves the shares of
-// the next ones half way toward share_x ~ pairs_x / time_x.  Short launches (start-up and the last pairs dominate)
-// and implausible stamps are ignored; a share stays within 0.85 .. 1.15 of an eighth.  EPA_TH_XCD_BALANCE=0: off.
+// the next ones half way toward share_x ~ pairs_x / time_x.  Launches shorter than 1 ms (start-up and the last
+// pairs dominate) and implausible stamps are ignored; a share stays within 0.85 .. 1.15 of an eighth.  EPA_TH_XCD_BALANCE=0: off.
 void epa_xcd_feedback(epa_ctx* ctx, uint64_t n_pairs, const unsigned long long* hst) {
   static const bool off = getenv("EPA_TH_XCD_BALANCE") && atoi(getenv("EPA_TH_XCD_BALANCE")) == 0;
-  if (off || n_pairs < 65536 || hst[7] == 0) return;
+  if (off || hst[7] == 0) return;
   double sp[8], tot = 0.0;
   for (int x = 0; x < 8; ++x) {
     if (hst[8 + x] <= hst[7]) return;
     const double t = (double)(hst[8 + x] - hst[7]);               // 10 ns ticks
     const double share = (double)(ctx->xcd_cum[x + 1] - ctx->xcd_cum[x]) / (double)(1u << 20);
-    if (t < 1e4 || t > 1e9) return;                                // < 0.1 ms or > 10 s: not a launch worth learning from
+    if (t < 1e5 || t > 1e9) return;                                // < 1 ms (start-up and the last pairs dominate) or > 10 s
     sp[x] = share / t;
     tot += sp[x];
   }

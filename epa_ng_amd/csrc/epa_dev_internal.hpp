@@ -198,6 +198,7 @@ struct epa_ctx {
   // fixed point; thorough_dna.hip ThArgs::xcum), adapted to the speeds the XCDs showed: epa_xcd_feedback
   uint32_t xcd_cum[9] = {0u, 1u << 17, 2u << 17, 3u << 17, 4u << 17, 5u << 17, 6u << 17, 7u << 17, 1u << 20};
   double xcd_w[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
+  bool xstamp_ok = false;   // launch_thorough: this call is ONE kernel launch (one span class): its stamps mean something
   hipEvent_t ev_rb[N_BANKS] = {};   // per bank: behind the selection's read-back copy (SelectPending::ev_rb)
   int t_last[3] = {0, 0, 0};
   epa_thorough_stats last_stats{};

@@ -62,6 +62,8 @@ struct ThArgsAM {
   uint64_t n_pairs;
   uint32_t W;
   uint32_t* qctr;          // one work counter per XCD slice of the pair list (resident workgroups), or null
+  uint32_t xcum[9];        // XCD shares of the pair list and the drain stamps behind them: see thorough_dna.hip ThArgs
+  uint32_t xstamp;
 };
 
 // LDS is read with ds_read_b128 wherever two neighbouring doubles go to the same lane: 256 B/clk from
@@ -213,9 +215,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
   // take the pairs of their slice from a counter (requested one pair ahead); without a counter the
   // slice is dealt round-robin to an oversubscribed grid.
   const uint32_t xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
-  const uint64_t per_xcd = (a.n_pairs + 7) / 8;
-  const uint64_t slice_lo = (uint64_t)xcd * per_xcd;
-  const uint64_t slice_hi = slice_lo + per_xcd < a.n_pairs ? slice_lo + per_xcd : a.n_pairs;
+  const uint64_t slice_lo = (a.n_pairs * a.xcum[xcd]) >> 20;
+  const uint64_t slice_hi = (a.n_pairs * a.xcum[xcd + 1]) >> 20;
+  if (a.xstamp && blockIdx.x == 0 && tid == 0) a.stats[7] = __builtin_amdgcn_s_memrealtime();
   const uint32_t slice_n = (uint32_t)(slice_hi > slice_lo ? slice_hi - slice_lo : 0);
   uint32_t* const ctr = a.qctr ? a.qctr + xcd : nullptr;
   uint32_t cur = wg_in_xcd;
@@ -657,6 +659,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
     atomicAdd(&a.stats[0], (unsigned long long)wrounds);
     atomicAdd(&a.stats[1], (unsigned long long)wevals);
     atomicAdd(&a.stats[2], (unsigned long long)wreverts);
+    if (a.xstamp) atomicMax(&a.stats[8 + xcd], (unsigned long long)__builtin_amdgcn_s_memrealtime());
   }
 }
 
@@ -709,6 +712,8 @@ int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_
     nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * wg_per_cu);
   }
   nwg = (nwg + 7) / 8 * 8;
+  for (int i = 0; i < 9; ++i) a.xcum[i] = ctx->xcd_cum[i];
+  a.xstamp = (a.qctr && ctx->xstamp_ok) ? 1u : 0u;
 #define AAM(NT_, NC_, NW_)                                                                                        \
   do {                                                                                                            \
     if (!ctx->blo.sliding) hipLaunchKernelGGL((k_thorough_aa_mfma<NT_, true, NC_, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \

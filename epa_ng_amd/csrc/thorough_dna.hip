@@ -1797,6 +1797,7 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
   epa_timer_start(ctx, epa_t(ctx, epa_ctx::T_THOROUGH));
   int rc = EPA_OK;
   uint64_t off = 0;
+  ctx->xstamp_ok = present == 1;
   // window bound of a class (slab sizing of the 20-state LDS kernel, the long-window kernel)
   static const uint32_t dna_bound[EPA_N_CLS] = {64, 128, 192, 256, 384, 512, 768, 1024, 1536, 0xffffffffu, 96, 160};
   for (int c = 0; c < EPA_N_CLS && rc == EPA_OK; ++c) {
