@@ -525,6 +525,7 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
   if (ctx->lookup) (void)hipFree(ctx->lookup);
   if (ctx->lookup2) (void)hipFree(ctx->lookup2);
   if (ctx->th_ctr) (void)hipFree(ctx->th_ctr);
+  for (hipEvent_t e : ctx->ev_rb) if (e) (void)hipEventDestroy(e);
   if (ctx->refI) (void)hipFree(ctx->refI);
   if (ctx->cinv) (void)hipFree(ctx->cinv);
   if (ctx->resc0) (void)hipFree(ctx->resc0);
