@@ -131,6 +131,8 @@ def dev_lib():
         L.epa_comm_carried_rows.argtypes = [C.c_void_p]
         L.epa_comm_carried_rows.restype = C.c_uint64
         L.epa_dev_mem_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.epa_dev_xcd_shares.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.epa_dev_xcd_shares.restype = C.c_int
         L.epa_dev_last_kernel_ms.restype = C.c_double
         L.epa_dev_last_kernel_ms.argtypes = [C.c_void_p, C.c_char_p]
         _LIB = L
@@ -464,6 +466,12 @@ class Evaluator:
         v = C.c_double(0.0)
         self._check(self.L.epa_dev_tree_logl(self.h, branch, C.byref(v)))
         return v.value
+
+    def xcd_shares(self):
+        """shares of a Newton launch's pair list the eight XCDs currently take (epa_dev_xcd_shares)"""
+        out = (C.c_double * 8)()
+        self._check(self.L.epa_dev_xcd_shares(self.h, out))
+        return np.array(list(out))
 
     def kernel_ms(self, which):
         return self.L.epa_dev_last_kernel_ms(self.h, which.encode())

@@ -1872,6 +1872,12 @@ extern "C" int epa_dev_mem_info(epa_ctx* ctx, uint64_t* free_bytes, uint64_t* to
   return EPA_OK;
 }
 
+extern "C" int epa_dev_xcd_shares(const epa_ctx* ctx, double shares[8]) {
+  if (!ctx || !shares) return EPA_ERR_INVALID_ARG;
+  for (int x = 0; x < 8; ++x) shares[x] = (double)(ctx->xcd_cum[x + 1] - ctx->xcd_cum[x]) / (double)(1u << 20);
+  return EPA_OK;
+}
+
 extern "C" double epa_dev_last_kernel_ms(const epa_ctx* ctx, const char* which) {
   if (!ctx || !which) return -1.0;
   const EvTimer* t = nullptr;

@@ -426,6 +426,12 @@ uint64_t epa_comm_carried_rows(const epa_comm* comm);
  * table live (`--chunk-size` is the user's memory knob, src/main.cpp:234-238). */
 int epa_dev_mem_info(epa_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 
+/* Diagnostics, no reference counterpart: the shares of a Newton launch's (branch-sorted) pair list that the device's
+ * eight XCDs currently take.  0.125 each on a new context; every launch of one span class that ran for >= 1 ms reports
+ * when each XCD ran out of pairs, and the next launches' shares move half way toward share / time (the XCDs of one
+ * MI355X differ in speed by a few per cent: DESIGN.md 4.1).  Results do not depend on the shares. */
+int epa_dev_xcd_shares(const epa_ctx* ctx, double shares[8]);
+
 /* duration in milliseconds of the last launch of the named kernel family on ctx's stream,
  * measured with HIP events ("preplace", "thorough", "lookup", "select"); < 0 if never run. */
 double epa_dev_last_kernel_ms(const epa_ctx* ctx, const char* which);
