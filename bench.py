@@ -403,6 +403,10 @@ def main():
             "ms_per_launch": round(t_th * 1e3, 4),
             "hbm_algorithmic_GBs": round(pairs * bytes_pair / t_th / 1e9, 1),
             "hbm_frac": round(pairs * bytes_pair / t_th / 1e9 / HBM_PEAK_GBS, 4)}
+    try:   # the XCDs' current shares of a Newton launch's pair list (epa_dev_xcd_shares; an eighth each = not adapted)
+        roof["xcd_shares"] = [round(float(x), 4) for x in ev.xcd_shares()]
+    except Exception:  # noqa: BLE001
+        pass
     # preplacement kernel against the HBM roofline, SURVEY 8d's algorithmic bytes for ONE launch:
     # query windows + the Q x B result table + one read of the lookup table
     ncol = 16 if states == 4 else 24
