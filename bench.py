@@ -21,8 +21,10 @@ grows with N.  --scaling strong --reads R: the job is R reads whatever N is, ste
 ceil(R / (chunk x N)) -- BASELINE configs[3] (cfg4) is `--gpus 8 --scaling strong --reads 10000000`.
 Every default run ALSO times that fixed 10^7-read job on its N GPUs (`strong_cfg4` in the line), so
 that the driver's N = 1, 2, 4, 8 lines carry a strong-scaling curve next to the weak one.
-The only exchange is the RCCL gather of the per-pair results to rank 0, overlapped; no per-chunk
-host synchronisation (epa_ng_amd/parallel.py).
+The only exchange is the RCCL gather of the per-pair results to rank 0, overlapped, no per-chunk
+host synchronisation: the PRODUCT's gather (libepa_dev.so epa_comm_*, csrc/comm.hip); torch.distributed
+launches, barriers and broadcasts the 128-byte id (EPA_BENCH_GATHER=torch: the torch harness of the same
+protocol, epa_ng_amd/parallel.py).
 
     python bench.py --gpus 1 --steps 5 --warmup 1
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps 5 --warmup 1
@@ -131,6 +133,8 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the only compute path")
+    if os.environ.get("EPA_BENCH_ONE_GPU") == "1":
+        local = 0     # plumbing runs on a 1-GPU box: every rank on device 0, the gather over tests/fake_rccl.cpp
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -227,7 +231,66 @@ def main():
     # rows per gather: 4 candidates per read on average is ample for the dynamic heuristic at
     # 0.99999 (2.6 measured on cfg2); a chunk beyond it is carried into the next gather
     rows_cap = min(cap, 4 * max(Q, 1))
-    exch = parallel.AsyncResultGather(dist, rows_cap, dev) if world > 1 else None
+    # N > 1: the gather is the PRODUCT's (libepa_dev.so: epa_comm_create / epa_dev_gather_results /
+    # epa_comm_collect / epa_comm_flush, csrc/comm.hip -- RCCL bound by the library itself);
+    # torch.distributed only launches, barriers and broadcasts the 128-byte id.  EPA_BENCH_GATHER=torch
+    # selects the torch.distributed harness of the same protocol (epa_ng_amd/parallel.py) instead.
+    gather_path = os.environ.get("EPA_BENCH_GATHER", "epa_comm") if world > 1 else None
+
+    class ProductGather:
+        """post / finish / carried_rows of parallel.AsyncResultGather, on api.Comm"""
+
+        def __init__(self, host_copy):
+            idt = torch.zeros(128, dtype=torch.uint8, device=cdev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(epa.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            self.depth = 2
+            self.comm = epa.Comm(ev, bytes(idt.cpu().numpy().tobytes()), rank, world, rows_cap, depth=self.depth)
+            self.host_copy, self.posted, self.collected, self.rows_seen = host_copy, 0, 0, 0
+            self.counts = []
+
+        def _collect(self, t):
+            if self.host_copy:
+                got = self.comm.collect(t)                 # VALID rows of every rank -> pinned host memory
+                cnt = [len(g) for g in got]
+            else:
+                cnt = self.comm.collect_counts(t)          # rows stay in HBM (the contract's `value`)
+            self.counts.append(cnt)
+            self.rows_seen += sum(cnt)
+
+        def post(self, pairs, res, n):
+            # global sequence id of this rank's first read of the step (contiguous slices, local_seq_package)
+            off = ((self.posted * world + rank) * a.chunk) & 0x7fffffff
+            t = self.comm.post(pairs, res, n, seq_offset=off)
+            self.posted += 1
+            if rank == 0:                                  # a gather posted `depth - 1` chunks ago has landed
+                for u in range(self.collected, t - (self.depth - 1) + 1):
+                    self._collect(u)
+                self.collected = max(self.collected, t - (self.depth - 1) + 1)
+
+        def finish(self):
+            if rank == 0:
+                for t in range(self.collected, self.posted):
+                    self._collect(t)
+                self.collected = self.posted
+            extra = self.comm.flush(on_ticket=self._collect if rank == 0 else None)
+            self.posted += len(extra)                      # tickets count the flush's extra gathers as well
+            self.collected = self.posted
+            torch.cuda.synchronize()
+
+        @property
+        def carried_rows(self):
+            return self.comm.carried_rows
+
+    def make_gather(host_copy):
+        if world == 1:
+            return None
+        if gather_path == "torch":
+            return parallel.AsyncResultGather(dist, rows_cap, dev, host_copy=host_copy)
+        return ProductGather(host_copy)
+
+    exch = make_gather(False)
 
     # Both loops run the library's two-slot chunk pipeline in the same host order,
     #     launch_begin(i); finish(i-1); stage(i+1); launch_end(i)
@@ -312,7 +375,7 @@ def main():
     elapsed = timed(step_resident, fin_resident, "resident")
 
     # ---------------- loop 2: PCIe inside the step, overlapped on the copy streams
-    exch2 = parallel.AsyncResultGather(dist, rows_cap, dev, host_copy=True) if world > 1 else None
+    exch2 = make_gather(True)
     state, step_pcie, finish_pcie = make_loop(False, exch2)
     elapsed_pcie = timed(step_pcie, finish_pcie, "pcie")
 
@@ -589,9 +652,17 @@ def main():
                                              "select": round(float(np.mean(sel_ms)), 3),
                                              "thorough": round(float(np.mean(th_ms)), 3)}},
            "pcie_inclusive": pcie, "strong_cfg4": strong,
-           "rccl_ranks": world if (world > 1 and dist.get_backend() == "nccl") else 0,
-           # rank 0's view of the result gather: rows per rank and gather, rows that took the carry path (0 expected)
-           "gather": ({"rows_cap": rows_cap, "carried_rows_rank0": int(exch.carried_rows + exch2.carried_rows)}
+           "rccl_ranks": world if (world > 1 and (dist.get_backend() == "nccl" if gather_path == "torch"
+                                                  else not os.environ.get("EPA_RCCL_LIB"))) else 0,
+           # rank 0's view of the result gather: which implementation ran, rows per rank and gather, rows that
+           # took the carry path (0 expected)
+           "gather": ({"path": ("epa_comm: libepa_dev.so epa_dev_gather_results / epa_comm_collect / epa_comm_flush (csrc/comm.hip)"
+                                if gather_path != "torch" else "torch.distributed harness (epa_ng_amd/parallel.py AsyncResultGather)"),
+                       "transport": (("stand-in " + os.path.basename(os.environ["EPA_RCCL_LIB"]) + " (test infrastructure, not a scaling measurement)")
+                                     if (gather_path != "torch" and os.environ.get("EPA_RCCL_LIB")) else
+                                     ("RCCL" if (gather_path != "torch" or dist.get_backend() == "nccl") else dist.get_backend())),
+                       "rows_cap": rows_cap, "carried_rows_rank0": int(exch.carried_rows + exch2.carried_rows),
+                       "rows_collected_rank0": (int(exch.rows_seen + exch2.rows_seen) if gather_path != "torch" else None)}
                       if world > 1 else None),
            "per_rank_ms_per_step": [round(x / a.steps * 1e3, 3) for x in rank_elapsed["resident"]],
            "roofline": roof, "roofline_preplace": roof_pre, "cpu_baseline": cpu, "parity": parity}

@@ -130,6 +130,10 @@ def dev_lib():
         L.epa_comm_flush.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.epa_comm_carried_rows.argtypes = [C.c_void_p]
         L.epa_comm_carried_rows.restype = C.c_uint64
+        L.epa_comm_abort.argtypes = [C.c_void_p]
+        L.epa_comm_abort.restype = None
+        L.epa_comm_device_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+        L.epa_comm_device_rows.restype = C.c_void_p
         L.epa_dev_mem_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.epa_dev_xcd_shares.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.epa_dev_xcd_shares.restype = C.c_int
@@ -517,6 +521,25 @@ class Comm:
         t = C.c_uint64(0)
         self.ev._check(self.L.epa_dev_gather_slot(self.ev.h, self.h, slot, seq_offset, C.byref(t)))
         return t.value
+
+    def abort(self):
+        """a failing rank's way out: ncclCommAbort + release without waiting for the peers"""
+        if getattr(self, "h", None):
+            self.L.epa_comm_abort(self.h)
+            self.h = None
+
+    def collect_counts(self, ticket):
+        """rank 0: waits for gather `ticket`; -> per-rank valid row counts.  The rows stay in HBM
+        (device_rows)."""
+        cnt = (C.c_uint32 * self.world)()
+        pend = (C.c_uint64 * self.world)()
+        self.ev._check(self.L.epa_comm_collect(self.h, ticket, None, cnt, pend))
+        self.last_pending = [int(x) for x in pend]
+        return [int(x) for x in cnt]
+
+    def device_rows(self, ticket, rank):
+        """device address of rank's row block of gather `ticket` on rank 0 (None once the slot is reused)"""
+        return self.L.epa_comm_device_rows(self.h, ticket, rank)
 
     def collect(self, ticket):
         """rank 0: list (one ROW_DTYPE array per rank) of gather `ticket`"""

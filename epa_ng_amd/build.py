@@ -33,7 +33,7 @@ def build_dev(force=False, verbose=False):
     out = os.path.join(HERE, "libepa_dev.so")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "epa_dev_internal.hpp"), os.path.join(CSRC, "wave_util.hpp"),
+    hdrs = [os.path.join(CSRC, "epa_dev_internal.hpp"), os.path.join(CSRC, "wave_util.hpp"), os.path.join(CSRC, "rccl_abi.hpp"),
             os.path.join(ROOT, "include", "epa_dev.h")]
     objs, procs = [], []
     for src in DEV_SOURCES:

@@ -20,11 +20,15 @@
 // that never creates a communicator never loads it.
 #include "epa_dev_internal.hpp"
 
-#include <dlfcn.h>
-#include <rccl/rccl.h>
+#include "rccl_abi.hpp"   // the ten entry points' shapes, declared locally: no RCCL headers needed to build
 
+#include <dlfcn.h>
+
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 static_assert(sizeof(epa_row) == 32, "row layout");
@@ -32,25 +36,14 @@ static_assert(sizeof(ncclUniqueId) == EPA_COMM_ID_BYTES, "unique id size");
 
 namespace {
 
-struct Rccl {
+struct Rccl : epa_rccl_api {
   void* h = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*GroupStart)() = nullptr;
-  ncclResult_t (*GroupEnd)() = nullptr;
-  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string err;
 };
 
-Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return &r;
-  tried = true;
+void load_rccl(Rccl& r) {
+  // EPA_RCCL_LIB names another library with the same ten symbols (tests/fake_rccl.cpp: a same-device
+  // transport stand-in, so that world > 1 runs on a 1-GPU box)
   const char* names[] = {getenv("EPA_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) {
     if (!n || !*n) continue;
@@ -58,13 +51,14 @@ Rccl* rccl() {
     if (r.h) break;
     r.err = dlerror();
   }
-  if (!r.h) return &r;
+  if (!r.h) return;
 #define SYM(field, name)                                              \
   *(void**)(&r.field) = dlsym(r.h, name);                             \
-  if (!r.field) { r.err = std::string("missing symbol ") + name; r.h = nullptr; return &r; }
+  if (!r.field) { r.err = std::string("missing symbol ") + name; r.h = nullptr; return; }
   SYM(GetUniqueId, "ncclGetUniqueId")
   SYM(CommInitRank, "ncclCommInitRank")
   SYM(CommDestroy, "ncclCommDestroy")
+  SYM(CommAbort, "ncclCommAbort")
   SYM(Send, "ncclSend")
   SYM(Recv, "ncclRecv")
   SYM(GroupStart, "ncclGroupStart")
@@ -72,7 +66,37 @@ Rccl* rccl() {
   SYM(AllReduce, "ncclAllReduce")
   SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+}
+
+Rccl* rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] { load_rccl(r); });
   return &r;
+}
+
+// the wait of a collective's host side: an event that a healthy job completes in milliseconds.  A peer
+// that died leaves it pending for ever (the reference's MPI build would abort the job): give up after
+// EPA_COMM_TIMEOUT_S (default 600) so that the caller can epa_comm_abort() and exit non-zero.
+double comm_timeout_s() {
+  const char* e = getenv("EPA_COMM_TIMEOUT_S");
+  const double v = e ? atof(e) : 600.0;
+  return v > 0 ? v : 600.0;
+}
+
+hipError_t wait_event(hipEvent_t ev, bool* timed_out) {
+  *timed_out = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  const double lim = comm_timeout_s();
+  for (unsigned spin = 0;; ++spin) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    if (spin > 4000) std::this_thread::sleep_for(std::chrono::microseconds(spin > 40000 ? 200 : 20));
+    if ((spin & 255) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > lim) {
+      *timed_out = true;
+      return hipSuccess;
+    }
+  }
 }
 
 // rows [0, n) of dst <- (pairs, results)[src_off + i], sequence ids made global
@@ -281,14 +305,22 @@ extern "C" int epa_dev_gather_results(epa_ctx* ctx, epa_comm* c, const epa_pair*
   const size_t msg = sizeof(epa_row) * ((size_t)cap + 1);
   if (c->world > 1 || c->self_send) {
     EPA_NCCL(ctx, R->GroupStart());
+    // a failure inside the group still closes it: an open group would swallow every later call of the thread
+    ncclResult_t gr = ncclSuccess;
+    const char* what = "";
     if (c->rank == 0) {
-      for (int r = c->self_send ? 0 : 1; r < c->world; ++r)
-        EPA_NCCL(ctx, R->Recv((char*)g.recv + msg * r, msg, ncclChar, r, c->comm, cs));
-      if (c->self_send) EPA_NCCL(ctx, R->Send(g.send, msg, ncclChar, 0, c->comm, cs));
+      for (int r = c->self_send ? 0 : 1; r < c->world && gr == ncclSuccess; ++r) {
+        gr = R->Recv((char*)g.recv + msg * r, msg, ncclChar, r, c->comm, cs);
+        what = "ncclRecv";
+      }
+      if (c->self_send && gr == ncclSuccess) { gr = R->Send(g.send, msg, ncclChar, 0, c->comm, cs); what = "ncclSend"; }
     } else {
-      EPA_NCCL(ctx, R->Send(g.send, msg, ncclChar, 0, c->comm, cs));
+      gr = R->Send(g.send, msg, ncclChar, 0, c->comm, cs);
+      what = "ncclSend";
     }
-    EPA_NCCL(ctx, R->GroupEnd());
+    const ncclResult_t ge = R->GroupEnd();
+    if (gr != ncclSuccess) return epa_fail(ctx, EPA_ERR_HIP, std::string(what) + ": " + R->GetErrorString(gr));
+    if (ge != ncclSuccess) return epa_fail(ctx, EPA_ERR_HIP, std::string("ncclGroupEnd: ") + R->GetErrorString(ge));
   }
   if (c->rank == 0)   // the sentinel rows (valid counts) to pinned memory: what collect() reads first
     EPA_HIP(ctx, hipMemcpy2DAsync(g.h_cnt, sizeof(epa_row), g.recv + cap, msg, sizeof(epa_row), c->world,
@@ -315,7 +347,9 @@ extern "C" int epa_comm_collect(epa_comm* c, uint64_t ticket, const epa_row** ro
   epa_comm::GSlot& g = c->gs[ticket % c->depth];
   if (g.ticket != ticket) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "comm_collect: the gather's slot has been reused (collect within `depth` posts)");
   EPA_HIP(ctx, hipSetDevice(ctx->device));
-  EPA_HIP(ctx, hipEventSynchronize(g.ev_gather));
+  bool late = false;
+  EPA_HIP(ctx, wait_event(g.ev_gather, &late));
+  if (late) return epa_fail(ctx, EPA_ERR_HIP, "comm_collect: gather " + std::to_string(ticket) + " did not complete within EPA_COMM_TIMEOUT_S (a peer failed?): epa_comm_abort and exit");
   const size_t msg_rows = (size_t)c->cap + 1;
   for (int r = 0; r < c->world; ++r) {
     const epa_row& s = g.h_cnt[r];
@@ -323,12 +357,16 @@ extern "C" int epa_comm_collect(epa_comm* c, uint64_t ticket, const epa_row** ro
       return epa_fail(ctx, EPA_ERR_HIP, "comm_collect: rank " + std::to_string(r) + " sent no sentinel row");
     g.counts[r] = s.branch_id;
     g.ptrs[r] = g.h_rows + (size_t)r * c->cap;
-    if (s.branch_id)
+    // rows == NULL: the caller only wants the counts; the rows stay in HBM (epa_comm_device_rows)
+    if (s.branch_id && rows)
       EPA_HIP(ctx, hipMemcpyAsync(g.h_rows + (size_t)r * c->cap, g.recv + msg_rows * r, sizeof(epa_row) * s.branch_id,
                                   hipMemcpyDeviceToHost, c->cs));
   }
-  EPA_HIP(ctx, hipEventRecord(g.ev_host, c->cs));
-  EPA_HIP(ctx, hipEventSynchronize(g.ev_host));
+  if (rows) {
+    EPA_HIP(ctx, hipEventRecord(g.ev_host, c->cs));
+    EPA_HIP(ctx, wait_event(g.ev_host, &late));
+    if (late) return epa_fail(ctx, EPA_ERR_HIP, "comm_collect: the copy of the rows to the host did not complete");
+  }
   for (int r = 0; r < c->world; ++r) {
     if (rows) rows[r] = g.ptrs[r];
     if (counts) counts[r] = g.counts[r];
@@ -348,7 +386,10 @@ extern "C" int epa_comm_flush(epa_ctx* ctx, epa_comm* c, uint64_t* first_extra_t
   else
     EPA_HIP(ctx, hipMemcpyAsync(c->d_pend + 1, c->d_pend, 8, hipMemcpyDeviceToDevice, c->cs));
   EPA_HIP(ctx, hipMemcpyAsync(c->h_pend + 1, c->d_pend + 1, 8, hipMemcpyDeviceToHost, c->cs));
-  EPA_HIP(ctx, hipStreamSynchronize(c->cs));
+  EPA_HIP(ctx, hipEventRecord(c->ev_src, c->cs));
+  bool late = false;
+  EPA_HIP(ctx, wait_event(c->ev_src, &late));
+  if (late) return epa_fail(ctx, EPA_ERR_HIP, "comm_flush: the all-reduce did not complete within EPA_COMM_TIMEOUT_S (a peer failed?): epa_comm_abort and exit");
   const uint64_t pend = c->h_pend[1];
   // every rank computed the same maximum (the all-reduce), so every rank posts the same number of rounds;
   // at most `depth` per call: rank 0 collects them before their slots are posted again
@@ -364,3 +405,22 @@ extern "C" int epa_comm_flush(epa_ctx* ctx, epa_comm* c, uint64_t* first_extra_t
 }
 
 extern "C" uint64_t epa_comm_carried_rows(const epa_comm* c) { return c ? c->carried_rows : 0; }
+
+extern "C" const epa_row* epa_comm_device_rows(const epa_comm* c, uint64_t ticket, int rank) {
+  if (!c || c->rank != 0 || rank < 0 || rank >= c->world) return nullptr;
+  const epa_comm::GSlot& g = c->gs[ticket % c->depth];
+  if (g.ticket != ticket) return nullptr;
+  return g.recv + ((size_t)c->cap + 1) * rank;
+}
+
+extern "C" void epa_comm_abort(epa_comm* c) {
+  // the failing rank's way out (the reference's MPI build would MPI_Abort): tears the communicator down
+  // without waiting for the peers, which then see errors / timeouts instead of waiting for ever
+  if (!c) return;
+  if (c->comm) {
+    Rccl* R = rccl();
+    if (R->CommAbort) (void)R->CommAbort(c->comm);
+    c->comm = nullptr;
+  }
+  epa_comm_destroy(c);
+}

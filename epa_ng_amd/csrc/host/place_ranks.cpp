@@ -15,6 +15,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
+#include <cstring>
+#include <exception>
 #include <fstream>
 #include <thread>
 #include <unordered_map>
@@ -34,26 +36,66 @@ std::pair<size_t, size_t> local_seq_package(size_t num_sequences, int rank, int 
   return {offset, std::min(part, num_sequences - offset)};
 }
 
-static void exchange_id(const std::string& path, int rank, unsigned char (&id)[EPA_COMM_ID_BYTES]) {
+// The 128-byte RCCL id travels through a file.  A file left behind by an earlier run (a crashed one: a
+// healthy rank 0 removes it once the communicator exists) must never be taken for this run's: the record
+// carries a nonce (--comm-nonce / EPA_COMM_NONCE / torchrun's TORCHELASTIC_RUN_ID, hashed) and rank 0's
+// wall-clock time of writing; a reader accepts a record only with its own nonce and, when no nonce was
+// given, only one written no earlier than a minute before the reader itself started.
+namespace {
+struct Id_Record {
+  char magic[8];
+  uint64_t nonce;
+  int64_t written_unix_ms;
+  unsigned char id[EPA_COMM_ID_BYTES];
+};
+
+uint64_t comm_nonce() {
+  const char* e = std::getenv("EPA_COMM_NONCE");
+  if (!e || !*e) e = std::getenv("TORCHELASTIC_RUN_ID");
+  if (!e || !*e) return 0;
+  uint64_t h = 1469598103934665603ull;   // FNV-1a
+  for (; *e; ++e) h = (h ^ (unsigned char)*e) * 1099511628211ull;
+  return h ? h : 1;
+}
+
+int64_t unix_ms() {
+  return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+static void publish_id(const std::string& path, unsigned char (&id)[EPA_COMM_ID_BYTES]) {
   if (path.empty()) throw std::runtime_error{"--world > 1 needs --comm-file (or EPA_COMM_FILE): where rank 0 leaves the RCCL id"};
-  if (rank == 0) {
-    if (epa_comm_get_unique_id(id) != EPA_OK) throw std::runtime_error{epa_dev_last_error(nullptr)};
-    const std::string tmp = path + ".tmp";
-    std::FILE* f = std::fopen(tmp.c_str(), "wb");
-    if (!f || std::fwrite(id, 1, sizeof(id), f) != sizeof(id)) throw std::runtime_error{"cannot write " + tmp};
-    std::fclose(f);
-    if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error{"cannot rename " + tmp};
-    return;
-  }
+  std::remove(path.c_str());   // whatever an earlier run left there
+  if (epa_comm_get_unique_id(id) != EPA_OK) throw std::runtime_error{epa_dev_last_error(nullptr)};
+  Id_Record rec{};
+  std::memcpy(rec.magic, "EPACOMM1", 8);
+  rec.nonce = comm_nonce();
+  rec.written_unix_ms = unix_ms();
+  std::memcpy(rec.id, id, sizeof(id));
+  const std::string tmp = path + ".tmp";
+  std::FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f || std::fwrite(&rec, 1, sizeof(rec), f) != sizeof(rec)) throw std::runtime_error{"cannot write " + tmp};
+  std::fclose(f);
+  if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error{"cannot rename " + tmp};
+}
+
+static void await_id(const std::string& path, int rank, int64_t started_unix_ms, unsigned char (&id)[EPA_COMM_ID_BYTES]) {
+  if (path.empty()) throw std::runtime_error{"--world > 1 needs --comm-file (or EPA_COMM_FILE): where rank 0 leaves the RCCL id"};
+  const uint64_t nonce = comm_nonce();
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
     if (std::FILE* f = std::fopen(path.c_str(), "rb")) {
-      const size_t n = std::fread(id, 1, sizeof(id), f);
+      Id_Record rec{};
+      const size_t n = std::fread(&rec, 1, sizeof(rec), f);
       std::fclose(f);
-      if (n == sizeof(id)) return;
+      if (n == sizeof(rec) && std::memcmp(rec.magic, "EPACOMM1", 8) == 0 && rec.nonce == nonce &&
+          (nonce != 0 || rec.written_unix_ms >= started_unix_ms - 60000)) {
+        std::memcpy(id, rec.id, sizeof(id));
+        return;
+      }
     }
     if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300))
-      throw std::runtime_error{"rank " + std::to_string(rank) + ": no RCCL id in " + path + " after 300 s"};
+      throw std::runtime_error{"rank " + std::to_string(rank) + ": no RCCL id of this run in " + path + " after 300 s"};
     std::this_thread::sleep_for(std::chrono::milliseconds(20));
   }
 }
@@ -63,6 +105,11 @@ Run_Stats simple_mpi_ranks(const Tree& tree, const std::string& query_file, cons
                            int device, int rank, int world, const std::string& comm_file) {
   using clk = std::chrono::steady_clock;
   if (!options.prescoring) throw std::runtime_error{"--no-heur is not available in the one-process-per-GPU mode"};
+  const int64_t started = unix_ms();
+  unsigned char id[EPA_COMM_ID_BYTES] = {};
+  // rank 0 replaces the id file before anything slow (the reference precompute, the scan of the query
+  // file): the other ranks, which only look for it after their own setup, never meet an older run's
+  if (rank == 0) publish_id(comm_file, id);
   const bool premask = options.premasking && msa_info.gap_count() > 0;
   Run_Stats st;
   configure_host_threads();
@@ -94,12 +141,18 @@ Run_Stats simple_mpi_ranks(const Tree& tree, const std::string& query_file, cons
   // the carry path takes over (EPA_COMM_ROWS_PER_READ overrides)
   size_t rows_per_read = 8;
   if (const char* e = std::getenv("EPA_COMM_ROWS_PER_READ")) rows_per_read = (size_t)std::max(1, std::atoi(e));
-  unsigned char id[EPA_COMM_ID_BYTES] = {};
-  exchange_id(comm_file, rank, id);
+  if (rank != 0) await_id(comm_file, rank, started, id);
   epa_comm* comm = nullptr;
   int rc = epa_comm_create(dev.ctx(), id, rank, world, (uint32_t)std::min<size_t>(per_chunk * rows_per_read, 0x7fffffffu), 2, &comm);
+  if (rank == 0) std::remove(comm_file.c_str());   // collective: every rank has read it by now
   if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
-  struct Guard { epa_comm* c; ~Guard() { epa_comm_destroy(c); } } guard{comm};
+  // a rank that fails from here on aborts the communicator instead of leaving its peers blocked in a
+  // send / receive for ever (they fail or time out, EPA_COMM_TIMEOUT_S); the reference's MPI build aborts the job
+  struct Guard {
+    epa_comm* c;
+    int live = std::uncaught_exceptions();
+    ~Guard() { if (std::uncaught_exceptions() > live) epa_comm_abort(c); else epa_comm_destroy(c); }
+  } guard{comm};
   st.seconds_setup = std::chrono::duration<double>(clk::now() - ts).count();
 
   std::ofstream os;

@@ -393,7 +393,7 @@ int epa_dev_place_all(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_
  *                           the communicator's own stream.  Never blocks the host; rows beyond rows_cap
  *                           are carried into the rank's next gather.  *ticket names the gather.
  *   epa_dev_gather_slot     the same for a chunk slot launched with EPA_CHUNK_NO_D2H (after launch_end)
- *   epa_comm_collect        rank 0: waits for gather `ticket`, copies its VALID rows to pinned host
+ *   epa_comm_collect        rank 0: waits for gather `ticket` (at most EPA_COMM_TIMEOUT_S), copies its VALID rows to pinned host
  *                           memory and hands out one row block and count per rank; the blocks stay
  *                           valid until gather ticket + depth is posted.  pending[r] (optional): rows rank
  *                           r still carried after this gather -- 0 means every row it has posted so far
@@ -418,8 +418,15 @@ int epa_dev_gather_results(epa_ctx* ctx, epa_comm* comm, const epa_pair* d_pairs
                            uint64_t n, uint32_t seq_offset, uint64_t* ticket);
 int epa_dev_gather_slot(epa_ctx* ctx, epa_comm* comm, int slot, uint32_t seq_offset, uint64_t* ticket);
 int epa_comm_collect(epa_comm* comm, uint64_t ticket, const epa_row** rows, uint32_t* counts, uint64_t* pending);
+/* rows == NULL in epa_comm_collect: counts / pending only, the rows stay in HBM; this is rank r's block
+ * of gather `ticket` there (valid until gather ticket + depth is posted; NULL if the slot was reused) */
+const epa_row* epa_comm_device_rows(const epa_comm* comm, uint64_t ticket, int rank);
 int epa_comm_flush(epa_ctx* ctx, epa_comm* comm, uint64_t* first_extra_ticket, uint32_t* n_extra);
 uint64_t epa_comm_carried_rows(const epa_comm* comm);
+/* a rank that fails mid-job: ncclCommAbort + release, without waiting for the peers (their pending
+ * collect / flush calls then fail or time out after EPA_COMM_TIMEOUT_S seconds, default 600, instead of
+ * blocking for ever; the reference's MPI build aborts the whole job, src/main.cpp's MPI_Abort path) */
+void epa_comm_abort(epa_comm* comm);
 
 /* free / total bytes of the context's device (hipMemGetInfo): the chunk loop sizes its device chunks
  * against it -- a chunk of Q queries keeps 2 pipeline slots x Q x pitch(B) x 8 bytes of preplacement

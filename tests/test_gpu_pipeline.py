@@ -1244,12 +1244,14 @@ def test_cli_named_models_rate_scalers_raxml_blo(tmp_path, states, model, flags,
     assert np.max(np.abs(res["lnl"] - tl)) < 1e-6
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_two_ranks_on_one_gpu(scaling):
-    """bench.py's N > 1 branch end to end on the 1-GPU box: two ranks (both on device 0, gloo for the
-    collectives; RCCL needs one GPU per rank), query sharding with local_seq_package, both timed
-    loops incl. the asynchronous result gather to rank 0, MAX-over-ranks timing, one JSON line from
-    rank 0 whose aggregate value counts the reads of both ranks."""
+@pytest.mark.parametrize("scaling,gather", [("weak", "epa_comm"), ("strong", "epa_comm"), ("weak", "torch")])
+def test_bench_two_ranks_on_one_gpu(scaling, gather):
+    """bench.py's N > 1 branch end to end on the 1-GPU box: two ranks, both on device 0 (RCCL needs one
+    GPU per rank, so gloo carries the launcher's barrier / id broadcast), query sharding with
+    local_seq_package, both timed loops incl. the asynchronous result gather to rank 0, MAX-over-ranks
+    timing, one JSON line from rank 0 whose aggregate value counts the reads of both ranks.  gather =
+    "epa_comm": the default, the PRODUCT's gather (libepa_dev.so epa_comm_*, comm.hip) over the transport
+    stand-in tests/fake_rccl.cpp; "torch": the torch.distributed harness of the same protocol."""
     import socket
     import subprocess
     import sys
@@ -1258,7 +1260,10 @@ def test_bench_two_ranks_on_one_gpu(scaling):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, EPA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-               WORLD_SIZE="2", LOCAL_RANK="0")
+               WORLD_SIZE="2", LOCAL_RANK="0", EPA_BENCH_GATHER=gather)
+    if gather == "epa_comm":
+        import fake_rccl_util
+        env = fake_rccl_util.env(env)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--chunk", "6000", "--tips", "64", "--width", "600", "--scaling", scaling, "--no-cpu-baseline"]
     # strong: a fixed job of 36 000 reads = 3 steps of 2 x 6000; weak: the 3 steps asked for, plus the
@@ -1283,6 +1288,12 @@ def test_bench_two_ranks_on_one_gpu(scaling):
     assert len(line["per_rank_ms_per_step"]) == 2 and line["rccl_ranks"] == 0   # gloo here
     assert abs(line["value"] - 3 * per_step / (line["ms_per_step"] * 3e-3)) < 1e-3 * line["value"]
     assert line["pcie_inclusive"]["value"] > 0 and line["roofline"]["frac"] > 0
+    g = line["gather"]
+    if gather == "epa_comm":
+        assert g["path"].startswith("epa_comm") and "stand-in" in g["transport"]
+        assert g["rows_collected_rank0"] > 2 * 6000      # both loops' rows of both ranks reached rank 0
+    else:
+        assert g["path"].startswith("torch.distributed")
 
 
 NCCL_WORKER = r"""
@@ -1371,5 +1382,6 @@ def test_bench_over_rccl_on_all_visible_gpus():
                        "--no-cpu-baseline"], n, timeout=900)
     line = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == n and line["rccl_ranks"] == n
+    assert line["gather"]["path"].startswith("epa_comm") and line["gather"]["transport"] == "RCCL"
     assert line["config"]["reads_per_step_whole_job"] == 20000 * n
     assert line["strong_cfg4"]["steps_per_rank"] == 4 and line["strong_cfg4"]["value"] > 0

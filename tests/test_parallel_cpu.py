@@ -139,3 +139,17 @@ def test_two_rank_gloo_gather(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0] and "ASYNC_OK" in outs[0] and "CARRY_OK" in outs[0]
+
+
+def test_transport_standin_builds_and_exports_what_the_product_binds():
+    """tests/fake_rccl.cpp (test infrastructure for the N > 1 protocol tests on a 1-GPU box) exports exactly the
+    ten entry points csrc/comm.hip resolves with dlsym"""
+    import re
+    import subprocess
+    import fake_rccl_util
+    so = fake_rccl_util.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    have = set(re.findall(r" T (nccl\w+)", out))
+    assert have == set(fake_rccl_util.SYMBOLS)
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "epa_ng_amd", "csrc", "comm.hip")).read()
+    assert set(re.findall(r'SYM\(\w+, "(nccl\w+)"\)', src)) == have
