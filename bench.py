@@ -72,7 +72,7 @@ def parse():
                    help="with --no-cpu-baseline: still check this many reads of step 0 against the oracle (untimed)")
     p.add_argument("--no-extras", action="store_true",
                    help="skip the secondary measurements (chunk-5000 rate, reference-binary hook)")
-    p.add_argument("--workload", choices=["dna", "aa"], default="dna",
+    p.add_argument("--workload", choices=["dna", "aa", "cfg5"], default="dna",
                    help="dna = cfg2 (the metric's config); aa = cfg3 shape (use --tips 2000 --width 500 "
                         "--read-len 100), a parity/measurement case, not the headline")
     return p.parse_args()
@@ -119,8 +119,101 @@ def reference_binary_check(newick, labels, seqs, sample_codes, wb, ws, W, states
         return {"status": "hook error: %r" % (e,)}
 
 
+def sclk_fields(clks, exec_tflops):
+    """the shader clock the timed Newton launches really ran at (in-kernel s_memtime over s_memrealtime of a
+    wave that lives as long as the launch: epa_dev_last_sclk_mhz) and the kernel's fp64 rate against the
+    peak AT THAT CLOCK: 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x sclk"""
+    clks = [c for c in clks if c > 0]
+    if not clks:
+        return {"sclk_mhz": None, "frac_at_measured_clock": None}
+    mhz = float(np.mean(clks))
+    peak = 256 * 4 * 16 * 2 * mhz * 1e6 / 1e12
+    return {"sclk_mhz": round(mhz, 1), "peak_at_measured_clock": round(peak, 2),
+            "frac_at_measured_clock": round(exec_tflops / peak, 4),
+            "sclk_note": "spec peak assumes 2400 MHz; sclk_mhz = shader cycles / wall time of the launch's first wave "
+                         "(profiles/r5_fma_clock.txt: the clock and cycles per FMA of a bare v_fma_f64 stream)"}
+
+
+def cfg5_leg(a):
+    """BASELINE configs[4] shape on ONE GPU, the `prescoring == false` branch of the chunk body
+    (src/core/place.cpp:219-231: Work = all B x Q pairs, every one gets the Newton-Raphson BLO): 4000-tip
+    DNA reference (B = 7997, per-rate scalers as the reference turns on above 2000 tips,
+    src/io/file_io.cpp:211-214), `--chunk` reads x 7997 branches through epa_dev_place_all (thorough on every
+    pair, LWR over all branches + filter on the device).  Prints one JSON object: pairs/s, the Newton
+    kernel's roofline, and a 6-read parity sample against the oracle (47 982 pairs)."""
+    import epa_ng_amd as epa
+    from epa_ng_amd import hostlib, synth
+    root = synth.random_tree(4000, 21)
+    rates = synth.gamma_rates(synth.CFG2_ALPHA)
+    labels, seqs = synth.simulate_msa(root, a.width, synth.CFG2_SUBST, synth.CFG2_FREQS, rates, 22)
+    newick = synth.newick(root)
+    ref = hostlib.Reference(newick, labels, seqs, states=4, subst=synth.CFG2_SUBST, freqs=synth.CFG2_FREQS, rates=rates)
+    ev = ref.evaluator(device=0, rate_scalers=True)
+    B, Q, nq = ref.B, a.chunk, a.read_len
+    codes, wb, ws = synth.make_reads_compact(seqs, Q, nq, 0.03, 23, 4)
+    wire = epa.pack_codes_4bit(codes)
+    times, th, stats = [], [], None
+    for i in range(a.warmup + a.steps):
+        t0 = time.perf_counter()
+        got = ev.place_all(wire, wb, ws, Q=Q, min_lwr=0.01, filter_min=1, filter_max=7, max_span=nq)
+        if i >= a.warmup:
+            times.append(time.perf_counter() - t0)
+            th.append(ev.kernel_ms("thorough"))
+            stats = dict(ev.last_stats)
+    pairs = float(stats["pairs"])
+    R = stats["rounds"] / pairs
+    kbar = stats["newton_evals"] / max(1.0, 2.0 * stats["rounds"])
+    flops_pair = nq * (884.0 + R * (1258.0 + 240.0 * kbar))          # SURVEY 8d
+    flops_exec = nq * (452.0 + R * (1258.0 + 240.0 * kbar))          # the initial inner CLV comes from the lookup precompute
+    t_th = float(np.mean(th)) * 1e-3
+    t_all = float(np.mean(times))
+    out = {"workload": "cfg5 shape: 4000-tip DNA GTR+G4 ref (B=%d, per-rate scalers), W=%d, %d x %d bp reads, --no-heur: "
+                       "all B x Q pairs through epa_dev_place_all (NR BLO on every pair, LWR + filter on device)" % (B, a.width, Q, nq),
+           "value": round(pairs / t_all, 1), "unit": "pairs/s", "reads_per_s": round(Q / t_all, 2),
+           "pairs_per_call": int(pairs), "ms_per_call": round(t_all * 1e3, 3), "calls_timed": a.steps,
+           "kept_per_query": round(float(np.mean([len(g[0]) for g in got])), 3),
+           "roofline": {"bound": "fp64-valu", "kernel": "k_thorough_dna", "achieved": round(pairs * flops_exec / t_th / 1e12, 3),
+                        "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(pairs * flops_exec / t_th / 1e12 / FP64_PEAK_TFLOPS, 4),
+                        "achieved_algorithmic": round(pairs * flops_pair / t_th / 1e12, 3),
+                        "frac_algorithmic": round(pairs * flops_pair / t_th / 1e12 / FP64_PEAK_TFLOPS, 4),
+                        "ms_per_launch": round(t_th * 1e3, 3), "pairs_per_launch": int(pairs),
+                        **sclk_fields([ev.sclk_mhz()], pairs * flops_exec / t_th / 1e12),
+                        "rounds_per_pair": round(R, 3), "newton_iters_per_solve": round(kbar, 3),
+                        "traffic": None, "traffic_source": "no PMC pass of this leg"},
+           "eight_gpu_projection": "cfg5 = 10^6 reads over 8 GPUs = 125 000 reads = %.3g pairs per GPU: %.1f s at this rate"
+                                   % (125000.0 * B, 125000.0 * B / (pairs / t_all))}
+    if a.parity_sample > 0:
+        import oracle_lib
+        from oracle_lib import Oracle
+        hostlib.configure_threads()
+        ns = min(a.parity_sample, Q)
+        sample = synth.compact_to_ascii(codes[:ns], wb[:ns], ws[:ns], a.width, 4)
+        o = Oracle(newick, labels, seqs, 4, synth.CFG2_SUBST, synth.CFG2_FREQS, rates, rate_scalers=True)
+        pb = np.repeat(np.arange(B), ns)
+        ps = np.tile(np.arange(ns), B)
+        al, ap, ad = o.thorough(pb, ps, sample)
+        al = al.reshape(B, ns)
+        dl, edges_same = 0.0, 0
+        c6 = np.ascontiguousarray(codes[:ns])
+        got6 = ev.place_all(epa.pack_codes_4bit(c6), wb[:ns].copy(), ws[:ns].copy(), Q=ns, min_lwr=0.01, filter_min=1,
+                            filter_max=7, max_span=nq)
+        rounds_equal = bool(ev.last_stats["rounds"] == o.last_stats["rounds"])
+        for q in range(ns):
+            bid, l = got6[q][0], got6[q][1]
+            assert np.array_equal(bid, got[q][0]) and np.array_equal(l, got[q][1])   # a read's result does not depend on the call's size
+            dl = max(dl, float(np.max(np.abs(l - al[bid, q]))))
+            order = np.lexsort((np.arange(B), -al[:, q]))[:len(bid)]
+            edges_same += int(np.array_equal(np.sort(order), np.sort(bid)))
+        out["parity"] = {"reads_checked": ns, "pairs_checked": int(ns * B),
+                         "kept_placements_max_abs_dlnl": dl, "kept_edge_sets_equal": "%d / %d" % (edges_same, ns),
+                         "optimiser_rounds_equal_oracle": rounds_equal}
+    print(json.dumps(out))
+
+
 def main():
     a = parse()
+    if a.workload == "cfg5":
+        return cfg5_leg(a)
     import torch
     import epa_ng_amd as epa
     from epa_ng_amd import hostlib, parallel, synth
@@ -191,7 +284,7 @@ def main():
     d_pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
     d_res = torch.zeros((cap, 3), dtype=torch.float64, device=dev)
 
-    th_ms, th_pairs, th_rounds, th_evals, pre_ms, sel_ms = [], [], [], [], [], []
+    th_ms, th_pairs, th_rounds, th_evals, pre_ms, sel_ms, th_clk = [], [], [], [], [], [], []
 
     rank_elapsed = {}
 
@@ -303,7 +396,7 @@ def main():
     bufs = [(d_pairs, d_res), (torch.empty_like(d_pairs), torch.empty_like(d_res))]
 
     def make_loop(resident, gather):
-        st = {"staged": None, "inflight": None, "rec": False, "bytes_up": 0, "bytes_down": 0,
+        st = {"staged": None, "inflight": None, "rec": False, "bytes_up": 0, "bytes_down": 0, "n_of_slot": {},
               "t_stage": 0.0, "t_launch": 0.0, "t_end": 0.0, "t_finish": 0.0, "timed": False}
 
         def stage(i):
@@ -331,9 +424,10 @@ def main():
                 p, r = ev.chunk_finish(slot, copy=False)        # views of the slot's pinned host buffer
                 n = len(p)
             st["t_finish"] += (time.perf_counter() - t) if st["timed"] else 0.0
+            st["n_of_slot"][slot] = n
             st["bytes_down"] += n * 32
             if st["rec"]:                                        # the retired chunk's Newton kernel
-                th_ms.append(ev.kernel_ms("thorough")); th_pairs.append(n)
+                th_ms.append(ev.kernel_ms("thorough")); th_pairs.append(n); th_clk.append(ev.sclk_mhz())
                 th_rounds.append(ev.last_stats["rounds"]); th_evals.append(ev.last_stats["newton_evals"])
             st["inflight"] = None
 
@@ -371,8 +465,15 @@ def main():
 
         return st, step, finish
 
-    _, step_resident, fin_resident = make_loop(True, exch)
+    st_res, step_resident, fin_resident = make_loop(True, exch)
     elapsed = timed(step_resident, fin_resident, "resident")
+    # what the LAST TIMED step left in HBM (outside the clock): the rows the `parity` block checks
+    last_i = a.warmup + a.steps - 1
+    last_out = None
+    if rank == 0 and world == 1 and Q:
+        n_last = st_res["n_of_slot"].get(last_i & 1, 0)
+        last_out = (last_i % n_chunks, bufs[last_i & 1][0][:n_last].cpu().numpy().copy(),
+                    bufs[last_i & 1][1][:n_last].cpu().numpy().copy())
 
     # ---------------- loop 2: PCIe inside the step, overlapped on the copy streams
     exch2 = make_gather(True)
@@ -441,7 +542,7 @@ def main():
             if tj["reads_per_step"] == Q and abs(tj["pairs_per_launch"] - pairs) < 0.02 * pairs:
                 # FETCH_SIZE x its calibrated correction (2.0 on gfx950, profiles/r2_traffic_calibration.txt)
                 traffic = (tall.get("fetch_correction", 1.0) * tj["fetch_kb"] + tj["write_kb"]) * 1024.0
-                traffic_pre = tall.get("k_preplace_pairs")
+                traffic_pre = tall.get("k_preplace_pairs" if states == 4 else "k_preplace_sites")
                 if traffic_pre:
                     traffic_pre = (tall.get("fetch_correction", 1.0) * traffic_pre["fetch_kb"] + traffic_pre["write_kb"]) * 1024.0
                 traffic_note = "profiles/" + tf
@@ -460,6 +561,7 @@ def main():
                            "guide lists no fp64 row); measured ceiling of a dependency-free v_fma_f64 "
                            "stream on this chip: %.1f TFLOP/s (profiles/r1_mfma_overlap.txt)" % FP64_MEASURED_CEILING,
             "frac_of_measured_fma_ceiling": round(exec_tflops / FP64_MEASURED_CEILING, 4),
+            **sclk_fields(th_clk, exec_tflops),
             "achieved_algorithmic": round(alg_tflops, 3), "frac_algorithmic": round(alg_tflops / FP64_PEAK_TFLOPS, 4),
             "pairs_per_launch": pairs, "rounds_per_pair": round(R, 3), "newton_iters_per_solve": round(kbar, 3),
             "flops_per_pair": round(flops_pair), "flops_executed_per_pair": round(flops_exec),
@@ -496,12 +598,21 @@ def main():
         import oracle_lib
         from oracle_lib import Oracle
         ns = min(a.parity_sample if a.no_cpu_baseline else a.cpu_sample, Q)
-        hc, hb, hs, _ = host_chunks[a.warmup % n_chunks]
+        # the sample = the first ns reads of the chunk the LAST TIMED step placed; the (pair, result) rows
+        # checked against the oracle are the ones that step left in its output buffers
+        hc, hb, hs, _ = host_chunks[last_out[0]]
         sample = synth.compact_to_ascii(hc[:ns], hb[:ns], hs[:ns], W, states)
         codes, wb, ws = epa.encode_queries(states, sample)
-        lnl_gpu = ev.preplace(codes, wb, ws)
-        prs = ev.select(lnl_gpu, ns, 0.99999)
-        res_gpu = ev.thorough(prs, codes, wb, ws)
+        lnl_gpu = ev.preplace(codes, wb, ws)              # the Q x B table is internal to the chunk body: recomputed
+        prs_sep = ev.select(lnl_gpu, ns, 0.99999)
+        keep = last_out[1][:, 1] < ns                     # rows of the sample's reads, branch-major order kept
+        prs = np.zeros(int(keep.sum()), epa.PAIR_DTYPE)
+        prs["branch_id"], prs["seq_id"] = last_out[1][keep, 0], last_out[1][keep, 1]
+        res_gpu = np.zeros(len(prs), epa.RESULT_DTYPE)
+        for j, k_ in enumerate(("lnl", "pendant_length", "distal_length")):
+            res_gpu[k_] = last_out[2][keep, j]
+        same_candidates = bool(len(prs) == len(prs_sep) and np.array_equal(prs["branch_id"], prs_sep["branch_id"])
+                               and np.array_equal(prs["seq_id"], prs_sep["seq_id"]))
         # timed leg: the oracle's source built with full optimisation for THIS host CPU
         # (oracle_lib.FAST_CFLAGS); parity leg: the strict build (-O2, no FMA contraction), untimed
         if not a.no_cpu_baseline:
@@ -539,6 +650,8 @@ def main():
                   "thorough_max_abs_dlnl": float(np.max(np.abs(res_gpu["lnl"] - tl))),
                   "evaluator_max_abs_dlnl_at_device_lengths": float(np.max(np.abs(res_gpu["lnl"] - sc_at))),
                   "pairs_checked": int(len(prs)), "reads_checked": int(ns),
+                  "rows_checked": "pairs / results the last timed step (chunk %d) left in its HBM output buffers" % last_out[0],
+                  "timed_step_candidates_equal_separate_select_call": same_candidates,
                   "flat_pairs": rep["flat_pairs"], "flat_reproduced": rep["flat_reproduced"],
                   "max_variant": rep["max_amplitude_log2_ulp"], "flat_decisions": rep["decisions"],
                   "max_variant_unit": "log2 ulp of the rounding sibling needed (0 with no flat pair)"}
@@ -560,7 +673,7 @@ def main():
     if world == 1 and not a.no_extras and Q >= 5000:
         # the reference's default chunk size (--chunk-size 5000, src/util/Options.hpp) through the
         # same double-buffered pipeline: 40 chunks cut from step 0's reads, PCIe inside the clock
-        hc, hb, hs, wire = host_chunks[a.warmup % n_chunks]
+        hc, hb, hs, wire = host_chunks[last_i % n_chunks]
         nsm = min(40, Q // 5000)
         small = []
         for k in range(nsm):
@@ -613,12 +726,21 @@ def main():
                                  "workload": aj["config"]["workload"], "reads_per_step": aj["config"]["reads_per_step_per_gpu"],
                                  "kernel_ms_per_step": aj["config"]["kernel_ms_per_step"],
                                  "pcie_inclusive": aj["pcie_inclusive"]["value"],
-                                 "roofline": {k: aj["roofline"][k] for k in ("bound", "kernel", "achieved", "frac", "achieved_algorithmic",
-                                                                            "frac_algorithmic", "pairs_per_launch", "ms_per_launch",
-                                                                            "traffic", "traffic_source")},
+                                 "roofline": {k: aj["roofline"].get(k) for k in ("bound", "kernel", "achieved", "frac", "achieved_algorithmic",
+                                                                                "frac_algorithmic", "pairs_per_launch", "ms_per_launch",
+                                                                                "sclk_mhz", "frac_at_measured_clock",
+                                                                                "traffic", "traffic_source")},
+                                 "roofline_preplace": aj.get("roofline_preplace"),
                                  "parity": aj.get("parity")}
         except Exception as e:  # noqa: BLE001  (a secondary measurement must never take the bench line down)
             extras["cfg3_aa"] = {"status": "failed: %r" % (e,)}
+        # BASELINE configs[4] (cfg5) at a 2000-read sample of one GPU's shard: --no-heur, every pair optimised
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "cfg5", "--chunk", "2000", "--steps", "3",
+                                "--warmup", "1", "--parity-sample", "6"], capture_output=True, text=True, timeout=900)
+            extras["cfg5_noheur"] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception as e:  # noqa: BLE001
+            extras["cfg5_noheur"] = {"status": "failed: %r" % (e,)}
 
     metric = ("query placements/sec (whole node), 512-tip GTR+G4 DNA ref, preplace+thorough" if states == 4
               else "query placements/sec (whole node), AA PROTGTR+G4 ref (cfg3 shape), preplace+thorough")

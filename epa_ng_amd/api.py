@@ -138,6 +138,8 @@ def dev_lib():
         L.epa_dev_xcd_shares.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.epa_dev_xcd_shares.restype = C.c_int
         L.epa_dev_last_kernel_ms.restype = C.c_double
+        L.epa_dev_last_sclk_mhz.argtypes = [C.c_void_p]
+        L.epa_dev_last_sclk_mhz.restype = C.c_double
         L.epa_dev_last_kernel_ms.argtypes = [C.c_void_p, C.c_char_p]
         _LIB = L
     return _LIB
@@ -476,6 +478,10 @@ class Evaluator:
         out = (C.c_double * 8)()
         self._check(self.L.epa_dev_xcd_shares(self.h, out))
         return np.array(list(out))
+
+    def sclk_mhz(self):
+        """shader clock (MHz) the last single-class Newton launch ran at (epa_dev_last_sclk_mhz)"""
+        return float(self.L.epa_dev_last_sclk_mhz(self.h))
 
     def kernel_ms(self, which):
         return self.L.epa_dev_last_kernel_ms(self.h, which.encode())

@@ -112,12 +112,18 @@ const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_
 // pairs dominate) and implausible stamps are ignored; a share stays within 0.85 .. 1.15 of an eighth.  EPA_TH_XCD_BALANCE=0: off.
 void epa_xcd_feedback(epa_ctx* ctx, uint64_t n_pairs, const unsigned long long* hst) {
   static const bool off = getenv("EPA_TH_XCD_BALANCE") && atoi(getenv("EPA_TH_XCD_BALANCE")) == 0;
+  // the shader clock of the launch, whatever the shares do: cycles / (10 ns ticks) of workgroup 0's first wave
+  if (hst[6] > 1000) ctx->last_sclk_mhz = 100.0 * (double)hst[5] / (double)hst[6];
   if (off || hst[7] == 0) return;
   double sp[8], tot = 0.0;
   for (int x = 0; x < 8; ++x) {
-    if (hst[8 + x] <= hst[7]) return;
-    const double t = (double)(hst[8 + x] - hst[7]);               // 10 ns ticks
-    const double share = (double)(ctx->xcd_cum[x + 1] - ctx->xcd_cum[x]) / (double)(1u << 20);
+    const unsigned long long tx = hst[8 + x] >> 21;
+    if (tx <= hst[7]) return;
+    const double t = (double)(tx - hst[7]);                        // 10 ns ticks
+    // the share the XCD had IN THE MEASURED LAUNCH (stamped by the kernel), not the context's current one: with
+    // several slots in flight a later launch may already have been issued with updated shares
+    const double share = (double)(hst[8 + x] & 0x1fffffu) / (double)(1u << 20);
+    if (share <= 0.0) return;
     if (t < 1e5 || t > 1e9) return;                                // < 1 ms (start-up and the last pairs dominate) or > 10 s
     sp[x] = share / t;
     tot += sp[x];
@@ -1877,6 +1883,8 @@ extern "C" int epa_dev_xcd_shares(const epa_ctx* ctx, double shares[8]) {
   for (int x = 0; x < 8; ++x) shares[x] = (double)(ctx->xcd_cum[x + 1] - ctx->xcd_cum[x]) / (double)(1u << 20);
   return EPA_OK;
 }
+
+extern "C" double epa_dev_last_sclk_mhz(const epa_ctx* ctx) { return ctx ? ctx->last_sclk_mhz : 0.0; }
 
 extern "C" double epa_dev_last_kernel_ms(const epa_ctx* ctx, const char* which) {
   if (!ctx || !which) return -1.0;

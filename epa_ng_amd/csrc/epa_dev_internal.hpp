@@ -198,6 +198,7 @@ struct epa_ctx {
   // fixed point; thorough_dna.hip ThArgs::xcum), adapted to the speeds the XCDs showed: epa_xcd_feedback
   uint32_t xcd_cum[9] = {0u, 1u << 17, 2u << 17, 3u << 17, 4u << 17, 5u << 17, 6u << 17, 7u << 17, 1u << 20};
   double xcd_w[8] = {0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125, 0.125};
+  double last_sclk_mhz = 0.0;   // shader clock of the last stamped Newton launch (s_memtime / s_memrealtime)
   bool xstamp_ok = false;   // launch_thorough: this call is ONE kernel launch (one span class): its stamps mean something
   hipEvent_t ev_rb[N_BANKS] = {};   // per bank: behind the selection's read-back copy (SelectPending::ev_rb)
   int t_last[3] = {0, 0, 0};
@@ -217,6 +218,8 @@ const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_
 const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_t Q);
 // hst: the 16 statistics words of a thorough launch ([7] start, [8 + x] last exit of XCD x: ThArgs::xstamp)
 void epa_xcd_feedback(epa_ctx* ctx, uint64_t n_pairs, const unsigned long long* hst);
+// in-kernel s_memrealtime stamps are kept to 43 bits (24 h at 100 MHz) so that the XCD's share fits below them
+#define EPA_XSTAMP_MASK 0x7ffffffffffull
 void epa_timer_start(epa_ctx* ctx, EvTimer& t);
 void epa_timer_stop(epa_ctx* ctx, EvTimer& t);
 // the current bank's timer of a kernel family (epa_ctx::T_*)

@@ -217,7 +217,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
   const uint32_t xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
   const uint64_t slice_lo = (a.n_pairs * a.xcum[xcd]) >> 20;
   const uint64_t slice_hi = (a.n_pairs * a.xcum[xcd + 1]) >> 20;
-  if (a.xstamp && blockIdx.x == 0 && tid == 0) a.stats[7] = __builtin_amdgcn_s_memrealtime();
+  if (a.xstamp && blockIdx.x == 0 && tid == 0) a.stats[7] = __builtin_amdgcn_s_memrealtime() & EPA_XSTAMP_MASK;
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
   const uint32_t slice_n = (uint32_t)(slice_hi > slice_lo ? slice_hi - slice_lo : 0);
   uint32_t* const ctr = a.qctr ? a.qctr + xcd : nullptr;
   uint32_t cur = wg_in_xcd;
@@ -659,7 +660,12 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
     atomicAdd(&a.stats[0], (unsigned long long)wrounds);
     atomicAdd(&a.stats[1], (unsigned long long)wevals);
     atomicAdd(&a.stats[2], (unsigned long long)wreverts);
-    if (a.xstamp) atomicMax(&a.stats[8 + xcd], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (a.xstamp) atomicMax(&a.stats[8 + xcd], ((unsigned long long)(__builtin_amdgcn_s_memrealtime() & EPA_XSTAMP_MASK) << 21) |
+                                                     (unsigned long long)(a.xcum[xcd + 1] - a.xcum[xcd]));
+    if (a.xstamp && blockIdx.x == 0) {   // the shader clock this launch ran at (epa_dev_last_sclk_mhz)
+      a.stats[5] = __builtin_amdgcn_s_memtime() - clk0;
+      a.stats[6] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
   }
 }
 

@@ -83,7 +83,9 @@ struct ThArgs {
   // shares follow the speed each XCD showed in the context's previous launches (epa_xcd_feedback): in-kernel stamps
   // showed the eight equal slices of a 262k-pair launch draining up to 250 us apart, the same XCDs early / late from
   // launch to launch and other ones on another box.  xstamp != 0: the launch records stats[7] = start and
-  // stats[8 + x] = the last exit of XCD x's waves (s_memrealtime, 100 MHz) for that feedback.
+  // stats[8 + x] = the last exit of XCD x's waves (s_memrealtime, 100 MHz, << 21) | the XCD's share in this launch
+  // for that feedback; stats[5] / stats[6] = shader cycles / 100 MHz ticks of workgroup 0's first wave (the clock
+  // the launch ran at: epa_dev_last_sclk_mhz).
   uint32_t xcum[9];
   uint32_t xstamp;
 };
@@ -1222,8 +1224,11 @@ __global__ void __launch_bounds__(64 * NW * NG, TH_WAVES) k_thorough_dna(const T
   if constexpr (NW == 1 && NG == 1) {
     lo = (n_pairs * a.xcum[x]) >> 20;
     hi = (n_pairs * a.xcum[x + 1]) >> 20;
-    if (a.xstamp && blockIdx.x == 0 && threadIdx.x == 0) a.stats[7] = __builtin_amdgcn_s_memrealtime();
+    if (a.xstamp && blockIdx.x == 0 && threadIdx.x == 0) a.stats[7] = __builtin_amdgcn_s_memrealtime() & EPA_XSTAMP_MASK;
   }
+  // clock-true roofline: workgroup 0's first wave lives as long as the launch (resident waves); its s_memtime
+  // (shader cycles) over s_memrealtime (100 MHz) is the shader clock the launch really ran at
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
   uint32_t wstat[3] = {0, 0, 0};
   if constexpr (NW == 1 && NG == 1) {
     // resident waves fetch the next pair of their XCD slice from a counter: no relaunches, no
@@ -1272,7 +1277,13 @@ __global__ void __launch_bounds__(64 * NW * NG, TH_WAVES) k_thorough_dna(const T
     atomicAdd(&a.stats[1], (unsigned long long)wstat[1]);
     atomicAdd(&a.stats[2], (unsigned long long)wstat[2]);
     if constexpr (NW == 1 && NG == 1) {
-      if (a.xstamp) atomicMax(&a.stats[8 + x], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+      // last exit of XCD x's waves, with the share of the pair list the XCD had in THIS launch in the low bits
+      if (a.xstamp) atomicMax(&a.stats[8 + x], ((unsigned long long)(__builtin_amdgcn_s_memrealtime() & EPA_XSTAMP_MASK) << 21) |
+                                                   (unsigned long long)(a.xcum[x + 1] - a.xcum[x]));
+    }
+    if (a.xstamp && blockIdx.x == 0) {
+      a.stats[5] = __builtin_amdgcn_s_memtime() - clk0;
+      a.stats[6] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
   }
 }

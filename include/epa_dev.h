@@ -439,6 +439,12 @@ int epa_dev_mem_info(epa_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
  * MI355X differ in speed by a few per cent: DESIGN.md 4.1).  Results do not depend on the shares. */
 int epa_dev_xcd_shares(const epa_ctx* ctx, double shares[8]);
 
+/* Diagnostics, no reference counterpart: the shader clock (MHz) the last single-class Newton launch really ran
+ * at -- shader cycles (s_memtime) over 100 MHz ticks (s_memrealtime) of the launch's first wave, which lives as
+ * long as the launch.  0 before the first such launch.  The bench line prices the kernel's fp64 rate against the
+ * peak AT THIS CLOCK next to the spec-sheet peak at 2400 MHz (roofline.sclk_mhz, frac_at_measured_clock). */
+double epa_dev_last_sclk_mhz(const epa_ctx* ctx);
+
 /* duration in milliseconds of the last launch of the named kernel family on ctx's stream,
  * measured with HIP events ("preplace", "thorough", "lookup", "select"); < 0 if never run. */
 double epa_dev_last_kernel_ms(const epa_ctx* ctx, const char* which);

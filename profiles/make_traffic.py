@@ -49,6 +49,9 @@ if __name__ == "__main__":
                 out[name]["pairs_per_launch"] = pairs
     if len(sys.argv) > 5:
         aa = parse(os.path.join(ROOT, "gpurun_out", tag + "_aa_pmc_summary.txt"))
+        if "k_preplace_sites" in aa and "FETCH_SIZE" in aa["k_preplace_sites"]:
+            out["k_preplace_sites"] = {"reads_per_step": int(sys.argv[4]), "fetch_kb": aa["k_preplace_sites"]["FETCH_SIZE"],
+                                       "write_kb": aa["k_preplace_sites"].get("WRITE_SIZE", 0.0)}
         if "k_thorough" in aa and "FETCH_SIZE" in aa["k_thorough"]:
             out["k_thorough_aa_mfma"] = {"reads_per_step": int(sys.argv[4]), "pairs_per_launch": float(sys.argv[5]),
                                          "fetch_kb": aa["k_thorough"]["FETCH_SIZE"], "write_kb": aa["k_thorough"].get("WRITE_SIZE", 0.0)}

@@ -47,12 +47,15 @@ import subprocess
 subprocess.check_call(["python", "profiles/make_traffic.py", "${tag}", str(d["config"]["reads_per_step_per_gpu"]),
                        str(d["roofline"]["pairs_per_launch"]), str(a["config"]["reads_per_step_per_gpu"]), str(a["roofline"]["pairs_per_launch"])])
 PY
-# cfg5 at per-GPU shard size (BASELINE configs[4]: 4k tips, 1M reads, --no-heur on 8 GPUs = 125k reads per GPU);
-# bounded here: the place_all path on a slice of the shard, kernel trace committed
+# cfg5 at per-GPU shard size (BASELINE configs[4]: 4k tips, 1M reads, --no-heur on 8 GPUs = 125k reads per GPU):
+# one epa_dev_place_all call over 125 000 reads x 7997 branches = 1e9 pairs, kernel trace committed
 cd /tmp
 rm -rf $R/gpurun_out/${tag}_cfg5_stats
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_cfg5_stats -o st -- \
-  python $R/exp/noheur_cfg5.py > $R/gpurun_out/${tag}_cfg5.log 2>&1
+  python $R/bench.py --workload cfg5 --chunk 125000 --steps 1 --warmup 0 --parity-sample 0 > $R/gpurun_out/${tag}_cfg5.log 2>&1
 cd $R
 python profiles/db_to_txt.py gpurun_out/${tag}_cfg5_stats/st_results.db > gpurun_out/${tag}_cfg5_kernel_trace_stats.txt
-tail -3 gpurun_out/${tag}_cfg5.log; head -6 gpurun_out/${tag}_cfg5_kernel_trace_stats.txt
+grep "^{" gpurun_out/${tag}_cfg5.log | cut -c1-600; head -6 gpurun_out/${tag}_cfg5_kernel_trace_stats.txt
+# the clock under a bare fp64 FMA stream (profiles/fma_clock.hip)
+hipcc --offload-arch=gfx950 -O3 profiles/fma_clock.hip -o /tmp/fma_clock && /tmp/fma_clock > gpurun_out/${tag}_fma_clock.txt 2>&1
+cat gpurun_out/${tag}_fma_clock.txt

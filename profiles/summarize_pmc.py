@@ -13,6 +13,7 @@ for f in sorted(glob.glob(prefix + "*/pmc_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         k = ("k_thorough" if "k_thorough" in k else "k_preplace_pairs" if "k_preplace_pairs" in k else
+             "k_preplace_sites" if "k_preplace_sites" in k else
              "k_preplace" if "k_preplace" in k else "k_select" if "k_select" in k else k[:30])
         per[(k, r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
         per[(k, r["Dispatch_Id"])]["_vgpr"] = float(r.get("VGPR_Count", 0) or 0)
