@@ -128,7 +128,7 @@ def sclk_fields(clks, exec_tflops):
         return {"sclk_mhz": None, "frac_at_measured_clock": None}
     mhz = float(np.mean(clks))
     peak = 256 * 4 * 16 * 2 * mhz * 1e6 / 1e12
-    return {"sclk_mhz": round(mhz, 1), "peak_at_measured_clock": round(peak, 2),
+    return {"sclk_mhz": round(mhz, 1), "sclk_mhz_per_launch": [round(c) for c in clks[:32]], "peak_at_measured_clock": round(peak, 2),
             "frac_at_measured_clock": round(exec_tflops / peak, 4),
             "sclk_note": "spec peak assumes 2400 MHz; sclk_mhz = shader cycles / wall time of the launch's first wave "
                          "(profiles/r5_fma_clock.txt: the clock and cycles per FMA of a bare v_fma_f64 stream)"}

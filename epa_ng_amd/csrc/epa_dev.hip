@@ -1852,10 +1852,11 @@ extern "C" int epa_dev_place_all(epa_ctx* ctx, const uint8_t* q_codes, const uin
   if (!r_dev) EPA_HIP(ctx, hipMemcpyAsync(results, o_r, sizeof(epa_result) * slots, hipMemcpyDeviceToHost, ctx->stream));
   if (!l_dev) EPA_HIP(ctx, hipMemcpyAsync(lwr, o_l, sizeof(double) * slots, hipMemcpyDeviceToHost, ctx->stream));
   if (!c_dev) EPA_HIP(ctx, hipMemcpyAsync(counts, o_c, sizeof(uint32_t) * Q, hipMemcpyDeviceToHost, ctx->stream));
-  unsigned long long hst[8];
-  EPA_HIP(ctx, hipMemcpyAsync(hst, d_stats, 64, hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long hst[16];
+  EPA_HIP(ctx, hipMemcpyAsync(hst, d_stats, 128, hipMemcpyDeviceToHost, ctx->stream));
   EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   EPA_HIP(ctx, hipGetLastError());
+  epa_xcd_feedback(ctx, n, hst);
   ctx->last_stats.pairs = n;
   ctx->last_stats.rounds = hst[0];
   ctx->last_stats.newton_evals = hst[1];

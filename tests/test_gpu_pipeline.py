@@ -286,19 +286,24 @@ def test_full_size_cfg2_properties():
     assert np.allclose(lw.sum(1), 1.0)
     # repeats: every launch of this size moves the XCDs' shares of the pair list toward the speeds the previous one
     # measured (epa_xcd_feedback) -- which wave places a pair must not show in any bit of the results
-    shares = [ev.xcd_shares()]
+    shares, th_ms = [ev.xcd_shares()], []
     for _ in range(3):
         p2, r2 = ev.place_chunk(codes, wb, ws, max_span=150)
         assert np.array_equal(p2, pairs) and np.array_equal(r2, res)
         shares.append(ev.xcd_shares())
+        th_ms.append(ev.kernel_ms("thorough"))
+    # the invariants, whatever the box's speed: the shares sum to 1 and stay within the clamp
     for sh in shares:
         assert abs(sh.sum() - 1.0) < 1e-5 and np.all(sh > 0.125 * 0.84) and np.all(sh < 0.125 * 1.16)
-    if os.environ.get("EPA_TH_XCD_BALANCE", "1") != "0":
-        assert not np.array_equal(shares[-1], np.full(8, 0.125))   # launches of 5 ms have been learnt from
+    # learning is gated on the launch's MEASURED duration (>= 1 ms), not on what this box is expected to take
+    if os.environ.get("EPA_TH_XCD_BALANCE", "1") != "0" and min(th_ms) >= 1.5:
+        assert not np.array_equal(shares[-1], np.full(8, 0.125))
+    assert 500.0 < ev.sclk_mhz() < 3000.0                               # the launch stamped its shader clock
     small = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"], freqs=w["freqs"],
                               rates=w["rates"]).evaluator()
     small.place_chunk(codes[:500], wb[:500], ws[:500], max_span=150)
-    assert np.array_equal(small.xcd_shares(), np.full(8, 0.125))       # a launch far below 1 ms teaches nothing
+    if small.kernel_ms("thorough") < 0.7:
+        assert np.array_equal(small.xcd_shares(), np.full(8, 0.125))   # a launch below 1 ms teaches nothing
 
 
 @pytest.mark.parametrize("states", [4, 20])
