@@ -488,7 +488,7 @@ def main():
         el_s = timed(step_resident, fin_resident, "strong", n_timed=s_steps, n_warm=1, record=False)
         strong = {"reads": s_steps * a.chunk * world, "value": round(s_steps * a.chunk * world / el_s, 2),
                   "unit": "placements/s", "seconds": round(el_s, 4), "steps_per_rank": s_steps,
-                  "reads_per_step_per_gpu": Q,
+                  "reads_per_step_per_gpu": Q, "sclk_mhz_last_launch": round(ev.sclk_mhz(), 1),
                   "per_rank_seconds": [round(x, 4) for x in rank_elapsed["strong"]],
                   "note": "BASELINE configs[3] (cfg4): a fixed job of 10^7 reads dealt over the N GPUs in "
                           "contiguous slices, %d-read chunks per GPU cycling through %d distinct resident "
@@ -708,10 +708,54 @@ def main():
             for k in range(max(0, nsm - 2), nsm):
                 call("finish", ev.chunk_finish, k % S5, copy=False)
             t5 = time.perf_counter() - t0
-        extras["chunk5000"] = {"value": round(nsm * 5000 / t5, 1), "unit": "placements/s", "chunks": nsm,
-                               "ms_per_chunk": round(t5 / nsm * 1e3, 3),
-                               "host_ms_per_chunk": {k_: round(v_ / nsm * 1e3, 3) for k_, v_ in hostt.items()},
-                               "note": "reference default --chunk-size 5000, H2D/D2H inside the clock, five pipeline slots"}
+        per_chunk = {"value": round(nsm * 5000 / t5, 1), "unit": "placements/s", "chunks": nsm,
+                     "ms_per_chunk": round(t5 / nsm * 1e3, 3),
+                     "host_ms_per_chunk": {k_: round(v_ / nsm * 1e3, 3) for k_, v_ in hostt.items()},
+                     "note": "one chunk body per 5000-read chunk, H2D/D2H inside the clock, five pipeline slots, three chunks begun ahead"}
+        # the same 5000-read chunks through GROUP launches (epa_dev_chunk_launch_many): the caller still stages and
+        # finishes chunk by chunk, the library runs one chunk body -- one preplacement, one selection, one Newton
+        # launch -- per four staged chunks and regroups the rows by chunk.  Twelve slots, two groups begun ahead.
+        G = int(os.environ.get("EPA_BENCH_GROUP", "4"))
+        small = small * (40 // nsm) if nsm < 40 else small      # 40 chunks: the pipeline's fill / drain amortised
+        ngr = len(small) // G
+        kwg = dict(threshold=0.99999, max_span=a.read_len, max_pairs=G * 5000 * 64)
+        slots_of = lambda g: [(g % 3) * G + j for j in range(G)]
+        for rep in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hostg = {"stage": 0.0, "begin": 0.0, "end": 0.0, "finish": 0.0}
+
+            def callg(name, fn, *aa, **kw):
+                t = time.perf_counter()
+                r_ = fn(*aa, **kw)
+                hostg[name] += time.perf_counter() - t
+                return r_
+
+            def gbegin(g):
+                for j, sl in enumerate(slots_of(g)):
+                    callg("stage", ev.chunk_stage, sl, *small[g * G + j])
+                callg("begin", ev.chunk_launch_many_begin, slots_of(g), **kwg)
+            rows5 = 0
+            for g in range(min(2, ngr)):
+                gbegin(g)
+            for g in range(ngr):
+                callg("end", ev.chunk_launch_end, slots_of(g)[0])
+                if g >= 1:
+                    for sl in slots_of(g - 1):
+                        rows5 += len(callg("finish", ev.chunk_finish, sl, copy=False)[0])
+                if g + 2 < ngr:
+                    gbegin(g + 2)
+            for sl in slots_of(ngr - 1):
+                rows5 += len(callg("finish", ev.chunk_finish, sl, copy=False)[0])
+            t5g = time.perf_counter() - t0
+        extras["chunk5000"] = {"value": round(ngr * G * 5000 / t5g, 1), "unit": "placements/s", "chunks": ngr * G,
+                               "ms_per_chunk": round(t5g / (ngr * G) * 1e3, 3), "chunks_per_group_launch": G,
+                               "rows": rows5,
+                               "host_ms_per_chunk": {k_: round(v_ / (ngr * G) * 1e3, 3) for k_, v_ in hostg.items()},
+                               "note": "reference default --chunk-size 5000 (src/util/Options.hpp:20) through the C-ABI: stage / finish per "
+                                       "5000-read chunk, H2D/D2H inside the clock; epa_dev_chunk_launch_many runs ONE chunk body per four "
+                                       "staged chunks (twelve slots, two groups begun ahead); per chunk the same bits as a launch of its own",
+                               "per_chunk_launch": per_chunk}
 
     if world == 1 and states == 4 and not a.no_extras and not os.environ.get("EPA_BENCH_NO_CFG3"):
         # BASELINE configs[2] (cfg3: 2000-tip 20-state reference, 100-residue queries) as a short second

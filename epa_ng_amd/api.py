@@ -110,6 +110,9 @@ def dev_lib():
         L.epa_dev_chunk_launch_begin.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_double, C.c_void_p,
                                            C.c_void_p, C.c_uint64, C.c_uint32]
         L.epa_dev_chunk_launch_end.argtypes = [C.c_void_p, C.c_int]
+        L.epa_dev_chunk_launch_many_begin.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_uint32, C.c_double,
+                                                      C.c_uint64, C.c_uint32]
+        L.epa_dev_chunk_launch_many.argtypes = L.epa_dev_chunk_launch_many_begin.argtypes
         L.epa_dev_chunk_finish.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(_Stats)]
         L.epa_dev_tree_logl.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
@@ -410,6 +413,18 @@ class Evaluator:
         assert max_pairs is not None
         self._check(self.L.epa_dev_chunk_launch_begin(self.h, slot, max_span, threshold, _ptr(pairs_out),
                                                       _ptr(results_out), max_pairs, 1 if keep_on_device else 0))
+
+    def chunk_launch_many_begin(self, slots, threshold=0.99999, max_span=0, max_pairs=None, keep_on_device=False):
+        """group launch of several STAGED slots (one chunk body over their concatenated queries); slots[0] leads:
+        chunk_launch_end(slots[0]), then chunk_finish(slot) for every member"""
+        assert max_pairs is not None
+        arr = (C.c_int * len(slots))(*slots)
+        self._check(self.L.epa_dev_chunk_launch_many_begin(self.h, arr, len(slots), max_span, threshold, max_pairs,
+                                                           1 if keep_on_device else 0))
+
+    def chunk_launch_many(self, slots, **kw):
+        self.chunk_launch_many_begin(slots, **kw)
+        self.chunk_launch_end(slots[0])
 
     def chunk_launch_end(self, slot):
         """second half: waits for the candidate count, queues the thorough kernels + result D2H"""

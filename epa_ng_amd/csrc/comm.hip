@@ -337,6 +337,8 @@ extern "C" int epa_dev_gather_slot(epa_ctx* ctx, epa_comm* c, int slot, uint32_t
   ChunkSlot* s = &ctx->slots[slot];
   if (s->state != 2 || !(s->l_flags & EPA_CHUNK_NO_D2H))
     return epa_fail(ctx, EPA_ERR_INVALID_ARG, "gather_slot: the slot needs a finished launch with EPA_CHUNK_NO_D2H");
+  if (s->leader >= 0)   // its rows are a range of the group's regrouped buffers, known to the host only at finish
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "gather_slot: the slot is part of a group launch: epa_dev_chunk_finish it and post its rows with epa_dev_gather_results");
   return epa_dev_gather_results(ctx, c, s->l_pairs, s->l_res, s->n, seq_offset, ticket);
 }
 

@@ -546,6 +546,11 @@ extern "C" void epa_dev_destroy(epa_ctx* ctx) {
     if (sl.d_pairs) (void)hipFree(sl.d_pairs);
     if (sl.d_res) (void)hipFree(sl.d_res);
     if (sl.d_stats) (void)hipFree(sl.d_stats);
+    if (sl.d_merge) (void)hipFree(sl.d_merge);
+    if (sl.d_gpairs) (void)hipFree(sl.d_gpairs);
+    if (sl.d_gres) (void)hipFree(sl.d_gres);
+    if (sl.d_goff) (void)hipFree(sl.d_goff);
+    if (sl.h_goff) (void)hipHostFree(sl.h_goff);
     for (hipEvent_t e : {sl.ev_up, sl.ev_done, sl.ev_down, sl.ev_base}) if (e) (void)hipEventDestroy(e);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
@@ -1469,7 +1474,7 @@ extern "C" int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const u
 // ---------------------------------------------------------------------------------------------
 static int slot_of(epa_ctx* ctx, int slot, ChunkSlot** out) {
   if (!ctx) return EPA_ERR_INVALID_ARG;
-  if (slot < 0 || slot >= epa_ctx::N_SLOTS) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk pipeline: slot must be 0 .. 5");
+  if (slot < 0 || slot >= epa_ctx::N_SLOTS) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk pipeline: slot must be 0 .. 23");
   ChunkSlot& s = ctx->slots[slot];
   if (!ctx->copy_stream) EPA_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
   if (!ctx->down_stream) EPA_HIP(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
@@ -1513,7 +1518,8 @@ extern "C" int epa_dev_chunk_stage(epa_ctx* ctx, int slot, const uint8_t* q_code
   int rc = slot_of(ctx, slot, &s);
   if (rc) return rc;
   if (!q_codes || !win_begin || !win_span || Q == 0) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_stage: null / empty chunk");
-  if (s->state == 2 || s->state == 3) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_stage: the slot has an unfinished launch");
+  if (s->state == 2 || s->state == 3 || s->state == 4) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_stage: the slot has an unfinished launch");
+  if (s->g_left > 0) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_stage: members of this slot's group launch are not finished yet (their results live in its buffers)");
   EPA_HIP(ctx, hipSetDevice(ctx->device));
   s->stride = ctx->code_stride ? ctx->code_stride : ctx->W;
   s->packed4 = ctx->code_packed4;
@@ -1560,12 +1566,9 @@ struct SlotScope {
 };
 }  // namespace
 
-extern "C" int epa_dev_chunk_launch_begin(epa_ctx* ctx, int slot, uint32_t max_span, double threshold,
-                                          epa_pair* d_pairs, epa_result* d_results, uint64_t max_pairs,
-                                          uint32_t flags) {
-  ChunkSlot* s;
-  int rc = slot_of(ctx, slot, &s);
-  if (rc) return rc;
+static int chunk_launch_begin_impl(epa_ctx* ctx, int slot, ChunkSlot* s, uint32_t max_span, double threshold,
+                                   epa_pair* d_pairs, epa_result* d_results, uint64_t max_pairs, uint32_t flags) {
+  int rc = EPA_OK;
   if (s->state != 1) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_launch: the slot holds no staged chunk");
   if ((d_pairs == nullptr) != (d_results == nullptr))
     return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_launch: pass both result buffers or neither");
@@ -1619,10 +1622,202 @@ extern "C" int epa_dev_chunk_launch_begin(epa_ctx* ctx, int slot, uint32_t max_s
   return EPA_OK;
 }
 
+extern "C" int epa_dev_chunk_launch_begin(epa_ctx* ctx, int slot, uint32_t max_span, double threshold,
+                                          epa_pair* d_pairs, epa_result* d_results, uint64_t max_pairs,
+                                          uint32_t flags) {
+  ChunkSlot* s;
+  int rc = slot_of(ctx, slot, &s);
+  if (rc) return rc;
+  return chunk_launch_begin_impl(ctx, slot, s, max_span, threshold, d_pairs, d_results, max_pairs, flags);
+}
+
+// ---- group launches ---------------------------------------------------------------------------------
+namespace {
+struct GroupDesc {
+  const uint8_t* codes[EPA_MAX_GROUP];
+  const uint32_t* begin[EPA_MAX_GROUP];
+  const uint32_t* span[EPA_MAX_GROUP];
+  uint32_t qoff[EPA_MAX_GROUP + 1];   // first merged query index of every member; [n] = total
+  uint32_t n, row;                    // members; bytes per code row (the same for all of them)
+};
+
+__device__ __forceinline__ int group_member(const uint32_t* qoff, int n, uint32_t q) {
+  int m = 0;
+  for (int i = 1; i < n; ++i) m += q >= qoff[i];
+  return m;
+}
+
+// the members' staged arrays -> one chunk: codes rows, window begins, window spans back to back
+__global__ void __launch_bounds__(256) k_concat_chunks(const GroupDesc g, uint8_t* __restrict__ codes, uint32_t* __restrict__ begin,
+                                                       uint32_t* __restrict__ span) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t total_bytes = (uint64_t)g.qoff[g.n] * g.row;
+  const uint64_t nwords = (total_bytes + 3) / 4;
+  if (i < nwords) {
+    uint32_t v = 0;
+    for (int k = 0; k < 4; ++k) {
+      const uint64_t b = i * 4 + k;
+      if (b >= total_bytes) break;
+      const uint32_t q = (uint32_t)(b / g.row);
+      const int m = group_member(g.qoff, (int)g.n, q);
+      v |= (uint32_t)g.codes[m][b - (uint64_t)g.qoff[m] * g.row] << (8 * k);
+    }
+    if (i * 4 + 4 <= total_bytes) reinterpret_cast<uint32_t*>(codes)[i] = v;
+    else for (int k = 0; i * 4 + k < total_bytes; ++k) codes[i * 4 + k] = (uint8_t)(v >> (8 * k));
+    return;
+  }
+  const uint64_t q = i - nwords;
+  if (q >= g.qoff[g.n]) return;
+  const int m = group_member(g.qoff, (int)g.n, (uint32_t)q);
+  begin[q] = g.begin[m][q - g.qoff[m]];
+  span[q] = g.span[m][q - g.qoff[m]];
+}
+
+// Stable partition of the group's n (pair, result) rows by member: member m's rows keep their order (branch-major,
+// queries ascending -- the order of its own chunk's Work, src/core/Work.hpp:21-113) and get their chunk-local
+// sequence ids back; goff[m] = first row of member m, goff[n_members] = n.  One 1024-thread workgroup (group
+// launches exist for SMALL chunks: tens of thousands of rows; correct for any n).
+__global__ void __launch_bounds__(1024) k_split_group(const epa_pair* __restrict__ pairs, const epa_result* __restrict__ res,
+                                                      uint32_t n, const GroupDesc g, epa_pair* __restrict__ o_pairs,
+                                                      epa_result* __restrict__ o_res, uint32_t* __restrict__ goff) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t base[EPA_MAX_GROUP + 1];
+  const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const uint32_t per = (n + 1023) / 1024;
+  const uint32_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+  uint32_t cnt[EPA_MAX_GROUP] = {};
+  for (uint32_t i = lo; i < hi; ++i) {
+    const int m = group_member(g.qoff, (int)g.n, pairs[i].seq_id);
+#pragma unroll
+    for (int k = 0; k < EPA_MAX_GROUP; ++k) cnt[k] += (k == m);
+  }
+  // per member: exclusive prefix of the threads' counts (wave scan + wave totals), then the members' bases
+  uint32_t pre[EPA_MAX_GROUP];
+  uint32_t run = 0;
+  for (int k = 0; k < EPA_MAX_GROUP; ++k) {
+    uint32_t v = cnt[k];
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t u = __shfl_up(v, d, 64);
+      if ((int)lane >= d) v += u;
+    }
+    if (lane == 63) wsum[wv] = v;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < 16; ++w) { const uint32_t x = wsum[w]; total += x; if (w < (int)wv) before += x; }
+    pre[k] = run + before + v - cnt[k];
+    if (t == 0) base[k] = run;
+    run += total;
+    __syncthreads();
+  }
+  if (t == 0) {
+    for (int k = 0; k <= (int)g.n && k < EPA_MAX_GROUP; ++k) goff[k] = base[k];
+    goff[g.n] = n;
+  }
+  for (uint32_t i = lo; i < hi; ++i) {
+    epa_pair p = pairs[i];
+    const int m = group_member(g.qoff, (int)g.n, p.seq_id);
+    uint32_t dst = 0;
+#pragma unroll
+    for (int k = 0; k < EPA_MAX_GROUP; ++k)
+      if (k == m) dst = pre[k]++;
+    p.seq_id -= g.qoff[m];
+    o_pairs[dst] = p;
+    o_res[dst] = res[i];
+  }
+}
+
+void group_restore_leader(ChunkSlot* L) {
+  L->Q = L->own_Q;
+  L->x_codes = L->own_x_codes; L->x_begin = L->own_x_begin; L->x_span = L->own_x_span;
+}
+
+GroupDesc group_desc(epa_ctx* ctx, const ChunkSlot* L) {
+  GroupDesc g{};
+  g.n = (uint32_t)L->g_n;
+  for (int i = 0; i <= L->g_n; ++i) g.qoff[i] = L->g_qoff[i];
+  (void)ctx;
+  return g;
+}
+}  // namespace
+
+extern "C" int epa_dev_chunk_launch_many_begin(epa_ctx* ctx, const int* slots, int n_slots, uint32_t max_span,
+                                               double threshold, uint64_t max_pairs, uint32_t flags) {
+  if (!ctx || !slots || n_slots < 1 || n_slots > EPA_MAX_GROUP)
+    return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_launch_many: 1 .. 8 slots");
+  ChunkSlot* m[EPA_MAX_GROUP];
+  for (int i = 0; i < n_slots; ++i) {
+    int rc = slot_of(ctx, slots[i], &m[i]);
+    if (rc) return rc;
+    for (int j = 0; j < i; ++j)
+      if (slots[j] == slots[i]) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_launch_many: a slot is listed twice");
+    if (m[i]->state != 1) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_launch_many: slot " + std::to_string(slots[i]) + " holds no staged chunk");
+    if (m[i]->stride != m[0]->stride || m[i]->packed4 != m[0]->packed4)
+      return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_launch_many: the chunks were staged with different query layouts");
+  }
+  ChunkSlot* L = m[0];
+  if (L->g_left > 0) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_launch_many: members of the leader's previous group are not finished yet");
+  if (n_slots == 1) return chunk_launch_begin_impl(ctx, slots[0], L, max_span, threshold, nullptr, nullptr, max_pairs, flags);
+  EPA_HIP(ctx, hipSetDevice(ctx->device));
+  GroupDesc g{};
+  g.n = (uint32_t)n_slots;
+  g.row = L->packed4 ? (L->stride + 1) / 2 : L->stride;
+  uint64_t total = 0;
+  for (int i = 0; i < n_slots; ++i) {
+    const char* d = (const char*)m[i]->d_in;
+    g.codes[i] = m[i]->x_codes ? m[i]->x_codes : (const uint8_t*)d;
+    g.begin[i] = m[i]->x_codes ? m[i]->x_begin : (const uint32_t*)(d + m[i]->codes_bytes);
+    g.span[i] = m[i]->x_codes ? m[i]->x_span : g.begin[i] + m[i]->Q;
+    g.qoff[i] = (uint32_t)total;
+    total += m[i]->Q;
+  }
+  if (total > 0x7fffffffull) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_launch_many: too many queries in one group");
+  g.qoff[n_slots] = (uint32_t)total;
+  const size_t cbytes = ((size_t)total * g.row + 255) & ~(size_t)255;
+  int rc = grow_dev(ctx, (char**)&L->d_merge, &L->d_merge_sz, cbytes + 2 * sizeof(uint32_t) * (size_t)total + 1024);
+  if (rc) return rc;
+  if (!L->d_goff) {
+    EPA_HIP(ctx, hipMalloc((void**)&L->d_goff, sizeof(uint32_t) * (EPA_MAX_GROUP + 1)));
+    EPA_HIP(ctx, hipHostMalloc((void**)&L->h_goff, sizeof(uint32_t) * (EPA_MAX_GROUP + 1), hipHostMallocDefault));
+  }
+  // the merge runs on the leader's stream, behind the caller's stream (device-resident chunks) and every member's upload
+  EPA_HIP(ctx, hipEventRecord(L->ev_base, ctx->stream));
+  EPA_HIP(ctx, hipStreamWaitEvent(L->stream, L->ev_base, 0));
+  for (int i = 0; i < n_slots; ++i)
+    if (!m[i]->x_codes) EPA_HIP(ctx, hipStreamWaitEvent(L->stream, m[i]->ev_up, 0));
+  uint8_t* mc = (uint8_t*)L->d_merge;
+  uint32_t* mb = (uint32_t*)(mc + cbytes);
+  uint32_t* ms = mb + total;
+  const uint64_t threads = ((uint64_t)total * g.row + 3) / 4 + total;
+  hipLaunchKernelGGL(k_concat_chunks, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, L->stream, g, mc, mb, ms);
+  EPA_HIP(ctx, hipGetLastError());
+  // the leader now stands for the merged chunk (read in place, like an HBM-resident one)
+  L->own_Q = L->Q; L->own_x_codes = L->x_codes; L->own_x_begin = L->x_begin; L->own_x_span = L->x_span;
+  L->Q = (uint32_t)total; L->x_codes = mc; L->x_begin = mb; L->x_span = ms;
+  rc = chunk_launch_begin_impl(ctx, slots[0], L, max_span, threshold, nullptr, nullptr, max_pairs, flags);
+  if (rc) { group_restore_leader(L); return rc; }   // every member stays staged
+  L->g_n = n_slots;
+  for (int i = 0; i <= n_slots; ++i) L->g_qoff[i] = g.qoff[i];
+  for (int i = 0; i < n_slots; ++i) {
+    L->g_slots[i] = slots[i];
+    m[i]->leader = slots[0];
+    m[i]->g_index = i;
+    if (i) m[i]->state = 4;
+  }
+  return EPA_OK;
+}
+
+extern "C" int epa_dev_chunk_launch_many(epa_ctx* ctx, const int* slots, int n_slots, uint32_t max_span, double threshold,
+                                         uint64_t max_pairs, uint32_t flags) {
+  int rc = epa_dev_chunk_launch_many_begin(ctx, slots, n_slots, max_span, threshold, max_pairs, flags);
+  if (rc) return rc;
+  return epa_dev_chunk_launch_end(ctx, slots[0]);
+}
+
 extern "C" int epa_dev_chunk_launch_end(epa_ctx* ctx, int slot) {
   ChunkSlot* s;
   int rc = slot_of(ctx, slot, &s);
   if (rc) return rc;
+  if (s->state == 4) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_launch_end: the slot is a member of a group launch: end the group's first slot");
   if (s->state != 3) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_launch_end: no launch was begun on the slot");
   EPA_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t base = ctx->stream;
@@ -1635,16 +1830,61 @@ extern "C" int epa_dev_chunk_launch_end(epa_ctx* ctx, int slot) {
   // slot stays staged (launch again with a larger max_pairs).  Any other failure may leave kernels of this
   // chunk in flight on the slot's stream: wait for them and free the slot, so that it cannot be re-staged or
   // re-launched (its result buffers re-allocated) under running kernels.
+  const int gn = s->g_n;
+  auto group_release = [&](int member_state) {   // the group is over (error): members back to `member_state`
+    if (gn <= 1) return;
+    group_restore_leader(s);
+    for (int i = 0; i < gn; ++i) {
+      ChunkSlot& mm = ctx->slots[s->g_slots[i]];
+      mm.leader = -1;
+      if (i) mm.state = member_state;
+    }
+    s->g_n = 0;
+  };
   auto abandon = [&](int code) {
     (void)hipStreamSynchronize(s->stream);
     s->state = 0;
+    group_release(0);
     return code;
   };
-  if (rc == EPA_ERR_PAIR_OVERFLOW || rc == EPA_ERR_QUERY_ALL_GAP || rc == EPA_ERR_QUERY_WIDTH) { s->state = 1; return rc; }
+  if (rc == EPA_ERR_PAIR_OVERFLOW || rc == EPA_ERR_QUERY_ALL_GAP || rc == EPA_ERR_QUERY_WIDTH) {
+    s->state = 1;
+    group_release(1);   // every member stays staged: launch the group again (larger max_pairs) or one by one
+    return rc;
+  }
   if (rc) return abandon(rc);
   s->n = n;
+  if (gn > 1) {
+    // regroup the rows by member (stable), chunk-local sequence ids back
+    if (s->g_cap < n) {
+      if (s->d_gpairs) (void)hipFree(s->d_gpairs);
+      if (s->d_gres) (void)hipFree(s->d_gres);
+      s->d_gpairs = nullptr; s->d_gres = nullptr; s->g_cap = 0;
+      const size_t want = n + n / 4 + 1024;
+      if (hipMalloc((void**)&s->d_gpairs, sizeof(epa_pair) * want) != hipSuccess ||
+          hipMalloc((void**)&s->d_gres, sizeof(epa_result) * want) != hipSuccess)
+        return abandon(epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(group rows)"));
+      s->g_cap = want;
+    }
+    GroupDesc g = group_desc(ctx, s);
+    hipLaunchKernelGGL(k_split_group, dim3(1), dim3(1024), 0, ctx->stream, d_pairs, d_results, (uint32_t)n, g, s->d_gpairs,
+                       s->d_gres, s->d_goff);
+    if (hipGetLastError() != hipSuccess) return abandon(epa_fail(ctx, EPA_ERR_HIP, "k_split_group launch"));
+    d_pairs = s->d_gpairs;
+    d_results = s->d_gres;
+  }
   if (hipEventRecord(s->ev_done, ctx->stream) != hipSuccess) return abandon(epa_fail(ctx, EPA_ERR_HIP, "hipEventRecord(chunk done)"));
   EPA_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, s->ev_done, 0));
+  if (gn > 1) {
+    EPA_HIP(ctx, hipMemcpyAsync(s->h_goff, s->d_goff, sizeof(uint32_t) * (EPA_MAX_GROUP + 1), hipMemcpyDeviceToHost, ctx->down_stream));
+    group_restore_leader(s);
+    s->g_left = gn;
+    for (int i = 1; i < gn; ++i) {
+      ChunkSlot& mm = ctx->slots[s->g_slots[i]];
+      mm.state = 2;
+      mm.l_flags = s->l_flags;
+    }
+  }
   if (s->l_flags & EPA_CHUNK_NO_D2H) {
     s->out_pairs = d_pairs;
     s->out_res = d_results;
@@ -1682,6 +1922,32 @@ extern "C" int epa_dev_chunk_finish(epa_ctx* ctx, int slot, const epa_pair** pai
   int rc = slot_of(ctx, slot, &s);
   if (rc) return rc;
   if (s->state != 2) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "chunk_finish: the slot has no launch in flight");
+  if (s->leader >= 0) {   // member of a group launch: its rows are a range of the leader's regrouped buffers
+    ChunkSlot* L = &ctx->slots[s->leader];
+    EPA_HIP(ctx, hipEventSynchronize(L->ev_down));
+    const uint32_t lo = L->h_goff[s->g_index], hi = L->h_goff[s->g_index + 1];
+    const uint64_t group_rows = L->n;   // (the leader's own n is replaced by its member count below)
+    s->n = hi - lo;
+    s->out_pairs = L->out_pairs + lo;
+    s->out_res = L->out_res + lo;
+    s->state = 0;
+    s->leader = -1;
+    if (--L->g_left == 0) L->g_n = 0;
+    if (pairs) *pairs = s->out_pairs;
+    if (results) *results = s->out_res;
+    if (n_pairs) *n_pairs = s->n;
+    // the Newton launch was ONE launch for the group: its counters are reported with the group's first slot
+    if (s->g_index == 0) {
+      const int rc2 = chunk_stats(ctx, group_rows, L->h_stats, stats);
+      ctx->last_stats.pairs = s->n;
+      if (stats) stats->pairs = s->n;
+      return rc2;
+    }
+    ctx->last_stats = epa_thorough_stats{};
+    ctx->last_stats.pairs = s->n;
+    if (stats) *stats = ctx->last_stats;
+    return EPA_OK;
+  }
   EPA_HIP(ctx, hipEventSynchronize(s->ev_down));
   s->state = 0;
   if (pairs) *pairs = s->out_pairs;

@@ -104,7 +104,7 @@ struct ChunkSlot {
   const epa_pair* out_pairs = nullptr;    // what finish() hands out
   const epa_result* out_res = nullptr;
   uint64_t n = 0;
-  int state = 0;              // 0 free, 1 staged, 3 launch begun (selection in flight), 2 launched
+  int state = 0;              // 0 free, 1 staged, 3 launch begun (selection in flight), 2 launched, 4 member of a group whose launch was begun
   // between launch_begin and launch_end
   SelectPending sel;
   uint32_t* h_sel = nullptr;  // pinned, 64 words: the selection's read-back block
@@ -113,7 +113,28 @@ struct ChunkSlot {
   epa_pair* l_pairs = nullptr;
   epa_result* l_res = nullptr;
   uint32_t l_max_span = 0, l_flags = 0;
+  // group launches (epa_dev_chunk_launch_many): ONE chunk body over the concatenated queries of up to
+  // EPA_MAX_GROUP staged slots -- one preplacement, one selection, one Newton launch instead of one each per
+  // small chunk -- run on the first slot (the leader); a kernel regroups the (pair, result) rows by member
+  // afterwards (stable: every member keeps the branch-major order of its own chunk, sequence ids local again).
+  int leader = -1;            // >= 0: this slot's chunk is member g_index of slot `leader`'s group (the leader: itself)
+  int g_index = 0;
+  int g_n = 0;                // leader: members of the group in flight (0: an ordinary launch)
+  int g_left = 0;             // leader: members not finished yet (their results live in the leader's buffers)
+  int g_slots[8] = {};
+  uint32_t g_qoff[9] = {};    // leader: first merged query index of every member
+  uint32_t own_Q = 0;         // leader: its own chunk (restored after the group launch / on a recoverable error)
+  const uint8_t* own_x_codes = nullptr;
+  const uint32_t *own_x_begin = nullptr, *own_x_span = nullptr;
+  void* d_merge = nullptr;    // leader: merged codes | win_begin | win_span
+  size_t d_merge_sz = 0;
+  epa_pair* d_gpairs = nullptr;   // leader: rows regrouped by member
+  epa_result* d_gres = nullptr;
+  size_t g_cap = 0;
+  uint32_t* d_goff = nullptr;     // [9] member offsets into the regrouped rows (device / pinned)
+  uint32_t* h_goff = nullptr;
 };
+constexpr int EPA_MAX_GROUP = 8;
 
 struct epa_ctx {
   int device = 0;
@@ -160,7 +181,7 @@ struct epa_ctx {
   // pipeline, whose kernels run concurrently on their own streams and therefore share no scratch
   // (allocated on first use: a two-slot caller pays for two).
   static constexpr int N_SCRATCH = 11;
-  static constexpr int N_SLOTS = 6;
+  static constexpr int N_SLOTS = 24;
   static constexpr int N_BANKS = 1 + N_SLOTS;
   int bank = 0;
   void* scratch[N_BANKS * N_SCRATCH] = {};

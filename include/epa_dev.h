@@ -316,7 +316,7 @@ int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* wi
  * The same chunk body as a double-buffered pipeline, the device-side counterpart of the
  * reference's read-ahead of the next chunk (src/seq/MSA_Stream.cpp:79-82, the prefetch in
  * src/core/place.cpp:190-215): the query upload of chunk k+1 and the result download of chunk k-1
- * run on a copy stream while the kernels of chunk k run.  Slots 0 .. 5 (the loops below use two; a
+ * run on a copy stream while the kernels of chunk k run.  Slots 0 .. 23 (the loops below use two; a
  * caller of many small chunks keeps more in flight, see launch_begin), each walks
  *     stage -> launch -> finish -> stage -> ...
  *   stage   copies the caller's HOST arrays (layout / packing as set for the context) into the
@@ -358,6 +358,32 @@ int epa_dev_chunk_launch_begin(epa_ctx* ctx, int slot, uint32_t max_span, double
 int epa_dev_chunk_launch_end(epa_ctx* ctx, int slot);
 int epa_dev_chunk_finish(epa_ctx* ctx, int slot, const epa_pair** pairs, const epa_result** results,
                          uint64_t* n_pairs, epa_thorough_stats* stats);
+
+/*
+ * Small chunks (the reference's default --chunk-size is 5000, src/util/Options.hpp:20; the chunk body of
+ * src/core/place.cpp:207-246 then runs once per 5000 reads): every launch of the Newton kernel costs a fixed
+ * ~0.11 ms, a preplacement over a handful of query groups another ~0.15 ms, and a chunk body is ~23 dispatches.
+ * A GROUP LAUNCH runs ONE chunk body -- one preplacement, one selection, one Newton launch -- over the
+ * concatenated queries of up to 8 STAGED slots and regroups the rows by chunk afterwards:
+ *   launch_many_begin  slots[0] is the group's leader; every listed slot must be staged (same query layout).
+ *                      Queues merge + preplacement + selection on the leader's stream, returns without waiting.
+ *                      max_pairs bounds the candidates of the WHOLE group; results live in library buffers.
+ *   epa_dev_chunk_launch_end(ctx, slots[0])   as for a single slot: waits for the candidate count, queues the
+ *                      Newton kernel, the regrouping and the D2H (one copy per group)
+ *   epa_dev_chunk_finish(ctx, slot) for EVERY member, in any order: that chunk's rows, bit-identical to a launch
+ *                      of its own -- branch-major, queries ascending, sequence ids local to the chunk -- as a
+ *                      range of the leader's buffers: valid until the LEADER is staged again, which is refused
+ *                      while members are unfinished.  The Newton counters of the one launch are reported with
+ *                      slots[0] (the other members report their pair count only).
+ * EPA_ERR_PAIR_OVERFLOW and the window errors leave every member staged.  A loop for 5000-read chunks, groups
+ * of four on twelve slots, two groups begun ahead (bench.py's chunk5000 leg):
+ *     stage + many_begin(g0); stage + many_begin(g1);
+ *     for g: { launch_end(leader(g)); finish(members of g-1); stage + many_begin(g+2); }
+ */
+int epa_dev_chunk_launch_many_begin(epa_ctx* ctx, const int* slots, int n_slots, uint32_t max_span,
+                                    double threshold, uint64_t max_pairs, uint32_t flags);
+int epa_dev_chunk_launch_many(epa_ctx* ctx, const int* slots, int n_slots, uint32_t max_span, double threshold,
+                              uint64_t max_pairs, uint32_t flags);
 
 /*
  * --no-heur (src/core/place.cpp:189,228: every branch gets a thorough placement) with the

@@ -1015,7 +1015,102 @@ def test_five_slot_order_for_small_chunks():
     for (p, r), (ep, er) in zip(got, expect):
         assert np.array_equal(p, ep) and np.array_equal(r, er)
     with pytest.raises(epa.EpaError):
-        ev.chunk_stage(6, *chunks[0])
+        ev.chunk_stage(24, *chunks[0])
+
+
+def test_group_launch_of_small_chunks_equals_per_chunk_launches():
+    """epa_dev_chunk_launch_many: ONE chunk body (one preplacement, one selection, one Newton launch) over the
+    concatenated queries of several staged slots, rows regrouped by chunk afterwards.  Every member's finish()
+    returns the bits of epa_dev_place_chunk on that chunk alone -- branch-major order, chunk-local sequence ids --
+    for groups of 4, 3 and 1 chunks of DIFFERENT sizes, host-staged (4-bit wire) and HBM-resident members mixed,
+    members finished in any order; the bench's pipelined order (groups of four on twelve slots, two groups begun
+    ahead); the Newton counters of a group are those of its members' own launches added up."""
+    import torch
+    w = synth.dna_workload(40, 600, 2600, 150, (81, 82, 83))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    ev = ref.evaluator()
+    sizes = [150, 97, 230, 1, 64, 200, 150, 33, 150, 150, 150, 150, 150, 150, 150, 150]
+    chunks, lo = [], 0
+    for q in sizes:
+        codes, wb, ws = epa.encode_queries(4, w["reads"][lo:lo + q], compact=True)
+        chunks.append((epa.pack_codes_4bit(codes), wb, ws))
+        lo += q
+    expect, rounds = [], []
+    for ch in chunks:
+        expect.append(ev.place_chunk(*ch, max_span=150))
+        rounds.append((ev.last_stats["rounds"], ev.last_stats["newton_evals"]))
+    kw = dict(threshold=0.99999, max_span=150, max_pairs=4 * 230 * 64)
+
+    def same(got, k):
+        p, r = got
+        assert np.array_equal(p, expect[k][0]) and np.array_equal(r, expect[k][1])
+
+    # --- a group of four (sizes 150 / 97 / 230 / 1), finished out of order
+    for j in range(4):
+        ev.chunk_stage(j, *chunks[j])
+    ev.chunk_launch_many([0, 1, 2, 3], **kw)
+    with pytest.raises(epa.EpaError):
+        ev.chunk_stage(0, *chunks[0])                       # busy
+    got_stats = {}
+    for j in (2, 0, 3):
+        same(ev.chunk_finish(j), j)
+        got_stats[j] = dict(ev.last_stats)
+    with pytest.raises(epa.EpaError):
+        ev.chunk_stage(0, *chunks[4])                       # the leader's buffers still hold member 1's rows
+    same(ev.chunk_finish(1), 1)
+    got_stats[1] = dict(ev.last_stats)
+    assert [got_stats[j]["pairs"] for j in range(4)] == [len(expect[j][0]) for j in range(4)]
+    assert got_stats[0]["rounds"] == sum(rounds[j][0] for j in range(4))
+    assert got_stats[0]["newton_evals"] == sum(rounds[j][1] for j in range(4))
+    assert all(got_stats[j]["rounds"] == 0 for j in (1, 2, 3))
+    # --- a group of three led by another slot, one member HBM-resident and unpacked; then a "group" of one
+    dev = torch.device("cuda", 0)
+    c5 = epa.encode_queries(4, w["reads"][sum(sizes[:5]):sum(sizes[:6])], compact=True)
+    with pytest.raises(epa.EpaError):                       # mixed layouts in one group: refused, nothing launched
+        ev.chunk_stage(7, *chunks[4]); ev.chunk_stage(5, *c5)
+        ev.chunk_launch_many([7, 5], **kw)
+    # (slot 7 holds chunk 4 packed, slot 5 chunk 5 unpacked: launch them one by one instead)
+    ev.chunk_launch(7, **kw); same(ev.chunk_finish(7), 4)
+    ev.chunk_launch(5, **kw); same(ev.chunk_finish(5), 5)
+    for j, k in ((9, 4), (4, 5), (6, 6)):
+        ev.chunk_stage(j, *chunks[k])
+    ev.chunk_launch_many_begin([9, 4, 6], **kw)
+    with pytest.raises(epa.EpaError):
+        ev.chunk_launch_end(4)                              # a member, not the leader
+    ev.chunk_launch_end(9)
+    for j, k in ((9, 4), (4, 5), (6, 6)):
+        same(ev.chunk_finish(j), k)
+    ev.chunk_stage(2, *chunks[7])
+    ev.chunk_launch_many([2], **kw)
+    same(ev.chunk_finish(2), 7)
+    # --- candidate overflow leaves every member staged: relaunch with room
+    for j in range(3):
+        ev.chunk_stage(j, *chunks[j])
+    with pytest.raises(epa.EpaError) as ei:
+        ev.chunk_launch_many([0, 1, 2], threshold=0.99999, max_span=150, max_pairs=100)
+    assert ei.value.code == -9                          # EPA_ERR_PAIR_OVERFLOW
+    ev.chunk_launch_many([0, 1, 2], **kw)
+    for j in range(3):
+        same(ev.chunk_finish(j), j)
+    # --- the pipelined order of bench.py's chunk5000 leg: groups of four on twelve slots, two groups begun ahead
+    groups = [list(range(8 + 4 * g, 12 + 4 * g)) for g in range(2)] + [[0, 1, 2, 3]]      # chunk indices per group
+    slots_of = lambda g: [(g % 3) * 4 + j for j in range(4)]
+
+    def begin(g):
+        for sl, k in zip(slots_of(g), groups[g]):
+            ev.chunk_stage(sl, *chunks[k])
+        ev.chunk_launch_many_begin(slots_of(g), **kw)
+    begin(0); begin(1)
+    for g in range(len(groups)):
+        ev.chunk_launch_end(slots_of(g)[0])
+        if g >= 1:
+            for sl, k in zip(slots_of(g - 1), groups[g - 1]):
+                same(ev.chunk_finish(sl), k)
+        if g + 2 < len(groups):
+            begin(g + 2)
+    for sl, k in zip(slots_of(len(groups) - 1), groups[-1]):
+        same(ev.chunk_finish(sl), k)
 
 
 def test_queued_thorough_launch_equals_host_launched(monkeypatch):
