@@ -636,9 +636,11 @@ def main():
                    "sample": "%d reads of step 0 through the oracle's OpenMP preplace (B=%d) + thorough "
                              "(%d pairs), lookups prebuilt" % (ns, B, len(prs)),
                    "strict_build_seconds_same_sample": round(strict_t, 2),
-                   "kernels": "4-state x 4-category loops in libpll's AVX2 shape (states of a site = one vector, transposed "
-                              "matrices, omp simd; oracle/epa_oracle.c ORC_FAST_KERNELS); the preplacement gathers are "
-                              "scalar as in src/core/Lookup_Store.hpp:110-141",
+                   "kernels": ("4-state x 4-category loops in libpll's AVX2 shape (states of a site = one vector, transposed "
+                               "matrices, omp simd; oracle/epa_oracle.c ORC_FAST_KERNELS)" if states == 4 else
+                               "20-state x 4-category loops in libpll's AVX2 shape (matrix-vector products accumulate whole columns "
+                               "of the transposed matrix, five 4-wide FMAs per entry, omp simd; oracle/epa_oracle.c ORC_FAST_KERNELS)")
+                              + "; the preplacement gathers are scalar as in src/core/Lookup_Store.hpp:110-141",
                    "fast_vs_strict_max_abs_dlnl": float(np.max(np.abs(tl_fast - tl)))}
         # the optimiser-path rule of the parity sweep (tests/sweep_util.py) on this sample: pairs whose
         # lengths differ from the oracle's own must be reproduced by a rounded sibling of the oracle
@@ -763,7 +765,7 @@ def main():
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "aa", "--tips", "2000", "--width", "500",
                                 "--read-len", "100", "--chunk", "50000", "--steps", "6", "--warmup", "2", "--pool", "3",
-                                "--no-cpu-baseline", "--parity-sample", "400", "--no-extras"],
+                                "--cpu-sample", "1000", "--no-extras"],
                                capture_output=True, text=True, timeout=900)
             aj = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
             extras["cfg3_aa"] = {"value": aj["value"], "unit": aj["unit"], "ms_per_step": aj["ms_per_step"],
@@ -775,6 +777,7 @@ def main():
                                                                                 "sclk_mhz", "frac_at_measured_clock",
                                                                                 "traffic", "traffic_source")},
                                  "roofline_preplace": aj.get("roofline_preplace"),
+                                 "cpu_baseline": aj.get("cpu_baseline"),
                                  "parity": aj.get("parity")}
         except Exception as e:  # noqa: BLE001  (a secondary measurement must never take the bench line down)
             extras["cfg3_aa"] = {"status": "failed: %r" % (e,)}

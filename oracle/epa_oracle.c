@@ -655,6 +655,131 @@ static void lk_derivatives_fast(const orc_model* m, const double* S, size_t n, d
   *d1 = f;
   *d2 = df;
 }
+/* ---- the same four loops for 20 states x 4 categories (the cfg3 CPU baseline): libpll's AVX2 shape for amino
+ * acids -- a matrix-vector product accumulates whole columns of the TRANSPOSED matrix scaled by one entry of
+ * the vector (`y[0..19] += MT[j][0..19] * x[j]`: five 4-wide FMAs per j, no horizontal adds), a tip child
+ * contributes only the columns of its set states. */
+/* (explicit alignment: gcc 11 at -O3 -march=native stores 32-byte vectors to these locals with aligned moves) */
+#define ORC_AL __attribute__((aligned(64)))
+static inline int orc_fast20_ok(const orc_model* m) {
+  return m->s == 20 && m->c == 4 && !m->rate_scalers && !m->rounding_variant && m->pinv == 0.0;
+}
+static inline void matvec_t20(const double* MT, const orc_side* sd, size_t site, int k, double* y) {
+#pragma omp simd
+  for (int i = 0; i < 20; ++i) y[i] = 0.0;
+  if (sd->clv) {
+    const double* x = sd->clv + (site * 4 + k) * 20;
+    for (int j = 0; j < 20; ++j) {
+      const double xj = x[j];
+#pragma omp simd
+      for (int i = 0; i < 20; ++i) y[i] += MT[j * 20 + i] * xj;
+    }
+  } else {
+    uint32_t mk = sd->tipmask[site] & 0xfffffu;
+    for (int j = 0; mk; ++j, mk >>= 1)
+      if (mk & 1u) {
+#pragma omp simd
+        for (int i = 0; i < 20; ++i) y[i] += MT[j * 20 + i];
+      }
+  }
+}
+static inline void transpose_p20(const double* P, double* PT) {   /* P[k][i][j] -> PT[k][j][i] */
+  for (int k = 0; k < 4; ++k)
+    for (int i = 0; i < 20; ++i)
+      for (int j = 0; j < 20; ++j) PT[(k * 20 + j) * 20 + i] = P[(k * 20 + i) * 20 + j];
+}
+static void update_partial_fast20(const orc_side* l, const double* Pl, const orc_side* r, const double* Pr,
+                                  double* parent, uint32_t* parent_sc, size_t b, size_t n) {
+  const double thr = orc_scale_threshold(), fac = orc_scale_factor();
+  ORC_AL double PlT[1600]; ORC_AL double PrT[1600];
+  transpose_p20(Pl, PlT);
+  transpose_p20(Pr, PrT);
+  for (size_t site = b; site < b + n; ++site) {
+    double* p = parent + site * 80;
+    double mx = 0.0;
+    for (int k = 0; k < 4; ++k) {
+      ORC_AL double ta[20]; ORC_AL double tb[20];
+      matvec_t20(PlT + k * 400, l, site, k, ta);
+      matvec_t20(PrT + k * 400, r, site, k, tb);
+#pragma omp simd reduction(max : mx)
+      for (int i = 0; i < 20; ++i) {
+        const double v = ta[i] * tb[i];
+        p[k * 20 + i] = v;
+        mx = v > mx ? v : mx;
+      }
+    }
+    uint32_t sc = (l->scaler ? l->scaler[site] : 0) + (r->scaler ? r->scaler[site] : 0);
+    if (mx < thr) {
+#pragma omp simd
+      for (int x = 0; x < 80; ++x) p[x] *= fac;
+      sc += 1;
+    }
+    parent_sc[site] = sc;
+  }
+}
+static double edge_lnl_fast20(const orc_model* m, const orc_side* par, const orc_side* ch, const double* P,
+                              double* persite, size_t b, size_t n) {
+  const double log_thr = log(orc_scale_threshold());
+  ORC_AL double PT[1600]; double logl = 0.0;
+  transpose_p20(P, PT);
+  for (size_t site = b; site < b + n; ++site) {
+    double terma = 0.0;
+    for (int k = 0; k < 4; ++k) {
+      ORC_AL double tb[20]; double acc = 0.0;
+      matvec_t20(PT + k * 400, ch, site, k, tb);
+      if (par->clv) {
+        const double* pv = par->clv + (site * 4 + k) * 20;
+#pragma omp simd reduction(+ : acc)
+        for (int i = 0; i < 20; ++i) acc += pv[i] * m->freqs[i] * tb[i];
+      } else {
+        uint32_t mk = par->tipmask[site] & 0xfffffu;
+        for (int i = 0; mk; ++i, mk >>= 1)
+          if (mk & 1u) acc += m->freqs[i] * tb[i];
+      }
+      terma += acc * m->weights[k];
+    }
+    const uint32_t sc = (par->scaler ? par->scaler[site] : 0) + (ch->scaler ? ch->scaler[site] : 0);
+    double site_lk = log(terma);
+    if (sc) site_lk += sc * log_thr;
+    if (persite) persite[site] = site_lk;
+    logl += site_lk;
+  }
+  return logl;
+}
+static void update_sumtable_fast20(const orc_model* m, const orc_side* A, const orc_side* Bs, double* S, size_t b, size_t n) {
+  ORC_AL double piU[400]; ORC_AL double UiT[400];   /* piU[i][j] = pi_i U[i][j];  UiT[i][j] = Uinv[j][i] */
+  for (int i = 0; i < 20; ++i)
+    for (int j = 0; j < 20; ++j) { piU[i * 20 + j] = m->freqs[i] * m->u[i * 20 + j]; UiT[i * 20 + j] = m->uinv[j * 20 + i]; }
+  for (size_t site = b; site < b + n; ++site)
+    for (int k = 0; k < 4; ++k) {
+      ORC_AL double lt[20]; ORC_AL double rt[20];
+      matvec_t20(piU, A, site, k, lt);
+      matvec_t20(UiT, Bs, site, k, rt);
+      double* o = S + ((site - b) * 4 + k) * 20;
+#pragma omp simd
+      for (int j = 0; j < 20; ++j) o[j] = lt[j] * rt[j];
+    }
+}
+static void lk_derivatives_fast20(const orc_model* m, const double* S, size_t n, double t, double* d1, double* d2) {
+  ORC_AL double d0[80]; ORC_AL double dg1[80]; ORC_AL double dg2[80];   /* weights folded in */
+  for (int k = 0; k < 4; ++k)
+    for (int j = 0; j < 20; ++j) {
+      const double lr = m->evals[j] * m->rates[k], e0 = exp(lr * t) * m->weights[k];
+      d0[k * 20 + j] = e0; dg1[k * 20 + j] = lr * e0; dg2[k * 20 + j] = lr * lr * e0;
+    }
+  double f = 0.0, df = 0.0;
+  for (size_t x = 0; x < n; ++x) {
+    const double* sm = S + x * 80;
+    double l0 = 0.0, l1 = 0.0, l2 = 0.0;
+#pragma omp simd reduction(+ : l0, l1, l2)
+    for (int j = 0; j < 80; ++j) { l0 += sm[j] * d0[j]; l1 += sm[j] * dg1[j]; l2 += sm[j] * dg2[j]; }
+    const double dv1 = -l1 / l0;
+    f += dv1;
+    df += dv1 * dv1 - l2 / l0;
+  }
+  *d1 = f;
+  *d2 = df;
+}
 #endif /* ORC_FAST_KERNELS */
 
 /* restates pll_update_partials for one op over sites [b, b+n)
@@ -665,6 +790,7 @@ static void update_partial(const orc_model* m, const orc_side* l, const double* 
                            uint32_t* parent_sc, size_t b, size_t n) {
 #ifdef ORC_FAST_KERNELS
   if (orc_fast_ok(m)) { update_partial_fast(l, Pl, r, Pr, parent, parent_sc, b, n); return; }
+  if (orc_fast20_ok(m)) { update_partial_fast20(l, Pl, r, Pr, parent, parent_sc, b, n); return; }
 #endif
   const int s = m->s, c = m->c;
   const double thr = orc_scale_threshold(), fac = orc_scale_factor();
@@ -722,6 +848,7 @@ static double edge_lnl(const orc_model* m, const orc_side* par, const orc_side* 
                        size_t n) {
 #ifdef ORC_FAST_KERNELS
   if (orc_fast_ok(m)) return edge_lnl_fast(m, par, ch, P, persite, b, n);
+  if (orc_fast20_ok(m)) return edge_lnl_fast20(m, par, ch, P, persite, b, n);
 #endif
   const int s = m->s, c = m->c;
   const double log_thr = log(orc_scale_threshold());
@@ -766,6 +893,7 @@ static void update_sumtable(const orc_model* m, const orc_side* A, const orc_sid
                             size_t b, size_t n) {
 #ifdef ORC_FAST_KERNELS
   if (orc_fast_ok(m)) { update_sumtable_fast(m, A, Bs, S, b, n); return; }
+  if (orc_fast20_ok(m)) { update_sumtable_fast20(m, A, Bs, S, b, n); return; }
 #endif
   const int s = m->s, c = m->c;
   for (size_t site = b; site < b + n; ++site) {
@@ -799,6 +927,7 @@ static void lk_derivatives(const orc_model* m, const double* S, size_t n, double
                            const int8_t* invariant, size_t b, double* d1, double* d2) {
 #ifdef ORC_FAST_KERNELS
   if (orc_fast_ok(m)) { lk_derivatives_fast(m, S, n, t, d1, d2); return; }
+  if (orc_fast20_ok(m)) { lk_derivatives_fast20(m, S, n, t, d1, d2); return; }
 #endif
   const int s = m->s, c = m->c;
   double dg[ORC_MAX_C * ORC_MAX_S * 3];
