@@ -174,7 +174,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
   constexpr int CS = NC * S;          // component rows of a reference vector
   __shared__ alignas(16) SharedM<NC> sh;
   const ModelDev* __restrict__ m = a.m;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // wave-uniform values are told to the compiler as such (v_readfirstlane): the pair's ids, window and row
+  // pointers then live in SGPRs, the reference rows are loaded as (scalar base)[lane offset] without a 64-bit
+  // vector add per load, and the per-tile "is this tile inside the window" tests are scalar branches
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kq = lane >> 4;            // component residue of this lane (state 4 t + kq of vector register t)
   const int sl = lane & 15;            // site inside a 16-site tile
   const int aoff = kq * 4 + (lane & 3);  // this lane's element of an A-operand tile
@@ -225,22 +228,24 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
   if (ctr) {
     if (tid == 0) sh.next_pair = atomicAdd(ctr, 1u);
     __syncthreads();
-    cur = sh.next_pair;
+    cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.next_pair);
   }
+  auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
   while (cur < slice_n) {
     uint32_t ahead = 0;
     if (ctr && tid == 0) ahead = atomicAdd(ctr, 1u);
     const uint64_t pidx = slice_lo + cur;
-    const uint64_t pid = a.order ? a.order[pidx] : pidx;
+    const uint64_t pid = a.order ? (uint64_t)uni(a.order[pidx]) : pidx;
     const epa_pair pr = a.pairs[pid];
-    const uint32_t b = pr.branch_id, q = pr.seq_id;
-    const uint32_t begin = a.win_begin[q], n = a.win_span[q];
+    const uint32_t b = uni(pr.branch_id), q = uni(pr.seq_id);
+    const uint32_t begin = uni(a.win_begin[q]), n = uni(a.win_span[q]);
     const size_t cW = a.W;
     const double* Xt = a.refT + (size_t)(2 * b) * CS * cW + begin;       // proximal
     const double* Dt = a.refT + (size_t)(2 * b + 1) * CS * cW + begin;   // distal
     const uint32_t* scp = a.scSum + (size_t)b * cW + begin;
     const uint8_t* qc = a.codes + (size_t)q * a.cstride + (a.crel ? 0u : begin);
-    const double orig = a.blen[b];
+    double orig = a.blen[b];
+    orig = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(orig)), __builtin_amdgcn_readfirstlane(__double2loint(orig)));
 
     // this wave's tiles: tile g = wv + NW j covers sites 16 g .. 16 g + 15 of the window
     // loads are (wave-uniform row pointer)[32-bit lane offset]: scalar base + one offset VGPR per tile,
@@ -645,7 +650,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
       // the last phase of the pair ended with a workgroup barrier: next_pair has been read by all
       if (tid == 0) sh.next_pair = ahead;
       __syncthreads();
-      cur = sh.next_pair;
+      cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.next_pair);
     } else {
       cur += wgs_per_xcd;
     }
