@@ -376,12 +376,30 @@ def main():
         def carried_rows(self):
             return self.comm.carried_rows
 
+    gather_note = []
+
     def make_gather(host_copy):
+        nonlocal gather_path
         if world == 1:
             return None
-        if gather_path == "torch":
-            return parallel.AsyncResultGather(dist, rows_cap, dev, host_copy=host_copy)
-        return ProductGather(host_copy)
+        if gather_path != "torch":
+            # collective creation: if ANY rank cannot create the product's communicator (no RCCL library, an
+            # ncclCommInitRank failure) every rank falls back to the torch.distributed harness together --
+            # the line then says so instead of the job hanging half way
+            g, err = None, ""
+            try:
+                g = ProductGather(host_copy)
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+            ok = torch.tensor([1 if g is not None else 0], dtype=torch.int32, device=cdev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                return g
+            if g is not None:
+                g.comm.abort()
+            gather_note.append("epa_comm gather unavailable on some rank (%s): torch.distributed harness used" % (err or "another rank"))
+            gather_path = "torch"
+        return parallel.AsyncResultGather(dist, rows_cap, dev, host_copy=host_copy)
 
     exch = make_gather(False)
 
@@ -830,8 +848,9 @@ def main():
                        "transport": (("stand-in " + os.path.basename(os.environ["EPA_RCCL_LIB"]) + " (test infrastructure, not a scaling measurement)")
                                      if (gather_path != "torch" and os.environ.get("EPA_RCCL_LIB")) else
                                      ("RCCL" if (gather_path != "torch" or dist.get_backend() == "nccl") else dist.get_backend())),
+                       "fallback": gather_note or None,
                        "rows_cap": rows_cap, "carried_rows_rank0": int(exch.carried_rows + exch2.carried_rows),
-                       "rows_collected_rank0": (int(exch.rows_seen + exch2.rows_seen) if gather_path != "torch" else None)}
+                       "rows_collected_rank0": (int(getattr(exch, "rows_seen", 0) + getattr(exch2, "rows_seen", 0)) if gather_path != "torch" else None)}
                       if world > 1 else None),
            "per_rank_ms_per_step": [round(x / a.steps * 1e3, 3) for x in rank_elapsed["resident"]],
            "roofline": roof, "roofline_preplace": roof_pre, "cpu_baseline": cpu, "parity": parity}

@@ -135,6 +135,22 @@ __device__ __forceinline__ void lds_tiles(const double* U2, int p, int ao, doubl
 __device__ __forceinline__ double ldg_off(const double* base, uint32_t byte_off) {
   return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+// The reference rows of a pair through a buffer descriptor: address = base + (scalar row offset) + (lane offset).
+// The row offset of every (category, state block) is formed on the SCALAR unit and the lane offset is one VGPR
+// per tile -- no vector instruction per load.  (global_load kept the first row of a category in the scalar-base
+// form and chained a 64-bit v_lshl_add_u64 per further row: 8 vector instructions per category step, each paid in
+// full between the fp64 MFMAs, profiles/r4_mfma_fill_microbench.txt.)
+#ifndef AAM_BUFFER_LOADS
+#define AAM_BUFFER_LOADS 1
+#endif
+typedef unsigned int aam_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const double* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ double ldb_off(__amdgpu_buffer_rsrc_t r, uint32_t lane_off, uint32_t row_off) {
+  const aam_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_off, (int)row_off, 0);
+  return __hiloint2double((int)v.y, (int)v.x);
+}
 // combine the four component rows (lanes l, l ^ 16, l ^ 32, l ^ 48) of a site: v_permlane16_swap /
 // v_permlane32_swap of a register with itself put row r ^ 1 (half h ^ 1) beside row r -- four
 // cross-lane instructions and two adds, no LDS round trip (__shfl_xor is ds_bpermute)
@@ -242,6 +258,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
     const size_t cW = a.W;
     const double* Xt = a.refT + (size_t)(2 * b) * CS * cW + begin;       // proximal
     const double* Dt = a.refT + (size_t)(2 * b + 1) * CS * cW + begin;   // distal
+#if AAM_BUFFER_LOADS
+    // one descriptor for both sides of the branch (distal = + CS W doubles), one for the precomputed inner rows
+    const __amdgpu_buffer_rsrc_t rsT = row_rsrc(Xt), rsI = row_rsrc(a.refI ? a.refI + (size_t)b * CS * cW + begin : Xt);
+    const uint32_t side_off = (uint32_t)(CS * cW * 8);
+#endif
     const uint32_t* scp = a.scSum + (size_t)b * cW + begin;
     const uint8_t* qc = a.codes + (size_t)q * a.cstride + (a.crel ? 0u : begin);
     double orig = a.blen[b];
@@ -299,6 +320,23 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
         double Bn[NTS], Dn[NTS];
         auto fetch = [&](int cat, int zf) {
           const uint32_t lof = lo[j] + (uint32_t)zf;   // the token keeps the (read-only, phase-invariant) loads in this phase
+#if AAM_BUFFER_LOADS
+          // (the row pitch re-derived behind the token: twenty loop-invariant row offsets per side would otherwise be
+          // hoisted out of the pair loop into SGPRs the kernel does not have -- spilled, each use a v_readlane)
+          const uint32_t cw8 = uni((uint32_t)cW * 8u + (uint32_t)zf);
+          const uint32_t r0 = (uint32_t)(cat * S) * cw8, rstep = 4u * cw8;   // scalar
+          if (mode == 2) {
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) Bn[t] = ldb_off(rsI, lof, r0 + (uint32_t)t * rstep);
+            return;
+          }
+          const uint32_t ob = mode == 3 ? side_off : 0u, of = mode == 3 ? 0u : side_off;
+#pragma unroll
+          for (int t = 0; t < NTS; ++t) {
+            Bn[t] = ldb_off(rsT, lof, ob + r0 + (uint32_t)t * rstep);
+            Dn[t] = ldb_off(rsT, lof, of + r0 + (uint32_t)t * rstep);
+          }
+#else
           const size_t c0 = (size_t)(cat * S) * cW;   // uniform; component 4 t + kq: + 4 t cW + lo
           if (mode == 2) {
 #pragma unroll
@@ -312,6 +350,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
             Bn[t] = ldg_off(Pb + c0 + (size_t)(4 * t) * cW, lof);
             Dn[t] = ldg_off(Pf + c0 + (size_t)(4 * t) * cW, lof);
           }
+#endif
         };
         fetch(0, zero_after(mant));
 #pragma unroll
