@@ -218,7 +218,13 @@ extern "C" int epa_comm_create(epa_ctx* ctx, const void* id128, int rank, int wo
     }
   }
 #define TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(epa_fail(ctx, EPA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__))); } while (0)
-  TRY(hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking));
+  {
+    // the exchange runs beside the next chunk's kernels, which fill the device: the highest stream priority lets
+    // the (small) pack / send / receive kernels take the first slot that frees up instead of queueing behind them
+    int lo = 0, hi = 0;
+    TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    TRY(hipStreamCreateWithPriority(&c->cs, hipStreamNonBlocking, hi));
+  }
   TRY(hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming));
   TRY(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
   TRY(hipMalloc((void**)&c->d_pend, 16));
