@@ -133,6 +133,10 @@ def dev_lib():
         L.epa_comm_flush.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.epa_comm_carried_rows.argtypes = [C.c_void_p]
         L.epa_comm_carried_rows.restype = C.c_uint64
+        L.epa_dev_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.epa_dev_place_all_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_double,
+                                             C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p),
+                                             C.POINTER(C.c_uint64), C.c_void_p]
         L.epa_comm_abort.argtypes = [C.c_void_p]
         L.epa_comm_abort.restype = None
         L.epa_comm_device_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_int]

@@ -261,11 +261,26 @@ static int grow_carry(epa_comm* c, int which, uint64_t rows) {
   return EPA_OK;
 }
 
+// d_rows != nullptr: the rows are already packed (epa_dev_place_all_rows); else they are made from (pairs, results)
+static int gather_post(epa_ctx* ctx, epa_comm* c, const epa_pair* d_pairs, const epa_result* d_results, const epa_row* d_rows,
+                       uint64_t n, uint32_t seq_offset, uint64_t* ticket);
+
 extern "C" int epa_dev_gather_results(epa_ctx* ctx, epa_comm* c, const epa_pair* d_pairs, const epa_result* d_results,
                                       uint64_t n, uint32_t seq_offset, uint64_t* ticket) {
   if (!ctx || !c || c->ctx != ctx) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "gather_results: communicator of another context");
   if (n && (!epa_is_device_ptr(d_pairs) || !epa_is_device_ptr(d_results)))
     return epa_fail(ctx, EPA_ERR_INVALID_ARG, "gather_results: pairs / results must be device memory (EPA_CHUNK_NO_D2H)");
+  return gather_post(ctx, c, d_pairs, d_results, nullptr, n, seq_offset, ticket);
+}
+
+extern "C" int epa_dev_gather_rows(epa_ctx* ctx, epa_comm* c, const epa_row* d_rows, uint64_t n, uint64_t* ticket) {
+  if (!ctx || !c || c->ctx != ctx) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "gather_rows: communicator of another context");
+  if (n && !epa_is_device_ptr(d_rows)) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "gather_rows: the rows must be device memory");
+  return gather_post(ctx, c, nullptr, nullptr, n ? d_rows : nullptr, n, 0, ticket);
+}
+
+static int gather_post(epa_ctx* ctx, epa_comm* c, const epa_pair* d_pairs, const epa_result* d_results, const epa_row* d_rows,
+                       uint64_t n, uint32_t seq_offset, uint64_t* ticket) {
   Rccl* R = rccl();
   EPA_HIP(ctx, hipSetDevice(ctx->device));
   const uint64_t tk = c->next_ticket;
@@ -285,18 +300,25 @@ extern "C" int epa_dev_gather_results(epa_ctx* ctx, epa_comm* c, const epa_pair*
   epa_row* old = c->carry[c->carry_cur];
   if (from_carry)
     EPA_HIP(ctx, hipMemcpyAsync(dst, old, sizeof(epa_row) * from_carry, hipMemcpyDeviceToDevice, cs));
-  if (from_new)
-    hipLaunchKernelGGL(k_pack_rows, dim3((uint32_t)((from_new + 255) / 256)), dim3(256), 0, cs, d_pairs, d_results,
-                       (uint64_t)0, from_new, seq_offset, dst + from_carry);
+  if (from_new) {
+    if (d_rows) EPA_HIP(ctx, hipMemcpyAsync(dst + from_carry, d_rows, sizeof(epa_row) * from_new, hipMemcpyDeviceToDevice, cs));
+    else
+      hipLaunchKernelGGL(k_pack_rows, dim3((uint32_t)((from_new + 255) / 256)), dim3(256), 0, cs, d_pairs, d_results,
+                         (uint64_t)0, from_new, seq_offset, dst + from_carry);
+  }
   if (left_carry + left_new) {
     const int nx = c->carry_cur ^ 1;
     int rc = grow_carry(c, nx, left_carry + left_new);
     if (rc) return rc;
     if (left_carry)
       EPA_HIP(ctx, hipMemcpyAsync(c->carry[nx], old + from_carry, sizeof(epa_row) * left_carry, hipMemcpyDeviceToDevice, cs));
-    if (left_new)
-      hipLaunchKernelGGL(k_pack_rows, dim3((uint32_t)((left_new + 255) / 256)), dim3(256), 0, cs, d_pairs, d_results,
-                         from_new, left_new, seq_offset, c->carry[nx] + left_carry);
+    if (left_new) {
+      if (d_rows)
+        EPA_HIP(ctx, hipMemcpyAsync(c->carry[nx] + left_carry, d_rows + from_new, sizeof(epa_row) * left_new, hipMemcpyDeviceToDevice, cs));
+      else
+        hipLaunchKernelGGL(k_pack_rows, dim3((uint32_t)((left_new + 255) / 256)), dim3(256), 0, cs, d_pairs, d_results,
+                           from_new, left_new, seq_offset, c->carry[nx] + left_carry);
+    }
     c->carry_cur = nx;
     c->carried_rows += left_new;
   }
@@ -406,7 +428,7 @@ extern "C" int epa_comm_flush(epa_ctx* ctx, epa_comm* c, uint64_t* first_extra_t
   if (first_extra_ticket) *first_extra_ticket = c->next_ticket;
   if (n_extra) *n_extra = (uint32_t)extra;
   for (uint64_t i = 0; i < extra; ++i) {
-    int rc = epa_dev_gather_results(ctx, c, nullptr, nullptr, 0, 0, nullptr);
+    int rc = gather_post(ctx, c, nullptr, nullptr, nullptr, 0, 0, nullptr);
     if (rc) return rc;
   }
   return EPA_OK;

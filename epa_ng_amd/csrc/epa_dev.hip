@@ -2135,6 +2135,80 @@ extern "C" int epa_dev_place_all(epa_ctx* ctx, const uint8_t* q_codes, const uin
   return EPA_OK;
 }
 
+// --no-heur in the one-process-per-GPU mode: the filtered placements of epa_dev_place_all as gather rows.  Query q
+// (count k) owns rows [off_q, off_q + 2 k): per kept placement, best first, its (branch, GLOBAL sequence id, lnL,
+// pendant, distal) row followed by a row {EPA_ROW_LWR, sequence id, lnl = its like-weight ratio} -- the LWR of a
+// --no-heur placement is normalised over ALL B branches (src/core/place.cpp:238 on the full Work), so it cannot be
+// recomputed from the rows that travel.  One 1024-thread workgroup: counts -> offsets (wave scan) -> rows.
+__global__ void __launch_bounds__(1024) k_all_rows(const epa_pair* __restrict__ pairs, const epa_result* __restrict__ res,
+                                                   const double* __restrict__ lwr, const uint32_t* __restrict__ counts, uint32_t Q,
+                                                   uint32_t fmax, uint32_t seq_offset, epa_row* __restrict__ rows,
+                                                   unsigned long long* __restrict__ n_rows) {
+  __shared__ uint32_t wsum[16];
+  const uint32_t t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const uint32_t per = (Q + 1023) / 1024;
+  const uint32_t lo = t * per < Q ? t * per : Q, hi = lo + per < Q ? lo + per : Q;
+  uint32_t mine = 0;
+  for (uint32_t q = lo; q < hi; ++q) mine += 2u * counts[q];
+  uint32_t v = mine;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t u = __shfl_up(v, d, 64);
+    if ((int)lane >= d) v += u;
+  }
+  if (lane == 63) wsum[wv] = v;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (int w = 0; w < 16; ++w) { const uint32_t x = wsum[w]; total += x; if (w < (int)wv) before += x; }
+  uint32_t o = before + v - mine;
+  if (t == 0) *n_rows = total;
+  for (uint32_t q = lo; q < hi; ++q) {
+    const uint32_t k = counts[q];
+    for (uint32_t i = 0; i < k; ++i) {
+      const size_t src = (size_t)q * fmax + i;
+      epa_row r;
+      r.branch_id = pairs[src].branch_id;
+      r.seq_id = pairs[src].seq_id + seq_offset;
+      r.lnl = res[src].lnl; r.pendant_length = res[src].pendant_length; r.distal_length = res[src].distal_length;
+      rows[o++] = r;
+      epa_row w;
+      w.branch_id = EPA_ROW_LWR; w.seq_id = r.seq_id; w.lnl = lwr[src]; w.pendant_length = 0.0; w.distal_length = 0.0;
+      rows[o++] = w;
+    }
+  }
+}
+
+extern "C" int epa_dev_place_all_rows(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_begin, const uint32_t* win_span,
+                                      uint32_t Q, uint32_t max_span, double min_lwr, int acc_threshold, uint32_t filter_min,
+                                      uint32_t filter_max, uint32_t seq_offset, const epa_row** d_rows, uint64_t* n_rows,
+                                      epa_thorough_stats* stats) {
+  if (!ctx || !d_rows || !n_rows) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "null argument");
+  *d_rows = nullptr;
+  *n_rows = 0;
+  if (Q == 0) return EPA_OK;
+  if (filter_max < 1 || filter_max > 64) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "place_all: need 1 <= filter_min <= filter_max <= 64");
+  EPA_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t slots = (size_t)Q * filter_max;
+  const size_t off_r = (sizeof(epa_pair) * slots + 255) & ~(size_t)255;
+  const size_t off_l = off_r + ((sizeof(epa_result) * slots + 255) & ~(size_t)255);
+  const size_t off_c = off_l + ((sizeof(double) * slots + 255) & ~(size_t)255);
+  const size_t off_n = off_c + ((sizeof(uint32_t) * Q + 255) & ~(size_t)255);
+  char* out = (char*)epa_scratch(ctx, 11, off_n + 256);
+  epa_row* rows = (epa_row*)epa_scratch(ctx, 12, sizeof(epa_row) * 2 * slots);
+  if (!out || !rows) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(place_all rows)");
+  int rc = epa_dev_place_all(ctx, q_codes, win_begin, win_span, Q, max_span, min_lwr, acc_threshold, filter_min, filter_max,
+                             (epa_pair*)out, (epa_result*)(out + off_r), (double*)(out + off_l), (uint32_t*)(out + off_c), stats);
+  if (rc) return rc;
+  unsigned long long* d_n = (unsigned long long*)(out + off_n);
+  hipLaunchKernelGGL(k_all_rows, dim3(1), dim3(1024), 0, ctx->stream, (const epa_pair*)out, (const epa_result*)(out + off_r),
+                     (const double*)(out + off_l), (const uint32_t*)(out + off_c), Q, filter_max, seq_offset, rows, d_n);
+  unsigned long long h_n = 0;
+  EPA_HIP(ctx, hipMemcpyAsync(&h_n, d_n, sizeof(h_n), hipMemcpyDeviceToHost, ctx->stream));
+  EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *d_rows = rows;
+  *n_rows = h_n;
+  return EPA_OK;
+}
+
 extern "C" int epa_dev_mem_info(epa_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes) {
   if (!ctx) return EPA_ERR_INVALID_ARG;
   EPA_HIP(ctx, hipSetDevice(ctx->device));

@@ -180,7 +180,7 @@ struct epa_ctx {
   // Banks: 0 = the direct entry points (caller's stream), 1 .. N_SLOTS = the slots of the chunk
   // pipeline, whose kernels run concurrently on their own streams and therefore share no scratch
   // (allocated on first use: a two-slot caller pays for two).
-  static constexpr int N_SCRATCH = 11;
+  static constexpr int N_SCRATCH = 13;
   static constexpr int N_SLOTS = 24;
   static constexpr int N_BANKS = 1 + N_SLOTS;
   int bank = 0;

@@ -104,7 +104,11 @@ Run_Stats simple_mpi_ranks(const Tree& tree, const std::string& query_file, cons
                            const std::string& outdir, const Options& options, const std::string& invocation,
                            int device, int rank, int world, const std::string& comm_file) {
   using clk = std::chrono::steady_clock;
-  if (!options.prescoring) throw std::runtime_error{"--no-heur is not available in the one-process-per-GPU mode"};
+  // --no-heur (prescoring == false, src/core/place.cpp:219-231): every branch is placed thoroughly, LWR over all of them
+  // and the filter run on the device (epa_dev_place_all_rows); the kept placements travel WITH their like-weight ratios
+  const bool no_heur = !options.prescoring;
+  if (no_heur && !(options.filter_min >= 1 && options.filter_max >= options.filter_min && options.filter_max <= 64))
+    throw std::runtime_error{"--no-heur in the one-process-per-GPU mode needs 1 <= --filter-min <= --filter-max <= 64"};
   const int64_t started = unix_ms();
   unsigned char id[EPA_COMM_ID_BYTES] = {};
   // rank 0 replaces the id file before anything slow (the reference precompute, the scan of the query
@@ -135,6 +139,7 @@ Run_Stats simple_mpi_ranks(const Tree& tree, const std::string& query_file, cons
   const auto slice = local_seq_package(total, rank, world);
   size_t per_chunk = options.chunk_size;
   if (!options.chunk_size_given || options.device_min_chunk_given) per_chunk = std::max<size_t>(per_chunk, options.device_min_chunk);
+  if (no_heur) per_chunk = std::max<size_t>(1, std::min<size_t>(per_chunk, 0xffffffffull / std::max<size_t>(1, tree.num_branches())));   // B x Q pairs per call < 2^32
   const size_t part = (total + (size_t)world - 1) / (size_t)world;
   const size_t nchunks = (part + per_chunk - 1) / per_chunk;   // the SAME on every rank: posts are collective
   // rows per rank and gather: candidates per read average 2 .. 3 under the default heuristic; beyond that
@@ -174,20 +179,30 @@ Run_Stats simple_mpi_ranks(const Tree& tree, const std::string& query_file, cons
     const auto t0 = clk::now();
     std::unordered_map<uint32_t, size_t> at;
     Sample smp;
+    size_t n_placements = 0;
     for (const epa_row& r : rows) {   // arrival order = (chunk, branch) order: kept inside every pquery
       auto it = at.find(r.seq_id);
+      if (r.branch_id == EPA_ROW_LWR) {   // --no-heur: the like-weight ratio of the placement row just before it
+        if (it == at.end() || smp[it->second].size() == 0) throw std::runtime_error{"LWR row without its placement"};
+        PQuery& pq = smp[it->second];
+        pq[pq.size() - 1].lwr(r.lnl);
+        continue;
+      }
       if (it == at.end()) {
         it = at.emplace(r.seq_id, smp.size()).first;
         smp.emplace_back((size_t)r.seq_id, headers.at(r.seq_id));
       }
       smp[it->second].emplace_back((size_t)r.branch_id, r.lnl, r.pendant_length, r.distal_length);
+      ++n_placements;
     }
     std::stable_sort(smp.begin(), smp.end(), [](const PQuery& a, const PQuery& b) { return a.sequence_id() < b.sequence_id(); });
-    st.pairs += rows.size();
+    st.pairs += no_heur ? smp.size() * tree.num_branches() : n_placements;
     st.queries += smp.size();
     rows.clear();
-    compute_and_set_lwr(smp);
-    filter(smp, options);
+    if (!no_heur) {   // (--no-heur: LWR and filter ran on the device, over all branches)
+      compute_and_set_lwr(smp);
+      filter(smp, options);
+    }
     const auto t1 = clk::now();
     const std::string text = jplace_chunk_text(smp, options.precision, &tree.mapper());
     if (!text.empty()) {
@@ -235,7 +250,25 @@ Run_Stats simple_mpi_ranks(const Tree& tree, const std::string& query_file, cons
     if (done < slice.second) reader.read_next(chunk, std::min(per_chunk, slice.second - done));
     st.seconds_read += std::chrono::duration<double>(clk::now() - r0).count();
     const auto t0 = clk::now();
-    if (!chunk.empty()) {
+    if (!chunk.empty() && no_heur) {
+      if (premask) chunk = subset_msa(chunk, msa_info.gap_mask());
+      const Encoded_Chunk enc = encode_chunk(chunk, tree, options);
+      const size_t Q = chunk.size();
+      uint32_t max_span = 0;
+      for (uint32_t s : enc.win_span) max_span = std::max(max_span, s);
+      epa_dev_set_query_layout(dev.ctx(), enc.stride);
+      epa_dev_set_query_packing(dev.ctx(), enc.bits);
+      const epa_row* d_rows = nullptr;
+      uint64_t n_rows = 0;
+      rc = epa_dev_place_all_rows(dev.ctx(), enc.codes.data(), enc.win_begin.data(), enc.win_span.data(), (uint32_t)Q, max_span,
+                                  options.support_threshold, options.acc_threshold ? 1 : 0, options.filter_min, options.filter_max,
+                                  (uint32_t)(slice.first + done), &d_rows, &n_rows, nullptr);
+      if (rc == EPA_ERR_NEG_INF) throw std::runtime_error{epa_dev_last_error(dev.ctx())};
+      if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
+      rc = epa_dev_gather_rows(dev.ctx(), comm, d_rows, n_rows, &tickets[k]);
+      if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
+      done += Q;
+    } else if (!chunk.empty()) {
       if (premask) chunk = subset_msa(chunk, msa_info.gap_mask());
       const Encoded_Chunk enc = encode_chunk(chunk, tree, options);
       const size_t Q = chunk.size();
@@ -270,7 +303,7 @@ Run_Stats simple_mpi_ranks(const Tree& tree, const std::string& query_file, cons
       if (rc == EPA_ERR_NEG_INF) throw std::runtime_error{epa_dev_last_error(dev.ctx())};
       if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
     }
-    prev_slot = chunk.empty() ? -1 : slot;
+    prev_slot = (chunk.empty() || no_heur) ? -1 : slot;
     st.seconds_place += std::chrono::duration<double>(clk::now() - t0).count();
     if (rank == 0 && k >= 1) collect(tickets[k - 1]);
   }

@@ -443,6 +443,17 @@ void epa_comm_destroy(epa_comm* comm);
 int epa_dev_gather_results(epa_ctx* ctx, epa_comm* comm, const epa_pair* d_pairs, const epa_result* d_results,
                            uint64_t n, uint32_t seq_offset, uint64_t* ticket);
 int epa_dev_gather_slot(epa_ctx* ctx, epa_comm* comm, int slot, uint32_t seq_offset, uint64_t* ticket);
+/* --no-heur (src/core/place.cpp:219-231 with prescoring == false) in the one-process-per-GPU mode: epa_dev_place_all with
+ * its filtered placements left in HBM as gather rows -- per kept placement, best first, its row followed by a row
+ * {branch_id = EPA_ROW_LWR, seq_id, lnl = its like-weight ratio} (normalised over ALL branches on the device: it cannot
+ * be recomputed from the kept rows) -- and epa_dev_gather_rows posts such rows (collective, asynchronous, carry-over:
+ * exactly as epa_dev_gather_results).  *d_rows stays valid until the context's next place_all_rows call. */
+#define EPA_ROW_LWR 0xfffffffeu
+int epa_dev_place_all_rows(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_begin, const uint32_t* win_span,
+                           uint32_t Q, uint32_t max_span, double min_lwr, int acc_threshold, uint32_t filter_min,
+                           uint32_t filter_max, uint32_t seq_offset, const epa_row** d_rows, uint64_t* n_rows,
+                           epa_thorough_stats* stats);
+int epa_dev_gather_rows(epa_ctx* ctx, epa_comm* comm, const epa_row* d_rows, uint64_t n, uint64_t* ticket);
 int epa_comm_collect(epa_comm* comm, uint64_t ticket, const epa_row** rows, uint32_t* counts, uint64_t* pending);
 /* rows == NULL in epa_comm_collect: counts / pending only, the rows stay in HBM; this is rank r's block
  * of gather `ticket` there (valid until gather ticket + depth is posted; NULL if the slot was reused) */

@@ -392,3 +392,34 @@ def test_cli_n_processes_on_one_gpu_same_jplace(tmp_path, world, rows_per_read, 
     assert sorted(a["placements"], key=key) == sorted(b["placements"], key=key)
     assert a["tree"] == b["tree"]
     assert not idf.exists()        # rank 0 removes the id file once the communicator exists
+
+
+@pytest.mark.parametrize("world,standin", [(1, False), (3, True), (8, True)])
+def test_cli_rank_mode_no_heur_same_jplace(tmp_path, world, standin):
+    """--no-heur (every branch placed thoroughly, LWR over ALL branches + filter on the device) in the one-process-per-GPU
+    mode: the kept placements travel as gather rows together with their like-weight ratios (epa_dev_place_all_rows /
+    epa_dev_gather_rows; EPA_ROW_LWR rows) -- rows_per_read = 1 forces the carry path, so a placement and its LWR row
+    arrive in different gathers.  Same jplace as the threaded chunk loop's --no-heur.  world = 1: real RCCL with rank 0
+    sending to itself; world = 3 / 8: the transport stand-in (8 ranks over 60 reads in 10-read chunks: short and empty
+    trailing slices)."""
+    import fake_rccl_util
+    base, load = _cli_case(tmp_path, nreads=60)
+    base = [x if x != "100" else "10" for x in base] + ["--no-heur"]        # --chunk-size 10
+    ref_dir = tmp_path / "out_threads"
+    ref_dir.mkdir()
+    r = subprocess.run(base + ["-w", str(ref_dir)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    od = tmp_path / "out_ranks"
+    od.mkdir()
+    env = dict(os.environ, EPA_COMM_ROWS_PER_READ="1")
+    if standin:
+        env = fake_rccl_util.env(env)
+    else:
+        env["EPA_COMM_SELF_SEND"] = "1"
+    procs, outs = _run_ranks([(base + ["-w", str(od), "--rank", str(k), "--world", str(world), "--device", "0",
+                                       "--comm-file", str(tmp_path / "uid")], env) for k in range(world)])
+    assert all(p.returncode == 0 for p in procs), outs
+    a, b = load(ref_dir), load(od)
+    key = lambda p: p["n"][0]
+    assert len(b["placements"]) == 60
+    assert sorted(a["placements"], key=key) == sorted(b["placements"], key=key)
