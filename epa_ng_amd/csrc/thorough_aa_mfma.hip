@@ -227,6 +227,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
   uint32_t wrounds = 0, wevals = 0, wreverts = 0;
 #ifdef AAM_PROFILE
   long long cyc_phase = 0, cyc_newton = 0, cyc_pub = 0, cyc_total = 0, n_phase = 0, n_pairs_done = 0;
+  long long cyc_d[5] = {0, 0, 0, 0, 0};   // per evaluation: exp + table write | barrier | table reads + MFMAs + ratios | wave sum + exchange write | barrier + cross-wave sum
   const long long cyc_begin = clock64();
 #endif
   // Workgroup g runs on XCD g % 8 (observed; used for speed only): XCD x owns the x-th eighth of the
@@ -485,10 +486,19 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
     // column 3 zeros); D puts l_0, l_1, l_2 of a site in lanes 0, 1, 2 of one quad
     uint32_t evals = 0;
     auto derivatives = [&](double t, double& f, double& df) {
+#ifdef AAM_PROFILE
+      const long long d0_ = clock64();
+#endif
 #pragma unroll
       for (int i = 0; i < NE; ++i)
         if (tid + i * NTHR < NENT) sh.tab[tslot[i]][tpos[i]] = exp_tab(t_lr[i] * t, sh.e2t) * t_c[i];
+#ifdef AAM_PROFILE
+      const long long d1_ = clock64();
+#endif
       __syncthreads();
+#ifdef AAM_PROFILE
+      const long long d2_ = clock64();
+#endif
       const int row = lane & 3;
       double fl = 0.0, dfl = 0.0;
       // the B operands (this lane's five table entries of each category) are the same for every tile:
@@ -520,17 +530,27 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
           dfl += fma(d1, d1, -l2 * inv);
         }
       }
+#ifdef AAM_PROFILE
+      const long long d3_ = clock64() + (long long)(fl != 12345.678 ? 0 : 1);
+#endif
       double ft, dft;
       wave_sum2(fl, dfl, ft, dft);
       if (lane == 0) { sh.bc[wv] = ft; sh.bc[8 + wv] = dft; }
+#ifdef AAM_PROFILE
+      const long long d4_ = clock64() + (long long)(ft != 12345.678 ? 0 : 1);
+#endif
       __syncthreads();   // also: every wave is past its table reads
       f = sum_waves<NW>(sh.bc);
       df = sum_waves<NW>(sh.bc + 8);
       ++evals;
+#ifdef AAM_PROFILE
+      const long long d5_ = clock64() + (long long)(f != 12345.678 ? 0 : 1);
+      cyc_d[0] += d1_ - d0_; cyc_d[1] += d2_ - d1_; cyc_d[2] += d3_ - d2_; cyc_d[3] += d4_ - d3_; cyc_d[4] += d5_ - d4_;
+#endif
     };
 
     // pllmod_opt_minimize_newton (rtsafe-style), uniform across the workgroup
-    auto newton = [&](double x1, double xguess, double x2, double tol, int max_iters) -> double {
+    auto newton_body = [&](double x1, double xguess, double x2, double tol, int max_iters) -> double {
       double rts = xguess, f, df, xl, xh, dx;
       if (rts < x1) rts = x1;
       if (rts > x2) rts = x2;
@@ -559,6 +579,19 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
       return NAN;
     };
 
+    // A Newton solve is a chain of short dependent steps (exp, table round trip, 40 MFMAs, ratios, reductions, two
+    // barriers, the scalar decisions): while it runs its wave is raised above the OTHER workgroup's wave on the same
+    // SIMD, which is typically streaming the 75-MFMA tile bodies of a phase -- the latency-bound wave issues as soon as
+    // the matrix pipe frees up instead of queueing behind an equally old stream (s_setprio; AAM_SETPRIO=0: off)
+#ifndef AAM_SETPRIO
+#define AAM_SETPRIO 1
+#endif
+    auto newton = [&](double x1, double xguess, double x2, double tol, int max_iters) -> double {
+      if (AAM_SETPRIO) __builtin_amdgcn_s_setprio(3);
+      const double r = newton_body(x1, xguess, x2, tol, max_iters);
+      if (AAM_SETPRIO) __builtin_amdgcn_s_setprio(0);
+      return r;
+    };
     double tp = a.blo.pendant_default, td = orig * 0.5, tx = orig * 0.5;
     uint32_t rounds = 0, reverted = 0;
     // window lnL at the pendant length of table slot 2 from the sumtable in registers (LOCAL only:
@@ -697,8 +730,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
 #ifdef AAM_PROFILE
   cyc_total = clock64() - cyc_begin;
   if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 777))
-    printf("AAM blk %d: pairs %lld total %lld phase %lld (%lld phases) newton %lld (%u evals) publish %lld\n", (int)blockIdx.x,
-           n_pairs_done, cyc_total, cyc_phase, n_phase, cyc_newton, wevals, cyc_pub);
+    printf("AAM blk %d: pairs %lld total %lld phase %lld (%lld phases) newton %lld (%u evals) publish %lld | per eval: exp+write %lld barrier %lld reads+mfma+ratio %lld wavesum+write %lld barrier+sum %lld\n", (int)blockIdx.x,
+           n_pairs_done, cyc_total, cyc_phase, n_phase, cyc_newton, wevals, cyc_pub, cyc_d[0] / (wevals ? wevals : 1), cyc_d[1] / (wevals ? wevals : 1),
+           cyc_d[2] / (wevals ? wevals : 1), cyc_d[3] / (wevals ? wevals : 1), cyc_d[4] / (wevals ? wevals : 1));
 #endif
   if (tid == 0) {
     atomicAdd(&a.stats[0], (unsigned long long)wrounds);
