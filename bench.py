@@ -355,12 +355,15 @@ def main():
         def post(self, pairs, res, n):
             # global sequence id of this rank's first read of the step (contiguous slices, local_seq_package)
             off = ((self.posted * world + rank) * a.chunk) & 0x7fffffff
-            t = self.comm.post(pairs, res, n, seq_offset=off)
-            self.posted += 1
-            if rank == 0:                                  # a gather posted `depth - 1` chunks ago has landed
-                for u in range(self.collected, t - (self.depth - 1) + 1):
+            if rank == 0:
+                # the laziest schedule the slots allow: gather T reuses the slot of gather T - depth, so that one is
+                # collected right before T is posted -- it has had `depth` whole steps to land, rank 0's host never
+                # waits for a transfer that is still queued behind the next chunk's kernels
+                for u in range(self.collected, self.posted - self.depth + 1):
                     self._collect(u)
-                self.collected = max(self.collected, t - (self.depth - 1) + 1)
+                self.collected = max(self.collected, self.posted - self.depth + 1)
+            self.comm.post(pairs, res, n, seq_offset=off)
+            self.posted += 1
 
         def finish(self):
             if rank == 0:

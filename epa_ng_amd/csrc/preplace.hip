@@ -641,7 +641,11 @@ __device__ __forceinline__ uint32_t choose_tile(uint32_t ng, uint32_t B, uint32_
 #else
 #define PP_SCHED_BARRIER()
 #endif
-template <bool ACC, int SPR, int ROWL, bool DB = false>
+// DUO (with DB's two-buffer layout): the slices of TWO consecutive branches are staged between one pair of barriers
+// and gathered together -- a query's offsets are extracted once for both (the second slice sits DB_OFF further on, an
+// immediate of its ds_reads: 1.5 instead of 2 vector instructions per gather), and the drain of the workgroup's 16
+// waves at the barrier (1200 of 5200 clocks per branch, profiles/r4_preplace_cycles.txt) is paid once per two branches.
+template <bool ACC, int SPR, int ROWL, bool DB = false, bool DUO = false>
 __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     const double* __restrict__ lookup2, const uint16_t* __restrict__ packed,
     const uint16_t* __restrict__ tails, const uint32_t* __restrict__ win_begin,
@@ -653,7 +657,11 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [TR2][PE] doubles, then accs
   static_assert(ROWL % 16 == 0 && ROWL >= PROWB && ((TR2 - 1) * ROWL + PROWB) < 65536, "16-bit LDS offsets");
   static_assert(!DB || !ACC, "double-buffered slices: single-chunk variant only");
-  constexpr uint32_t DB_OFF = (uint32_t)TR2 * ROWL;   // byte offset of the second slice buffer
+  static_assert(!DUO || DB, "two branches per stage use the two-buffer layout");
+  // byte offset of the second slice buffer.  DUO: + 256 B (same banks) so that it is NOT a multiple of 512 -- with a
+  // multiple the compiler fuses the two slices' gathers of one offset into ds_read2st64_b64, which serves these
+  // scattered 8-byte reads at half the rate of two ds_read_b64 (1.47 against 0.97 ms per launch)
+  constexpr uint32_t DB_OFF = (uint32_t)TR2 * ROWL + (DUO ? 256u : 0u);
   double* accs = reinterpret_cast<double*>(smem + (DB ? DB_OFF + (size_t)db_rows * ROWL : (size_t)TR2 * ROWL));  // [NB2_ACC][GQ2] / burst rows
   __shared__ uint32_t s_maxspan;
   __shared__ uint32_t s_qi[DB ? 1 : GQ2];   // query of thread t (burst write-out), ~0 = nothing to write
@@ -845,7 +853,57 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
         __builtin_amdgcn_wave_barrier();
       }
     };
-    if constexpr (DB) {
+    if constexpr (DUO) {
+      // sums of branches j (slice A) and j + 1 (slice B) of this thread's query; same association order as gather()
+      auto gather2 = [&](uint32_t j, bool two) {
+        if (mine) {
+          double sumA = 0.0, sumB = 0.0;
+#pragma unroll
+          for (int i = 0; i < PW; ++i) asm volatile("" : "+v"(cw[i]));
+          double ra[2][2], rbb[2][2];
+          auto issue = [&](int bt) {
+            const uint32_t v = cw[bt];
+            const uint32_t o0 = v & 0xffffu, o1 = v >> 16;
+            ra[bt & 1][0] = at(o0);
+            ra[bt & 1][1] = at(o1);
+            rbb[bt & 1][0] = at(o0 + DB_OFF);
+            rbb[bt & 1][1] = at(o1 + DB_OFF);
+          };
+          issue(0);
+#pragma unroll
+          for (int bt = 0; bt < PW; ++bt) {
+            if (bt + 1 < PW) issue(bt + 1);
+            sumA += ra[bt & 1][0] + ra[bt & 1][1];      // (a0+a1) + (a2+a3)
+            sumB += rbb[bt & 1][0] + rbb[bt & 1][1];
+          }
+          if (c == tailchunk) {  // singles of the window tail, in order
+            sumA += at(t0); sumA += at(t1); sumA += at(t2);
+            sumB += at(t0 + DB_OFF); sumB += at(t1 + DB_OFF); sumB += at(t2 + DB_OFF);
+          }
+          accs[(j & 7u) * BSTR + t] = sumA;
+          if (segmax) seg.add(segmax, segp, qi, b0 + j, j + 1 == nb, sumA);
+          if (two) {
+            accs[((j + 1) & 7u) * BSTR + t] = sumB;
+            if (segmax) seg.add(segmax, segp, qi, b0 + j + 1, j + 2 == nb, sumB);
+          }
+        }
+      };
+      double2 pfa[PF], pfb[PF];
+      request(0, pfa);
+      if (nb > 1) request(1, pfb);
+      for (uint32_t j = 0; j < nb; j += 2) {
+        const bool two = j + 1 < nb;
+        __syncthreads();                    // the previous pair's readers are done with both buffers
+        stage(pfa, 0);
+        if (two) stage(pfb, DB_OFF);
+        __syncthreads();
+        if (j + 2 < nb) request(j + 2, pfa);
+        if (j + 3 < nb) request(j + 3, pfb);
+        gather2(j, two);
+        flush(j);
+        if (two) flush(j + 1);
+      }
+    } else if constexpr (DB) {
       double2 pf[PF];
       request(0, pf);
       __syncthreads();                      // both buffers are free (the previous item's consumers are done)
@@ -1696,8 +1754,14 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     // measured (round 4, same box): 0.966 ms double-buffered against 0.930 ms single-buffered per 100k-read launch --
     // the gather phase is bound by the LDS itself, overlapping staging / write-out with it buys nothing: opt-in only
     static const bool db_off = getenv("EPA_PREPLACE_DB") == nullptr;
+    static const bool duo = getenv("EPA_PREPLACE_DUO") != nullptr && atoi(getenv("EPA_PREPLACE_DUO")) != 0;
     if (acc) PRE2(true, SPREAD, ROWL_PACKED, lds2);
-    else if (!db_off && lds_db + 64 <= 163840) {
+    else if (duo && lds_db + 256 + 64 <= 163840) {
+      EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<false, SPREAD, ROWL_NARROW, true, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_db + 256)));
+      hipLaunchKernelGGL((k_preplace_pairs<false, SPREAD, ROWL_NARROW, true, true>), grid2, dim3(GQ2), lds_db + 256, ctx->stream, ctx->lookup2,
+                         packed, tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl, db_rows, segmax, segp);
+    } else if (!db_off && lds_db + 64 <= 163840) {
       EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<false, SPREAD, ROWL_NARROW, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_db));
       hipLaunchKernelGGL((k_preplace_pairs<false, SPREAD, ROWL_NARROW, true>), grid2, dim3(GQ2), lds_db, ctx->stream, ctx->lookup2,
