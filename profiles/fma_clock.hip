@@ -69,8 +69,10 @@ int main() {
     std::sort(mhz.begin(), mhz.end());
     std::sort(cyc.begin(), cyc.end());
     const double fl = (double)grid * 256 * iters * 32.0 * 2;
-    // a SIMD executes waves_per_simd waves x 32 x iters wave-level FMAs during the median wave's cycles
-    const double cpf = cyc[cyc.size() / 2] / ((double)waves_per_simd * 32.0 * iters);
+    // a SIMD executes waves_per_simd waves x 32 x iters wave-level FMAs during the launch: wall time x the clock the
+    // waves saw (a single wave's own cycle count is shorter than the launch when the waves of a SIMD do not all start together)
+    const double cpf = (double)ms * 1e-3 * mhz[mhz.size() / 2] * 1e6 / ((double)waves_per_simd * 32.0 * iters);
+    (void)cyc;
     printf("  %9d  %6d  %7d  %9.3f  %8.2f  %13.0f  %8.0f..%-8.0f  %10.3f\n", waves_per_simd, chains, iters, ms, fl / ms / 1e9,
            mhz[mhz.size() / 2], mhz.front(), mhz.back(), cpf);
   };
