@@ -674,9 +674,9 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   // the tuned thorough kernels are built for 4 categories (the Newton-variant switches exist to pin
   // parity once a reference build is at hand, not for production runs: they are served by the general
   // kernel too, the tuned kernels cost 1.7 % with them).  --raxml-blo has tuned instantiations for
-  // nucleotide models without +I (k_thorough_dna<.., LOCAL>) and for 20-state models
-  // (k_thorough_aa_mfma<.., LOCAL>); everything else local goes general.
-  const bool tuned_local = (s == 4 && ctx->dna_zero0 && !(pinv > 0.0)) || s == 20;
+  // nucleotide models with an exact zero eigenvalue, with or without +I (k_thorough_dna<.., INV, .., LOCAL>),
+  // and for 20-state models (k_thorough_aa_mfma<.., LOCAL>); everything else local goes general.
+  const bool tuned_local = (s == 4 && ctx->dna_zero0) || s == 20;
   // (more than 4 categories: tuned for nucleotide models, sliding rule, zero eigenvalue -- the class
   // launcher of thorough_dna.hip sends what it does not serve to the general kernel itself)
   const bool tuned_cats = c == 4 || (dna_groups && ctx->blo.sliding && ctx->dna_zero0 && !getenv("EPA_NO_CAT_GROUPS")) ||

@@ -1577,10 +1577,13 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
     constexpr bool TH_ = (NW_) == 1 && ((N) == 2 || (N) == 3);   /* half-chunk tail instantiations exist for these */  \
     if (tailh && TH_ && ctx->dna_zero0 && !ctx->blo.sliding && !a.cinv)                                                \
       hipLaunchKernelGGL((k_thorough_dna<N, true, false, 1, true, TH_>), dim3(nwg), dim3(64), 0, ctx->stream, a);      \
+    else if (tailh && TH_ && ctx->dna_zero0 && !ctx->blo.sliding)   /* --raxml-blo with +I */                          \
+      hipLaunchKernelGGL((k_thorough_dna<N, true, true, 1, true, TH_>), dim3(nwg), dim3(64), 0, ctx->stream, a);       \
     else if (tailh && TH_ && ctx->dna_zero0 && ctx->blo.sliding && a.cinv)                                            \
       hipLaunchKernelGGL((k_thorough_dna<N, true, true, 1, false, TH_>), dim3(nwg), dim3(64), 0, ctx->stream, a);      \
     else if (tailh && TH_ && ctx->dna_zero0 && ctx->blo.sliding)                                                       \
       hipLaunchKernelGGL((k_thorough_dna<N, true, false, 1, false, TH_>), dim3(nwg), dim3(64), 0, ctx->stream, a);     \
+    else if (!ctx->blo.sliding && a.cinv) hipLaunchKernelGGL((k_thorough_dna<N, true, true, NW_, true>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
     else if (!ctx->blo.sliding) hipLaunchKernelGGL((k_thorough_dna<N, true, false, NW_, true>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
     else if (a.cinv) hipLaunchKernelGGL((k_thorough_dna<N, true, true, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \
     else if (ctx->dna_zero0) hipLaunchKernelGGL((k_thorough_dna<N, true, false, NW_>), dim3(nwg), dim3(64 * (NW_)), 0, ctx->stream, a); \

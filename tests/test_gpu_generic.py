@@ -218,10 +218,10 @@ def test_raxml_blo_local_optimisation(states, rs):
     assert np.all(res["lnl"] >= sliding["lnl"] - 0.5)
 
 
-@pytest.mark.parametrize("states,pinv", [(4, 0.0), (20, 0.0), (20, 0.2)])
+@pytest.mark.parametrize("states,pinv", [(4, 0.0), (4, 0.15), (20, 0.0), (20, 0.2)])
 def test_raxml_blo_tuned_kernels_equal_general_kernel(monkeypatch, states, pinv):
     """--raxml-blo runs on the LOCAL instantiations of k_thorough_dna (register sumtable, 1 - 8 waves per
-    pair) and k_thorough_aa_mfma (windows up to 192 sites; +I included); the general kernel
+    pair; with +I since round 5) and k_thorough_aa_mfma (windows up to 192 sites; +I included); the general kernel
     (EPA_TH_GENERIC=1) is the cross-check.  The window lengths cover every span class of the tuned
     kernels and, for 20 states, the hand-over to the general kernel beyond 192 sites."""
     root = synth.random_tree(40, 61)
