@@ -405,3 +405,13 @@ np.save(sys.argv[1], ev.preplace(codes, wb, ws))
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(out))
     assert outs[0].shape[0] == 3000 and np.array_equal(outs[0], outs[1])
+
+
+def test_noise_flat_pair_of_the_round5_hand_run():
+    """Seed 10714 of round 5's hand run (profiles/r5_sweep_10000_11999.log): 1-site reads under alpha = 0.05 on a 90-tip
+    tree -- for one pair the likelihood is numerically constant in BOTH lengths (every derivative along the oracle's own
+    path is ~1e-15), the device and the oracle end at different lengths with the same lnL to 3e-13, and no single
+    rounding sibling reproduces the device's combination of end points.  The rule's noise-flat clause (sweep_util)
+    takes it -- only because the oracle's trace is flat and the lnL equal; the evaluator check at the device's lengths
+    holds as for every pair."""
+    check_sweep_case(10714)
