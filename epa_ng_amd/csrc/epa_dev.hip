@@ -18,6 +18,31 @@ int epa_fail(epa_ctx* ctx, int code, const std::string& msg) {
   return code;
 }
 
+namespace {
+__global__ void __launch_bounds__(256) k_zero(uint4* __restrict__ a, size_t na, uint4* __restrict__ b, size_t nb) {
+  const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = i0; i < na; i += stride) a[i] = z;
+  for (size_t i = i0; i < nb; i += stride) b[i] = z;
+}
+}  // namespace
+
+int epa_zero_async(epa_ctx* ctx, void* p, size_t bytes, void* p2, size_t bytes2) {
+  if (!p) bytes = 0;
+  if (!p2) bytes2 = 0;
+  if (bytes + bytes2 == 0) return EPA_OK;
+  if (((bytes | bytes2) & 15u) || (((uintptr_t)p | (uintptr_t)p2) & 15u)) {
+    if (bytes) EPA_HIP(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream));
+    if (bytes2) EPA_HIP(ctx, hipMemsetAsync(p2, 0, bytes2, ctx->stream));
+    return EPA_OK;
+  }
+  const size_t na = bytes / 16, nb = bytes2 / 16;
+  const uint32_t grid = (uint32_t)std::min<size_t>((std::max(na, nb) + 255) / 256, (size_t)ctx->n_cu * 8);
+  hipLaunchKernelGGL(k_zero, dim3(grid), dim3(256), 0, ctx->stream, (uint4*)p, na, (uint4*)p2, nb);
+  EPA_HIP(ctx, hipGetLastError());
+  return EPA_OK;
+}
+
 void* epa_scratch(epa_ctx* ctx, int slot, size_t bytes) {
   slot += ctx->bank * epa_ctx::N_SCRATCH;
   if (bytes <= ctx->scratch_sz[slot]) return ctx->scratch[slot];
@@ -144,11 +169,14 @@ void epa_xcd_feedback(epa_ctx* ctx, uint64_t n_pairs, const unsigned long long* 
   ctx->xcd_cum[8] = 1u << 20;
 }
 
+static const bool epa_timers_off = getenv("EPA_NO_TIMERS") != nullptr;   // experiment switch: what the event records cost
 void epa_timer_start(epa_ctx* ctx, EvTimer& t) {
+  if (epa_timers_off) return;
   if (!t.a) { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
   (void)hipEventRecord(t.a, ctx->stream);
 }
 void epa_timer_stop(epa_ctx* ctx, EvTimer& t) {
+  if (epa_timers_off) return;
   (void)hipEventRecord(t.b, ctx->stream);
   t.valid = true;
 }
@@ -1278,7 +1306,8 @@ extern "C" int epa_dev_thorough(epa_ctx* ctx, const epa_pair* pairs, uint64_t n_
   epa_result* d_out = out_dev ? out : (epa_result*)epa_scratch(ctx, 5, sizeof(epa_result) * n_pairs);
   unsigned long long* d_stats = (unsigned long long*)epa_scratch(ctx, 6, 256);
   if (!d_out || !d_stats) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(thorough out)");
-  EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, ctx->stream));
+  rc = epa_zero_async(ctx, d_stats, 128);
+  if (rc) return rc;
   rc = launch_thorough(ctx, d_pairs, n_pairs, d_codes, d_begin, d_span, max_span, d_out, d_stats);
   if (rc) return rc;
   unsigned long long hst[16];
@@ -1347,9 +1376,14 @@ static int chunk_body_begin(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t
     ctx->segp = (nseg + 7u) & ~7u;
     ctx->segmax = (unsigned long long*)epa_scratch(ctx, 10, sizeof(unsigned long long) * (size_t)Q * ctx->segp);
     if (!ctx->segmax) return epa_fail(ctx, EPA_ERR_HIP, "hipMalloc(segment maxima)");
-    EPA_HIP(ctx, hipMemsetAsync(ctx->segmax, 0, sizeof(unsigned long long) * (size_t)Q * ctx->segp, ctx->stream));
+    // zeroed by launch_preplace together with its status words and key counts (one kernel: ctx->segmax_zero_bytes)
+    ctx->segmax_zero_bytes = sizeof(unsigned long long) * (size_t)Q * ctx->segp;
   }
   int rc = launch_preplace(ctx, d_codes, d_begin, d_span, Q, d_lnl, max_span);
+  if (ctx->segmax_zero_bytes) {   // launch_preplace returned before its fill
+    ctx->segmax_zero_bytes = 0;
+    if (!rc) rc = epa_fail(ctx, EPA_ERR_HIP, "segment maxima not cleared");
+  }
   if (!rc) rc = launch_select_begin(ctx, d_lnl, Q, threshold, d_pairs, max_pairs, d_span, rb, sp);
   ctx->lnl_pitch = 0;
   ctx->segmax = nullptr;
@@ -1359,6 +1393,18 @@ static int chunk_body_begin(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t
   // measured (profiles/r4_queued_thorough.txt) it buys nothing -- a chunk's preplacement and its Newton kernel each
   // need whole CUs, so they serialise on the device whichever is queued first -- and with HIP's default four
   // hardware queues the early Newton kernel blocks the other slots' chains that share its queue (8.5 -> 7.7 M/s).
+  // Bitmap form: the pair list is written behind the read-back at once (k_emit_pairs refuses a list that would not fit),
+  // and the statistics block + work counters of the chunk's Newton launch are cleared behind it -- both in the shadow
+  // of the host's round trip for the candidate count (15 - 25 us) instead of after it (profiles/r5_step_timeline.txt)
+  static const bool early_emit = getenv("EPA_EARLY_EMIT") == nullptr || atoi(getenv("EPA_EARLY_EMIT")) != 0;
+  if (!rc && early_emit && d_stats && sp->d_rb && sp->bitmap && max_pairs <= 0xffffffffull) {
+    rc = launch_select_emit(ctx, sp);
+    if (!rc) rc = epa_zero_async(ctx, d_stats, 128, epa_th_ctr(ctx), epa_th_ctr(ctx) ? 64 : 0);
+    if (!rc) {
+      ctx->clean_stats[ctx->bank] = d_stats;
+      ctx->clean_ctr[ctx->bank] = epa_th_ctr(ctx) != nullptr;
+    }
+  }
   if (!rc && d_res && d_stats && sp->d_rb && sp->bitmap && max_pairs <= 0xffffffffull) {
     const bool off = getenv("EPA_QUEUED_THOROUGH") == nullptr;
     const int cls = epa_span_class(ctx->s, max_span);
@@ -1366,7 +1412,8 @@ static int chunk_body_begin(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t
                           (cls <= 2 || cls == 10 || cls == 11);
     if (eligible) {
       rc = launch_select_emit(ctx, sp);
-      if (!rc) EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, ctx->stream));
+      if (!rc && ctx->clean_stats[ctx->bank] == d_stats) ctx->clean_stats[ctx->bank] = nullptr;
+      else if (!rc) rc = epa_zero_async(ctx, d_stats, 128);
       if (!rc) {
         const int q = launch_thorough_queued(ctx, d_pairs, sp->d_rb, max_pairs, d_codes, d_begin, d_span, max_span, d_res, d_stats);
         if (q == -2) return EPA_ERR_HIP;
@@ -1392,7 +1439,12 @@ static int chunk_body_end(epa_ctx* ctx, SelectPending* sp, const uint8_t* d_code
   // the queued launch ran iff all n pairs are of its class (no overflow / window error: checked above) -- the test
   // k_thorough_dna applied to the same block
   if (sp->queued_cls >= 0 && sp->rb[9 + sp->queued_cls] == (uint32_t)n) { ctx->cls_hist_pairs = 0; return EPA_OK; }
-  EPA_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, ctx->stream));
+  if (ctx->clean_stats[ctx->bank] == d_stats && sp->queued_cls < 0) ctx->clean_stats[ctx->bank] = nullptr;   // cleared behind the selection
+  else {
+    ctx->clean_stats[ctx->bank] = nullptr;
+    rc = epa_zero_async(ctx, d_stats, 128);
+    if (rc) return rc;
+  }
   if (n == 0) return EPA_OK;
   return launch_thorough(ctx, d_pairs, n, d_codes, d_begin, d_span, max_span, d_res, d_stats);
 }

@@ -200,6 +200,7 @@ struct epa_ctx {
   // (written by the preplacement fast paths, read by k_select_seg; preplace.hip), or null
   unsigned long long* segmax = nullptr;
   uint32_t segp = 0;
+  size_t segmax_zero_bytes = 0;   // chunk_body_begin -> launch_preplace: clear segmax with the status / key-count fill
   bool code_packed4 = false;  // q_codes arrive in the 4-bit wire format (epa_dev_set_query_packing)
   int heur_mode = 0;        // EPA_HEUR_* (epa_dev_set_heuristic)
   double heur_param = 0.0;  // fixed: fraction of the branches
@@ -222,6 +223,10 @@ struct epa_ctx {
   double last_sclk_mhz = 0.0;   // shader clock of the last stamped Newton launch (s_memtime / s_memrealtime)
   bool xstamp_ok = false;   // launch_thorough: this call is ONE kernel launch (one span class): its stamps mean something
   hipEvent_t ev_rb[N_BANKS] = {};   // per bank: behind the selection's read-back copy (SelectPending::ev_rb)
+  // per bank: the statistics block / the work counters of the NEXT Newton launch were already zeroed behind the
+  // selection (chunk_body_begin: in the shadow of the host's round trip); the launch that uses them clears the mark
+  const void* clean_stats[N_BANKS] = {};
+  bool clean_ctr[N_BANKS] = {};
   int t_last[3] = {0, 0, 0};
   epa_thorough_stats last_stats{};
 };
@@ -230,6 +235,16 @@ struct epa_ctx {
 int epa_fail(epa_ctx* ctx, int code, const std::string& msg);
 void* epa_scratch(epa_ctx* ctx, int slot, size_t bytes);
 inline uint32_t* epa_th_ctr(epa_ctx* ctx) { return ctx->th_ctr ? ctx->th_ctr + 64 * ctx->bank : nullptr; }
+// Zero `bytes` at p (and optionally a second range) with ONE plain kernel on the context's stream.  A hipMemsetAsync is
+// a blit launch of its own with ~6 us of idle queue before and after it between kernels (profiles/r5_step_timeline.txt:
+// five of them per chunk body); a plain kernel follows its predecessor without a gap.  Ranges must be 16-byte aligned
+// multiples of 16 bytes (else: hipMemsetAsync).
+int epa_zero_async(epa_ctx* ctx, void* p, size_t bytes, void* p2 = nullptr, size_t bytes2 = 0);
+// the work counters of this bank's next Newton launch: zero them unless chunk_body_begin already did
+inline int epa_th_ctr_reset(epa_ctx* ctx) {
+  if (ctx->clean_ctr[ctx->bank]) { ctx->clean_ctr[ctx->bank] = false; return 0; }
+  return epa_zero_async(ctx, epa_th_ctr(ctx), 64);
+}
 bool epa_is_device_ptr(const void* p);
 // returns a device pointer holding `bytes` of *p (copying into scratch slot if p is on the host)
 const void* epa_to_device(epa_ctx* ctx, int slot, const void* p, size_t bytes);
@@ -241,6 +256,9 @@ const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_
 void epa_xcd_feedback(epa_ctx* ctx, uint64_t n_pairs, const unsigned long long* hst);
 // in-kernel s_memrealtime stamps are kept to 43 bits (24 h at 100 MHz) so that the XCD's share fits below them
 #define EPA_XSTAMP_MASK 0x7ffffffffffull
+// Kernel-family timers (hipEventRecord on the context's stream).  Each record costs ~5.5 us of idle queue between two
+// kernels (profiles/r5_step_timeline.txt: six per chunk body); events riding on the launches themselves
+// (hipExtLaunchKernelGGL start / stop events) were built and cost exactly the same on this runtime: not kept.
 void epa_timer_start(epa_ctx* ctx, EvTimer& t);
 void epa_timer_stop(epa_ctx* ctx, EvTimer& t);
 // the current bank's timer of a kernel family (epa_ctx::T_*)

@@ -485,9 +485,35 @@ __global__ void __launch_bounds__(256) k_build_lookup2(const double* __restrict_
   lookup2[(((size_t)b * 2 + (s & 1u)) * Wh + (s >> 1)) * PE + e] = v0 + v1;
 }
 
-// One wave per query: per-pair LDS offsets relative to the query's first pair row, 16 bit each
-// (pair p of the window sits in chunk p / CP at row p % CP), the three tail singles, the sort key
-// (class, window-start parity, window start) for the grouping.
+// Per-pair LDS offsets relative to the query's first pair row, 16 bit each (pair p of the window sits in
+// chunk p / CP at row p % CP), the three tail singles, the sort key (class, window-start parity, window
+// start) for the grouping.
+// (code of site, code of site + 1) -> 8 * pair entry, bit 15 = one of the two is a rare ambiguity code
+// (the query then goes to the generic kernel); codes above 15 are mapped to code 0 first (same symbol).
+struct PairTab {
+  uint16_t v[256];
+  constexpr PairTab() : v{} {
+    for (uint32_t i = 0; i < 256; ++i) {
+      const uint32_t c[2] = {i >> 4, i & 15u};
+      uint32_t s[2] = {0, 0};
+      for (int k = 0; k < 2; ++k)
+        s[k] = c[k] == 15 ? 4u : c[k] == 1 ? 0u : c[k] == 2 ? 1u : c[k] == 4 ? 2u : c[k] == 8 ? 3u : 6u;   // = dna_sym
+      const bool rare = s[0] > 4 || s[1] > 4;
+      const uint32_t s0 = s[0] > 5 ? 5u : s[0], s1 = s[1] > 5 ? 5u : s[1];
+      const uint32_t e = (s0 < 4 && s1 < 4) ? s0 * 4 + s1 : s0 < 4 ? 16 + s0 * 2 + (s1 - 4) : 24 + (s0 - 4) * NSYM + s1;   // = pair_entry
+      v[i] = (uint16_t)(e * 8 | (rare ? 0x8000u : 0u));
+    }
+  }
+};
+__device__ const PairTab PAIR_TAB{};
+
+// Sixteen lanes per query, four queries per wave, a persistent grid (grid-stride over blocks of sixteen
+// queries).  Round 5: a lane forms one 32-bit WORD (two pairs = four sites) per step -- four code bytes, two
+// table reads (LDS copy of PAIR_TAB), one add of the two row offsets, one 4-byte store (sixteen lanes: 64
+// contiguous bytes) -- where the first form walked dna_sym / pair_entry per site (branches: 352 vector + 640
+// scalar instructions per wave, 81 us per 100k reads: instruction-bound, profiles/r5_pmc_summary.txt).
+// Offsets stay below 2^15 ((CP - 1) * rowl + 35 * 8 <= 30616), so the table's rare bit survives the add in
+// bit 15 / 31 and is masked out of the stored word.
 __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ codes,
                                                     const uint32_t* __restrict__ win_begin,
                                                     const uint32_t* __restrict__ win_span, uint32_t Q,
@@ -497,62 +523,72 @@ __global__ void __launch_bounds__(256) k_pack_pairs(const uint8_t* __restrict__ 
                                                     uint16_t* __restrict__ tails,
                                                     uint32_t* __restrict__ keys, uint32_t K,
                                                     uint32_t* __restrict__ status) {
-  // sixteen lanes per query, four queries per wave: the kernel is a chain of three dependent memory
-  // round trips (window, codes, store) with little work between them -- a wave per query was 100k
-  // waves of it, 65 us per 100k reads
-  const uint32_t q = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + ((threadIdx.x >> 4) & 3u);
+  __shared__ uint16_t s_tab[256];
+  s_tab[threadIdx.x] = PAIR_TAB.v[threadIdx.x];
+  __syncthreads();
   const uint32_t l16 = threadIdx.x & 15, grp = (threadIdx.x >> 4) & 3u;
-  const bool live = q < Q;
-  const uint32_t begin = live ? win_begin[q] : 0u;
-  uint32_t span = live ? win_span[q] : 0u;
   // a window longer than the caller's max_span (or than a compact row) is an input error: the
   // kernel variant and the packed rows were sized by it
   const uint32_t cmax = min(span_bound, crel ? cstride : 0xffffffffu);
-  if (live && l16 == 0) validate_window(q, begin, span, W, cmax, status);
-  if ((uint64_t)begin + span > W || span > cmax) span = 0;  // invalid window (flagged above)
-  const uint8_t* c = codes + (size_t)(live ? q : 0u) * cstride + (crel ? 0u : begin);
-  const uint32_t nfull = span >> 2, ntail = span & 3, npairs = 2 * nfull;
-  bool rare = false;
-  // a chunk of CP = 80 pair slots at a time: its ten code loads per lane are issued together, then the offsets
-  // are formed and stored (NP16 is a multiple of CP).  Round 4, traced us per 100k reads: one loop of dependent
-  // load / store pairs 78, this form 74, four pairs per lane with an unaligned 8-byte load and an 8-byte store 96,
-  // byte loads + 8-byte store 88: neither the load nor the store width is what it waits for.
-  for (uint32_t pb = 0; pb < NP16; pb += CP) {
-    uint32_t c0[CP / 16], c1[CP / 16];
+  constexpr uint32_t ZERO_W = ZERO_OFF | (ZERO_OFF << 16);
+  constexpr int NWI = (PW + 15) / 16;     // word steps per chunk of CP pair slots
+  const uint32_t lane_base = (2u * l16 * rowl) * 0x10001u + (rowl << 16);   // rows 2 l16 and 2 l16 + 1
+  for (uint32_t q0 = blockIdx.x * 16; q0 < Q; q0 += gridDim.x * 16) {
+    const uint32_t q = q0 + (threadIdx.x >> 4);
+    const bool live = q < Q;
+    const uint32_t begin = live ? win_begin[q] : 0u;
+    uint32_t span = live ? win_span[q] : 0u;
+    if (live && l16 == 0) validate_window(q, begin, span, W, cmax, status);
+    if ((uint64_t)begin + span > W || span > cmax) span = 0;  // invalid window (flagged above)
+    const uint8_t* c = codes + (size_t)(live ? q : 0u) * cstride + (crel ? 0u : begin);
+    const uint32_t nfull = span >> 2, ntail = span & 3, npairs = 2 * nfull;
+    uint32_t* prow = reinterpret_cast<uint32_t*>(packed + (size_t)(live ? q : 0u) * NP16);   // NP16 is even, the base 256-byte aligned
+    uint32_t racc = 0;
+    // the tail singles' codes are requested with the first chunk's
+    uint32_t ctail = 0;
+    if (l16 < ntail) ctail = c[4 * nfull + l16];
+    for (uint32_t pb = 0; pb < NP16; pb += CP) {   // one chunk of CP = 80 pair slots = 40 words at a time
+      uint32_t cb[NWI][4];
 #pragma unroll
-    for (int i = 0; i < CP / 16; ++i) {
-      const uint32_t p = pb + (uint32_t)i * 16 + l16;
-      c0[i] = p < npairs ? c[2 * p] : 0u;
-      c1[i] = p < npairs ? c[2 * p + 1] : 0u;
-    }
+      for (int i = 0; i < NWI; ++i) {
+        const uint32_t gw = pb / 2 + (uint32_t)i * 16 + l16;   // word = pairs 2 gw, 2 gw + 1 = sites 4 gw .. 4 gw + 3
+        const bool on = (i * 16 + (int)l16 < PW) && gw < nfull;
 #pragma unroll
-    for (int i = 0; i < CP / 16; ++i) {
-      const uint32_t p = pb + (uint32_t)i * 16 + l16;
-      uint32_t v = ZERO_OFF;
-      if (p < npairs) {
-        const uint32_t s0 = dna_sym(c0[i]), s1 = dna_sym(c1[i]);
-        rare |= (s0 > 4) | (s1 > 4);
-        v = (p % CP) * rowl + pair_entry(min(s0, 5u), min(s1, 5u)) * 8;
+        for (int k = 0; k < 4; ++k) cb[i][k] = on ? c[4 * gw + k] : 0u;
       }
-      if (live) packed[(size_t)q * NP16 + p] = (uint16_t)v;
+#pragma unroll
+      for (int i = 0; i < NWI; ++i) {
+        const uint32_t wl = (uint32_t)i * 16 + l16, gw = pb / 2 + wl;
+        if (i * 16 + (int)l16 >= PW) continue;
+        uint32_t c0 = cb[i][0], c1 = cb[i][1], c2 = cb[i][2], c3 = cb[i][3];
+        if (__builtin_expect(((c0 | c1 | c2 | c3) >> 4) != 0u, 0)) {   // not a 4-bit state set: the symbol of code 0
+          c0 = c0 > 15u ? 0u : c0; c1 = c1 > 15u ? 0u : c1; c2 = c2 > 15u ? 0u : c2; c3 = c3 > 15u ? 0u : c3;
+        }
+        const uint32_t e0 = s_tab[(c0 << 4) | c1], e1 = s_tab[(c2 << 4) | c3];
+        const uint32_t word = ((e1 << 16) | e0) + lane_base + (uint32_t)i * ((32u * rowl) * 0x10001u);
+        const bool on = gw < nfull;
+        if (on) racc |= word;
+        if (live) prow[gw] = on ? (word & 0x7fff7fffu) : ZERO_W;
+      }
     }
-  }
-  if (l16 < 4) {
-    uint32_t v = ZERO_OFF;
-    if (l16 < ntail) {
-      uint32_t sy = dna_sym(c[4 * nfull + l16]);
-      rare |= sy > 4;
-      sy = min(sy, 5u);
-      const uint32_t kt = npairs % CP;  // row of the first tail site inside its chunk (even)
-      const uint32_t e = l16 == 1 ? pair_entry(5, sy) : pair_entry(sy, 5);
-      v = (kt + (l16 == 2 ? 1u : 0u)) * rowl + e * 8;
+    bool rare = (racc & 0x80008000u) != 0u;
+    if (l16 < 4) {
+      uint32_t v = ZERO_OFF;
+      if (l16 < ntail) {
+        uint32_t sy = dna_sym(ctail);
+        rare |= sy > 4;
+        sy = min(sy, 5u);
+        const uint32_t kt = npairs % CP;  // row of the first tail site inside its chunk (even)
+        const uint32_t e = l16 == 1 ? pair_entry(5, sy) : pair_entry(sy, 5);
+        v = (kt + (l16 == 2 ? 1u : 0u)) * rowl + e * 8;
+      }
+      if (live) tails[(size_t)q * 4 + l16] = (uint16_t)v;
     }
-    if (live) tails[(size_t)q * 4 + l16] = (uint16_t)v;
-  }
-  const bool any_rare = ((__ballot(rare) >> (16 * grp)) & 0xffffull) != 0ull;
-  if (live && l16 == 0) {   // an invalid window start (flagged above) must not leave the key space
-    const uint32_t key = min((any_rare ? 2 * Wp : 0) + (begin & 1u) * Wp + min(begin, Wp - 1), K - 1);
-    keys[q] = key;
+    const bool any_rare = ((__ballot(rare) >> (16 * grp)) & 0xffffull) != 0ull;
+    if (live && l16 == 0) {   // an invalid window start (flagged above) must not leave the key space
+      const uint32_t key = min((any_rare ? 2 * Wp : 0) + (begin & 1u) * Wp + min(begin, Wp - 1), K - 1);
+      keys[q] = key;
+    }
   }
 }
 
@@ -1247,7 +1283,10 @@ struct SelRule {
   const double* e2t = nullptr;   // LDS table of exp_tab (wave_util.hpp), or null: library exp
   __device__ __forceinline__ SelRule(int m, double t, uint32_t l, const double* tab = nullptr) : mode(m), thr(t), limit(l), e2t(tab) {}
   // exp(x), x <= 0; far below the underflow threshold either way once x < -800
-  __device__ __forceinline__ double ex(double x) const { return e2t ? epa_wave::exp_tab(fmax(x, -800.0), e2t) : exp(x); }
+  __device__ __forceinline__ double ex(double x) const {
+    if (!e2t) return exp(x);
+    return x == 0.0 ? 1.0 : epa_wave::exp_tab(fmax(x, -800.0), e2t);   // exp_tab(0) == 1 as well: the branch only saves the work
+  }
   __device__ __forceinline__ bool more(uint32_t taken, uint32_t B) const {
     if (mode == 0) return taken < B && sum < thr;
     if (mode == 1) return taken < limit;
@@ -1320,10 +1359,149 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
 // -- everything below sums to less than 1 - thr -- and a term below mx - (log B + 38) is less than 2^-54 / B of
 // tot: all B of them together cannot move its double.  So only the segments whose maximum lies inside those
 // bands are read: 1.5 of 16 on average at cfg2 (tests/...) -- 0.13 GB instead of the 0.82 GB row
-// read per 100k-read chunk.  Up to NRN candidate segments are held in registers; more (or a row without
-// published maxima: its query went through another preplacement kernel) are streamed per extraction.
-template <int NRN>
+// read per 100k-read chunk.  The candidate segments are held in registers (2 -- the usual case -- or up to NRN);
+// more (or a row without published maxima: its query went through another preplacement kernel) are streamed per
+// extraction.
+// Round 5 (the kernel was bound by its own vector instructions: 820 per query, 82 M per 100k reads = the 147 us it
+// took, profiles/r5_pmc_summary.txt): the two band widths come from the host (two library logs per wave), the
+// exponentials are exp_tab (16 instructions instead of ~45; exp_tab(0) = 1 exactly and the first candidate -- the
+// row maximum -- skips it), rows with at most two candidate segments run a two-register extraction loop, a wave
+// walks several queries (grid-stride, the next query's maxima requested ahead), and the span-class histogram of
+// the candidate counts (k_class_hist: 1563 atomics on one word, 20 us) is summed per workgroup in LDS.
+template <int N, bool DIAG = false>
+__device__ __forceinline__ uint32_t seg_extract(const double* __restrict__ src, uint32_t lane, uint32_t B,
+                                                unsigned long long mask_x, double mx, double tot, SelRule& rule,
+                                                const SelOut& so, uint32_t q, uint32_t* __restrict__ status) {
+  double v[N];
+  uint32_t base[N];
+  unsigned long long mm = mask_x;
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    if (mm) {
+      const uint32_t s = (uint32_t)__builtin_ctzll(mm);
+      mm &= mm - 1;
+      base[r] = s * 64;
+      const uint32_t i = s * 64 + lane;
+      v[r] = i < B ? src[i] : -INFINITY;
+    } else {
+      base[r] = 0;
+      v[r] = -INFINITY;
+    }
+  }
+  uint32_t taken = 0, cand = 0;
+  while (rule.more(taken, B)) {
+    double lbest = -INFINITY;
+    uint32_t lbi = 0xffffffffu;
+#pragma unroll
+    for (int r = 0; r < N; ++r)   // segments ascend with r: the first maximum has the lowest branch id
+      if (v[r] > lbest) { lbest = v[r]; lbi = base[r] + lane; }
+    const double best = epa_wave::wave_max_d(lbest);
+    const uint32_t bi = epa_wave::wave_min_u((lbest == best && lbest > -INFINITY) ? lbi : 0xffffffffu);
+    if (bi == 0xffffffffu) break;
+    if (!rule.accept(best, mx, tot, taken)) break;
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+      if (base[r] + lane == bi) v[r] = -INFINITY;
+    // candidate k waits in lane k: the atomics of a query leave together, one instruction per kind, after its loop
+    // (one pair of them per candidate from lane 0 sat between the next query's loads and their wait)
+    if (taken < 64u) { if (lane == taken) cand = bi; }
+    else if (!DIAG && lane == 0) so.put(q, bi, taken, status);
+    ++taken;
+  }
+  if (!DIAG && lane < min(taken, 64u)) so.put(q, cand, lane, status);
+  return taken;
+}
+
+template <int NRN, bool DIAG = false>   // DIAG: timing variant without the candidates' atomics (results unusable)
 __global__ void __launch_bounds__(256) k_select_seg(const double* __restrict__ lnl, const unsigned long long* __restrict__ segmax,
+                                                    uint32_t segp, uint32_t Q, uint32_t B, uint32_t pitch, double threshold,
+                                                    double band_x, double band_t,
+                                                    SelOut so, uint32_t* __restrict__ counts, uint32_t* __restrict__ status,
+                                                    const uint32_t* __restrict__ win_span, int states,
+                                                    uint32_t* __restrict__ hist) {
+  __shared__ double s_e2t[64];
+  __shared__ uint32_t s_hist[EPA_N_CLS];
+  if (threadIdx.x < 64) s_e2t[threadIdx.x] = exp2((double)threadIdx.x * 0.015625);
+  if (threadIdx.x < EPA_N_CLS) s_hist[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t nseg = (B + 63) >> 6;   // <= 64
+  const uint32_t stride = gridDim.x * 4;
+  uint32_t q = blockIdx.x * 4 + wv;
+  unsigned long long key_next = (q < Q && lane < nseg) ? segmax[(size_t)q * segp + lane] : ~0ull;
+  for (; q < Q; q += stride) {
+    const unsigned long long key = key_next;
+    {
+      const uint32_t qn = q + stride;
+      key_next = (qn < Q && lane < nseg) ? segmax[(size_t)qn * segp + lane] : ~0ull;
+    }
+    const double* src = lnl + (size_t)q * pitch;
+    auto value = [&](uint32_t s) -> double {   // this lane's element of segment s (-inf past the row)
+      const uint32_t i = s * 64 + lane;
+      return i < B ? src[i] : -INFINITY;
+    };
+    double m = -INFINITY;
+    if (__ballot(key == 0ull) == 0ull) {
+      if (lane < nseg) m = seg_val(key);
+    } else {   // no maxima for this row: build them from the row itself
+      for (uint32_t s = 0; s < nseg; ++s) {
+        const double xm = epa_wave::wave_max_d(value(s));
+        if (lane == s) m = xm;
+      }
+    }
+    const double mx = epa_wave::wave_max_d(m);
+    const unsigned long long mask_t = __ballot(m >= mx - band_t), mask_x = __ballot(m >= mx - band_x);
+    double tot = 0.0;
+    for (unsigned long long mm = mask_t; mm; mm &= mm - 1)
+      tot += epa_wave::exp_tab(fmax(value((uint32_t)__builtin_ctzll(mm)) - mx, -800.0), s_e2t);
+    tot = epa_wave::wave_sum(tot);
+    SelRule rule(0, threshold, 0u, s_e2t);
+    uint32_t taken = 0;
+    const int ncs = __popcll(mask_x);
+    if (ncs <= 2) {
+      taken = seg_extract<2, DIAG>(src, lane, B, mask_x, mx, tot, rule, so, q, status);
+    } else if (ncs <= NRN) {
+      taken = seg_extract<NRN, DIAG>(src, lane, B, mask_x, mx, tot, rule, so, q, status);
+    } else {
+      // many candidate segments: every extraction streams them again and takes the next element in
+      // (lnL descending, branch ascending) order after the previous one
+      double pbest = INFINITY;
+      uint32_t pbi = 0, cand = 0;
+      while (rule.more(taken, B)) {
+        double lbest = -INFINITY;
+        uint32_t lbi = 0xffffffffu;
+        for (unsigned long long mm = mask_x; mm; mm &= mm - 1) {
+          const uint32_t s = (uint32_t)__builtin_ctzll(mm), i = s * 64 + lane;
+          const double x = value(s);
+          const bool after = x < pbest || (x == pbest && i > pbi);
+          if (after && x > lbest) { lbest = x; lbi = i; }
+        }
+        const double best = epa_wave::wave_max_d(lbest);
+        const uint32_t bi = epa_wave::wave_min_u((lbest == best && lbest > -INFINITY) ? lbi : 0xffffffffu);
+        if (bi == 0xffffffffu) break;
+        if (!rule.accept(best, mx, tot, taken)) break;
+        pbest = best;
+        pbi = bi;
+        if (taken < 64u) { if (lane == taken) cand = bi; }
+        else if (!DIAG && lane == 0) so.put(q, bi, taken, status);
+        ++taken;
+      }
+      if (!DIAG && lane < min(taken, 64u)) so.put(q, cand, lane, status);
+    }
+    if (lane == 0) {
+      const uint32_t n = so.count(taken);
+      counts[q] = n;
+      if (hist && n) atomicAdd(&s_hist[epa_span_class(states, win_span[q])], n);
+    }
+  }
+  __syncthreads();
+  if (hist && threadIdx.x < EPA_N_CLS && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
+}
+
+// ---- round-4 forms of k_select_seg / k_pack_pairs, kept for same-box A/Bs (EPA_SEL_V1 / EPA_PACK_V1)
+template <int NRN>
+__global__ void __launch_bounds__(256) k_select_seg_v1(const double* __restrict__ lnl, const unsigned long long* __restrict__ segmax,
                                                     uint32_t segp, uint32_t Q, uint32_t B, uint32_t pitch, double threshold,
                                                     SelOut so, uint32_t* __restrict__ counts, uint32_t* __restrict__ status) {
   const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1412,6 +1590,75 @@ __global__ void __launch_bounds__(256) k_select_seg(const double* __restrict__ l
   }
   if (lane == 0) counts[q] = so.count(taken);
 }
+
+__global__ void __launch_bounds__(256) k_pack_pairs_v1(const uint8_t* __restrict__ codes,
+                                                    const uint32_t* __restrict__ win_begin,
+                                                    const uint32_t* __restrict__ win_span, uint32_t Q,
+                                                    uint32_t W, uint32_t cstride, uint32_t crel,
+                                                    uint32_t span_bound, uint32_t Wp, uint32_t NP16,
+                                                    uint32_t rowl, uint16_t* __restrict__ packed,
+                                                    uint16_t* __restrict__ tails,
+                                                    uint32_t* __restrict__ keys, uint32_t K,
+                                                    uint32_t* __restrict__ status) {
+  // sixteen lanes per query, four queries per wave: the kernel is a chain of three dependent memory
+  // round trips (window, codes, store) with little work between them -- a wave per query was 100k
+  // waves of it, 65 us per 100k reads
+  const uint32_t q = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + ((threadIdx.x >> 4) & 3u);
+  const uint32_t l16 = threadIdx.x & 15, grp = (threadIdx.x >> 4) & 3u;
+  const bool live = q < Q;
+  const uint32_t begin = live ? win_begin[q] : 0u;
+  uint32_t span = live ? win_span[q] : 0u;
+  // a window longer than the caller's max_span (or than a compact row) is an input error: the
+  // kernel variant and the packed rows were sized by it
+  const uint32_t cmax = min(span_bound, crel ? cstride : 0xffffffffu);
+  if (live && l16 == 0) validate_window(q, begin, span, W, cmax, status);
+  if ((uint64_t)begin + span > W || span > cmax) span = 0;  // invalid window (flagged above)
+  const uint8_t* c = codes + (size_t)(live ? q : 0u) * cstride + (crel ? 0u : begin);
+  const uint32_t nfull = span >> 2, ntail = span & 3, npairs = 2 * nfull;
+  bool rare = false;
+  // a chunk of CP = 80 pair slots at a time: its ten code loads per lane are issued together, then the offsets
+  // are formed and stored (NP16 is a multiple of CP).  Round 4, traced us per 100k reads: one loop of dependent
+  // load / store pairs 78, this form 74, four pairs per lane with an unaligned 8-byte load and an 8-byte store 96,
+  // byte loads + 8-byte store 88: neither the load nor the store width is what it waits for.
+  for (uint32_t pb = 0; pb < NP16; pb += CP) {
+    uint32_t c0[CP / 16], c1[CP / 16];
+#pragma unroll
+    for (int i = 0; i < CP / 16; ++i) {
+      const uint32_t p = pb + (uint32_t)i * 16 + l16;
+      c0[i] = p < npairs ? c[2 * p] : 0u;
+      c1[i] = p < npairs ? c[2 * p + 1] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < CP / 16; ++i) {
+      const uint32_t p = pb + (uint32_t)i * 16 + l16;
+      uint32_t v = ZERO_OFF;
+      if (p < npairs) {
+        const uint32_t s0 = dna_sym(c0[i]), s1 = dna_sym(c1[i]);
+        rare |= (s0 > 4) | (s1 > 4);
+        v = (p % CP) * rowl + pair_entry(min(s0, 5u), min(s1, 5u)) * 8;
+      }
+      if (live) packed[(size_t)q * NP16 + p] = (uint16_t)v;
+    }
+  }
+  if (l16 < 4) {
+    uint32_t v = ZERO_OFF;
+    if (l16 < ntail) {
+      uint32_t sy = dna_sym(c[4 * nfull + l16]);
+      rare |= sy > 4;
+      sy = min(sy, 5u);
+      const uint32_t kt = npairs % CP;  // row of the first tail site inside its chunk (even)
+      const uint32_t e = l16 == 1 ? pair_entry(5, sy) : pair_entry(sy, 5);
+      v = (kt + (l16 == 2 ? 1u : 0u)) * rowl + e * 8;
+    }
+    if (live) tails[(size_t)q * 4 + l16] = (uint16_t)v;
+  }
+  const bool any_rare = ((__ballot(rare) >> (16 * grp)) & 0xffffull) != 0ull;
+  if (live && l16 == 0) {   // an invalid window start (flagged above) must not leave the key space
+    const uint32_t key = min((any_rare ? 2 * Wp : 0) + (begin & 1u) * Wp + min(begin, Wp - 1), K - 1);
+    keys[q] = key;
+  }
+}
+
 
 // Same selection, workgroup per query (4 waves): the row of up to 256 x NRT branches lives in the
 // registers of the whole workgroup (element i in thread i % 256, slot i / 256), so the table is
@@ -1690,14 +1937,25 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   uint16_t* tails = reinterpret_cast<uint16_t*>(base + 256 + 4 * qb + gb + pb);
   void* temp = base + 256 + 4 * qb + gb + pb + tb;
   ctx->d_status = status;
-  EPA_HIP(ctx, hipMemsetAsync(status, 0, 256 + hb, ctx->stream));   // status words + key counts: one fill
+  {   // status words + key counts, and the fused chunk body's segment maxima: one kernel
+    const size_t zb = ctx->segmax_zero_bytes;
+    ctx->segmax_zero_bytes = 0;
+    const int zr = epa_zero_async(ctx, status, 256 + hb, zb ? ctx->segmax : nullptr, zb);
+    if (zr) return zr;
+  }
   // wide slices for the pair path when a chunk puts few reads on a window start (see k_preplace_pairs)
   const bool acc = max_span == 0 || max_span > (uint32_t)CH || getenv("EPA_PREPLACE_ACC");
   static const bool narrow_only = getenv("EPA_PREPLACE_NARROW") != nullptr;
   const bool wide = pairs && !acc && !narrow_only && (uint64_t)Q * SPREAD < (uint64_t)1400 * ctx->W;   // < ~700 reads per 96-site bucket and parity
   const uint32_t rowl = (wide || acc) ? ROWL_PACKED : ROWL_NARROW;  // LDS row stride the 16-bit offsets are built for
   if (pairs) {
-    hipLaunchKernelGGL(k_pack_pairs, dim3((Q + 15) / 16), dim3(256), 0, ctx->stream, d_codes, d_begin,
+    static const bool pack_v1 = getenv("EPA_PACK_V1") != nullptr;   // A/B switch (profiles/)
+    static const uint32_t pack_grid = getenv("EPA_PACK_GRID") ? (uint32_t)std::max(1, atoi(getenv("EPA_PACK_GRID"))) : 64u;   // workgroups per CU
+    if (pack_v1)
+      hipLaunchKernelGGL(k_pack_pairs_v1, dim3((Q + 15) / 16), dim3(256), 0, ctx->stream, d_codes, d_begin,
+                         d_span, Q, ctx->W, cstride, crel, span_bound, Wp, NP16, rowl, packed, tails, keys, K, status);
+    else
+    hipLaunchKernelGGL(k_pack_pairs, dim3(std::min<uint32_t>((Q + 15) / 16, (uint32_t)ctx->n_cu * pack_grid)), dim3(256), 0, ctx->stream, d_codes, d_begin,
                        d_span, Q, ctx->W, cstride, crel, span_bound, Wp, NP16, rowl, packed, tails, keys, K, status);
   } else if (sites) {
     hipLaunchKernelGGL(k_pack_sites<24>, dim3((Q + 3) / 4), dim3(256), 0, ctx->stream, d_codes, d_begin,
@@ -1741,8 +1999,8 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   do {                                                                                               \
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<A, SP, RL>,                       \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB)));      \
-    hipLaunchKernelGGL((k_preplace_pairs<A, SP, RL>), grid2, dim3(GQ2), (LDSB), ctx->stream, ctx->lookup2, packed, \
-                       tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl, 0u, (A) ? nullptr : segmax, segp);    \
+    hipLaunchKernelGGL((k_preplace_pairs<A, SP, RL>), grid2, dim3(GQ2), (uint32_t)(LDSB), ctx->stream, ctx->lookup2, (const uint16_t*)packed, \
+                       (const uint16_t*)tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl, 0u, (A) ? nullptr : segmax, segp);    \
   } while (0)
   if (pairs && wide) {
     const size_t lds2w = (size_t)((CH + SPREAD_WIDE) / 2) * ROWL_PACKED + sizeof(double) * NB2_BURST * (GQ2 + 4);
@@ -1789,7 +2047,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   do {                                                                                               \
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_sites<24, A>,                           \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));       \
-    hipLaunchKernelGGL((k_preplace_sites<24, A>), grid_s, dim3(GQ2), lds_s, ctx->stream, ctx->lookup, \
+    hipLaunchKernelGGL((k_preplace_sites<24, A>), grid_s, dim3(GQ2), (uint32_t)lds_s, ctx->stream, ctx->lookup, \
                        packed, tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl, (A) ? nullptr : segmax, segp); \
   } while (0)
     if (acc_s) PRES(true); else PRES(false);
@@ -1802,7 +2060,7 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   do {                                                                                              \
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace<NC, A>,                                \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
-    hipLaunchKernelGGL((k_preplace<NC, A>), grid, dim3(GQ), lds, ctx->stream, ctx->lookup, d_codes, \
+    hipLaunchKernelGGL((k_preplace<NC, A>), grid, dim3(GQ), (uint32_t)lds, ctx->stream, ctx->lookup, d_codes, \
                        d_begin, d_span, perm, groups, ctx->W, cstride, crel, ctx->B, pitch, codes_bytes, want_cls, status, d_lnl); \
   } while (0)
   if (ctx->ncols == 16) { if (acc) PRE(16, true); else PRE(16, false); }
@@ -1877,15 +2135,35 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
     sp->counts = counts; sp->offsets = nullptr;
     sp->d_lnl = d_lnl; sp->Q = Q; sp->threshold = threshold; sp->d_pairs = d_pairs; sp->max_pairs = max_pairs;
     sp->d_span = d_span; sp->cap = cap; sp->rb = rb;
-    EPA_HIP(ctx, hipMemsetAsync(base, 0, 512 + cb + mb, ctx->stream));   // status, counters, bitmap: one fill
+    { const int zr = epa_zero_async(ctx, base, 512 + cb + mb); if (zr) return zr; }   // status, counters, bitmap: one fill
     epa_timer_start(ctx, epa_t(ctx, epa_ctx::T_SELECT));
     const SelOut so{nullptr, 0u, bitmap, bcount, wpr};
     const dim3 grid((Q + 3) / 4);
     const int nr = (int)((B + 63) / 64);
 #define SEL(N) hipLaunchKernelGGL(k_select<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status)
     const bool seg_off = getenv("EPA_SELECT_FULL_ROWS") != nullptr;   // A/B and test switch: the full-row kernels
+    bool seg_hist = false;   // k_select_seg sums the span-class histogram itself
     if (ctx->segmax && !seg_off && mode == 0 && threshold < 1.0 && nr <= 64)
-      hipLaunchKernelGGL(k_select_seg<8>, grid, dim3(256), 0, ctx->stream, d_lnl, ctx->segmax, ctx->segp, Q, B, pitch, threshold, so, counts, status);
+    {
+      // band widths of the segment test (see k_select_seg): conservative margins, so the host's log is as good as the device's
+      const double band_x = 1.0 - std::log((1.0 - threshold) / (double)B);
+      const double band_t = std::max(band_x, std::log((double)B) + 38.0);
+      static const int sel_v1 = getenv("EPA_SEL_V1") ? atoi(getenv("EPA_SEL_V1")) : 0;          // A/B switches (profiles/)
+      static const int sel_grid = getenv("EPA_SEL_GRID") ? atoi(getenv("EPA_SEL_GRID")) : 16;   // workgroups per CU, 0 = a wave per query
+      static const int sel_diag = getenv("EPA_SEL_DIAG") ? atoi(getenv("EPA_SEL_DIAG")) : 0;
+      const dim3 grid_seg(sel_grid > 0 ? std::min<uint32_t>((Q + 3) / 4, (uint32_t)ctx->n_cu * (uint32_t)sel_grid) : (Q + 3) / 4);
+      if (sel_v1) {
+        hipLaunchKernelGGL(k_select_seg_v1<8>, grid, dim3(256), 0, ctx->stream, d_lnl, ctx->segmax, ctx->segp, Q, B, pitch, threshold, so, counts, status);
+      } else if (sel_diag) {
+        hipLaunchKernelGGL((k_select_seg<8, true>), grid_seg, dim3(256), 0, ctx->stream, d_lnl, ctx->segmax, ctx->segp, Q, B, pitch, threshold,
+                           band_x, band_t, so, counts, status, d_span, ctx->s, d_span ? status + 8 : nullptr);
+        seg_hist = d_span != nullptr;
+      } else {
+        hipLaunchKernelGGL(k_select_seg<8>, grid_seg, dim3(256), 0, ctx->stream, d_lnl, ctx->segmax, ctx->segp, Q, B, pitch, threshold,
+                           band_x, band_t, so, counts, status, d_span, ctx->s, d_span ? status + 8 : nullptr);
+        seg_hist = d_span != nullptr;
+      }
+    }
     else if (nr <= 2) SEL(2); else if (nr <= 4) SEL(4); else if (nr <= 8) SEL(8); else if (nr <= 16) SEL(16);
     else if (nr <= 32) SEL(32); else if (nr <= 64) SEL(64);
     else if (nr <= 128) hipLaunchKernelGGL(k_select_wg<32>, dim3(Q), dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status);
@@ -1893,7 +2171,7 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
     else hipLaunchKernelGGL(k_select_big<16>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status);
 #undef SEL
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ctx->stream, bcount, B + 1);   // bcount[B] = total
-    if (d_span)
+    if (d_span && !seg_hist)
       hipLaunchKernelGGL(k_class_hist, dim3((Q + 255) / 256), dim3(256), 0, ctx->stream, counts, d_span, Q,
                          ctx->s, status + 8);
     hipLaunchKernelGGL(k_pack_readback, dim3(1), dim3(64), 0, ctx->stream, status, bcount + B,
@@ -1962,8 +2240,7 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
 // list that would not fit); the selection's timer stops here.
 int launch_select_emit(epa_ctx* ctx, SelectPending* sp) {
   if (!sp->bitmap || !sp->d_rb || sp->emitted) return EPA_OK;
-  hipLaunchKernelGGL(k_emit_pairs, dim3(ctx->B), dim3(256), 0, ctx->stream, sp->bitmap, sp->wpr, sp->boffs, sp->d_pairs, ctx->B,
-                     (uint32_t)std::min<uint64_t>(sp->max_pairs, 0xffffffffu));
+  hipLaunchKernelGGL(k_emit_pairs, dim3(ctx->B), dim3(256), 0, ctx->stream, sp->bitmap, sp->wpr, sp->boffs, sp->d_pairs, ctx->B, (uint32_t)std::min<uint64_t>(sp->max_pairs, 0xffffffffu));
   epa_timer_stop(ctx, epa_t(ctx, epa_ctx::T_SELECT));
   EPA_HIP(ctx, hipGetLastError());
   sp->emitted = true;
@@ -1993,8 +2270,7 @@ int launch_select_end(epa_ctx* ctx, SelectPending* sp, uint64_t* n_pairs) {
                       "select_candidates: " + std::to_string(total) + " candidates exceed max_pairs");
     if (total && sp->bitmap) {
       if (!sp->emitted)
-        hipLaunchKernelGGL(k_emit_pairs, dim3(B), dim3(256), 0, ctx->stream, sp->bitmap, sp->wpr, sp->boffs, sp->d_pairs, B,
-                           (uint32_t)std::min<uint64_t>(sp->max_pairs, 0xffffffffu));
+        hipLaunchKernelGGL(k_emit_pairs, dim3(B), dim3(256), 0, ctx->stream, sp->bitmap, sp->wpr, sp->boffs, sp->d_pairs, B, (uint32_t)std::min<uint64_t>(sp->max_pairs, 0xffffffffu));
     } else if (total) {
       const dim3 grid((Q + 3) / 4);
       hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, ctx->stream, sp->stage, sp->counts, sp->offsets, Q, sp->cap,

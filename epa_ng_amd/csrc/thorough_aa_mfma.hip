@@ -791,7 +791,7 @@ int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_
   uint32_t nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * wg_per_cu * per_slot);
   a.qctr = nullptr;
   if (!(getenv("EPA_TH_QUEUE") && atoi(getenv("EPA_TH_QUEUE")) == 0) && ctx->th_ctr) {
-    EPA_HIP(ctx, hipMemsetAsync(epa_th_ctr(ctx), 0, 64, ctx->stream));
+    { const int zr = epa_th_ctr_reset(ctx); if (zr) return zr; }
     a.qctr = epa_th_ctr(ctx);
     nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * wg_per_cu);
   }

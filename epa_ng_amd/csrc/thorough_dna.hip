@@ -1568,7 +1568,7 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
     a.qctr = nullptr;                                                                              \
     if ((NW_) == 1) {                                                                              \
       TH_TIMING_ALLOC                                                                              \
-      EPA_HIP(ctx, hipMemsetAsync(epa_th_ctr(ctx), 0, 64, ctx->stream));                               \
+      { const int zr_ = epa_th_ctr_reset(ctx); if (zr_) return zr_; }                                  \
       a.qctr = epa_th_ctr(ctx);                                                                        \
       want = th_grid_waves ? th_grid_waves : 1024 * TH_WAVES;                                                   \
     }                                                                                              \
