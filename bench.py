@@ -461,6 +461,9 @@ def main():
             if st["staged"] != i:                                # first step of a loop: nothing prefetched
                 stage(i)
             kw = dict(pairs_out=bufs[slot][0], results_out=bufs[slot][1], keep_on_device=True) if (resident or world > 1) else {}
+            # EPA_CHUNK_HOST_ORDERED: this loop touches a slot's rows only after chunk_finish returned (N > 1: the gather's
+            # pack kernel reads them stream-ordered, so the library's stream ordering stays on)
+            kw["host_ordered"] = world == 1
             t = time.perf_counter()
             ev.chunk_launch_begin(slot, threshold=0.99999, max_span=a.read_len, max_pairs=cap, **kw)
             st["t_launch"] += (time.perf_counter() - t) if i >= a.warmup else 0.0
@@ -716,7 +719,7 @@ def main():
                 t = time.perf_counter()
                 fn(*aa, **kw)
                 hostt[name] += time.perf_counter() - t
-            kw5 = dict(threshold=0.99999, max_span=a.read_len, max_pairs=5000 * 64)
+            kw5 = dict(threshold=0.99999, max_span=a.read_len, max_pairs=5000 * 64, host_ordered=True)
             S5, A5 = 5, 3
             for k in range(min(A5, nsm)):
                 call("stage", ev.chunk_stage, k % S5, *small[k])
@@ -741,7 +744,7 @@ def main():
         G = int(os.environ.get("EPA_BENCH_GROUP", "4"))
         small = small * (40 // nsm) if nsm < 40 else small      # 40 chunks: the pipeline's fill / drain amortised
         ngr = len(small) // G
-        kwg = dict(threshold=0.99999, max_span=a.read_len, max_pairs=G * 5000 * 64)
+        kwg = dict(threshold=0.99999, max_span=a.read_len, max_pairs=G * 5000 * 64, host_ordered=True)
         slots_of = lambda g: [(g % 3) * G + j for j in range(G)]
         for rep in range(3):
             torch.cuda.synchronize()

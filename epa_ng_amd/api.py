@@ -402,29 +402,36 @@ class Evaluator:
         self._check(self.L.epa_dev_chunk_stage(self.h, slot, _ptr(codes), _ptr(win_begin), _ptr(win_span),
                                                len(win_begin)))
 
+    @staticmethod
+    def _chunk_flags(keep_on_device, host_ordered):
+        # EPA_CHUNK_NO_D2H | EPA_CHUNK_HOST_ORDERED (include/epa_dev.h): host_ordered = the caller touches staged-in-place
+        # inputs / device-resident results only before launch / after finish, no stream-level ordering wanted
+        return (1 if keep_on_device else 0) | (2 if host_ordered else 0)
+
     def chunk_launch(self, slot, threshold=0.99999, max_span=0, max_pairs=None, pairs_out=None,
-                     results_out=None, keep_on_device=False):
+                     results_out=None, keep_on_device=False, host_ordered=False):
         """preplace -> heuristic -> thorough of the staged chunk; blocks only until the candidate
         count is known.  pairs_out / results_out: optional device buffers (torch) of max_pairs rows"""
         assert max_pairs is not None
         self._check(self.L.epa_dev_chunk_launch(self.h, slot, max_span, threshold, _ptr(pairs_out),
-                                                _ptr(results_out), max_pairs, 1 if keep_on_device else 0))
+                                                _ptr(results_out), max_pairs, self._chunk_flags(keep_on_device, host_ordered)))
 
     def chunk_launch_begin(self, slot, threshold=0.99999, max_span=0, max_pairs=None, pairs_out=None,
-                           results_out=None, keep_on_device=False):
+                           results_out=None, keep_on_device=False, host_ordered=False):
         """first half of chunk_launch: preplacement + candidate selection queued on the slot's own
         stream, returns without waiting"""
         assert max_pairs is not None
         self._check(self.L.epa_dev_chunk_launch_begin(self.h, slot, max_span, threshold, _ptr(pairs_out),
-                                                      _ptr(results_out), max_pairs, 1 if keep_on_device else 0))
+                                                      _ptr(results_out), max_pairs, self._chunk_flags(keep_on_device, host_ordered)))
 
-    def chunk_launch_many_begin(self, slots, threshold=0.99999, max_span=0, max_pairs=None, keep_on_device=False):
+    def chunk_launch_many_begin(self, slots, threshold=0.99999, max_span=0, max_pairs=None, keep_on_device=False,
+                                host_ordered=False):
         """group launch of several STAGED slots (one chunk body over their concatenated queries); slots[0] leads:
         chunk_launch_end(slots[0]), then chunk_finish(slot) for every member"""
         assert max_pairs is not None
         arr = (C.c_int * len(slots))(*slots)
         self._check(self.L.epa_dev_chunk_launch_many_begin(self.h, arr, len(slots), max_span, threshold, max_pairs,
-                                                           1 if keep_on_device else 0))
+                                                           self._chunk_flags(keep_on_device, host_ordered)))
 
     def chunk_launch_many(self, slots, **kw):
         self.chunk_launch_many_begin(slots, **kw)

@@ -1649,8 +1649,10 @@ static int chunk_launch_begin_impl(epa_ctx* ctx, int slot, ChunkSlot* s, uint32_
   // k's Newton kernel) and the wait for chunk k + 1's candidate count does not wait for chunk k's
   // kernels.  The slot stream starts behind what the caller's stream has queued so far (lookup
   // build; with device-resident results, the caller's reads of the result buffers).
-  EPA_HIP(ctx, hipEventRecord(s->ev_base, ctx->stream));
-  EPA_HIP(ctx, hipStreamWaitEvent(s->stream, s->ev_base, 0));
+  if (!(flags & EPA_CHUNK_HOST_ORDERED)) {
+    EPA_HIP(ctx, hipEventRecord(s->ev_base, ctx->stream));
+    EPA_HIP(ctx, hipStreamWaitEvent(s->stream, s->ev_base, 0));
+  }
   if (!s->x_codes) EPA_HIP(ctx, hipStreamWaitEvent(s->stream, s->ev_up, 0));
   SlotScope scope(ctx, s, slot);
   const char* d = (const char*)s->d_in;
@@ -1832,8 +1834,10 @@ extern "C" int epa_dev_chunk_launch_many_begin(epa_ctx* ctx, const int* slots, i
     EPA_HIP(ctx, hipHostMalloc((void**)&L->h_goff, sizeof(uint32_t) * (EPA_MAX_GROUP + 1), hipHostMallocDefault));
   }
   // the merge runs on the leader's stream, behind the caller's stream (device-resident chunks) and every member's upload
-  EPA_HIP(ctx, hipEventRecord(L->ev_base, ctx->stream));
-  EPA_HIP(ctx, hipStreamWaitEvent(L->stream, L->ev_base, 0));
+  if (!(flags & EPA_CHUNK_HOST_ORDERED)) {
+    EPA_HIP(ctx, hipEventRecord(L->ev_base, ctx->stream));
+    EPA_HIP(ctx, hipStreamWaitEvent(L->stream, L->ev_base, 0));
+  }
   for (int i = 0; i < n_slots; ++i)
     if (!m[i]->x_codes) EPA_HIP(ctx, hipStreamWaitEvent(L->stream, m[i]->ev_up, 0));
   uint8_t* mc = (uint8_t*)L->d_merge;
@@ -1941,7 +1945,7 @@ extern "C" int epa_dev_chunk_launch_end(epa_ctx* ctx, int slot) {
     s->out_pairs = d_pairs;
     s->out_res = d_results;
     // device-resident results are consumed on the caller's stream
-    EPA_HIP(ctx, hipStreamWaitEvent(base, s->ev_done, 0));
+    if (!(s->l_flags & EPA_CHUNK_HOST_ORDERED)) EPA_HIP(ctx, hipStreamWaitEvent(base, s->ev_done, 0));
   } else {
     const size_t off_r = (sizeof(epa_pair) * n + 255) & ~(size_t)255;
     rc = grow_pinned(ctx, &s->h_out, &s->h_out_sz, off_r + sizeof(epa_result) * n);

@@ -328,7 +328,8 @@ void chunk_launch(const Encoded_Chunk& enc, size_t Q, const Tree& tree, Device_E
                                (uint32_t)Q);
   if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
   for (;;) {
-    rc = epa_dev_chunk_launch(dev.ctx(), slot, max_span, options.prescoring_threshold, nullptr, nullptr, cap, 0);
+    // host arrays in, host rows out, read after finish: no stream-level ordering against the context's stream needed
+    rc = epa_dev_chunk_launch(dev.ctx(), slot, max_span, options.prescoring_threshold, nullptr, nullptr, cap, EPA_CHUNK_HOST_ORDERED);
     if (rc == EPA_ERR_PAIR_OVERFLOW && cap < (uint64_t)Q * nb) {
       cap = std::min<uint64_t>(cap * 8, (uint64_t)Q * nb);  // candidate overflow: the slot stays staged
       continue;

@@ -329,6 +329,11 @@ int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* wi
  *           d_pairs / d_results: optional DEVICE buffers of max_pairs entries that receive the
  *           results (e.g. the send buffers of a collective); NULL = buffers owned by the slot.
  *           EPA_CHUNK_NO_D2H: results stay in HBM (finish() hands out the device pointers).
+ *           EPA_CHUNK_HOST_ORDERED: the caller orders this chunk through the HOST only -- device arrays staged in
+ *           place were complete when launch was called, and device-resident results are touched only after finish()
+ *           returned.  Without it the library orders the slot's stream behind the context's stream at launch and
+ *           the context's stream behind the chunk at the end of launch (stream-ordered consumers); those two event
+ *           hops put ~20 us of idle queue between one chunk's Newton kernel and the next chunk's first kernel.
  *   finish  waits for the slot's download; *pairs / *results point into the slot's pinned host
  *           buffer (or HBM with EPA_CHUNK_NO_D2H), valid until the slot is staged again.
  *   launch_begin / launch_end: launch in two halves for callers that keep two chunks in flight --
@@ -347,6 +352,7 @@ int epa_dev_place_chunk(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* wi
  * staged: launch again with a larger max_pairs.
  */
 #define EPA_CHUNK_NO_D2H 0x1u
+#define EPA_CHUNK_HOST_ORDERED 0x2u
 int epa_dev_chunk_stage(epa_ctx* ctx, int slot, const uint8_t* q_codes, const uint32_t* win_begin,
                         const uint32_t* win_span, uint32_t Q);
 int epa_dev_chunk_launch(epa_ctx* ctx, int slot, uint32_t max_span, double threshold,

@@ -19,8 +19,8 @@ run() {   # name, env...
   python $R/profiles/db_to_txt.py /tmp/abst/st_results.db | grep -E "k_select_seg|k_pack_pairs|k_class_hist|k_thorough_dna|k_preplace_pairs" | cut -c1-60,96-140 >> $out
 }
 run cur A=1
-run record EPA_TIMER_RECORD=1
+run nohop EPA_NO_BASE_HOP=1
 run cur2 A=1
-run record2 EPA_TIMER_RECORD=1
+run nohop2 EPA_NO_BASE_HOP=1
 cd $R
 cat $out

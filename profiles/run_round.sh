@@ -12,6 +12,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_stats -o st
   python $R/bench.py --no-cpu-baseline --no-extras > $R/gpurun_out/${tag}_stats.log 2>&1
 cd $R
 python profiles/db_to_txt.py gpurun_out/${tag}_stats/st_results.db > gpurun_out/${tag}_kernel_trace_stats.txt
+python profiles/step_timeline.py gpurun_out/${tag}_stats/st_results.db 12 > gpurun_out/${tag}_step_timeline.txt 2>/dev/null
 head -12 gpurun_out/${tag}_kernel_trace_stats.txt
 bash profiles/run_pmc.sh ${tag} \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" \
@@ -47,6 +48,7 @@ import subprocess
 subprocess.check_call(["python", "profiles/make_traffic.py", "${tag}", str(d["config"]["reads_per_step_per_gpu"]),
                        str(d["roofline"]["pairs_per_launch"]), str(a["config"]["reads_per_step_per_gpu"]), str(a["roofline"]["pairs_per_launch"])])
 PY
+if [ -n "$EPA_ROUND_SHORT" ]; then rm -rf gpurun_out/${tag}_stats gpurun_out/${tag}_aa_stats gpurun_out/${tag}_pmc_*/ gpurun_out/${tag}_aa_pmc_*/; exit 0; fi   # EPA_ROUND_SHORT=1: without the 1e9-pair cfg5 trace and the FMA clock microbenchmark
 # cfg5 at per-GPU shard size (BASELINE configs[4]: 4k tips, 1M reads, --no-heur on 8 GPUs = 125k reads per GPU):
 # one epa_dev_place_all call over 125 000 reads x 7997 branches = 1e9 pairs, kernel trace committed
 cd /tmp

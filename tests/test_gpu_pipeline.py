@@ -928,6 +928,16 @@ def test_staged_chunk_pipeline_equals_place_chunk(packed):
     assert n == len(expect[2][0])
     assert np.array_equal(d_pairs[:n, 0].cpu().numpy().view(np.uint32), expect[2][0]["branch_id"])
     assert np.array_equal(d_res[:n, 0].cpu().numpy(), expect[2][1]["lnl"])
+    # the same with EPA_CHUNK_HOST_ORDERED (no stream-level ordering against the context's stream: rows read after finish)
+    d_pairs.zero_(); d_res.zero_()
+    torch.cuda.synchronize()
+    ev.chunk_stage(0, *chunks[3])
+    ev.chunk_launch(0, max_span=150, max_pairs=cap, pairs_out=d_pairs, results_out=d_res, keep_on_device=True,
+                    host_ordered=True)
+    n = ev.chunk_finish_device(0)
+    assert n == len(expect[3][0])
+    assert np.array_equal(d_pairs[:n, 0].cpu().numpy().view(np.uint32), expect[3][0]["branch_id"])
+    assert np.array_equal(d_res[:n, 0].cpu().numpy(), expect[3][1]["lnl"])
 
 
 @pytest.mark.parametrize("packed", [False, True])
@@ -961,11 +971,15 @@ def test_staged_chunks_in_hbm_and_two_half_launch_order(packed):
             host = chunks
             hbm = [(torch.from_numpy(c).to(dev), torch.from_numpy(b.view(np.int32)).to(dev),
                     torch.from_numpy(s.view(np.int32)).to(dev)) for c, b, s in chunks]
-        for src in (host, hbm):
+        # host_ordered (EPA_CHUNK_HOST_ORDERED): the same loop without the library's stream-level ordering against the
+        # context's stream -- legal here (inputs synchronised, rows read after finish), same bits
+        for src, ho in ((host, False), (hbm, False), (host, True), (hbm, True)):
+            if ho:
+                torch.cuda.synchronize()
             got = []
             ev.chunk_stage(0, *src[0])
             for k in range(len(src)):
-                ev.chunk_launch_begin(k & 1, max_span=150, max_pairs=cap)
+                ev.chunk_launch_begin(k & 1, max_span=150, max_pairs=cap, host_ordered=ho)
                 if k:
                     got.append(ev.chunk_finish((k - 1) & 1))
                 if k + 1 < len(src):
