@@ -629,6 +629,39 @@ struct SegTrack {   // running maximum of the current segment of one query
   }
 };
 
+// Progress-based wave priority in the gather loops (round 5).  The SIMD's arbiter is oldest-first, so the sixteen waves
+// of the workgroup get through a branch's gathers at different speeds and the average wave waited 1200 of a branch's
+// 5200 clocks at the barrier for the slowest one (profiles/r4_preplace_cycles.txt).  A wave now starts its gathers at
+// priority 3 and steps down to 0 a quarter of its batches at a time: whoever is behind issues first, the waves reach
+// the barrier together.  Same box, cfg2: 0.965 -> 0.910 ms per launch (PP_PRIO=0: off; two levels 0.929, thresholds at
+// 40 / 70 / 90 % 0.914, at 10 / 30 / 60 % 0.930; the double-buffered and two-branch loops still lose with it:
+// 0.949 / 1.011; profiles/r5_preplace_prio_ab.txt).
+#ifndef PP_PRIO
+#define PP_PRIO 1
+#endif
+template <int NBATCH>
+__device__ __forceinline__ void gather_prio(int bt) {
+#if PP_PRIO == 1
+  if (bt == 0) __builtin_amdgcn_s_setprio(3);
+  else if (bt == NBATCH / 4) __builtin_amdgcn_s_setprio(2);
+  else if (bt == NBATCH / 2) __builtin_amdgcn_s_setprio(1);
+  else if (bt == (3 * NBATCH) / 4) __builtin_amdgcn_s_setprio(0);
+#elif PP_PRIO == 2   // two levels
+  if (bt == 0) __builtin_amdgcn_s_setprio(3);
+  else if (bt == NBATCH / 2) __builtin_amdgcn_s_setprio(0);
+#elif PP_PRIO == 3   // late thresholds
+  if (bt == 0) __builtin_amdgcn_s_setprio(3);
+  else if (bt == (2 * NBATCH) / 5) __builtin_amdgcn_s_setprio(2);
+  else if (bt == (7 * NBATCH) / 10) __builtin_amdgcn_s_setprio(1);
+  else if (bt == (9 * NBATCH) / 10) __builtin_amdgcn_s_setprio(0);
+#elif PP_PRIO == 4   // early thresholds
+  if (bt == 0) __builtin_amdgcn_s_setprio(3);
+  else if (bt == NBATCH / 10) __builtin_amdgcn_s_setprio(2);
+  else if (bt == (3 * NBATCH) / 10) __builtin_amdgcn_s_setprio(1);
+  else if (bt == (6 * NBATCH) / 10) __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 struct ItemWalk { uint32_t pos, end, step; };
 __device__ __forceinline__ ItemWalk item_walk(uint32_t total) {
   if (PP_XCD && (gridDim.x & 7u) == 0) {
@@ -839,6 +872,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
         PP_SCHED_BARRIER();
 #pragma unroll
         for (int bt = 0; bt < NBATCH; ++bt) {
+          gather_prio<NBATCH>(bt);
           if (bt + 1 < NBATCH) issue(bt + 1);
           PP_SCHED_BARRIER();
 #pragma unroll
@@ -1177,6 +1211,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_sites(
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int bt = 0; bt < NBATCH; ++bt) {
+            gather_prio<NBATCH>(bt);
             if (bt + 1 < NBATCH) issue(bt + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
