@@ -34,6 +34,16 @@ def test_c_abi_exports_every_declared_symbol():
     assert epa.device_count() >= 0
 
 
+def test_chunk_flags_of_the_python_harness_match_the_header():
+    """EPA_CHUNK_NO_D2H / EPA_CHUNK_HOST_ORDERED: the ctypes harness passes the header's bit values"""
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "epa_dev.h")).read()
+    vals = {k: int(v, 16) for k, v in re.findall(r"#define (EPA_CHUNK_[A-Z0-9_]+) (0x[0-9a-f]+)u", hdr)}
+    assert vals == {"EPA_CHUNK_NO_D2H": 1, "EPA_CHUNK_HOST_ORDERED": 2}
+    f = epa.Evaluator._chunk_flags
+    assert f(False, False) == 0 and f(True, False) == vals["EPA_CHUNK_NO_D2H"]
+    assert f(False, True) == vals["EPA_CHUNK_HOST_ORDERED"] and f(True, True) == 3
+
+
 def test_no_device_is_loud_not_a_fallback():
     if epa.device_count() > 0:
         pytest.skip("a GPU is visible")
