@@ -662,14 +662,37 @@ __device__ __forceinline__ void gather_prio(int bt) {
 #endif
 }
 
-struct ItemWalk { uint32_t pos, end, step; };
+struct ItemWalk { uint32_t pos, end, step, lo; };
 __device__ __forceinline__ ItemWalk item_walk(uint32_t total) {
   if (PP_XCD && (gridDim.x & 7u) == 0) {
     const uint32_t x = blockIdx.x & 7u, local = blockIdx.x >> 3;
     const uint32_t lo = (uint32_t)((uint64_t)total * x / 8), hi = (uint32_t)((uint64_t)total * (x + 1) / 8);
-    return {lo + local, hi, gridDim.x >> 3};
+    return {lo + local, hi, gridDim.x >> 3, lo};
   }
-  return {blockIdx.x, total, gridDim.x};
+  return {blockIdx.x, total, gridDim.x, 0u};
+}
+
+// Which (group, tile) a position v of an XCD's contiguous range [lo, hi) stands for.  The RANGES are cut in group-major
+// order (u = group * ntiles + tile): an XCD owns ~ng / 8 whole groups (a boundary group is shared by two), so the
+// packed offsets of a group -- 160 B per query, read again by every one of its tiles -- come out of ONE L2 instead of
+// a different one per tile (0.2 GB of the launch's HBM-side traffic at cfg2).  INSIDE its range an XCD still walks
+// tile-major (tile t: the range's groups ascending), so the workgroups running at the same time stage overlapping
+// slices of the same branches.  With lo = 0, hi = total this is the plain tile-major order (tile = v / ng).
+#ifndef PP_XCD_GROUPS
+#define PP_XCD_GROUPS 1
+#endif
+__device__ __forceinline__ void item_group_tile(uint32_t v, uint32_t lo, uint32_t hi, uint32_t ng, uint32_t ntiles,
+                                                uint32_t& grp, uint32_t& tile) {
+  if (!PP_XCD_GROUPS) { grp = v % ng; tile = v / ng; return; }
+  const uint32_t gl = lo / ntiles, tl = lo - gl * ntiles, gh = (hi - 1) / ntiles, th = (hi - 1) - gh * ntiles;
+  uint32_t r = v - lo;
+  for (uint32_t t = 0; t < ntiles; ++t) {
+    const uint32_t first = gl + (t < tl ? 1u : 0u), last1 = gh + 1u - (t > th ? 1u : 0u);   // [first, last1)
+    const uint32_t c = last1 > first ? last1 - first : 0u;
+    if (r < c) { grp = first + r; tile = t; return; }
+    r -= c;
+  }
+  grp = 0; tile = ntiles;   // not reached for lo <= v < hi
 }
 
 // Branches per work item of the single-chunk fast paths (ng groups x ceil(B / n) items on nwg
@@ -756,8 +779,10 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
 #ifdef PP_PROFILE
   pp_item_t0 = __builtin_readcyclecounter();
 #endif
-  const Group g = groups[item % ng];
-  const uint32_t b0 = (item / ng) * NBP;
+  uint32_t item_g, item_t;
+  item_group_tile(item, iw.lo, iw.end, ng, ntiles, item_g, item_t);
+  const Group g = groups[item_g];
+  const uint32_t b0 = item_t * NBP;
   const uint32_t nb = min(NBP, B - b0);
   __syncthreads();  // the previous item's readers of s_maxspan / accs / the tile are done
   if (g.count == 0) continue;
