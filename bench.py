@@ -330,16 +330,45 @@ def main():
     # selects the torch.distributed harness of the same protocol (epa_ng_amd/parallel.py) instead.
     gather_path = os.environ.get("EPA_BENCH_GATHER", "epa_comm") if world > 1 else None
 
+    # The first real N > 1 run must not be able to lose the line: the product's communicator
+    # is created and PROBED -- one one-row gather + one all-reduce through everything a real gather uses, every wait
+    # bounded by probe_s -- inside the collective agreement below; a transport that cannot move data between these
+    # processes costs probe_s seconds, then all ranks abort it and run the torch.distributed harness together.
+    probe_s = float(os.environ.get("EPA_BENCH_PROBE_S", "45"))
+    run_timeout_s = float(os.environ.get("EPA_BENCH_COMM_TIMEOUT_S", "180"))
+    gather_info = {"rccl_path": None, "devices": None, "probe_seconds": None}
+
+    def bind_transport():
+        """the product binds the librccl this process has ALREADY mapped (torch's own copy once the nccl backend is
+        up) -- never a second RCCL beside it; EPA_RCCL_LIB (the tests' stand-in) wins"""
+        if os.environ.get("EPA_RCCL_LIB"):
+            return
+        path = epa.mapped_rccl_path()
+        if path:
+            try:
+                epa.comm_set_library(path)
+            except epa.EpaError:
+                pass          # already loaded by an earlier communicator of this process: the same file
+
     class ProductGather:
         """post / finish / carried_rows of parallel.AsyncResultGather, on api.Comm"""
 
         def __init__(self, host_copy):
+            bind_transport()
+            epa.comm_set_default_timeout(probe_s)            # bounds ncclCommInitRank as well
             idt = torch.zeros(128, dtype=torch.uint8, device=cdev)
             if rank == 0:
                 idt.copy_(torch.frombuffer(bytearray(epa.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(idt, 0)
             self.depth = 2
+            self.comm = None
+            t0 = time.perf_counter()
             self.comm = epa.Comm(ev, bytes(idt.cpu().numpy().tobytes()), rank, world, rows_cap, depth=self.depth)
+            devices = self.comm.probe(probe_s)               # raises within ~probe_s if the transport does not deliver
+            self.comm.set_timeout(run_timeout_s)
+            if rank == 0:
+                gather_info.update(rccl_path=epa.comm_library_path(), devices=devices,
+                                   probe_seconds=round(time.perf_counter() - t0, 3))
             self.host_copy, self.posted, self.collected, self.rows_seen = host_copy, 0, 0, 0
             self.counts = []
 
@@ -390,18 +419,35 @@ def main():
             # ncclCommInitRank failure) every rank falls back to the torch.distributed harness together --
             # the line then says so instead of the job hanging half way
             g, err = None, ""
+            holder = {}
             try:
-                g = ProductGather(host_copy)
+                g = ProductGather.__new__(ProductGather)
+                holder["g"] = g
+                g.__init__(host_copy)
             except Exception as e:  # noqa: BLE001
-                err = repr(e)
+                err, g = repr(e), None
             ok = torch.tensor([1 if g is not None else 0], dtype=torch.int32, device=cdev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1:
+                gather_info["devices_known"] = True       # (on every rank: rank 0 holds the list)
                 return g
-            if g is not None:
-                g.comm.abort()
-            gather_note.append("epa_comm gather unavailable on some rank (%s): torch.distributed harness used" % (err or "another rank"))
+            half = holder.get("g")
+            if half is not None and getattr(half, "comm", None) is not None:
+                half.comm.abort()            # ncclCommAbort: nobody waits for a peer that gave up
+                half.comm = None
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            gather_note.append("epa_comm gather unavailable (%s): torch.distributed harness used"
+                               % "; ".join("rank %d: %s" % (r_, e_) for r_, e_ in enumerate(errs) if e_))
             gather_path = "torch"
+        if not gather_info.get("devices_known"):
+            # the torch harness: still say which devices the ranks sat on
+            gather_info["devices_known"] = True
+            devs = [None] * world
+            pr = torch.cuda.get_device_properties(local)
+            dist.all_gather_object(devs, "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0),
+                                                             getattr(pr, "pci_device_id", 0)))
+            gather_info["devices"] = devs
         return parallel.AsyncResultGather(dist, rows_cap, dev, host_copy=host_copy)
 
     exch = make_gather(False)
@@ -855,6 +901,9 @@ def main():
                                      if (gather_path != "torch" and os.environ.get("EPA_RCCL_LIB")) else
                                      ("RCCL" if (gather_path != "torch" or dist.get_backend() == "nccl") else dist.get_backend())),
                        "fallback": gather_note or None,
+                       "rccl_path": gather_info["rccl_path"], "devices": gather_info["devices"],
+                       "distinct_devices": len(set(gather_info["devices"] or [])),
+                       "probe_seconds": gather_info["probe_seconds"],
                        "rows_cap": rows_cap, "carried_rows_rank0": int(exch.carried_rows + exch2.carried_rows),
                        "rows_collected_rank0": (int(getattr(exch, "rows_seen", 0) + getattr(exch2, "rows_seen", 0)) if gather_path != "torch" else None)}
                       if world > 1 else None),

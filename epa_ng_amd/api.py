@@ -17,7 +17,8 @@ DEV_SO = os.environ.get("EPA_DEV_SO", os.path.join(HERE, "libepa_dev.so"))
 
 __all__ = ["EpaError", "dev_lib", "device_count", "encode_queries", "Evaluator", "PAIR_DTYPE",
            "RESULT_DTYPE", "ROW_DTYPE", "DEV_SO", "Packed4", "pack_codes_4bit", "unpack_codes_4bit", "Comm",
-           "comm_unique_id"]
+           "comm_unique_id", "mapped_rccl_path", "comm_set_library", "comm_library_path", "comm_set_default_timeout",
+           "pci_id_str"]
 
 PAIR_DTYPE = np.dtype([("branch_id", np.uint32), ("seq_id", np.uint32)])
 RESULT_DTYPE = np.dtype([("lnl", np.float64), ("pendant_length", np.float64),
@@ -139,6 +140,11 @@ def dev_lib():
                                              C.POINTER(C.c_uint64), C.c_void_p]
         L.epa_comm_abort.argtypes = [C.c_void_p]
         L.epa_comm_abort.restype = None
+        L.epa_comm_set_library.argtypes = [C.c_char_p]
+        L.epa_comm_library_path.restype = C.c_char_p
+        L.epa_comm_set_timeout.argtypes = [C.c_void_p, C.c_double]
+        L.epa_comm_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.c_uint64)]
+        L.epa_comm_set_self_send.argtypes = [C.c_void_p, C.c_int]
         L.epa_comm_device_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
         L.epa_comm_device_rows.restype = C.c_void_p
         L.epa_dev_mem_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -523,15 +529,62 @@ def comm_unique_id():
     return buf.raw
 
 
+def mapped_rccl_path():
+    """the librccl this process has ALREADY mapped (PyTorch's torch/lib/librccl.so once torch.distributed's nccl
+    backend is up), or None -- what comm_set_library() should be given so that the product binds the same copy"""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                i = line.find("/")
+                if i >= 0 and os.path.basename(line[i:].strip()).startswith("librccl.so"):
+                    return line[i:].strip()
+    except OSError:
+        pass
+    return None
+
+
+def comm_set_library(path):
+    """the transport library of every later Comm (before the first one): epa_comm_set_library"""
+    L = dev_lib()
+    rc = L.epa_comm_set_library(path.encode() if path else None)
+    if rc:
+        raise EpaError(rc, (L.epa_dev_last_error(None) or b"").decode())
+
+
+def comm_library_path():
+    """the file the product bound its ten RCCL entry points from ('' if none could be loaded)"""
+    return (dev_lib().epa_comm_library_path() or b"").decode()
+
+
+def comm_set_default_timeout(seconds):
+    """process default of every communicator's host-side waits, incl. ncclCommInitRank inside Comm()"""
+    dev_lib().epa_comm_set_timeout(None, float(seconds))
+
+
+def pci_id_str(v):
+    return "%04x:%02x:%02x" % (v >> 16, (v >> 8) & 0xff, v & 0xff)
+
+
 class Comm:
     """The product library's RCCL gather of (pair, result) rows to rank 0 (include/epa_dev.h, epa_comm_*;
     epa_ng_amd/csrc/comm.hip).  One per process / Evaluator."""
 
-    def __init__(self, ev, unique_id, rank, world, rows_cap, depth=2):
+    def __init__(self, ev, unique_id, rank, world, rows_cap, depth=2, self_send=False):
         self.ev, self.L, self.rank, self.world, self.rows_cap, self.depth = ev, ev.L, rank, world, rows_cap, depth
         h = C.c_void_p()
         ev._check(self.L.epa_comm_create(ev.h, unique_id, rank, world, rows_cap, depth, C.byref(h)))
         self.h = h
+        if self_send:
+            ev._check(self.L.epa_comm_set_self_send(self.h, 1))
+
+    def set_timeout(self, seconds):
+        self.ev._check(self.L.epa_comm_set_timeout(self.h, float(seconds)))
+
+    def probe(self, timeout_s=60.0):
+        """collective handshake (epa_comm_probe); rank 0 -> the PCI ids of every rank's device, others -> None"""
+        ids = (C.c_uint64 * self.world)()
+        self.ev._check(self.L.epa_comm_probe(self.ev.h, self.h, float(timeout_s), ids))
+        return [pci_id_str(int(x)) for x in ids] if self.rank == 0 else None
 
     def close(self):
         if getattr(self, "h", None):

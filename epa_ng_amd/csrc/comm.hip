@@ -25,6 +25,8 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -38,17 +40,54 @@ namespace {
 
 struct Rccl : epa_rccl_api {
   void* h = nullptr;
-  std::string err;
+  std::string err, path;
 };
+bool g_rccl_loaded = false;
+
+// Which library carries the ten entry points, in this order:
+//   1. the path handed to epa_comm_set_library() (an API call: the host program decides),
+//   2. EPA_RCCL_LIB (the same as an environment override: how the CLI and the tests point at
+//      tests/fake_rccl.cpp, a same-device transport stand-in, so that world > 1 runs on a 1-GPU box),
+//   3. a librccl that is ALREADY MAPPED in this process (/proc/self/maps) -- a host program that brought
+//      its own RCCL (PyTorch ships torch/lib/librccl.so) must not end up with a second copy of the
+//      library, with its own topology detection and its own IPC state, beside the one it already uses,
+//   4. the loader's search path: librccl.so.1, librccl.so, /opt/rocm/lib/librccl.so.1.
+std::string g_rccl_pref;          // epa_comm_set_library
+std::mutex g_rccl_mu;
+
+std::string mapped_rccl() {
+  std::string found;
+  if (FILE* f = fopen("/proc/self/maps", "r")) {
+    char line[4352];
+    while (fgets(line, sizeof line, f)) {
+      const char* sl = strchr(line, '/');
+      if (!sl) continue;
+      std::string path(sl);
+      while (!path.empty() && (path.back() == '\n' || path.back() == ' ')) path.pop_back();
+      const size_t b = path.rfind('/');
+      if (path.compare(b + 1, 10, "librccl.so") == 0) { found = path; break; }
+    }
+    fclose(f);
+  }
+  return found;
+}
 
 void load_rccl(Rccl& r) {
-  // EPA_RCCL_LIB names another library with the same ten symbols (tests/fake_rccl.cpp: a same-device
-  // transport stand-in, so that world > 1 runs on a 1-GPU box)
-  const char* names[] = {getenv("EPA_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) {
-    if (!n || !*n) continue;
-    r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (r.h) break;
+  std::vector<std::string> names;
+  {
+    std::lock_guard<std::mutex> g(g_rccl_mu);
+    if (!g_rccl_pref.empty()) names.push_back(g_rccl_pref);
+  }
+  const bool pinned = !names.empty();
+  if (const char* e = getenv("EPA_RCCL_LIB")) if (*e && !pinned) names.push_back(e);
+  if (names.empty()) {   // an explicit choice is final: no silent fallback to another library
+    const std::string m = mapped_rccl();
+    if (!m.empty()) names.push_back(m);
+    names.insert(names.end(), {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"});
+  }
+  for (const std::string& n : names) {
+    r.h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (r.h) { r.path = n; break; }
     r.err = dlerror();
   }
   if (!r.h) return;
@@ -66,28 +105,32 @@ void load_rccl(Rccl& r) {
   SYM(AllReduce, "ncclAllReduce")
   SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+  Dl_info di;   // the file the loader really bound (a bare soname resolves through the search path)
+  if (dladdr((void*)r.CommInitRank, &di) && di.dli_fname && *di.dli_fname) r.path = di.dli_fname;
 }
 
 Rccl* rccl() {
   static Rccl r;
   static std::once_flag once;
-  std::call_once(once, [] { load_rccl(r); });
+  std::call_once(once, [] { load_rccl(r); std::lock_guard<std::mutex> g(g_rccl_mu); g_rccl_loaded = true; });
   return &r;
 }
 
 // the wait of a collective's host side: an event that a healthy job completes in milliseconds.  A peer
-// that died leaves it pending for ever (the reference's MPI build would abort the job): give up after
-// EPA_COMM_TIMEOUT_S (default 600) so that the caller can epa_comm_abort() and exit non-zero.
+// that died leaves it pending for ever (the reference's MPI build would abort the job): give up after the
+// communicator's timeout -- epa_comm_set_timeout(), else the process default (epa_comm_set_timeout(NULL, s)),
+// else EPA_COMM_TIMEOUT_S, else 600 s -- so that the caller can epa_comm_abort() and exit non-zero.
+double g_default_timeout = 0.0;   // 0: not set through the API
 double comm_timeout_s() {
+  if (g_default_timeout > 0) return g_default_timeout;
   const char* e = getenv("EPA_COMM_TIMEOUT_S");
   const double v = e ? atof(e) : 600.0;
   return v > 0 ? v : 600.0;
 }
 
-hipError_t wait_event(hipEvent_t ev, bool* timed_out) {
+hipError_t wait_event(hipEvent_t ev, bool* timed_out, double lim) {
   *timed_out = false;
   const auto t0 = std::chrono::steady_clock::now();
-  const double lim = comm_timeout_s();
   for (unsigned spin = 0;; ++spin) {
     const hipError_t e = hipEventQuery(ev);
     if (e != hipErrorNotReady) return e;
@@ -154,6 +197,9 @@ struct epa_comm {
   uint64_t carried_rows = 0, next_ticket = 0;
   unsigned long long* d_pend = nullptr;   // all-reduce scratch (2 words)
   unsigned long long* h_pend = nullptr;   // pinned
+  epa_row* d_probe = nullptr;             // one row: this rank's identity in epa_comm_probe
+  double timeout = 0.0;                   // seconds a host-side wait may take; 0 = the process default
+  double lim() const { return timeout > 0 ? timeout : comm_timeout_s(); }
 };
 
 #define EPA_NCCL(ctx, call)                                                                               \
@@ -162,6 +208,30 @@ struct epa_comm {
     if (r__ != ncclSuccess)                                                                               \
       return epa_fail(ctx, EPA_ERR_HIP, std::string(#call) + ": " + rccl()->GetErrorString(r__));        \
   } while (0)
+
+extern "C" int epa_comm_set_library(const char* path) {
+  std::lock_guard<std::mutex> g(g_rccl_mu);
+  if (g_rccl_loaded) return epa_fail(nullptr, EPA_ERR_INVALID_ARG, "comm_set_library: the transport library is already loaded");
+  g_rccl_pref = path ? path : "";
+  return EPA_OK;
+}
+
+extern "C" const char* epa_comm_library_path(void) {
+  Rccl* R = rccl();
+  return R->h ? R->path.c_str() : "";
+}
+
+extern "C" int epa_comm_set_timeout(epa_comm* c, double seconds) {
+  if (!(seconds >= 0)) return EPA_ERR_INVALID_ARG;
+  if (c) c->timeout = seconds; else g_default_timeout = seconds;
+  return EPA_OK;
+}
+
+extern "C" int epa_comm_set_self_send(epa_comm* c, int on) {
+  if (!c || c->next_ticket) return EPA_ERR_INVALID_ARG;
+  c->self_send = on != 0;
+  return EPA_OK;
+}
 
 extern "C" int epa_comm_get_unique_id(void* id128) {
   Rccl* R = rccl();
@@ -188,6 +258,7 @@ extern "C" void epa_comm_destroy(epa_comm* c) {
   for (int i = 0; i < 2; ++i)
     if (c->carry[i]) (void)hipFree(c->carry[i]);
   if (c->d_pend) (void)hipFree(c->d_pend);
+  if (c->d_probe) (void)hipFree(c->d_probe);
   if (c->h_pend) (void)hipHostFree(c->h_pend);
   if (c->ev_src) (void)hipEventDestroy(c->ev_src);
   if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
@@ -206,16 +277,34 @@ extern "C" int epa_comm_create(epa_ctx* ctx, const void* id128, int rank, int wo
   EPA_HIP(ctx, hipSetDevice(ctx->device));
   epa_comm* c = new epa_comm;
   c->ctx = ctx; c->rank = rank; c->world = world; c->cap = rows_cap; c->depth = depth;
-  c->self_send = getenv("EPA_COMM_SELF_SEND") != nullptr;
   auto fail = [&](int rc) { epa_comm_destroy(c); return rc; };
   ncclUniqueId id;
   std::memcpy(&id, id128, sizeof(id));
   {
-    const ncclResult_t rc = R->CommInitRank(&c->comm, world, id, rank);
-    if (rc != ncclSuccess) {
+    // ncclCommInitRank blocks until every rank has joined: a rank that never arrives would hold this one for ever.
+    // It runs on a helper thread; past the timeout the caller gets an error (the helper, still inside RCCL's
+    // bootstrap, is left behind -- the process is expected to fall back or exit)
+    struct Init { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t rc = ncclSuccess; ncclComm_t comm = nullptr; };
+    auto st = std::make_shared<Init>();
+    const int dev = ctx->device;
+    std::thread([st, R, world, id, rank, dev] {
+      (void)hipSetDevice(dev);
+      ncclComm_t cm = nullptr;
+      const ncclResult_t rc = R->CommInitRank(&cm, world, id, rank);
+      std::lock_guard<std::mutex> g(st->mu);
+      st->rc = rc; st->comm = cm; st->done = true;
+      st->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(st->mu);
+    const double lim = comm_timeout_s();
+    if (!st->cv.wait_for(lk, std::chrono::duration<double>(lim), [&] { return st->done; }))
+      return fail(epa_fail(ctx, EPA_ERR_HIP, "ncclCommInitRank: not all " + std::to_string(world) + " ranks joined within " +
+                                                 std::to_string((int)lim) + " s"));
+    if (st->rc != ncclSuccess) {
       c->comm = nullptr;
-      return fail(epa_fail(ctx, EPA_ERR_HIP, std::string("ncclCommInitRank: ") + R->GetErrorString(rc)));
+      return fail(epa_fail(ctx, EPA_ERR_HIP, std::string("ncclCommInitRank: ") + R->GetErrorString(st->rc)));
     }
+    c->comm = st->comm;
   }
 #define TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(epa_fail(ctx, EPA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__))); } while (0)
   {
@@ -228,6 +317,7 @@ extern "C" int epa_comm_create(epa_ctx* ctx, const void* id128, int rank, int wo
   TRY(hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming));
   TRY(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
   TRY(hipMalloc((void**)&c->d_pend, 16));
+  TRY(hipMalloc((void**)&c->d_probe, sizeof(epa_row)));
   TRY(hipHostMalloc((void**)&c->h_pend, 16));
   const size_t msg = sizeof(epa_row) * ((size_t)rows_cap + 1);
   c->gs.resize(depth);
@@ -378,8 +468,8 @@ extern "C" int epa_comm_collect(epa_comm* c, uint64_t ticket, const epa_row** ro
   if (g.ticket != ticket) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "comm_collect: the gather's slot has been reused (collect within `depth` posts)");
   EPA_HIP(ctx, hipSetDevice(ctx->device));
   bool late = false;
-  EPA_HIP(ctx, wait_event(g.ev_gather, &late));
-  if (late) return epa_fail(ctx, EPA_ERR_HIP, "comm_collect: gather " + std::to_string(ticket) + " did not complete within EPA_COMM_TIMEOUT_S (a peer failed?): epa_comm_abort and exit");
+  EPA_HIP(ctx, wait_event(g.ev_gather, &late, c->lim()));
+  if (late) return epa_fail(ctx, EPA_ERR_HIP, "comm_collect: gather " + std::to_string(ticket) + " did not complete within the communicator's timeout (a peer failed?): epa_comm_abort and exit");
   const size_t msg_rows = (size_t)c->cap + 1;
   for (int r = 0; r < c->world; ++r) {
     const epa_row& s = g.h_cnt[r];
@@ -394,7 +484,7 @@ extern "C" int epa_comm_collect(epa_comm* c, uint64_t ticket, const epa_row** ro
   }
   if (rows) {
     EPA_HIP(ctx, hipEventRecord(g.ev_host, c->cs));
-    EPA_HIP(ctx, wait_event(g.ev_host, &late));
+    EPA_HIP(ctx, wait_event(g.ev_host, &late, c->lim()));
     if (late) return epa_fail(ctx, EPA_ERR_HIP, "comm_collect: the copy of the rows to the host did not complete");
   }
   for (int r = 0; r < c->world; ++r) {
@@ -418,8 +508,8 @@ extern "C" int epa_comm_flush(epa_ctx* ctx, epa_comm* c, uint64_t* first_extra_t
   EPA_HIP(ctx, hipMemcpyAsync(c->h_pend + 1, c->d_pend + 1, 8, hipMemcpyDeviceToHost, c->cs));
   EPA_HIP(ctx, hipEventRecord(c->ev_src, c->cs));
   bool late = false;
-  EPA_HIP(ctx, wait_event(c->ev_src, &late));
-  if (late) return epa_fail(ctx, EPA_ERR_HIP, "comm_flush: the all-reduce did not complete within EPA_COMM_TIMEOUT_S (a peer failed?): epa_comm_abort and exit");
+  EPA_HIP(ctx, wait_event(c->ev_src, &late, c->lim()));
+  if (late) return epa_fail(ctx, EPA_ERR_HIP, "comm_flush: the all-reduce did not complete within the communicator's timeout (a peer failed?): epa_comm_abort and exit");
   const uint64_t pend = c->h_pend[1];
   // every rank computed the same maximum (the all-reduce), so every rank posts the same number of rounds;
   // at most `depth` per call: rank 0 collects them before their slots are posted again
@@ -443,14 +533,88 @@ extern "C" const epa_row* epa_comm_device_rows(const epa_comm* c, uint64_t ticke
   return g.recv + ((size_t)c->cap + 1) * rank;
 }
 
+// One round trip through everything a real gather uses, before any work depends on it: every rank posts a gather of
+// ONE row that names it (rank, PCI id of its device), rank 0 collects the world's rows, then all ranks meet in an
+// all-reduce (a sender's ncclSend may complete eagerly: the all-reduce is what tells every rank that every other rank
+// got this far).  Every wait is bounded by timeout_s.  On success the communicator is as created (tickets start at 0
+// again); on failure the caller epa_comm_abort()s it -- all ranks fail within about timeout_s of each other, since
+// none can pass the all-reduce alone.
+__global__ void k_probe_row(epa_row* row, uint32_t rank, double dev_id) {
+  epa_row o;
+  o.branch_id = rank;
+  o.seq_id = 0x9B0BE000u;
+  o.lnl = dev_id;
+  o.pendant_length = 0.0;
+  o.distal_length = 0.0;
+  *row = o;
+}
+
+extern "C" int epa_comm_probe(epa_ctx* ctx, epa_comm* c, double timeout_s, uint64_t* device_ids) {
+  if (!ctx || !c || c->ctx != ctx) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "comm_probe: communicator of another context");
+  if (c->next_ticket || c->carry_n) return epa_fail(ctx, EPA_ERR_INVALID_ARG, "comm_probe: only on a communicator that has not gathered yet");
+  Rccl* R = rccl();
+  EPA_HIP(ctx, hipSetDevice(ctx->device));
+  int dom = 0, bus = 0, devn = 0;
+  EPA_HIP(ctx, hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, ctx->device));
+  EPA_HIP(ctx, hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, ctx->device));
+  EPA_HIP(ctx, hipDeviceGetAttribute(&devn, hipDeviceAttributePciDeviceId, ctx->device));
+  const uint64_t my_id = ((uint64_t)(uint32_t)dom << 16) | ((uint64_t)(bus & 0xff) << 8) | (uint64_t)(devn & 0xff);
+  const double keep = c->timeout;
+  if (timeout_s > 0) c->timeout = timeout_s;
+  struct Restore { epa_comm* c; double t; ~Restore() { c->timeout = t; } } restore{c, keep};
+  hipLaunchKernelGGL(k_probe_row, dim3(1), dim3(1), 0, c->cs, c->d_probe, (uint32_t)c->rank, (double)my_id);
+  EPA_HIP(ctx, hipGetLastError());
+  uint64_t tk = 0;   // (the row is made on the communicator's stream, where gather_post queues its copy)
+  int rc = gather_post(ctx, c, nullptr, nullptr, c->d_probe, 1, 0, &tk);
+  if (rc) return rc;
+  if (c->rank == 0) {
+    std::vector<const epa_row*> rows(c->world);
+    std::vector<uint32_t> counts(c->world);
+    rc = epa_comm_collect(c, tk, rows.data(), counts.data(), nullptr);
+    if (rc) return rc;
+    for (int r = 0; r < c->world; ++r) {
+      if (counts[r] != 1 || rows[r][0].branch_id != (uint32_t)r || rows[r][0].seq_id != 0x9B0BE000u)
+        return epa_fail(ctx, EPA_ERR_HIP, "comm_probe: rank " + std::to_string(r) + " did not deliver its probe row");
+      if (device_ids) device_ids[r] = (uint64_t)rows[r][0].lnl;
+    }
+  }
+  // all ranks: sum of ones == world
+  c->h_pend[0] = 1;
+  EPA_HIP(ctx, hipMemcpyAsync(c->d_pend, c->h_pend, 8, hipMemcpyHostToDevice, c->cs));
+  if (c->world > 1)
+    EPA_NCCL(ctx, R->AllReduce(c->d_pend, c->d_pend + 1, 1, ncclUint64, ncclSum, c->comm, c->cs));
+  else
+    EPA_HIP(ctx, hipMemcpyAsync(c->d_pend + 1, c->d_pend, 8, hipMemcpyDeviceToDevice, c->cs));
+  EPA_HIP(ctx, hipMemcpyAsync(c->h_pend + 1, c->d_pend + 1, 8, hipMemcpyDeviceToHost, c->cs));
+  EPA_HIP(ctx, hipEventRecord(c->ev_src, c->cs));
+  bool late = false;
+  EPA_HIP(ctx, wait_event(c->ev_src, &late, c->lim()));
+  if (late) return epa_fail(ctx, EPA_ERR_HIP, "comm_probe: the all-reduce did not complete within " + std::to_string((int)c->lim()) + " s");
+  if (c->h_pend[1] != (unsigned long long)c->world)
+    return epa_fail(ctx, EPA_ERR_HIP, "comm_probe: the all-reduce saw " + std::to_string(c->h_pend[1]) + " ranks, not " + std::to_string(c->world));
+  // as created
+  c->next_ticket = 0;
+  for (auto& g : c->gs) g.ticket = ~0ull;
+  return EPA_OK;
+}
+
 extern "C" void epa_comm_abort(epa_comm* c) {
   // the failing rank's way out (the reference's MPI build would MPI_Abort): tears the communicator down
   // without waiting for the peers, which then see errors / timeouts instead of waiting for ever
   if (!c) return;
+  (void)hipSetDevice(c->ctx->device);
   if (c->comm) {
     Rccl* R = rccl();
     if (R->CommAbort) (void)R->CommAbort(c->comm);
     c->comm = nullptr;
   }
-  epa_comm_destroy(c);
+  // an aborted communicator's kernels leave the stream; should they not (a transport that ignores the abort), the
+  // buffers they may still touch are LEAKED rather than freed under them, and nobody waits for ever
+  bool idle = !c->cs;
+  const auto t0 = std::chrono::steady_clock::now();
+  while (!idle && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 10.0) {
+    idle = hipStreamQuery(c->cs) != hipErrorNotReady;
+    if (!idle) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+  }
+  if (idle) epa_comm_destroy(c);
 }

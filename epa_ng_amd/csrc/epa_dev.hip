@@ -1214,6 +1214,11 @@ extern "C" int epa_dev_build_lookup(epa_ctx* ctx) {
   EPA_HIP(ctx, hipSetDevice(ctx->device));
   int rc = launch_build_lookup(ctx);
   if (rc) return rc;
+  // once per context: the tables are COMPLETE when this returns.  The build runs on the context's stream, the
+  // chunk pipeline's slots on non-blocking streams of their own, and an EPA_CHUNK_HOST_ORDERED launch skips the
+  // event hop that would order a slot behind the context's stream -- a lazily built lookup must not be something
+  // any later launch on any stream has to be ordered against
+  EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->lookup_built = true;
   return EPA_OK;
 }

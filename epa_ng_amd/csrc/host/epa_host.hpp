@@ -60,6 +60,14 @@ struct Options {  // defaults: src/util/Options.hpp:13-34
   bool rate_scalers(size_t tips) const {
     return scaling == NumericalScaling::kOn || (scaling == NumericalScaling::kAuto && tips > 2000);
   }
+  // one-process-per-GPU mode (place_ranks.cpp; the reference's MPI build has no counterpart of these: mpirun is its launcher)
+  std::string comm_nonce;            // --comm-nonce / EPA_COMM_NONCE / TORCHELASTIC_RUN_ID: marks this run's id record in --comm-file
+  int comm_rows_per_read = 8;        // --comm-rows-per-read: rows per rank and gather = chunk x this (beyond it: the carry path)
+  double comm_probe_seconds = 120;   // --comm-probe-seconds: bound of the handshake after the communicator is created
+  double comm_timeout_seconds = 0;   // --comm-timeout: bound of every later wait for a peer (0: EPA_COMM_TIMEOUT_S, else 600)
+  bool comm_self_send = false;       // --comm-self-send (test hook): rank 0's own rows travel through ncclSend / ncclRecv
+  bool host_heuristic = false;       // --host-heuristic (diagnostic): candidate selection on the host from the Q x B table
+  bool no_pipeline = false;          // --no-pipeline (diagnostic): one chunk at a time, no read-ahead / staged slots
 };
 
 class Sequence {

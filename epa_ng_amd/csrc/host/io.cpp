@@ -108,7 +108,7 @@ Fasta_Stream::Fasta_Stream(const std::string& path) : f_(std::fopen(path.c_str()
   // a regular file is mapped: the parser reads the page cache directly (a 1.5 GB query file spent
   // 0.3 s of its 0.55 s in fread's copy); pipes and the like go through the read buffer
   struct stat sb;
-  if (::fstat(::fileno(f_), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && !std::getenv("EPA_NO_MMAP")) {
+  if (::fstat(::fileno(f_), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
     void* m = ::mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, ::fileno(f_), 0);
     if (m != MAP_FAILED) {
       ::madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);

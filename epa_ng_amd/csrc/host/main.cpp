@@ -39,7 +39,14 @@ static void usage() {
       "  --devices a,b,..      place on several GPUs of the node (chunks are dealt to them in turn)\n"
       "  --rank R --world N --comm-file F   one process per GPU: rank R places its contiguous slice of the\n"
       "                        queries, results are gathered to rank 0 over RCCL; rank 0 leaves the RCCL id in F\n"
-      "                        (defaults: RANK / WORLD_SIZE / LOCAL_RANK / EPA_COMM_FILE of the environment)\n";
+      "                        (defaults: RANK / WORLD_SIZE / LOCAL_RANK / EPA_COMM_FILE of the environment)\n"
+      "  --comm-nonce STR      marks this run's id record in F (default: EPA_COMM_NONCE / TORCHELASTIC_RUN_ID); give\n"
+      "                        one whenever the launcher can: without it a record is only checked for its age\n"
+      "  --comm-probe-seconds S  bound of the handshake every rank runs before placing (default 120)\n"
+      "  --comm-timeout S      bound of every later wait for a peer (default EPA_COMM_TIMEOUT_S, else 600)\n"
+      "  --comm-rows-per-read N  rows per rank and gather = chunk x N (default 8; more rows take the carry path)\n"
+      "                        RCCL is bound at run time: the library named by EPA_RCCL_LIB, else librccl.so.1 on the\n"
+      "                        loader's search path (LD_LIBRARY_PATH), else /opt/rocm/lib/librccl.so.1\n";
 }
 
 int main(int argc, char** argv) {
@@ -60,6 +67,8 @@ int main(int argc, char** argv) {
   int rank = env_int("EPA_RANK", "RANK", 0), world = env_int("EPA_WORLD", "WORLD_SIZE", 1);
   const int local_rank = env_int("EPA_LOCAL_RANK", "LOCAL_RANK", rank);
   std::string comm_file = std::getenv("EPA_COMM_FILE") ? std::getenv("EPA_COMM_FILE") : "";
+  if (const char* e = std::getenv("EPA_COMM_NONCE")) opt.comm_nonce = e;
+  if (opt.comm_nonce.empty()) if (const char* e = std::getenv("TORCHELASTIC_RUN_ID")) opt.comm_nonce = e;
   auto need = [&](int& i) -> std::string {
     if (i + 1 >= argc) { std::cerr << "missing value for " << argv[i] << "\n"; std::exit(1); }
     return argv[++i];
@@ -110,6 +119,13 @@ int main(int argc, char** argv) {
     else if (a == "--rank") rank = std::stoi(need(i));
     else if (a == "--world") world = std::stoi(need(i));
     else if (a == "--comm-file") comm_file = need(i);
+    else if (a == "--comm-nonce") opt.comm_nonce = need(i);
+    else if (a == "--comm-probe-seconds") opt.comm_probe_seconds = std::stod(need(i));
+    else if (a == "--comm-timeout") opt.comm_timeout_seconds = std::stod(need(i));
+    else if (a == "--comm-rows-per-read") opt.comm_rows_per_read = std::stoi(need(i));
+    else if (a == "--comm-self-send") opt.comm_self_send = true;       // test hook
+    else if (a == "--host-heuristic") opt.host_heuristic = true;       // diagnostics
+    else if (a == "--no-pipeline") opt.no_pipeline = true;
     else if (a == "--redo" || a == "--verbose") {}
     else if (a == "-h" || a == "--help") { usage(); return 0; }
     else { std::cerr << "option " << a << " is outside the placement hot path of this build\n"; return 1; }

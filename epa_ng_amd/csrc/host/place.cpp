@@ -447,8 +447,8 @@ Sample process_chunk(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tre
   const bool all_on_device = !options.prescoring && options.filter_min >= 1 &&
                              options.filter_max >= options.filter_min && options.filter_max <= 64 &&
                              (uint64_t)n * B <= 0xffffffffull;
-  // EPA_HOST_HEURISTIC=1: keep the Q x B table round trip and the host heuristics (cross-check)
-  static const bool host_heur = std::getenv("EPA_HOST_HEURISTIC") != nullptr;
+  // --host-heuristic: keep the Q x B table round trip and the host heuristics (cross-check)
+  const bool host_heur = options.host_heuristic;
   const bool fused = options.prescoring && options.device_select && B <= 65536 && !host_heur;
   if (all_on_device) {
     tm.pairs = place_all(chunk, enc, tree, dev, blo_sample, options, seq_id_offset);
@@ -607,9 +607,9 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
     cv_get.notify_all();
   });
 
-  // EPA_HOST_HEURISTIC=1: keep the Q x B table round trip and the host heuristics (cross-check)
+  // --host-heuristic: keep the Q x B table round trip and the host heuristics (cross-check); --no-pipeline: one chunk at a time
   const bool pipelined = options.prescoring && options.device_select && tree.num_branches() <= 65536 &&
-                         std::getenv("EPA_HOST_HEURISTIC") == nullptr && std::getenv("EPA_NO_PIPELINE") == nullptr;
+                         !options.host_heuristic && !options.no_pipeline;
   auto worker = [&](size_t k) {
     try {
       auto take = [&](Staged& cur) -> bool {

@@ -38,9 +38,13 @@ std::pair<size_t, size_t> local_seq_package(size_t num_sequences, int rank, int 
 
 // The 128-byte RCCL id travels through a file.  A file left behind by an earlier run (a crashed one: a
 // healthy rank 0 removes it once the communicator exists) must never be taken for this run's: the record
-// carries a nonce (--comm-nonce / EPA_COMM_NONCE / torchrun's TORCHELASTIC_RUN_ID, hashed) and rank 0's
-// wall-clock time of writing; a reader accepts a record only with its own nonce and, when no nonce was
-// given, only one written no earlier than a minute before the reader itself started.
+// carries a nonce (Options::comm_nonce: --comm-nonce / EPA_COMM_NONCE / torchrun's TORCHELASTIC_RUN_ID, hashed) and rank 0's
+// wall-clock time of writing; a reader accepts a record only with its own nonce.  Without a nonce (plain mpirun /
+// srun / a shell loop) what keeps an older run's file out is rank 0 itself -- it REPLACES the file before anything
+// slow and removes it once the communicator exists -- plus a coarse age test: a record written more than 15 minutes
+// before the reader started is ignored (the ranks of one job start within that, and their clocks agree to within it;
+// a tighter bound would reject a valid id on a late rank or a skewed node: ADVICE round 5).  Give a nonce
+// (--comm-nonce) whenever the launcher can.
 namespace {
 struct Id_Record {
   char magic[8];
@@ -49,12 +53,10 @@ struct Id_Record {
   unsigned char id[EPA_COMM_ID_BYTES];
 };
 
-uint64_t comm_nonce() {
-  const char* e = std::getenv("EPA_COMM_NONCE");
-  if (!e || !*e) e = std::getenv("TORCHELASTIC_RUN_ID");
-  if (!e || !*e) return 0;
+uint64_t comm_nonce(const std::string& text) {   // Options::comm_nonce, hashed; 0 = none given
+  if (text.empty()) return 0;
   uint64_t h = 1469598103934665603ull;   // FNV-1a
-  for (; *e; ++e) h = (h ^ (unsigned char)*e) * 1099511628211ull;
+  for (const char ch : text) h = (h ^ (unsigned char)ch) * 1099511628211ull;
   return h ? h : 1;
 }
 
@@ -63,13 +65,13 @@ int64_t unix_ms() {
 }
 }  // namespace
 
-static void publish_id(const std::string& path, unsigned char (&id)[EPA_COMM_ID_BYTES]) {
+static void publish_id(const std::string& path, uint64_t nonce, unsigned char (&id)[EPA_COMM_ID_BYTES]) {
   if (path.empty()) throw std::runtime_error{"--world > 1 needs --comm-file (or EPA_COMM_FILE): where rank 0 leaves the RCCL id"};
   std::remove(path.c_str());   // whatever an earlier run left there
   if (epa_comm_get_unique_id(id) != EPA_OK) throw std::runtime_error{epa_dev_last_error(nullptr)};
   Id_Record rec{};
   std::memcpy(rec.magic, "EPACOMM1", 8);
-  rec.nonce = comm_nonce();
+  rec.nonce = nonce;
   rec.written_unix_ms = unix_ms();
   std::memcpy(rec.id, id, sizeof(id));
   const std::string tmp = path + ".tmp";
@@ -79,9 +81,8 @@ static void publish_id(const std::string& path, unsigned char (&id)[EPA_COMM_ID_
   if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error{"cannot rename " + tmp};
 }
 
-static void await_id(const std::string& path, int rank, int64_t started_unix_ms, unsigned char (&id)[EPA_COMM_ID_BYTES]) {
+static void await_id(const std::string& path, uint64_t nonce, int rank, int64_t started_unix_ms, unsigned char (&id)[EPA_COMM_ID_BYTES]) {
   if (path.empty()) throw std::runtime_error{"--world > 1 needs --comm-file (or EPA_COMM_FILE): where rank 0 leaves the RCCL id"};
-  const uint64_t nonce = comm_nonce();
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
     if (std::FILE* f = std::fopen(path.c_str(), "rb")) {
@@ -89,7 +90,7 @@ static void await_id(const std::string& path, int rank, int64_t started_unix_ms,
       const size_t n = std::fread(&rec, 1, sizeof(rec), f);
       std::fclose(f);
       if (n == sizeof(rec) && std::memcmp(rec.magic, "EPACOMM1", 8) == 0 && rec.nonce == nonce &&
-          (nonce != 0 || rec.written_unix_ms >= started_unix_ms - 60000)) {
+          (nonce != 0 || rec.written_unix_ms >= started_unix_ms - 15 * 60000)) {
         std::memcpy(id, rec.id, sizeof(id));
         return;
       }
@@ -113,7 +114,8 @@ Run_Stats simple_mpi_ranks(const Tree& tree, const std::string& query_file, cons
   unsigned char id[EPA_COMM_ID_BYTES] = {};
   // rank 0 replaces the id file before anything slow (the reference precompute, the scan of the query
   // file): the other ranks, which only look for it after their own setup, never meet an older run's
-  if (rank == 0) publish_id(comm_file, id);
+  const uint64_t nonce = comm_nonce(options.comm_nonce);
+  if (rank == 0) publish_id(comm_file, nonce, id);
   const bool premask = options.premasking && msa_info.gap_count() > 0;
   Run_Stats st;
   configure_host_threads();
@@ -143,21 +145,40 @@ Run_Stats simple_mpi_ranks(const Tree& tree, const std::string& query_file, cons
   const size_t part = (total + (size_t)world - 1) / (size_t)world;
   const size_t nchunks = (part + per_chunk - 1) / per_chunk;   // the SAME on every rank: posts are collective
   // rows per rank and gather: candidates per read average 2 .. 3 under the default heuristic; beyond that
-  // the carry path takes over (EPA_COMM_ROWS_PER_READ overrides)
-  size_t rows_per_read = 8;
-  if (const char* e = std::getenv("EPA_COMM_ROWS_PER_READ")) rows_per_read = (size_t)std::max(1, std::atoi(e));
-  if (rank != 0) await_id(comm_file, rank, started, id);
+  // the carry path takes over (--comm-rows-per-read)
+  const size_t rows_per_read = (size_t)std::max(1, options.comm_rows_per_read);
+  if (rank != 0) await_id(comm_file, nonce, rank, started, id);
+  if (options.comm_timeout_seconds > 0) epa_comm_set_timeout(nullptr, options.comm_timeout_seconds);
   epa_comm* comm = nullptr;
   int rc = epa_comm_create(dev.ctx(), id, rank, world, (uint32_t)std::min<size_t>(per_chunk * rows_per_read, 0x7fffffffu), 2, &comm);
   if (rank == 0) std::remove(comm_file.c_str());   // collective: every rank has read it by now
   if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
   // a rank that fails from here on aborts the communicator instead of leaving its peers blocked in a
-  // send / receive for ever (they fail or time out, EPA_COMM_TIMEOUT_S); the reference's MPI build aborts the job
+  // send / receive for ever (they fail or time out: epa_comm_set_timeout / EPA_COMM_TIMEOUT_S); the reference's MPI build aborts the job
   struct Guard {
     epa_comm* c;
     int live = std::uncaught_exceptions();
     ~Guard() { if (std::uncaught_exceptions() > live) epa_comm_abort(c); else epa_comm_destroy(c); }
   } guard{comm};
+  if (options.comm_self_send) epa_comm_set_self_send(comm, 1);
+  {
+    // handshake before any work depends on the transport: a one-row gather + an all-reduce, every wait bounded
+    std::vector<uint64_t> dev_ids((size_t)world);
+    rc = epa_comm_probe(dev.ctx(), comm, options.comm_probe_seconds, dev_ids.data());
+    if (rc != EPA_OK)
+      throw std::runtime_error{std::string("the ranks cannot exchange data (") + epa_dev_last_error(dev.ctx()) + "); transport library: " +
+                               epa_comm_library_path() + " -- see --help on EPA_RCCL_LIB / LD_LIBRARY_PATH"};
+    if (rank == 0) {
+      std::string devs;
+      for (int r = 0; r < world; ++r) {
+        char b[32];
+        std::snprintf(b, sizeof b, "%s%04x:%02x:%02x", r ? " " : "", (unsigned)(dev_ids[r] >> 16), (unsigned)((dev_ids[r] >> 8) & 0xff),
+                      (unsigned)(dev_ids[r] & 0xff));
+        devs += b;
+      }
+      std::fprintf(stderr, "epa-ng-amd: %d ranks on devices [%s], transport %s\n", world, devs.c_str(), epa_comm_library_path());
+    }
+  }
   st.seconds_setup = std::chrono::duration<double>(clk::now() - ts).count();
 
   std::ofstream os;

@@ -425,7 +425,7 @@ int epa_dev_place_all(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_
  *                           the communicator's own stream.  Never blocks the host; rows beyond rows_cap
  *                           are carried into the rank's next gather.  *ticket names the gather.
  *   epa_dev_gather_slot     the same for a chunk slot launched with EPA_CHUNK_NO_D2H (after launch_end)
- *   epa_comm_collect        rank 0: waits for gather `ticket` (at most EPA_COMM_TIMEOUT_S), copies its VALID rows to pinned host
+ *   epa_comm_collect        rank 0: waits for gather `ticket` (at most the communicator's timeout), copies its VALID rows to pinned host
  *                           memory and hands out one row block and count per rank; the blocks stay
  *                           valid until gather ticket + depth is posted.  pending[r] (optional): rows rank
  *                           r still carried after this gather -- 0 means every row it has posted so far
@@ -434,7 +434,20 @@ int epa_dev_place_all(epa_ctx* ctx, const uint8_t* q_codes, const uint32_t* win_
  *                           all-reduce) on whether any rank still carries rows and posts up to `depth` extra
  *                           gathers (tickets *first .. *first + *n_extra - 1) that drain them; rank 0
  *                           collects those before the next call
- * RCCL is loaded at run time (dlopen; EPA_RCCL_LIB overrides the name): EPA_ERR_UNSUPPORTED without it.
+ *   epa_comm_probe          collective, optional, right after create: one round trip through everything a gather
+ *                           uses (a one-row gather naming each rank and the PCI id of its device, then an all-reduce),
+ *                           every wait bounded by timeout_s -- so that a transport that cannot move data between THESE
+ *                           processes shows up in seconds, before any work depends on it, instead of as a gather that
+ *                           never completes.  Rank 0 receives device_ids[world] = (pci domain << 16 | bus << 8 | device)
+ *                           of every rank's GPU ("RCCL saw N ranks on N devices").  On failure: epa_comm_abort.
+ *   epa_comm_set_timeout    seconds a host-side wait of this communicator may take (collect, flush, probe); comm ==
+ *                           NULL sets the process default, which also bounds epa_comm_create (ncclCommInitRank waits
+ *                           for all ranks).  Default: EPA_COMM_TIMEOUT_S, else 600.
+ * RCCL is loaded at run time (dlopen): EPA_ERR_UNSUPPORTED without it.  Which library: the path given to
+ * epa_comm_set_library() (before the first communicator); else the environment's EPA_RCCL_LIB; else a librccl ALREADY
+ * MAPPED in the process (a host program that brought its own RCCL -- PyTorch ships torch/lib/librccl.so -- must not get a
+ * second copy beside it); else librccl.so.1 / librccl.so on the loader's search path (LD_LIBRARY_PATH), /opt/rocm/lib.
+ * epa_comm_library_path() names the file that was bound ("" if none): log it.
  */
 #define EPA_COMM_ID_BYTES 128
 typedef struct epa_comm epa_comm;
@@ -442,10 +455,17 @@ typedef struct {
   uint32_t branch_id, seq_id;   /* seq_id is GLOBAL (rank's offset added) */
   double lnl, pendant_length, distal_length;
 } epa_row;
+int epa_comm_set_library(const char* path);
+const char* epa_comm_library_path(void);
+int epa_comm_set_timeout(epa_comm* comm_or_null, double seconds);
 int epa_comm_get_unique_id(void* id128);
 int epa_comm_create(epa_ctx* ctx, const void* id128, int rank, int world, uint32_t rows_cap, int depth,
                     epa_comm** out);
 void epa_comm_destroy(epa_comm* comm);
+int epa_comm_probe(epa_ctx* ctx, epa_comm* comm, double timeout_s, uint64_t* device_ids);
+/* test hook: rank 0's own rows travel through ncclSend / ncclRecv to itself instead of a local copy (before the
+ * first gather only) */
+int epa_comm_set_self_send(epa_comm* comm, int on);
 int epa_dev_gather_results(epa_ctx* ctx, epa_comm* comm, const epa_pair* d_pairs, const epa_result* d_results,
                            uint64_t n, uint32_t seq_offset, uint64_t* ticket);
 int epa_dev_gather_slot(epa_ctx* ctx, epa_comm* comm, int slot, uint32_t seq_offset, uint64_t* ticket);
@@ -467,7 +487,7 @@ const epa_row* epa_comm_device_rows(const epa_comm* comm, uint64_t ticket, int r
 int epa_comm_flush(epa_ctx* ctx, epa_comm* comm, uint64_t* first_extra_ticket, uint32_t* n_extra);
 uint64_t epa_comm_carried_rows(const epa_comm* comm);
 /* a rank that fails mid-job: ncclCommAbort + release, without waiting for the peers (their pending
- * collect / flush calls then fail or time out after EPA_COMM_TIMEOUT_S seconds, default 600, instead of
+ * collect / flush calls then fail or time out after the communicator's timeout, default 600 s, instead of
  * blocking for ever; the reference's MPI build aborts the whole job, src/main.cpp's MPI_Abort path) */
 void epa_comm_abort(epa_comm* comm);
 

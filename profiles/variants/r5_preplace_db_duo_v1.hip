@@ -717,6 +717,15 @@ __device__ __forceinline__ uint32_t choose_tile(uint32_t ng, uint32_t B, uint32_
 // reference's default --chunk-size 5000 puts ~2 reads on a start: a 96-site bucket holds ~180 reads,
 // a workgroup's 1024 lanes would be 18 % full) -- the 16-bit LDS offsets still fit:
 // (288 / 2 + 79) * 288 + 35 * 8 < 65536.  ROWL: byte stride of the staged pair rows in LDS (see above).
+// DB (single-chunk narrow variant): the slices of consecutive branches alternate between two LDS buffers
+// and a branch costs ONE workgroup barrier.  In-kernel cycle counters of the single-buffer loop (cfg2,
+// per branch and wave): 2900 clocks in the gathers, 1200 waiting at the barrier for the slowest wave
+// (the LDS serves the 16 waves unevenly), 670 in staging + its barrier, 450 in the result write-out --
+// all three with the LDS gather path idle.  Here a wave that has finished its gathers of branch j stages
+// its part of slice j + 1 into the other buffer and writes its results out while the slower waves still
+// gather.  Buffer B starts at the fixed offset DB_OFF (a compile-time immediate of its ds_reads); the
+// burst staging rows follow its db_rows rows; the query ids of the write-out come from the wave's own
+// lanes (no s_qi array): 160 KB hold it for windows up to 158 sites.
 // (the batch structure was once pinned with sched_barriers; with two-word batches the compiler's own
 // schedule is as good or better: -DPP_SCHED_PIN restores them for an A/B)
 #ifdef PP_SCHED_PIN
@@ -724,24 +733,30 @@ __device__ __forceinline__ uint32_t choose_tile(uint32_t ng, uint32_t B, uint32_
 #else
 #define PP_SCHED_BARRIER()
 #endif
-// Two other loop forms were built, measured and dropped (source kept under profiles/variants/r5_preplace_db_duo_v1.hip,
-// A/Bs in profiles/r5_preplace_duo_ab.txt, r5_preplace_prio_ab.txt): slices of consecutive branches alternating between
-// two LDS buffers with one barrier per branch (0.966 / 0.949 against 0.930 / 0.910 ms), and two branches staged and
-// gathered between one pair of barriers (1.018 / 1.011 ms) -- the gather phase is bound by the LDS itself.
-template <bool ACC, int SPR, int ROWL>
+// DUO (with DB's two-buffer layout): the slices of TWO consecutive branches are staged between one pair of barriers
+// and gathered together -- a query's offsets are extracted once for both (the second slice sits DB_OFF further on, an
+// immediate of its ds_reads: 1.5 instead of 2 vector instructions per gather), and the drain of the workgroup's 16
+// waves at the barrier (1200 of 5200 clocks per branch, profiles/r4_preplace_cycles.txt) is paid once per two branches.
+template <bool ACC, int SPR, int ROWL, bool DB = false, bool DUO = false>
 __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     const double* __restrict__ lookup2, const uint16_t* __restrict__ packed,
     const uint16_t* __restrict__ tails, const uint32_t* __restrict__ win_begin,
     const uint32_t* __restrict__ win_span, const uint32_t* __restrict__ perm,
     const Group* __restrict__ groups, uint32_t W, uint32_t B, uint32_t pitch, uint32_t NP16,
-    const uint32_t* __restrict__ status, double* __restrict__ lnl,
+    const uint32_t* __restrict__ status, double* __restrict__ lnl, uint32_t db_rows,
     unsigned long long* __restrict__ segmax, uint32_t segp) {
   constexpr int TR2 = (CH + SPR) / 2;   // pair rows staged per (branch, chunk)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [TR2][PE] doubles, then accs
   static_assert(ROWL % 16 == 0 && ROWL >= PROWB && ((TR2 - 1) * ROWL + PROWB) < 65536, "16-bit LDS offsets");
-  double* accs = reinterpret_cast<double*>(smem + (size_t)TR2 * ROWL);  // [NB2_ACC][GQ2] / burst rows
+  static_assert(!DB || !ACC, "double-buffered slices: single-chunk variant only");
+  static_assert(!DUO || DB, "two branches per stage use the two-buffer layout");
+  // byte offset of the second slice buffer.  DUO: + 256 B (same banks) so that it is NOT a multiple of 512 -- with a
+  // multiple the compiler fuses the two slices' gathers of one offset into ds_read2st64_b64, which serves these
+  // scattered 8-byte reads at half the rate of two ds_read_b64 (1.47 against 0.97 ms per launch)
+  constexpr uint32_t DB_OFF = (uint32_t)TR2 * ROWL + (DUO ? 256u : 0u);
+  double* accs = reinterpret_cast<double*>(smem + (DB ? DB_OFF + (size_t)db_rows * ROWL : (size_t)TR2 * ROWL));  // [NB2_ACC][GQ2] / burst rows
   __shared__ uint32_t s_maxspan;
-  __shared__ uint32_t s_qi[GQ2];   // query of thread t (burst write-out), ~0 = nothing to write
+  __shared__ uint32_t s_qi[DB ? 1 : GQ2];   // query of thread t (burst write-out), ~0 = nothing to write
   constexpr uint32_t BSTR = GQ2 + 4;    // burst staging rows 4 doubles apart in the banks: conflict-free
   // persistent grid over (group, branch tile) items of class 0, see k_preplace
   const uint32_t ng = status[5];
@@ -781,7 +796,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
   }
   if (t == 0) s_maxspan = 0;
   const uint32_t my_q = (active && span > 0) ? qi : 0xffffffffu;
-  s_qi[t] = my_q;
+  if (!DB) s_qi[t] = my_q;
   __syncthreads();
   {   // one LDS atomic per wave, not per thread (1024 atomics on one word cost ~16k cycles per item)
     uint32_t m = span;
@@ -922,7 +937,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
           const uint32_t tq = wbase + k * 16 + (lane >> 2);
-          const uint32_t q = s_qi[tq];
+          const uint32_t q = DB ? (uint32_t)__shfl((int)my_q, (int)(k * 16 + (lane >> 2))) : s_qi[tq];
           if (q != 0xffffffffu && 2u * c4 < ncol) {
             const double a0 = accs[(2u * c4) * BSTR + tq];
             double* dst = lnl + (size_t)q * pitch + bcol;
@@ -933,7 +948,83 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
         __builtin_amdgcn_wave_barrier();
       }
     };
-    {
+    if constexpr (DUO) {
+      // sums of branches j (slice A) and j + 1 (slice B) of this thread's query; same association order as gather()
+      auto gather2 = [&](uint32_t j, bool two) {
+        if (mine) {
+          double sumA = 0.0, sumB = 0.0;
+#pragma unroll
+          for (int i = 0; i < PW; ++i) asm volatile("" : "+v"(cw[i]));
+          double ra[2][2], rbb[2][2];
+          auto issue = [&](int bt) {
+            const uint32_t v = cw[bt];
+            const uint32_t o0 = v & 0xffffu, o1 = v >> 16;
+            ra[bt & 1][0] = at(o0);
+            ra[bt & 1][1] = at(o1);
+            rbb[bt & 1][0] = at(o0 + DB_OFF);
+            rbb[bt & 1][1] = at(o1 + DB_OFF);
+          };
+          issue(0);
+#pragma unroll
+          for (int bt = 0; bt < PW; ++bt) {
+            if (bt + 1 < PW) issue(bt + 1);
+            sumA += ra[bt & 1][0] + ra[bt & 1][1];      // (a0+a1) + (a2+a3)
+            sumB += rbb[bt & 1][0] + rbb[bt & 1][1];
+          }
+          if (c == tailchunk) {  // singles of the window tail, in order
+            sumA += at(t0); sumA += at(t1); sumA += at(t2);
+            sumB += at(t0 + DB_OFF); sumB += at(t1 + DB_OFF); sumB += at(t2 + DB_OFF);
+          }
+          accs[(j & 7u) * BSTR + t] = sumA;
+          if (segmax) seg.add(segmax, segp, qi, b0 + j, j + 1 == nb, sumA);
+          if (two) {
+            accs[((j + 1) & 7u) * BSTR + t] = sumB;
+            if (segmax) seg.add(segmax, segp, qi, b0 + j + 1, j + 2 == nb, sumB);
+          }
+        }
+      };
+      double2 pfa[PF], pfb[PF];
+      request(0, pfa);
+      if (nb > 1) request(1, pfb);
+      for (uint32_t j = 0; j < nb; j += 2) {
+        const bool two = j + 1 < nb;
+        __syncthreads();                    // the previous pair's readers are done with both buffers
+        stage(pfa, 0);
+        if (two) stage(pfb, DB_OFF);
+        __syncthreads();
+        if (j + 2 < nb) request(j + 2, pfa);
+        if (j + 3 < nb) request(j + 3, pfb);
+        gather2(j, two);
+        flush(j);
+        if (two) flush(j + 1);
+      }
+    } else if constexpr (DB) {
+      double2 pf[PF];
+      request(0, pf);
+      __syncthreads();                      // both buffers are free (the previous item's consumers are done)
+      stage(pf, 0);
+      if (nb > 1) request(1, pf);
+      __syncthreads();
+      for (uint32_t j = 0; j < nb; j += 2) {
+        PP_STAMP(0);
+        PP_STAMP(1);
+        gather(j, 0);
+        PP_STAMP(2);
+        if (j + 1 < nb) { stage(pf, DB_OFF); if (j + 2 < nb) request(j + 2, pf); }   // buffer B: last read by branch j - 1
+        PP_STAMP(3);
+        flush(j);
+        PP_STAMP(4);
+        __syncthreads();
+        PP_STAMP(5);
+        PP_ACCUM();
+        if (j + 1 < nb) {
+          gather(j + 1, DB_OFF);
+          if (j + 2 < nb) { stage(pf, 0); if (j + 3 < nb) request(j + 3, pf); }      // buffer A: last read by branch j
+          flush(j + 1);
+          __syncthreads();
+        }
+      }
+    } else {
       // The slice of branch j+1 is requested (into registers) before the gathers of branch j start
       // and written to LDS after them: its HBM latency hides under the gather phase.
       double2 pf[PF];
@@ -1969,14 +2060,31 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<A, SP, RL>,                       \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB)));      \
     hipLaunchKernelGGL((k_preplace_pairs<A, SP, RL>), grid2, dim3(GQ2), (uint32_t)(LDSB), ctx->stream, ctx->lookup2, (const uint16_t*)packed, \
-                       (const uint16_t*)tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl, (A) ? nullptr : segmax, segp);    \
+                       (const uint16_t*)tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl, 0u, (A) ? nullptr : segmax, segp);    \
   } while (0)
   if (pairs && wide) {
     const size_t lds2w = (size_t)((CH + SPREAD_WIDE) / 2) * ROWL_PACKED + sizeof(double) * NB2_BURST * (GQ2 + 4);
     PRE2(false, SPREAD_WIDE, ROWL_PACKED, lds2w);
   } else if (pairs) {
+    // single-chunk narrow variant: double-buffered slices when both buffers + the burst rows fit the LDS
+    const uint32_t db_rows = SPREAD / 2 + (std::min<uint32_t>(span_bound, CH) + 1) / 2;
+    const size_t lds_db = (size_t)TROWS2 * ROWL_NARROW + (size_t)db_rows * ROWL_NARROW + sizeof(double) * NB2_BURST * (GQ2 + 4);
+    // measured (round 4, same box): 0.966 ms double-buffered against 0.930 ms single-buffered per 100k-read launch --
+    // the gather phase is bound by the LDS itself, overlapping staging / write-out with it buys nothing: opt-in only
+    static const bool db_off = getenv("EPA_PREPLACE_DB") == nullptr;
+    static const bool duo = getenv("EPA_PREPLACE_DUO") != nullptr && atoi(getenv("EPA_PREPLACE_DUO")) != 0;
     if (acc) PRE2(true, SPREAD, ROWL_PACKED, lds2);
-    else PRE2(false, SPREAD, ROWL_NARROW, lds2);
+    else if (duo && lds_db + 256 + 64 <= 163840) {
+      EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<false, SPREAD, ROWL_NARROW, true, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_db + 256)));
+      hipLaunchKernelGGL((k_preplace_pairs<false, SPREAD, ROWL_NARROW, true, true>), grid2, dim3(GQ2), lds_db + 256, ctx->stream, ctx->lookup2,
+                         packed, tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl, db_rows, segmax, segp);
+    } else if (!db_off && lds_db + 64 <= 163840) {
+      EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<false, SPREAD, ROWL_NARROW, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_db));
+      hipLaunchKernelGGL((k_preplace_pairs<false, SPREAD, ROWL_NARROW, true>), grid2, dim3(GQ2), lds_db, ctx->stream, ctx->lookup2,
+                         packed, tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status, d_lnl, db_rows, segmax, segp);
+    } else PRE2(false, SPREAD, ROWL_NARROW, lds2);
   }
 #undef PRE2
 #ifdef PP_PROFILE

@@ -15,6 +15,9 @@
 // host, and every wait has a timeout (EPA_FAKE_RCCL_TIMEOUT_S, default 120) that prints, poisons the
 // communicator and lets the stream continue -- a hung test must not hang the box.  Semantics covered:
 // point-to-point send / recv with matching sizes, in-order per (source, destination) channel.
+// Fault knob: EPA_FAKE_RCCL_HANG_RECV=1 makes every ncclRecv wait for a message that is never looked at (until
+// the communicator is aborted or the stand-in's own timeout) -- "the transport cannot move data between these
+// processes", the failure a first real multi-GPU run could meet; what epa_comm_probe exists for.
 #include <hip/hip_runtime.h>
 
 #include <fcntl.h>
@@ -151,7 +154,8 @@ void host_recv(void* u) {
   Op* o = (Op*)u;
   ncclComm* c = o->c;
   Ctl::Chan& ch = c->ctl->chan[o->peer][c->rank];
-  if (wait_for(c, [&] { return ch.sent.load(std::memory_order_acquire) > o->seq; }, "a message")) {
+  static const bool hang = getenv("EPA_FAKE_RCCL_HANG_RECV") != nullptr;
+  if (wait_for(c, [&] { return !hang && ch.sent.load(std::memory_order_acquire) > o->seq; }, "a message")) {
     const std::string path = c->msg_path(o->peer, c->rank, o->seq);
     int fd = open(path.c_str(), O_RDONLY);
     bool good = fd >= 0;

@@ -1,7 +1,7 @@
 """The product library's RCCL gather (include/epa_dev.h epa_comm_*, epa_ng_amd/csrc/comm.hip): the
 exchange that replaces src/net/epa_mpi_util.cpp:10-30 + src/io/jplace_writer.hpp:117-129 for the
 one-process-per-GPU mode.  On the 1-GPU box: a 1-rank communicator, once with rank 0's rows taken the
-local way and once sent to itself through ncclSend / ncclRecv (EPA_COMM_SELF_SEND), carry path and flush
+local way and once sent to itself through ncclSend / ncclRecv (epa_comm_set_self_send / --comm-self-send), carry path and flush
 included; wherever >= 2 GPUs are visible: one process per GPU over the C-ABI and the CLI's --rank mode."""
 import os
 import subprocess
@@ -41,10 +41,6 @@ def test_one_rank_gather_with_carry_and_flush(self_send, monkeypatch):
     so every post carries rows into the next one and flush() drains the rest.  What rank 0 collects,
     in ticket order, is exactly the chunks' (pair, result) rows with global sequence ids."""
     import torch
-    if self_send:
-        monkeypatch.setenv("EPA_COMM_SELF_SEND", "1")
-    else:
-        monkeypatch.delenv("EPA_COMM_SELF_SEND", raising=False)
     w, ref = _workload()
     ev = ref.evaluator()
     Q = 400
@@ -53,7 +49,9 @@ def test_one_rank_gather_with_carry_and_flush(self_send, monkeypatch):
     n_exp = [len(p) for p, _ in expect]
     cap = Q * 64
     rows_cap = max(n_exp) * 2 // 3            # forces the carry path
-    comm = epa.Comm(ev, epa.comm_unique_id(), 0, 1, rows_cap, depth=2)
+    comm = epa.Comm(ev, epa.comm_unique_id(), 0, 1, rows_cap, depth=2, self_send=self_send)
+    ids = comm.probe(30.0)                     # the handshake leaves the communicator as created (tickets from 0)
+    assert len(ids) == 1 and len(ids[0].split(":")) == 3
     dev = torch.device("cuda", 0)
     bufs = [(torch.zeros((cap, 2), dtype=torch.int32, device=dev), torch.zeros((cap, 3), dtype=torch.float64, device=dev))
             for _ in range(2)]
@@ -329,11 +327,9 @@ def test_cli_rank_mode_one_rank_same_jplace(tmp_path, rows_per_read, self_send):
     assert r.returncode == 0, r.stdout + r.stderr
     od = tmp_path / "out_rank"
     od.mkdir()
-    env = dict(os.environ, EPA_COMM_ROWS_PER_READ=str(rows_per_read))
-    if self_send:
-        env["EPA_COMM_SELF_SEND"] = "1"
-    r = subprocess.run(base + ["-w", str(od), "--rank", "0", "--world", "1", "--comm-file", str(tmp_path / "uid")],
-                       capture_output=True, text=True, timeout=600, env=env)
+    extra = ["--comm-rows-per-read", str(rows_per_read)] + (["--comm-self-send"] if self_send else [])
+    r = subprocess.run(base + ["-w", str(od), "--rank", "0", "--world", "1", "--comm-file", str(tmp_path / "uid")] + extra,
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     a, b = load(ref_dir), load(od)
     assert len(b["placements"]) == 900
@@ -380,11 +376,12 @@ def test_cli_n_processes_on_one_gpu_same_jplace(tmp_path, world, rows_per_read, 
     assert r.returncode == 0, r.stdout + r.stderr
     od = tmp_path / "out_ranks"
     od.mkdir()
-    env = fake_rccl_util.env(dict(os.environ, EPA_COMM_ROWS_PER_READ=str(rows_per_read)))
+    env = fake_rccl_util.env(dict(os.environ))
     idf = tmp_path / "uid"
     idf.write_bytes(b"\0" * 152)   # a stale record of an "earlier run": must be ignored, not hung on
     procs, outs = _run_ranks([(base + ["-w", str(od), "--rank", str(k), "--world", str(world), "--device", "0",
-                                       "--comm-file", str(idf)], env) for k in range(world)])
+                                       "--comm-file", str(idf), "--comm-rows-per-read", str(rows_per_read)], env)
+                              for k in range(world)])
     assert all(p.returncode == 0 for p in procs), outs
     a, b = load(ref_dir), load(od)
     key = lambda p: p["n"][0]
@@ -411,13 +408,14 @@ def test_cli_rank_mode_no_heur_same_jplace(tmp_path, world, standin):
     assert r.returncode == 0, r.stdout + r.stderr
     od = tmp_path / "out_ranks"
     od.mkdir()
-    env = dict(os.environ, EPA_COMM_ROWS_PER_READ="1")
+    env = dict(os.environ)
+    extra = ["--comm-rows-per-read", "1"]
     if standin:
         env = fake_rccl_util.env(env)
     else:
-        env["EPA_COMM_SELF_SEND"] = "1"
+        extra.append("--comm-self-send")
     procs, outs = _run_ranks([(base + ["-w", str(od), "--rank", str(k), "--world", str(world), "--device", "0",
-                                       "--comm-file", str(tmp_path / "uid")], env) for k in range(world)])
+                                       "--comm-file", str(tmp_path / "uid")] + extra, env) for k in range(world)])
     assert all(p.returncode == 0 for p in procs), outs
     a, b = load(ref_dir), load(od)
     key = lambda p: p["n"][0]

@@ -765,7 +765,7 @@ def test_fixed_and_baseball_heuristics_on_device(tips, width, reads, read_len):
 
 def test_cli_fix_and_baseball_heuristics(tmp_path):
     """-G / --baseball-heur through the CLI run fused on the device; same jplace as with the host
-    heuristic path (EPA_HOST_HEURISTIC=1 keeps the table round trip for this cross-check)."""
+    heuristic path (--host-heuristic keeps the table round trip for this cross-check)."""
     import subprocess
     from epa_ng_amd import synth
     w = synth.dna_workload(40, 300, 120, 100, (161, 162, 163))
@@ -784,11 +784,8 @@ def test_cli_fix_and_baseball_heuristics(tmp_path):
         for host in (False, True):
             od = tmp_path / ("o_%s_%d" % (flags[0].strip("-"), host))
             od.mkdir()
-            env = dict(os.environ)
-            if host:
-                env["EPA_HOST_HEURISTIC"] = "1"
-            r = subprocess.run([exe, "-t", str(tre), "-s", str(aln), "-q", str(qf), "-m", model, "-w", str(od)] + flags,
-                               capture_output=True, text=True, timeout=300, env=env)
+            r = subprocess.run([exe, "-t", str(tre), "-s", str(aln), "-q", str(qf), "-m", model, "-w", str(od)] + flags
+                               + (["--host-heuristic"] if host else []), capture_output=True, text=True, timeout=300)
             assert r.returncode == 0, r.stdout + r.stderr
             jp = json.load(open(od / "epa_result.jplace"))
             jp.pop("metadata", None)
@@ -993,6 +990,45 @@ def test_staged_chunks_in_hbm_and_two_half_launch_order(packed):
     with pytest.raises(epa.EpaError):                 # straight at the C-ABI: device codes, host windows
         ev._check(ev.L.epa_dev_chunk_stage(ev.h, 0, hbm[0][0].data.data_ptr() if packed else hbm[0][0].data_ptr(),
                                            chunks[0][1].ctypes.data, chunks[0][2].ctypes.data, Q))
+
+
+def test_host_ordered_launch_as_first_call_on_a_cold_context():
+    """the CLI's loop passes EPA_CHUNK_HOST_ORDERED on every launch and never builds
+    the lookup beforehand, so the lazily built tables (k_build_lookup / k_build_lookup2 on the context's
+    stream) must be complete before a slot's non-blocking stream reads them -- on BOTH slots' first calls.
+    A large B x W makes the build long enough for a race to show; the rows must be the bits a warm context
+    gives, for group launches as well."""
+    w = synth.dna_workload(400, 2000, 600, 150, (91, 92, 93))
+    ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"],
+                            freqs=w["freqs"], rates=w["rates"])
+    Q = 200
+    chunks = []
+    for c in range(3):
+        codes, wb, ws = epa.encode_queries(4, w["reads"][c * Q:(c + 1) * Q], compact=True)
+        chunks.append((epa.pack_codes_4bit(codes), wb, ws))
+    warm = ref.evaluator()
+    expect = [warm.place_chunk(*ch, max_span=150) for ch in chunks]
+    kw = dict(threshold=0.99999, max_span=150, max_pairs=Q * 64, host_ordered=True)
+    for rep in range(3):
+        ev = ref.evaluator()                      # cold: nothing has built the lookup
+        ev.chunk_stage(0, *chunks[0])
+        ev.chunk_stage(1, *chunks[1])
+        ev.chunk_launch_begin(0, **kw)            # builds the lookup lazily ...
+        ev.chunk_launch_begin(1, **kw)            # ... and the other slot's stream starts right behind
+        ev.chunk_launch_end(0)
+        ev.chunk_launch_end(1)
+        got = [ev.chunk_finish(0), ev.chunk_finish(1)]
+        for (p, r), (ep, er) in zip(got, expect):
+            assert np.array_equal(p, ep) and np.array_equal(r, er)
+        del ev
+    ev = ref.evaluator()                          # cold again: a group launch as the first call
+    for j in range(3):
+        ev.chunk_stage(j, *chunks[j])
+    ev.chunk_launch_many_begin([0, 1, 2], threshold=0.99999, max_span=150, max_pairs=3 * Q * 64, host_ordered=True)
+    ev.chunk_launch_end(0)
+    for j in range(3):
+        p, r = ev.chunk_finish(j)
+        assert np.array_equal(p, expect[j][0]) and np.array_equal(r, expect[j][1])
 
 
 def test_five_slot_order_for_small_chunks():
@@ -1408,6 +1444,67 @@ def test_bench_two_ranks_on_one_gpu(scaling, gather):
         assert g["rows_collected_rank0"] > 2 * 6000      # both loops' rows of both ranks reached rank 0
     else:
         assert g["path"].startswith("torch.distributed")
+
+
+def test_bench_two_ranks_transport_that_hangs_falls_back_within_the_probe_timeout():
+    """the first N > 1 run must not be able to lose the line.  The stand-in's fault knob
+    (EPA_FAKE_RCCL_HANG_RECV: every ncclRecv waits for a message it never looks at -- "the transport cannot move
+    data between these processes") makes the product's handshake (epa_comm_probe: a one-row gather + an all-reduce,
+    every wait bounded) fail on every rank within the probe timeout; all ranks abort the communicator TOGETHER and
+    run the torch.distributed harness; rank 0 prints a valid line that says so."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    import fake_rccl_util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, EPA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               WORLD_SIZE="2", LOCAL_RANK="0", EPA_BENCH_ONE_GPU="1", EPA_BENCH_PROBE_S="6", EPA_FAKE_RCCL_HANG_RECV="1")
+    env = fake_rccl_util.env(env, timeout_s=300)     # the stand-in's own give-up is far away: the PROBE must end the wait
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--chunk", "3000", "--tips", "64", "--width", "600", "--no-cpu-baseline", "--strong-reads", "0", "--pool", "2"]
+    t0 = time.time()
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in (1, 0)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    took = time.time() - t0
+    assert all(p.returncode == 0 for p in procs), outs
+    line = json.loads([l for l in outs[1][0].splitlines() if l.startswith("{")][-1])
+    g = line["gather"]
+    assert g["path"].startswith("torch.distributed"), g
+    assert g["fallback"] and "epa_comm gather unavailable" in g["fallback"][0] and "rank 0" in g["fallback"][0]
+    assert "rank 1" in g["fallback"][0]              # BOTH ranks saw the handshake fail (rank 1 in the all-reduce)
+    assert line["n_gpus"] == 2 and line["value"] > 0 and len(g["devices"]) == 2
+    assert took < 200, took                          # two probes of 6 s + the run, not the stand-in's 300 s
+
+
+def test_bench_two_ranks_line_names_devices_and_transport_library():
+    """the healthy case of the same handshake: `gather.devices` = the PCI ids rank 0 RECEIVED through the product's
+    gather (two ranks on the one GPU here: one distinct device), `gather.rccl_path` = the library the product bound"""
+    import socket
+    import subprocess
+    import sys
+    import fake_rccl_util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, EPA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               WORLD_SIZE="2", LOCAL_RANK="0", EPA_BENCH_ONE_GPU="1")
+    env = fake_rccl_util.env(env)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--chunk", "3000", "--tips", "64", "--width", "600", "--no-cpu-baseline", "--strong-reads", "0", "--pool", "2"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in (1, 0)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    g = json.loads([l for l in outs[1][0].splitlines() if l.startswith("{")][-1])["gather"]
+    assert g["path"].startswith("epa_comm") and g["fallback"] is None
+    assert len(g["devices"]) == 2 and g["distinct_devices"] == 1 and g["devices"][0] == g["devices"][1]
+    assert os.path.basename(g["rccl_path"]) == "libfake_rccl.so" and g["probe_seconds"] < 60
 
 
 NCCL_WORKER = r"""

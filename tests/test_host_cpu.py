@@ -599,3 +599,56 @@ def test_premasking_column_mask(tmp_path):
     qf.write_text(">q1\nACGT\n")
     with pytest.raises(RuntimeError, match="unequal site width"):
         hostlib.premask(rf, qf)
+
+
+def test_transport_library_resolution(tmp_path):
+    """comm.hip binds RCCL at run time; WHICH library must not be luck of the SONAME:
+    epa_comm_set_library() > EPA_RCCL_LIB > a librccl ALREADY MAPPED in the process (the copy a host program such as
+    PyTorch brought) > the loader's search path.  Each case in a fresh process (the binding happens once); the
+    stand-in of the N > 1 tests plays the library.  No compute: only dlopen + dlsym."""
+    import shutil
+    import subprocess
+    import sys
+    import fake_rccl_util
+    so = fake_rccl_util.build()
+    other = tmp_path / "b" / "libother_transport.so"
+    other.parent.mkdir()
+    shutil.copy(so, other)
+    mapped = "-"                                   # the host program's own copy: PyTorch maps torch/lib/librccl.so on import
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = r"""
+import ctypes, os, sys
+sys.path.insert(0, %r)
+import epa_ng_amd as epa
+mode, mapped, other = sys.argv[1:4]
+epa.dev_lib()                                               # imports torch: the process now has a librccl of its own
+print("MAPPED=" + str(epa.mapped_rccl_path()))
+if mode == "explicit":
+    epa.comm_set_library(other)                             # the API call wins over what is mapped
+if mode == "late":
+    epa.comm_library_path()                                 # binds ...
+    try:
+        epa.comm_set_library(other)                         # ... after which the choice is refused, not ignored
+        print("NOERROR")
+    except epa.EpaError:
+        pass
+print("PATH=" + epa.comm_library_path())
+""" % root
+    def run(mode, env=None):
+        e = dict(os.environ)
+        e.pop("EPA_RCCL_LIB", None)
+        e.update(env or {})
+        r = subprocess.run([sys.executable, "-c", prog, mode, str(mapped), str(other)], capture_output=True, text=True,
+                           timeout=300, env=e)
+        assert r.returncode == 0 and "NOERROR" not in r.stdout, r.stdout + r.stderr
+        mapped_here[0] = [l for l in r.stdout.splitlines() if l.startswith("MAPPED=")][-1][7:]
+        return [l for l in r.stdout.splitlines() if l.startswith("PATH=")][-1][5:]
+    mapped_here = [None]
+    got = run("mapped")
+    assert got == mapped_here[0] and os.path.basename(got).startswith("librccl.so") and "torch" in got
+    assert run("explicit") == str(other)
+    assert run("late") == mapped_here[0]
+    assert run("env", {"EPA_RCCL_LIB": str(other)}) == str(other)
+    assert run("mapped", {"EPA_RCCL_LIB": str(other)}) == str(other)      # the environment override beats the mapped copy
+    assert run("explicit", {"EPA_RCCL_LIB": "/nonexistent/lib.so"}) == str(other)
+    assert run("env", {"EPA_RCCL_LIB": "/nonexistent/lib.so"}) == ""      # an explicit choice is final: no silent fallback
