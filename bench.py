@@ -260,6 +260,8 @@ def main():
     # the library's kernels go to torch's current stream: everything torch enqueues around a chunk
     # call (the packing for the result gather) is stream-ordered with it, no host synchronisation
     ev.set_stream(torch.cuda.current_stream().cuda_stream)
+    if os.environ.get("EPA_BENCH_AA_VALU"):        # A/B: the lane = site VALU kernel for the 20-state windows
+        ev.set_option("aa_valu", 1)
     ev.build_lookup()
     torch.cuda.synchronize()
     lookup_ms = ev.kernel_ms("lookup")
@@ -592,7 +594,7 @@ def main():
     exec_tflops = pairs * flops_exec / t_th / 1e12
     alg_tflops = pairs * flops_pair / t_th / 1e12
     traffic = traffic_pre = None   # HBM bytes per launch from the committed PMC passes, same workload only
-    aa_mfma = states == 20 and a.read_len <= 192 and not os.environ.get("EPA_AA_VALU")
+    aa_mfma = states == 20 and a.read_len <= 192 and not os.environ.get("EPA_BENCH_AA_VALU")
     kname = "k_thorough_dna" if states == 4 else ("k_thorough_aa_mfma" if aa_mfma else "k_thorough_aa")
     # HBM bytes per launch come from the committed PMC passes of the SAME kernel sources (hash in the
     # file, profiles/make_traffic.py) and the same workload; anything else reports null

@@ -84,6 +84,7 @@ def dev_lib():
         L.epa_dev_last_error.argtypes = [C.c_void_p]
         L.epa_dev_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.epa_dev_build_lookup.argtypes = [C.c_void_p]
+        L.epa_dev_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.epa_encode_queries.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
@@ -320,6 +321,10 @@ class Evaluator:
 
     def set_stream(self, stream_ptr):
         self._check(self.L.epa_dev_set_stream(self.h, stream_ptr))
+
+    def set_option(self, key, value=1):
+        """diagnostic switch of this context (include/epa_dev.h epa_dev_set_option)"""
+        self._check(self.L.epa_dev_set_option(self.h, key.encode(), int(value)))
 
     def build_lookup(self):
         self._check(self.L.epa_dev_build_lookup(self.h))

@@ -134,9 +134,9 @@ const uint8_t* epa_codes_to_device(epa_ctx* ctx, const uint8_t* q_codes, uint32_
 // The eight XCDs of one device do not run the Newton kernel equally fast (a few per cent, stable from launch to
 // launch, different from box to box): a launch that stamped its XCDs' drain times (ThArgs::xstamp) moves the shares of
 // the next ones half way toward share_x ~ pairs_x / time_x.  Launches shorter than 1 ms (start-up and the last
-// pairs dominate) and implausible stamps are ignored; a share stays within 0.85 .. 1.15 of an eighth.  EPA_TH_XCD_BALANCE=0: off.
+// pairs dominate) and implausible stamps are ignored; a share stays within 0.85 .. 1.15 of an eighth.  Option xcd_balance = 0: off.
 void epa_xcd_feedback(epa_ctx* ctx, uint64_t n_pairs, const unsigned long long* hst) {
-  static const bool off = getenv("EPA_TH_XCD_BALANCE") && atoi(getenv("EPA_TH_XCD_BALANCE")) == 0;
+  const bool off = !ctx->opt.xcd_balance;
   // the shader clock of the launch, whatever the shares do: cycles / (10 ns ticks) of workgroup 0's first wave
   if (hst[6] > 1000) ctx->last_sclk_mhz = 100.0 * (double)hst[5] / (double)hst[6];
   if (off || hst[7] == 0) return;
@@ -169,14 +169,13 @@ void epa_xcd_feedback(epa_ctx* ctx, uint64_t n_pairs, const unsigned long long* 
   ctx->xcd_cum[8] = 1u << 20;
 }
 
-static const bool epa_timers_off = getenv("EPA_NO_TIMERS") != nullptr;   // experiment switch: what the event records cost
 void epa_timer_start(epa_ctx* ctx, EvTimer& t) {
-  if (epa_timers_off) return;
+  if (!ctx->opt.timers) return;   // (option timers = 0: what the event records cost)
   if (!t.a) { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
   (void)hipEventRecord(t.a, ctx->stream);
 }
 void epa_timer_stop(epa_ctx* ctx, EvTimer& t) {
-  if (epa_timers_off) return;
+  if (!ctx->opt.timers) return;
   (void)hipEventRecord(t.b, ctx->stream);
   t.valid = true;
 }
@@ -496,6 +495,24 @@ extern "C" int epa_dev_set_query_layout(epa_ctx* ctx, uint32_t code_stride) {
   return EPA_OK;
 }
 
+extern "C" int epa_dev_set_option(epa_ctx* ctx, const char* key, int value) {
+  if (!ctx || !key) return EPA_ERR_INVALID_ARG;
+  struct Entry { const char* name; int EpaOptions::*field; };
+  static const Entry table[] = {
+      {"thorough_generic", &EpaOptions::thorough_generic}, {"preplace_generic", &EpaOptions::preplace_generic},
+      {"select_full_rows", &EpaOptions::select_full_rows}, {"select_sort", &EpaOptions::select_sort},
+      {"queued_thorough", &EpaOptions::queued_thorough},   {"xcd_balance", &EpaOptions::xcd_balance},
+      {"aa_valu", &EpaOptions::aa_valu},                   {"timers", &EpaOptions::timers}};
+  for (const Entry& e : table)
+    if (strcmp(key, e.name) == 0) {
+      ctx->opt.*e.field = value;
+      // a context whose shape only the general kernel serves stays there whatever the switch says
+      ctx->generic_thorough = ctx->generic_native || ctx->opt.thorough_generic != 0;
+      return EPA_OK;
+    }
+  return epa_fail(ctx, EPA_ERR_INVALID_ARG, std::string("set_option: unknown key '") + key + "'");
+}
+
 extern "C" int epa_dev_set_heuristic(epa_ctx* ctx, int mode, double param) {
   if (!ctx) return EPA_ERR_INVALID_ARG;
   if (mode < EPA_HEUR_DYNAMIC || mode > EPA_HEUR_BASEBALL)
@@ -605,9 +622,9 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   // test (all entries < 2^-256) sees values it has already seen -- results are those of the
   // unpadded model, and k_thorough_dna serves them with one wave per group of four.
   int c = (c_in == 1 || c_in == 2) ? 4 : c_in;
-  if (s == 4 && c_in >= 3 && (c_in & 3) && !getenv("EPA_NO_CAT_PAD")) c = (c_in + 3) & ~3;
+  if (s == 4 && c_in >= 3 && (c_in & 3)) c = (c_in + 3) & ~3;
   // 20 states: 3 -> 4, 5 .. 7 -> 8 (k_thorough_aa_mfma serves 4 and 8 categories; more go to the general kernel)
-  if (s == 20 && (c_in == 3 || (c_in >= 5 && c_in <= 7)) && !getenv("EPA_NO_CAT_PAD")) c = (c_in + 3) & ~3;
+  if (s == 20 && (c_in == 3 || (c_in >= 5 && c_in <= 7))) c = (c_in + 3) & ~3;
   // per-rate scaler rows from the caller ([W][c_in]) cannot be padded here: such a context keeps its category
   // count and runs on the general kernel (as before the category groups existed)
   if (c_in >= 3 && c != c_in && (d->flags & EPA_FLAG_RATE_SCALERS) && !tree) c = c_in;
@@ -707,11 +724,12 @@ static int create_impl(const epa_ref_desc* d, int device, epa_ctx* ctx, const ep
   const bool tuned_local = (s == 4 && ctx->dna_zero0) || s == 20;
   // (more than 4 categories: tuned for nucleotide models, sliding rule, zero eigenvalue -- the class
   // launcher of thorough_dna.hip sends what it does not serve to the general kernel itself)
-  const bool tuned_cats = c == 4 || (dna_groups && ctx->blo.sliding && ctx->dna_zero0 && !getenv("EPA_NO_CAT_GROUPS")) ||
-                          (s == 20 && c == 8 && !getenv("EPA_NO_CAT_GROUPS"));   // k_thorough_aa_mfma<.., NC = 8>
+  const bool tuned_cats = c == 4 || (dna_groups && ctx->blo.sliding && ctx->dna_zero0) ||
+                          (s == 20 && c == 8);   // k_thorough_aa_mfma<.., NC = 8>
   ctx->generic_thorough = !tuned_cats || (!ctx->blo.sliding && !tuned_local) || ctx->blo.newton_variant != 0 ||
-                          (d->flags & EPA_FLAG_KEEP_EIGENVALUES) != 0 ||   // every term as libpll: the general kernel
-                          getenv("EPA_TH_GENERIC") != nullptr;   // (diagnostic switch: measure the general kernel)
+                          (d->flags & EPA_FLAG_KEEP_EIGENVALUES) != 0;     // every term as libpll: the general kernel
+  ctx->generic_native = ctx->generic_thorough;
+  // (epa_dev_set_option "thorough_generic" sends a context that has tuned kernels to the general one as well)
 
   EPA_HIP(ctx, hipMalloc(&ctx->dmodel, sizeof(ModelDev)));
   EPA_HIP(ctx, hipMemcpy(ctx->dmodel, &m, sizeof(ModelDev), hipMemcpyHostToDevice));
@@ -1401,8 +1419,7 @@ static int chunk_body_begin(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t
   // Bitmap form: the pair list is written behind the read-back at once (k_emit_pairs refuses a list that would not fit),
   // and the statistics block + work counters of the chunk's Newton launch are cleared behind it -- both in the shadow
   // of the host's round trip for the candidate count (15 - 25 us) instead of after it (profiles/r5_step_timeline.txt)
-  static const bool early_emit = getenv("EPA_EARLY_EMIT") == nullptr || atoi(getenv("EPA_EARLY_EMIT")) != 0;
-  if (!rc && early_emit && d_stats && sp->d_rb && sp->bitmap && max_pairs <= 0xffffffffull) {
+  if (!rc && d_stats && sp->d_rb && sp->bitmap && max_pairs <= 0xffffffffull) {
     rc = launch_select_emit(ctx, sp);
     if (!rc) rc = epa_zero_async(ctx, d_stats, 128, epa_th_ctr(ctx), epa_th_ctr(ctx) ? 64 : 0);
     if (!rc) {
@@ -1411,7 +1428,7 @@ static int chunk_body_begin(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t
     }
   }
   if (!rc && d_res && d_stats && sp->d_rb && sp->bitmap && max_pairs <= 0xffffffffull) {
-    const bool off = getenv("EPA_QUEUED_THOROUGH") == nullptr;
+    const bool off = !ctx->opt.queued_thorough;
     const int cls = epa_span_class(ctx->s, max_span);
     const bool eligible = !off && ctx->s == 4 && !ctx->generic_thorough && ctx->dna.ng == 1 && epa_th_ctr(ctx) &&
                           (cls <= 2 || cls == 10 || cls == 11);

@@ -136,8 +136,23 @@ struct ChunkSlot {
 };
 constexpr int EPA_MAX_GROUP = 8;
 
+// Diagnostic switches of a context (epa_dev_set_option; include/epa_dev.h lists them).  They select between code
+// paths that return the same results -- cross-check kernels for the parity tests, A/B switches of the bench -- and
+// replace the environment variables earlier rounds read inside the library.
+struct EpaOptions {
+  int thorough_generic = 0;   // every Newton launch on k_thorough_generic (the reference-shaped kernel)
+  int preplace_generic = 0;   // preplacement on k_preplace (per-site gathers) instead of the pair / site fast paths
+  int select_full_rows = 0;   // candidate selection from whole table rows instead of the segment maxima
+  int select_sort = 0;        // candidate list through the sorted staging path instead of the bitmap
+  int queued_thorough = 0;    // the Newton launch queued behind the selection, guarded by the device-side count
+  int xcd_balance = 1;        // XCD shares of a Newton launch follow the measured speeds (epa_xcd_feedback)
+  int aa_valu = 0;            // 20-state windows on the lane = site VALU kernel instead of the matrix-core kernel
+  int timers = 1;             // hipEvent records around the kernel families (epa_dev_last_kernel_ms)
+};
+
 struct epa_ctx {
   int device = 0;
+  EpaOptions opt;
   int n_cu = 256;  // compute units of the device (persistent-grid sizing)
   hipStream_t stream = nullptr;
   std::string err;
@@ -153,6 +168,7 @@ struct epa_ctx {
   // the tuned thorough kernels serve 4 categories + per-site scalers + sliding BLO; everything
   // else runs on k_thorough_generic (thorough_generic.hip)
   bool generic_thorough = false;
+  bool generic_native = false;   // ... by the context's shape (generic_thorough may also be the option thorough_generic)
   BloConsts blo;
   int aa_x_as_n = 0;
   uint32_t code_stride = 0;  // 0: query codes are Q x W rows; S: compact rows of S bytes (window only)

@@ -749,21 +749,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
   const uint32_t ntiles = (B + NBP - 1) / NBP;
   const int t = threadIdx.x;
   const ItemWalk iw = item_walk(ng * ntiles);
-#ifdef PP_PROFILE
-  // in-kernel cycle accounting (s_memtime): per wave and branch, the sections between the stamps
-  unsigned long long pp_t[6], pp_sum[6] = {0, 0, 0, 0, 0, 0};
-  unsigned long long pp_item_t0 = 0, pp_setup = 0;
-  const unsigned long long pp_k0 = __builtin_readcyclecounter();
-#define PP_STAMP(i) pp_t[i] = __builtin_readcyclecounter()
-#define PP_ACCUM() do { for (int s_ = 0; s_ < 5; ++s_) pp_sum[s_] += pp_t[s_ + 1] - pp_t[s_]; pp_sum[5] += 1; if (j == 0) pp_setup += pp_t[0] - pp_item_t0; } while (0)
-#else
-#define PP_STAMP(i)
-#define PP_ACCUM()
-#endif
   for (uint32_t item = iw.pos; item < iw.end; item += iw.step) {
-#ifdef PP_PROFILE
-  pp_item_t0 = __builtin_readcyclecounter();
-#endif
   uint32_t item_g, item_t;
   item_group_tile(item, iw.lo, iw.end, ng, ntiles, item_g, item_t);
   const Group g = groups[item_g];
@@ -939,20 +925,13 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
       double2 pf[PF];
       request(0, pf);
       for (uint32_t j = 0; j < nb; ++j) {
-        PP_STAMP(0);
         __syncthreads();  // previous consumers of the tile are done
-        PP_STAMP(1);
         stage(pf, 0);
-        PP_STAMP(2);
         __syncthreads();
-        PP_STAMP(3);
         if (j + 1 < nb) request(j + 1, pf);
         PP_SCHED_BARRIER();
         gather(j, 0);
-        PP_STAMP(4);
         flush(j);
-        PP_STAMP(5);
-        PP_ACCUM();
       }
     }
   }
@@ -961,15 +940,6 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     for (uint32_t j = 0; j < nb; ++j) out[j] = accs[j * GQ2 + t];
   }
   }  // work items
-#ifdef PP_PROFILE
-  if ((threadIdx.x & 63) == 0) {
-    uint32_t* st = const_cast<uint32_t*>(status) + 40;
-    for (int s_ = 0; s_ < 6; ++s_) atomicAdd(&st[s_], (uint32_t)(s_ < 5 ? pp_sum[s_] >> 10 : pp_sum[s_]));
-    atomicAdd(&st[6], (uint32_t)(pp_setup >> 10));
-    atomicAdd(&st[7], (uint32_t)((__builtin_readcyclecounter() - pp_k0) >> 10));
-    atomicAdd(&st[8], 1u);
-  }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1337,7 +1307,7 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ lnl, 
 // row maximum -- skips it), rows with at most two candidate segments run a two-register extraction loop, a wave
 // walks several queries (grid-stride, the next query's maxima requested ahead), and the span-class histogram of
 // the candidate counts (k_class_hist: 1563 atomics on one word, 20 us) is summed per workgroup in LDS.
-template <int N, bool DIAG = false>
+template <int N>
 __device__ __forceinline__ uint32_t seg_extract(const double* __restrict__ src, uint32_t lane, uint32_t B,
                                                 unsigned long long mask_x, double mx, double tot, SelRule& rule,
                                                 const SelOut& so, uint32_t q, uint32_t* __restrict__ status) {
@@ -1374,14 +1344,14 @@ __device__ __forceinline__ uint32_t seg_extract(const double* __restrict__ src, 
     // candidate k waits in lane k: the atomics of a query leave together, one instruction per kind, after its loop
     // (one pair of them per candidate from lane 0 sat between the next query's loads and their wait)
     if (taken < 64u) { if (lane == taken) cand = bi; }
-    else if (!DIAG && lane == 0) so.put(q, bi, taken, status);
+    else if (lane == 0) so.put(q, bi, taken, status);
     ++taken;
   }
-  if (!DIAG && lane < min(taken, 64u)) so.put(q, cand, lane, status);
+  if (lane < min(taken, 64u)) so.put(q, cand, lane, status);
   return taken;
 }
 
-template <int NRN, bool DIAG = false>   // DIAG: timing variant without the candidates' atomics (results unusable)
+template <int NRN>
 __global__ void __launch_bounds__(256) k_select_seg(const double* __restrict__ lnl, const unsigned long long* __restrict__ segmax,
                                                     uint32_t segp, uint32_t Q, uint32_t B, uint32_t pitch, double threshold,
                                                     double band_x, double band_t,
@@ -1429,9 +1399,9 @@ __global__ void __launch_bounds__(256) k_select_seg(const double* __restrict__ l
     uint32_t taken = 0;
     const int ncs = __popcll(mask_x);
     if (ncs <= 2) {
-      taken = seg_extract<2, DIAG>(src, lane, B, mask_x, mx, tot, rule, so, q, status);
+      taken = seg_extract<2>(src, lane, B, mask_x, mx, tot, rule, so, q, status);
     } else if (ncs <= NRN) {
-      taken = seg_extract<NRN, DIAG>(src, lane, B, mask_x, mx, tot, rule, so, q, status);
+      taken = seg_extract<NRN>(src, lane, B, mask_x, mx, tot, rule, so, q, status);
     } else {
       // many candidate segments: every extraction streams them again and takes the next element in
       // (lnL descending, branch ascending) order after the previous one
@@ -1453,10 +1423,10 @@ __global__ void __launch_bounds__(256) k_select_seg(const double* __restrict__ l
         pbest = best;
         pbi = bi;
         if (taken < 64u) { if (lane == taken) cand = bi; }
-        else if (!DIAG && lane == 0) so.put(q, bi, taken, status);
+        else if (lane == 0) so.put(q, bi, taken, status);
         ++taken;
       }
-      if (!DIAG && lane < min(taken, 64u)) so.put(q, cand, lane, status);
+      if (lane < min(taken, 64u)) so.put(q, cand, lane, status);
     }
     if (lane == 0) {
       const uint32_t n = so.count(taken);
@@ -1468,166 +1438,7 @@ __global__ void __launch_bounds__(256) k_select_seg(const double* __restrict__ l
   if (hist && threadIdx.x < EPA_N_CLS && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_hist[threadIdx.x]);
 }
 
-// ---- round-4 forms of k_select_seg / k_pack_pairs, kept for same-box A/Bs (EPA_SEL_V1 / EPA_PACK_V1)
-template <int NRN>
-__global__ void __launch_bounds__(256) k_select_seg_v1(const double* __restrict__ lnl, const unsigned long long* __restrict__ segmax,
-                                                    uint32_t segp, uint32_t Q, uint32_t B, uint32_t pitch, double threshold,
-                                                    SelOut so, uint32_t* __restrict__ counts, uint32_t* __restrict__ status) {
-  const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const uint32_t lane = threadIdx.x & 63;
-  if (q >= Q) return;
-  const uint32_t nseg = (B + 63) >> 6;   // <= 64
-  const double* src = lnl + (size_t)q * pitch;
-  auto value = [&](uint32_t s) -> double {   // this lane's element of segment s (-inf past the row)
-    const uint32_t i = s * 64 + lane;
-    return i < B ? src[i] : -INFINITY;
-  };
-  const unsigned long long key = lane < nseg ? segmax[(size_t)q * segp + lane] : ~0ull;
-  double m = -INFINITY;
-  if (__ballot(key == 0ull) == 0ull) {
-    if (lane < nseg) m = seg_val(key);
-  } else {   // no maxima for this row: build them from the row itself
-    for (uint32_t s = 0; s < nseg; ++s) {
-      const double xm = epa_wave::wave_max_d(value(s));
-      if (lane == s) m = xm;
-    }
-  }
-  const double mx = epa_wave::wave_max_d(m);
-  const double band_x = 1.0 - log((1.0 - threshold) / (double)B);
-  const double band_t = fmax(band_x, log((double)B) + 38.0);
-  const unsigned long long mask_t = __ballot(m >= mx - band_t), mask_x = __ballot(m >= mx - band_x);
-  double tot = 0.0;
-  for (unsigned long long mm = mask_t; mm; mm &= mm - 1) tot += exp(value((uint32_t)__builtin_ctzll(mm)) - mx);
-  tot = epa_wave::wave_sum(tot);
-  SelRule rule(0, threshold, 0u);
-  uint32_t taken = 0;
-  if (__popcll(mask_x) <= NRN) {
-    double v[NRN];
-    uint32_t base[NRN];
-    unsigned long long mm = mask_x;
-#pragma unroll
-    for (int r = 0; r < NRN; ++r) {
-      if (mm) {
-        const uint32_t s = (uint32_t)__builtin_ctzll(mm);
-        mm &= mm - 1;
-        base[r] = s * 64;
-        v[r] = value(s);
-      } else {
-        base[r] = 0;
-        v[r] = -INFINITY;
-      }
-    }
-    while (rule.more(taken, B)) {
-      double lbest = -INFINITY;
-      uint32_t lbi = 0xffffffffu;
-#pragma unroll
-      for (int r = 0; r < NRN; ++r)   // segments ascend with r: the first maximum has the lowest branch id
-        if (v[r] > lbest) { lbest = v[r]; lbi = base[r] + lane; }
-      const double best = epa_wave::wave_max_d(lbest);
-      const uint32_t bi = epa_wave::wave_min_u((lbest == best && lbest > -INFINITY) ? lbi : 0xffffffffu);
-      if (bi == 0xffffffffu) break;
-      if (!rule.accept(best, mx, tot, taken)) break;
-#pragma unroll
-      for (int r = 0; r < NRN; ++r)
-        if (base[r] + lane == bi) v[r] = -INFINITY;
-      if (lane == 0) so.put(q, bi, taken, status);
-      ++taken;
-    }
-  } else {
-    // many candidate segments: every extraction streams them again and takes the next element in
-    // (lnL descending, branch ascending) order after the previous one
-    double pbest = INFINITY;
-    uint32_t pbi = 0;
-    while (rule.more(taken, B)) {
-      double lbest = -INFINITY;
-      uint32_t lbi = 0xffffffffu;
-      for (unsigned long long mm = mask_x; mm; mm &= mm - 1) {
-        const uint32_t s = (uint32_t)__builtin_ctzll(mm), i = s * 64 + lane;
-        const double x = value(s);
-        const bool after = x < pbest || (x == pbest && i > pbi);
-        if (after && x > lbest) { lbest = x; lbi = i; }
-      }
-      const double best = epa_wave::wave_max_d(lbest);
-      const uint32_t bi = epa_wave::wave_min_u((lbest == best && lbest > -INFINITY) ? lbi : 0xffffffffu);
-      if (bi == 0xffffffffu) break;
-      if (!rule.accept(best, mx, tot, taken)) break;
-      pbest = best;
-      pbi = bi;
-      if (lane == 0) so.put(q, bi, taken, status);
-      ++taken;
-    }
-  }
-  if (lane == 0) counts[q] = so.count(taken);
-}
-
-__global__ void __launch_bounds__(256) k_pack_pairs_v1(const uint8_t* __restrict__ codes,
-                                                    const uint32_t* __restrict__ win_begin,
-                                                    const uint32_t* __restrict__ win_span, uint32_t Q,
-                                                    uint32_t W, uint32_t cstride, uint32_t crel,
-                                                    uint32_t span_bound, uint32_t Wp, uint32_t NP16,
-                                                    uint32_t rowl, uint16_t* __restrict__ packed,
-                                                    uint16_t* __restrict__ tails,
-                                                    uint32_t* __restrict__ keys, uint32_t K,
-                                                    uint32_t* __restrict__ status) {
-  // sixteen lanes per query, four queries per wave: the kernel is a chain of three dependent memory
-  // round trips (window, codes, store) with little work between them -- a wave per query was 100k
-  // waves of it, 65 us per 100k reads
-  const uint32_t q = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + ((threadIdx.x >> 4) & 3u);
-  const uint32_t l16 = threadIdx.x & 15, grp = (threadIdx.x >> 4) & 3u;
-  const bool live = q < Q;
-  const uint32_t begin = live ? win_begin[q] : 0u;
-  uint32_t span = live ? win_span[q] : 0u;
-  // a window longer than the caller's max_span (or than a compact row) is an input error: the
-  // kernel variant and the packed rows were sized by it
-  const uint32_t cmax = min(span_bound, crel ? cstride : 0xffffffffu);
-  if (live && l16 == 0) validate_window(q, begin, span, W, cmax, status);
-  if ((uint64_t)begin + span > W || span > cmax) span = 0;  // invalid window (flagged above)
-  const uint8_t* c = codes + (size_t)(live ? q : 0u) * cstride + (crel ? 0u : begin);
-  const uint32_t nfull = span >> 2, ntail = span & 3, npairs = 2 * nfull;
-  bool rare = false;
-  // a chunk of CP = 80 pair slots at a time: its ten code loads per lane are issued together, then the offsets
-  // are formed and stored (NP16 is a multiple of CP).  Round 4, traced us per 100k reads: one loop of dependent
-  // load / store pairs 78, this form 74, four pairs per lane with an unaligned 8-byte load and an 8-byte store 96,
-  // byte loads + 8-byte store 88: neither the load nor the store width is what it waits for.
-  for (uint32_t pb = 0; pb < NP16; pb += CP) {
-    uint32_t c0[CP / 16], c1[CP / 16];
-#pragma unroll
-    for (int i = 0; i < CP / 16; ++i) {
-      const uint32_t p = pb + (uint32_t)i * 16 + l16;
-      c0[i] = p < npairs ? c[2 * p] : 0u;
-      c1[i] = p < npairs ? c[2 * p + 1] : 0u;
-    }
-#pragma unroll
-    for (int i = 0; i < CP / 16; ++i) {
-      const uint32_t p = pb + (uint32_t)i * 16 + l16;
-      uint32_t v = ZERO_OFF;
-      if (p < npairs) {
-        const uint32_t s0 = dna_sym(c0[i]), s1 = dna_sym(c1[i]);
-        rare |= (s0 > 4) | (s1 > 4);
-        v = (p % CP) * rowl + pair_entry(min(s0, 5u), min(s1, 5u)) * 8;
-      }
-      if (live) packed[(size_t)q * NP16 + p] = (uint16_t)v;
-    }
-  }
-  if (l16 < 4) {
-    uint32_t v = ZERO_OFF;
-    if (l16 < ntail) {
-      uint32_t sy = dna_sym(c[4 * nfull + l16]);
-      rare |= sy > 4;
-      sy = min(sy, 5u);
-      const uint32_t kt = npairs % CP;  // row of the first tail site inside its chunk (even)
-      const uint32_t e = l16 == 1 ? pair_entry(5, sy) : pair_entry(sy, 5);
-      v = (kt + (l16 == 2 ? 1u : 0u)) * rowl + e * 8;
-    }
-    if (live) tails[(size_t)q * 4 + l16] = (uint16_t)v;
-  }
-  const bool any_rare = ((__ballot(rare) >> (16 * grp)) & 0xffffull) != 0ull;
-  if (live && l16 == 0) {   // an invalid window start (flagged above) must not leave the key space
-    const uint32_t key = min((any_rare ? 2 * Wp : 0) + (begin & 1u) * Wp + min(begin, Wp - 1), K - 1);
-    keys[q] = key;
-  }
-}
-
+// (the round-4 forms of k_select_seg / k_pack_pairs: profiles/variants/r5_preplace_db_duo_v1.hip; A/Bs in profiles/r5_select_pack_ab*.txt)
 
 // Same selection, workgroup per query (4 waves): the row of up to 256 x NRT branches lives in the
 // registers of the whole workgroup (element i in thread i % 256, slot i / 256), so the table is
@@ -1868,8 +1679,8 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
   const uint32_t pitch = ctx->lnl_pitch ? ctx->lnl_pitch : ctx->B;  // row pitch of d_lnl in doubles
   unsigned long long* const segmax = ctx->segmax;   // per-(query, 64-branch segment) maxima wanted by the fused chunk body, or null
   const uint32_t segp = ctx->segp;
-  const bool pairs = ctx->s == 4 && ctx->lookup2 && !getenv("EPA_PREPLACE_GENERIC");
-  const bool sites = ctx->s == 20 && ctx->ncols == 24 && !getenv("EPA_PREPLACE_GENERIC");
+  const bool pairs = ctx->s == 4 && ctx->lookup2 && !ctx->opt.preplace_generic;
+  const bool sites = ctx->s == 20 && ctx->ncols == 24 && !ctx->opt.preplace_generic;
   const uint32_t crel = ctx->code_stride ? 1u : 0u, cstride = crel ? ctx->code_stride : ctx->W;
   const uint32_t n_buckets = (ctx->W + SPREAD - 1) / SPREAD;
   const uint32_t Wp = n_buckets * SPREAD;  // key space of one (class, parity) block
@@ -1913,17 +1724,11 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     if (zr) return zr;
   }
   // wide slices for the pair path when a chunk puts few reads on a window start (see k_preplace_pairs)
-  const bool acc = max_span == 0 || max_span > (uint32_t)CH || getenv("EPA_PREPLACE_ACC");
-  static const bool narrow_only = getenv("EPA_PREPLACE_NARROW") != nullptr;
-  const bool wide = pairs && !acc && !narrow_only && (uint64_t)Q * SPREAD < (uint64_t)1400 * ctx->W;   // < ~700 reads per 96-site bucket and parity
+  const bool acc = max_span == 0 || max_span > (uint32_t)CH;
+  const bool wide = pairs && !acc && (uint64_t)Q * SPREAD < (uint64_t)1400 * ctx->W;   // < ~700 reads per 96-site bucket and parity
   const uint32_t rowl = (wide || acc) ? ROWL_PACKED : ROWL_NARROW;  // LDS row stride the 16-bit offsets are built for
   if (pairs) {
-    static const bool pack_v1 = getenv("EPA_PACK_V1") != nullptr;   // A/B switch (profiles/)
-    static const uint32_t pack_grid = getenv("EPA_PACK_GRID") ? (uint32_t)std::max(1, atoi(getenv("EPA_PACK_GRID"))) : 64u;   // workgroups per CU
-    if (pack_v1)
-      hipLaunchKernelGGL(k_pack_pairs_v1, dim3((Q + 15) / 16), dim3(256), 0, ctx->stream, d_codes, d_begin,
-                         d_span, Q, ctx->W, cstride, crel, span_bound, Wp, NP16, rowl, packed, tails, keys, K, status);
-    else
+    constexpr uint32_t pack_grid = 64;   // workgroups per CU of the persistent packing grid
     hipLaunchKernelGGL(k_pack_pairs, dim3(std::min<uint32_t>((Q + 15) / 16, (uint32_t)ctx->n_cu * pack_grid)), dim3(256), 0, ctx->stream, d_codes, d_begin,
                        d_span, Q, ctx->W, cstride, crel, span_bound, Wp, NP16, rowl, packed, tails, keys, K, status);
   } else if (sites) {
@@ -1979,19 +1784,8 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     else PRE2(false, SPREAD, ROWL_NARROW, lds2);
   }
 #undef PRE2
-#ifdef PP_PROFILE
-  if (pairs && getenv("EPA_PP_PROFILE")) {
-    uint32_t h[64];
-    EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    EPA_HIP(ctx, hipMemcpy(h, status, 256, hipMemcpyDeviceToHost));
-    const double nb_ = h[45] ? (double)h[45] : 1.0, nw_ = h[48] ? (double)h[48] : 1.0;
-    fprintf(stderr, "PP_PROFILE waves %u branch-iterations/wave %.1f | clk per branch and wave: wait-barrier1 %.0f stage %.0f barrier2 %.0f request+gather %.0f flush %.0f | "
-            "item setup clk/wave %.0f | kernel clk/wave %.0f\n", h[48], nb_ / nw_, 1024.0 * h[40] / nb_, 1024.0 * h[41] / nb_, 1024.0 * h[42] / nb_,
-            1024.0 * h[43] / nb_, 1024.0 * h[44] / nb_, 1024.0 * h[46] / nw_, 1024.0 * h[47] / nw_);
-  }
-#endif
   if (sites) {
-    const bool acc_s = max_span == 0 || max_span > (uint32_t)CHS || getenv("EPA_PREPLACE_ACC");
+    const bool acc_s = max_span == 0 || max_span > (uint32_t)CHS;
     const size_t lds_s = (size_t)TROWS_S * 24 * 8 + sizeof(double) * (acc_s ? NB2_ACC_S * GQ2 : NB2_BURST * (GQ2 + 4));  // accs / result staging
     const uint32_t ntiles_s = (ctx->B + (acc_s ? NB2_ACC_S : 16) - 1) / (acc_s ? NB2_ACC_S : 16);
     const dim3 grid_s((uint32_t)std::min<uint64_t>((uint64_t)max_groups * ntiles_s, (uint64_t)ctx->n_cu));
@@ -2070,7 +1864,7 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
                                  (unsigned long long*)nullptr, worst, 0, 64, ctx->stream);
   // Bitmap form (SelOut): [status 512 B | branch counters B+1 | bitmap B x wpr | counts Q+1]
   const uint32_t wpr = (Q + 31) / 32;
-  static const bool force_sort = getenv("EPA_SELECT_SORT") != nullptr;
+  const bool force_sort = ctx->opt.select_sort != 0;
   const bool bm = !force_sort && (size_t)B * wpr * sizeof(uint32_t) <= ((size_t)64 << 20);
   sp->bitmap = nullptr;
   if (bm) {
@@ -2093,28 +1887,18 @@ int launch_select_begin(epa_ctx* ctx, const double* d_lnl, uint32_t Q, double th
     const dim3 grid((Q + 3) / 4);
     const int nr = (int)((B + 63) / 64);
 #define SEL(N) hipLaunchKernelGGL(k_select<N>, grid, dim3(256), 0, ctx->stream, d_lnl, Q, B, pitch, threshold, mode, limit, so, counts, status)
-    const bool seg_off = getenv("EPA_SELECT_FULL_ROWS") != nullptr;   // A/B and test switch: the full-row kernels
+    const bool seg_off = ctx->opt.select_full_rows != 0;   // A/B and test switch: the full-row kernels
     bool seg_hist = false;   // k_select_seg sums the span-class histogram itself
     if (ctx->segmax && !seg_off && mode == 0 && threshold < 1.0 && nr <= 64)
     {
       // band widths of the segment test (see k_select_seg): conservative margins, so the host's log is as good as the device's
       const double band_x = 1.0 - std::log((1.0 - threshold) / (double)B);
       const double band_t = std::max(band_x, std::log((double)B) + 38.0);
-      static const int sel_v1 = getenv("EPA_SEL_V1") ? atoi(getenv("EPA_SEL_V1")) : 0;          // A/B switches (profiles/)
-      static const int sel_grid = getenv("EPA_SEL_GRID") ? atoi(getenv("EPA_SEL_GRID")) : 16;   // workgroups per CU, 0 = a wave per query
-      static const int sel_diag = getenv("EPA_SEL_DIAG") ? atoi(getenv("EPA_SEL_DIAG")) : 0;
-      const dim3 grid_seg(sel_grid > 0 ? std::min<uint32_t>((Q + 3) / 4, (uint32_t)ctx->n_cu * (uint32_t)sel_grid) : (Q + 3) / 4);
-      if (sel_v1) {
-        hipLaunchKernelGGL(k_select_seg_v1<8>, grid, dim3(256), 0, ctx->stream, d_lnl, ctx->segmax, ctx->segp, Q, B, pitch, threshold, so, counts, status);
-      } else if (sel_diag) {
-        hipLaunchKernelGGL((k_select_seg<8, true>), grid_seg, dim3(256), 0, ctx->stream, d_lnl, ctx->segmax, ctx->segp, Q, B, pitch, threshold,
-                           band_x, band_t, so, counts, status, d_span, ctx->s, d_span ? status + 8 : nullptr);
-        seg_hist = d_span != nullptr;
-      } else {
-        hipLaunchKernelGGL(k_select_seg<8>, grid_seg, dim3(256), 0, ctx->stream, d_lnl, ctx->segmax, ctx->segp, Q, B, pitch, threshold,
-                           band_x, band_t, so, counts, status, d_span, ctx->s, d_span ? status + 8 : nullptr);
-        seg_hist = d_span != nullptr;
-      }
+      constexpr uint32_t sel_grid = 16;   // workgroups per CU of the persistent selection grid
+      const dim3 grid_seg(std::min<uint32_t>((Q + 3) / 4, (uint32_t)ctx->n_cu * sel_grid));
+      hipLaunchKernelGGL(k_select_seg<8>, grid_seg, dim3(256), 0, ctx->stream, d_lnl, ctx->segmax, ctx->segp, Q, B, pitch, threshold,
+                         band_x, band_t, so, counts, status, d_span, ctx->s, d_span ? status + 8 : nullptr);
+      seg_hist = d_span != nullptr;
     }
     else if (nr <= 2) SEL(2); else if (nr <= 4) SEL(4); else if (nr <= 8) SEL(8); else if (nr <= 16) SEL(16);
     else if (nr <= 32) SEL(32); else if (nr <= 64) SEL(64);

@@ -506,9 +506,8 @@ int launch_thorough_aa(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_t* d_
   // balances the 10x cost spread of the pairs (a finished workgroup's slot is refilled at once)
   // (measured at 25.7k pairs: x1 6.47 ms, x4 6.2, x8 6.04, x16 6.0); the HBM-slab variant owns
   // 80 x Wpad doubles of scratch per workgroup and stays at x2
-  const bool lds_slab = want_lds && max_span <= EPA_AA_LDS_MAX_SPAN && !getenv("EPA_AA_HBM_SLAB");
+  const bool lds_slab = want_lds && max_span <= EPA_AA_LDS_MAX_SPAN;
   uint32_t per_slot = lds_slab ? 16 : 2;
-  if (const char* e = getenv("EPA_TH_WAVES_PER_SLOT")) per_slot = (uint32_t)std::max(1, atoi(e));
   uint32_t nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)512 * per_slot);
   const uint32_t wpad_lds = (max_span + 1) / 2 * 2 + 2;  // + spare column for lanes past the window
   // two workgroups per CU: static + dynamic LDS <= 80 KB each

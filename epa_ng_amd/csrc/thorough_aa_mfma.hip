@@ -787,10 +787,9 @@ int launch_thorough_aa_mfma(epa_ctx* ctx, const epa_pair* d_pairs, const uint32_
   // resident workgroups + a work counter per XCD slice (EPA_TH_QUEUE=0: an oversubscribed static grid,
   // the dispatcher balances the cost spread of the pairs)
   uint32_t per_slot = 16;
-  if (const char* e = getenv("EPA_TH_WAVES_PER_SLOT")) per_slot = (uint32_t)std::max(1, atoi(e));
   uint32_t nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * wg_per_cu * per_slot);
   a.qctr = nullptr;
-  if (!(getenv("EPA_TH_QUEUE") && atoi(getenv("EPA_TH_QUEUE")) == 0) && ctx->th_ctr) {
+  if (ctx->th_ctr) {
     { const int zr = epa_th_ctr_reset(ctx); if (zr) return zr; }
     a.qctr = epa_th_ctr(ctx);
     nwg = (uint32_t)std::min<uint64_t>(n_pairs, (uint64_t)ctx->n_cu * wg_per_cu);

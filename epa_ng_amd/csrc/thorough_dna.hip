@@ -218,67 +218,13 @@ __device__ __forceinline__ double xhalf_max(double v) {
   const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
   return fmax(__hiloint2double(hi[0], lo[0]), __hiloint2double(hi[1], lo[1]));
 }
-// ---- matrix-core form of the phases (TH_MFMA_PHASE): the three 4 x 4 products of a (site, category) step
-// run on v_mfma_f64_4x4x4_4b_f64.  A lane of that instruction is (k = lane / 16, block = lane / 4 % 4,
-// r = lane % 4): A holds A_block[i = r][k], B holds B_block[k][j = r], D returns D_block[i = lane / 16][j = r]
-// (impulse-response probe, see thorough_aa_mfma.hip).  With the four blocks = four groups of four
-// sites and the same matrix in every block a B / D register is
-//     lane (x = lane / 16, s16 = lane % 16)  =  component x of site s16 of a 16-site group,
-// one register per (category, 16-site group).  The reference rows are loaded in that layout directly
-// (four 128-byte segments per wave load), e o U is folded into the A operand once per phase, and the
-// finished sumtable entries go to the lane = site layout of the Newton evaluations with a 4 x 4
-// transposition between the register index and lane bits 4..5 = two v_permlane32_swap + two
-// v_permlane16_swap per 32-bit half: the product loop issues one instruction per 16 cycles of the
-// fp64 pipe instead of one per 4, and the non-arithmetic work around it issues in its shadow.
-#ifndef TH_MFMA_PHASE
-#define TH_MFMA_PHASE 0
-#endif
+// (A matrix-core form of the phases -- the three 4 x 4 products of a (site, category) step on v_mfma_f64_4x4x4_4b_f64,
+// reference rows loaded in the MFMA B layout, the sumtable transposed back with v_permlane16/32_swap -- was built in
+// round 4, is parity-green and SLOWER: 5.73 against 5.17 ms per 262k-pair launch; on gfx950 the fp64 matrix instruction
+// runs on the vector ALU's fp64 datapath and blocks its issue.  Source: profiles/variants/r5_thorough_dna_mfma_phase.hip
+// (-DTH_MFMA_PHASE=1), measurements: profiles/r4_mfma_phase_go_nogo.txt)
 constexpr int QA_STRIDE = 20;   // doubles per column code in the per-wave query table: codes A C G T 160 B
                                 // apart fall on disjoint LDS banks for the lane = (state, site) gathers
-__device__ __forceinline__ void swap32(int& a, int& b) {   // a = [a.lo | b.lo], b = [a.hi | b.hi] (32-lane halves)
-  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-  a = r[0]; b = r[1];
-}
-__device__ __forceinline__ void swap16(int& a, int& b) {   // a's odd 16-lane rows <-> b's even rows
-  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
-  a = r[0]; b = r[1];
-}
-// v[r] lane (x, s16)  ->  v[x] lane (r, s16)
-__device__ __forceinline__ void transpose4(int (&v)[4]) {
-  swap32(v[0], v[2]); swap32(v[1], v[3]);
-  swap16(v[0], v[1]); swap16(v[2], v[3]);
-}
-__device__ __forceinline__ void transpose4(double (&v)[4]) {
-  int lo[4], hi[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { lo[i] = __double2loint(v[i]); hi[i] = __double2hiint(v[i]); }
-  transpose4(lo);
-  transpose4(hi);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = __hiloint2double(hi[i], lo[i]);
-}
-// the same through a per-wave LDS tile (TH_MFMA_LDS_T): the LDS pipe runs beside the matrix pipe, the
-// permlane swaps do not (profiles/r4_mfma_fill_microbench.txt)
-__device__ __forceinline__ void transpose4_lds(double (&v)[4], double* tb, int lane) {
-  double* w = tb + (lane >> 4) * 64 + (lane & 15);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) w[r * 16] = v[r];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-  for (int x = 0; x < 4; ++x) v[x] = tb[x * 64 + lane];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-#ifndef TH_MFMA_LDS_T
-#define TH_MFMA_LDS_T 0
-#endif
-__device__ __forceinline__ double mfma4(double a, double b) {
-  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, 0.0, 0, 0, 0);
-}
-
 // one category of one site: I_i = (U (e0 o F))_i (U (e1 o G))_i, It = U^-1 I (unscaled; the caller
 // keeps the running maximum for the per-site rescale test).  The streamed phases (TH_STREAM_DEPTH)
 // walk a window category by category with this.
@@ -369,7 +315,6 @@ struct SiteState {
   uint32_t sc[NCH];    // proximal + distal scaler counts
   uint32_t resc[NCH];  // rescale flag of the last inner CLV toward the query
   uint32_t code[NCH];  // query column code
-  uint32_t codem[NCH]; // TH_MFMA_PHASE: the codes of sites s16, 16 + s16, 32 + s16, 48 + s16 of the chunk, 4 bits each
   bool valid[NCH];
 };
 
@@ -746,16 +691,6 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     st.sc[ch] = scp[sc];
     st.code[ch] = qc[sc];
     st.resc[ch] = 0;
-    if (TH_MFMA_PHASE) {
-      // lane (x, s16) of the matrix-core layout needs the code of site 16 g + s16 for every group g: the
-      // four 16-lane rows OR their codes together, 4 bits per group (half-chunk: rows 0 / 2 = group 0)
-      const bool halfc = TAILH && ch == NCH - 1;
-      int v = (int)(st.code[ch] << (4 * (halfc ? ((lane >> 4) & 1) : (lane >> 4))));
-      const auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-      v = (int)(r32[0] | r32[1]);
-      const auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-      st.codem[ch] = (uint32_t)(r16[0] | r16[1]);
-    }
   }
 
   double tp = a.blo.pendant_default, td = orig * 0.5, tx = orig * 0.5;
@@ -901,154 +836,7 @@ __device__ __forceinline__ void process_pair(const ThArgs& a, const uint64_t pid
     }
     chain = tok;
   };
-  // ---- the same phase on the matrix cores (MODE 0 / 1 / 3; layout and reasons at TH_MFMA_PHASE above).
-  // A step = one category of a 64-site chunk = four (category, 16-site group) registers; in a half-chunk
-  // the four registers of a step are (category 2 h + kk, group g) for h, g in {0, 1}, so that the
-  // transposition lands them in the half-chunk's lane = (h, site) layout.
-  const double* const umat = qts + 64;   // LDS: U [16], U^-1 [16]
-  auto stream_phase_mfma = [&](auto mode_c) {
-    constexpr int MODE = decltype(mode_c)::value;
-    static_assert(MODE == 0 || MODE == 1 || MODE == 3, "product phases only");
-    constexpr int DEPTH = TH_STREAM_DEPTH;
-    constexpr int NKL = TAILH ? 2 : 4;
-    constexpr int NS = 4 * (NCH - 1) + NKL;
-    constexpr int R = DEPTH + 1;
-    double wk[4];
-    {
-      KArgs kp = kargs_fresh();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wk[i] = kp->m.w[grp * 4 + i];
-    }
-    uint32_t W8p = W8;
-    asm volatile("" : "+s"(W8p));
-    uint32_t tok = chain;
-    const int xr = lane >> 4, s16 = lane & 15;
-    const uint32_t xrow = (uint32_t)xr * W8p;
-    if constexpr (MODE == 1 || MODE == 3) {
-      // lane = (code = lane >> 2, category = lane & 3): the four entries a_i of (code, category)
-      const int kq = lane & 3;
-      const double* qv = qts + (lane >> 2) * 4;
-      const double* e0 = tab + kq * 4;
-      double av[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) av[x] = qv[x] * e0[x];
-      double* dst = qa + (lane >> 2) * QA_STRIDE + kq * 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        double u[4];
-        lds_pair(umat + i * 4 + 2 * tok, u[0], u[1]); lds_pair(umat + i * 4 + 2 + 2 * tok, u[2], u[3]);
-        double v = u[0] * av[0];
-#pragma unroll
-        for (int x = 1; x < 4; ++x) v = fma(u[x], av[x], v);
-        dst[i] = v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    // A operands: lane (k = lane / 16, ., r = lane % 4) holds M[r][k]
-    double Ae0[4], Ae1[4];
-    const double Uil = umat[16 + (lane & 3) * 4 + xr + tok];
-    {
-      const double Ul = umat[(lane & 3) * 4 + xr + tok];
-      const double* tl = tab + xr + tok;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        Ae1[k] = Ul * tl[16 + k * 4];
-        if (MODE == 0) Ae0[k] = Ul * tl[k * 4];
-      }
-    }
-    auto slot_k = [&](int ch, int kq, int j) -> int { return (TAILH && ch == NCH - 1) ? 2 * (j >> 1) + kq : kq; };
-    auto slot_g = [&](int ch, int j) -> int { return (TAILH && ch == NCH - 1) ? (j & 1) : j; };
-    auto moff = [&](int ch, int g) -> uint32_t {   // byte offset of this lane's (component row, site) in a category block
-      uint32_t s = site0 + (uint32_t)(ch * 64 + g * 16 + s16);
-      if (!(NW == 1 && ch < NCH - 1)) s = s < n ? s : 0u;
-      return s * 8u + xrow;
-    };
-    double An[R][4], Bn[R][4];
-    auto issue = [&](int stp, uint32_t tk) {
-      const int ch = stp >> 2, kq = stp & 3, sl = stp % R;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = slot_k(ch, kq, j);
-        const uint32_t o = moff(ch, slot_g(ch, j)) + tk;
-        An[sl][j] = *reinterpret_cast<const double*>(ref + (o + (uint32_t)(16 * NG + k * 4) * W8p));
-        Bn[sl][j] = *reinterpret_cast<const double*>(ref + (o + (uint32_t)(k * 4) * W8p));
-      }
-    };
-#pragma unroll
-    for (int p = 0; p < DEPTH; ++p)
-      if (p < NS) issue(p, tok);
-    int mxg[4] = {0, 0, 0, 0};
-    double qf[4];
-#pragma unroll
-    for (int stp = 0; stp < NS; ++stp) {
-      const int ch = stp >> 2, kq = stp & 3, sl = stp % R;
-      const bool halfc = TAILH && ch == NCH - 1;
-      const int NK = halfc ? 2 : 4;
-      if (MODE == 0 && kq == 0) {
-        const double* qv = qts + st.code[ch] * 4;
-        qf[0] = qv[0]; qf[1] = qv[1]; qf[2] = qv[2]; qf[3] = qv[3];
-      }
-      if (stp + DEPTH < NS) issue(stp + DEPTH, tok);
-      asm volatile("" ::: "memory");   // the prefetch is issued here, not at its use
-      double It[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = slot_k(ch, kq, j), g = slot_g(ch, j);
-        double I;
-        if constexpr (MODE == 0) {
-          const double av = mfma4(Ae0[k], An[sl][j]);
-          const double bv = mfma4(Ae1[k], Bn[sl][j]);
-          I = av * bv;
-        } else {
-          const uint32_t code = (st.codem[ch] >> (4 * g)) & 15u;
-          const double Ap = qa[code * QA_STRIDE + k * 4 + xr];
-          const double bv = mfma4(Ae1[k], MODE == 1 ? Bn[sl][j] : An[sl][j]);
-          I = Ap * bv;
-        }
-        mxg[g] = max(mxg[g], __double2hiint(I));
-        It[j] = mfma4(Uil, I);
-        if (MODE == 1) It[j] *= An[sl][j];
-        if (MODE == 3) It[j] *= Bn[sl][j];
-      }
-      if (TH_MFMA_LDS_T) transpose4_lds(It, qa + 16 * QA_STRIDE, lane); else transpose4(It);
-#pragma unroll
-      for (int x = 0; x < 4; ++x) st.S[ch][kq * 4 + x] = MODE == 0 ? It[x] * qf[x] : It[x];
-      tok = zero_after(st.S[ch][kq * 4 + 3]);
-      if (kq == NK - 1) {   // chunk complete
-        int mt[4] = {mxg[0], mxg[1], halfc ? mxg[0] : mxg[2], halfc ? mxg[1] : mxg[3]};
-        transpose4(mt);     // the site's four states side by side in the lane = site layout
-        int mxs = max(max(mt[0], mt[1]), max(mt[2], mt[3]));
-        if constexpr (NG > 1) {   // the test spans all categories of the site: maximum over the groups
-          double mv[1] = {(double)mxs};
-          cb.template groups<1, true>(mv, lane);
-          mxs = (int)mv[0];
-        }
-        const uint32_t resc = (mxs < 0x2ff00000) ? 1u : 0u;
-        if (__builtin_amdgcn_ballot_w64(resc != 0) != 0) {   // rare: some site of the chunk underflowed
-          const double mult = resc ? 0x1p+256 : 1.0;
-#pragma unroll
-          for (int i = 0; i < 16; ++i)
-            if (i < NK * 4) st.S[ch][i] *= mult;
-        }
-        if (MODE == 0) st.resc[ch] = resc;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) mxg[g] = 0;
-        if constexpr (INV) st.S[ch][0] += cinv_of(ch);
-        if constexpr (ZERO0) {   // fold0 with the phase's copy of the weights
-          if (halfc) st.S[ch][0] = fma(half ? wk[3] : wk[1], st.S[ch][4], (half ? wk[2] : wk[0]) * st.S[ch][0]);
-          else st.S[ch][0] = fma(wk[3], st.S[ch][12], fma(wk[2], st.S[ch][8], fma(wk[1], st.S[ch][4], wk[0] * st.S[ch][0])));
-        }
-        tok = zero_after(st.S[ch][halfc ? 7 : 15]);
-      }
-    }
-    chain = tok;
-  };
-  auto product_phase = [&](auto mode_c) {
-    if constexpr (TH_MFMA_PHASE) stream_phase_mfma(mode_c);
-    else stream_phase(mode_c);
-  };
+  auto product_phase = [&](auto mode_c) { stream_phase(mode_c); };
   // Inner CLV toward the query at (td, tx) folded with the query, S = (U^-1 I) o qt, and the
   // window lnL at pendant length tp_.  One table pass: slot 0 -> exp(lr td), slot 1 ->
   // exp(lr tx), slot 2 -> w exp(lr tp).
@@ -1182,17 +970,16 @@ template <int NCH, bool ZERO0, bool INV, int NW, bool LOCAL = false, bool TAILH 
 __global__ void __launch_bounds__(64 * NW * NG, TH_WAVES) k_thorough_dna(const ThArgs a) {
   constexpr int NWV = NW * NG;     // waves of the workgroup: site blocks (NW) or category groups (NG)
   __shared__ __attribute__((aligned(16))) double tab[64 * NWV];  // broadcast table of each wave
-  __shared__ __attribute__((aligned(16))) double qts[96];   // U^-1 image of the 16 query column codes; [64..96): U, U^-1
+  __shared__ __attribute__((aligned(16))) double qts[64];   // U^-1 image of the 16 query column codes
   __shared__ double red[2 * NW * 2];
   __shared__ double e2t[64];
-  __shared__ __attribute__((aligned(16))) double qa[(16 * QA_STRIDE + (TH_MFMA_LDS_T ? 256 : 0)) * NWV];  // per wave: (U (e o q_code))_i for 16 codes x 16 (category, state)
+  __shared__ __attribute__((aligned(16))) double qa[(16 * QA_STRIDE) * NWV];  // per wave: (U (e o q_code))_i for 16 codes x 16 (category, state)
   __shared__ double xch[NG > 1 ? 2 * NG * Comb<NW, NG>::XCH_MAX * 64 : 1];
   const int lane = threadIdx.x & 63;
   Comb<NW, NG> cb{red, (int)(threadIdx.x >> 6), 0, xch, 0};
   if (threadIdx.x < 64) {
     qts[lane] = a.qt[lane];
     e2t[lane] = exp2((double)lane * 0.015625);
-    if (lane < 32) qts[64 + lane] = lane < 16 ? a.m.U[lane] : a.m.Ui[lane - 16];
   }
   LaneConst lc;
   lc.e2t = e2t;
@@ -1257,7 +1044,7 @@ __global__ void __launch_bounds__(64 * NW * NG, TH_WAVES) k_thorough_dna(const T
       const uint32_t cur = nxt;
       uint32_t f = 0;
       if (lane == 0) f = atomicAdd(ctr, 1u);
-      process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH, NG>(a, lo + cur, lane, tab + cb.wv * 64, qts, qa + cb.wv * (16 * QA_STRIDE + (TH_MFMA_LDS_T ? 256 : 0)), lc, cb, wstat);
+      process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH, NG>(a, lo + cur, lane, tab + cb.wv * 64, qts, qa + cb.wv * (16 * QA_STRIDE), lc, cb, wstat);
       nxt = (uint32_t)__builtin_amdgcn_readfirstlane((int)f);
 #ifdef TH_TIMING
       ++npr;
@@ -1270,7 +1057,7 @@ __global__ void __launch_bounds__(64 * NW * NG, TH_WAVES) k_thorough_dna(const T
 #endif
   } else {
     for (uint64_t p = lo + w; p < hi; p += stride)
-      process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH, NG>(a, p, lane, tab + cb.wv * 64, qts, qa + cb.wv * (16 * QA_STRIDE + (TH_MFMA_LDS_T ? 256 : 0)), lc, cb, wstat);
+      process_pair<NCH, ZERO0, INV, NW, LOCAL, TAILH, NG>(a, p, lane, tab + cb.wv * 64, qts, qa + cb.wv * (16 * QA_STRIDE), lc, cb, wstat);
   }
   if (threadIdx.x == 0) {
     atomicAdd(&a.stats[0], (unsigned long long)wstat[0]);
@@ -1546,10 +1333,9 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
   // 2048 / NW workgroups.  Oversubscribing the resident set lets the hardware dispatcher do the
   // load balancing (pairs differ 10x in cost): a finished workgroup's slot is refilled at once.
   // About four pairs per wave balance best (measured: 131k pairs 8 vs 16, 262k pairs 8 / 16 / 32
-  // / 64 -> 6.64 / 6.66 / 6.50 / 6.58 ms; one pair per wave: 10.2 ms).  EPA_TH_WAVES_PER_SLOT overrides.
+  // / 64 -> 6.64 / 6.66 / 6.50 / 6.58 ms; one pair per wave: 10.2 ms).
   uint32_t per_slot = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(8, n_pairs / (2048 * 4)));
-  if (const char* e = getenv("EPA_TH_WAVES_PER_SLOT")) per_slot = (uint32_t)std::max(1, atoi(e));
-  static const uint64_t th_grid_waves = getenv("EPA_TH_GRID_WAVES") ? (uint64_t)std::max(8, atoi(getenv("EPA_TH_GRID_WAVES"))) : 0;   // experiment: resident waves of the single-wave classes
+  constexpr uint64_t th_grid_waves = 0;   // (resident waves of the single-wave classes: 2048 = every slot; fewer were measured and lose)
   // class -> (wavefronts per pair NW, 64-site chunks per wavefront NCH): windows up to 192 sites
   // are one wave's job; longer ones are spread over 2 / 4 / 8 waves of a workgroup, each keeping
   // its part of the sumtable in registers (NCH stays <= 3: the kernel's register budget)
@@ -1618,9 +1404,8 @@ static int launch_thorough_dna_class(epa_ctx* ctx, ThArgs a, int cls, uint32_t m
 #undef LAUNCH_G
     return EPA_OK;
   }
-  static const bool tail_off = getenv("EPA_TH_TAIL") && atoi(getenv("EPA_TH_TAIL")) == 0;
-  const bool tailh = !tail_off && (cls == 10 || cls == 11);
-  static const bool n4_off = getenv("EPA_TH_N4") && atoi(getenv("EPA_TH_N4")) == 0;
+  const bool tailh = cls == 10 || cls == 11;
+  constexpr bool n4_off = false;
   switch (cls) {
     case 0: LAUNCH(1, 1); break;
     case 1: case 10: LAUNCH(2, 1); break;
@@ -1823,7 +1608,7 @@ int launch_thorough(epa_ctx* ctx, const epa_pair* d_pairs, uint64_t n_pairs, con
       // with 8 (+G8, +R5 ..); longer ones, or all of them with EPA_AA_VALU=1 (A/B switch, 4 categories), the
       // lane = site VALU kernel / the general kernel
       static const uint32_t aa_bound[4] = {64, 128, 192, 0xffffffffu};
-      static const bool aa_valu = getenv("EPA_AA_VALU") != nullptr;
+      const bool aa_valu = ctx->opt.aa_valu != 0;
       const uint32_t bound = std::min(max_span, aa_bound[c < 4 ? c : 3]);
       const uint32_t mfma_max = ctx->c == 4 ? 384u : 256u;
       // (the VALU kernel has no --raxml-blo instantiation: the A/B switch applies to the sliding rule only)

@@ -204,6 +204,22 @@ int epa_dev_tree_logl(epa_ctx* ctx, uint32_t branch, double* lnl);
 /* Optional: run all kernels of `ctx` on this hipStream_t (passed as void*). Default stream 0. */
 int epa_dev_set_stream(epa_ctx* ctx, void* hip_stream);
 
+/*
+ * Diagnostic switches of a context, no reference counterpart.  Every switch selects between code paths that return
+ * the same results (cross-check kernels of the parity tests, A/B switches of the bench); the library reads NO
+ * environment variable for its compute path (RCCL's location and timeout excepted: EPA_RCCL_LIB, EPA_COMM_TIMEOUT_S).
+ *   "thorough_generic"  1: every Newton launch on the general kernel (k_thorough_generic, the reference-shaped loop)
+ *   "preplace_generic"  1: preplacement on k_preplace (one gather per site) instead of the pair / site fast paths
+ *   "select_full_rows"  1: candidate selection from whole table rows instead of the segment maxima
+ *   "select_sort"       1: candidate list through staging rows + a stable sort instead of the [B][Q] bitmap
+ *   "queued_thorough"   1: the Newton launch queued behind the selection, guarded by the device-side count
+ *   "xcd_balance"       0: the eight XCDs keep equal shares of a Newton launch (default 1: epa_dev_xcd_shares)
+ *   "aa_valu"           1: 20-state windows on the lane = site VALU kernel instead of the matrix-core kernel
+ *   "timers"            0: no hipEvent records around the kernel families (epa_dev_last_kernel_ms returns < 0)
+ * Unknown key: EPA_ERR_INVALID_ARG.
+ */
+int epa_dev_set_option(epa_ctx* ctx, const char* key, int value);
+
 /* Builds T[b][site][col] for all branches (idempotent).  Replaces precompute_sites_static x C
  * + Lookup_Store::init_branch (Tiny_Tree.cpp:18-46,114-128). */
 int epa_dev_build_lookup(epa_ctx* ctx);

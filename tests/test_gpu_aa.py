@@ -104,17 +104,17 @@ def test_aa_preplace_site_path_bitwise_equals_generic(monkeypatch):
         codes, wb, ws = epa.encode_queries(20, reads, compact=compact)
         assert len(set(ws % 4)) == 4 and ws.max() > 384
         fast = ev.preplace(codes, wb, ws)
-        monkeypatch.setenv("EPA_PREPLACE_GENERIC", "1")
+        ev.set_option("preplace_generic", 1)
         generic = ev.preplace(codes, wb, ws)
-        monkeypatch.delenv("EPA_PREPLACE_GENERIC")
+        ev.set_option("preplace_generic", 0)
         assert np.array_equal(fast, generic)  # same association order, bit for bit
         assert np.max(np.abs(fast - o.preplace(reads))) < 1e-6
     short = make([1, 2, 3, 5, 6, 7, 64, 99, 100, 101, 102], 1300)
     codes, wb, ws = epa.encode_queries(20, short, compact=True)
     pf, rf = ev.place_chunk(codes, wb, ws, max_span=int(ws.max()))
-    monkeypatch.setenv("EPA_PREPLACE_GENERIC", "1")
+    ev.set_option("preplace_generic", 1)
     pg, rg = ev.place_chunk(codes, wb, ws, max_span=int(ws.max()))
-    monkeypatch.delenv("EPA_PREPLACE_GENERIC")
+    ev.set_option("preplace_generic", 0)
     assert np.array_equal(pf, pg) and np.array_equal(rf, rg)
     lnl = ev.preplace(codes, wb, ws)
     hb, hs = hostlib.heuristic(lnl, "dynamic", 0.99999)

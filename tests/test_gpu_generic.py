@@ -67,7 +67,7 @@ def test_any_number_of_rate_categories(states, cats, pinv):
 @pytest.mark.parametrize("cats,pinv", [(3, 0.0), (5, 0.0), (8, 0.0), (8, 0.25), (12, 0.0), (16, 0.0)])
 def test_category_group_kernel_equals_general_kernel(cats, pinv, monkeypatch):
     """Nucleotide models with 3 / 5 .. 16 rate categories run on k_thorough_dna with one wave per group
-    of four categories (padded with weight-0 copies of the last category); EPA_TH_GENERIC=1 sends the
+    of four categories (padded with weight-0 copies of the last category); the option thorough_generic sends the
     same context shape to k_thorough_generic.  Windows of every single-wave class (incl. the lengths
     the four-category kernel serves with half-chunk tails) and one beyond them (general kernel in both
     contexts): same pairs, lnL to 1e-9, lengths to 1e-9, identical round / Newton-evaluation counters;
@@ -90,10 +90,9 @@ def test_category_group_kernel_equals_general_kernel(cats, pinv, monkeypatch):
     ev = ref.evaluator()
     res = ev.thorough(pairs, codes, wb, ws)
     st = dict(ev.last_stats)
-    monkeypatch.setenv("EPA_TH_GENERIC", "1")
     evg = ref.evaluator()
+    evg.set_option("thorough_generic", 1)
     resg = evg.thorough(pairs, codes, wb, ws)
-    monkeypatch.delenv("EPA_TH_GENERIC")
     assert np.max(np.abs(res["lnl"] - resg["lnl"])) < 1e-9
     assert np.max(np.abs(res["pendant_length"] - resg["pendant_length"])) < 1e-9
     assert np.max(np.abs(res["distal_length"] - resg["distal_length"])) < 1e-9
@@ -110,7 +109,7 @@ def test_aa_matrix_core_kernel_8_categories_and_long_windows(cats, pinv, blo, mo
     """20-state models on k_thorough_aa_mfma beyond {4 categories, 192 sites}: 8 categories (+G8; +R5 padded
     with weight-0 copies of its last category) as NC = 8 instantiations, windows of up to 384 (4 categories)
     / 256 (8) residues on 8-wave workgroups; longer ones in the same chunk go to the lane = site / general
-    kernel.  EPA_TH_GENERIC=1 sends the same context shape to k_thorough_generic: same pairs, lnL and lengths
+    kernel.  The option thorough_generic sends the same context shape to k_thorough_generic: same pairs, lnL and lengths
     to 1e-9, identical round / Newton-evaluation counters; and the oracle on the mixed chunk."""
     rng = np.random.RandomState(700 + cats)
     rates = np.sort(rng.gamma(0.6, 1.5, cats)) + 1e-3
@@ -131,10 +130,9 @@ def test_aa_matrix_core_kernel_8_categories_and_long_windows(cats, pinv, blo, mo
     ev = ref.evaluator(**kw)
     res = ev.thorough(pairs, codes, wb, ws)
     st = dict(ev.last_stats)
-    monkeypatch.setenv("EPA_TH_GENERIC", "1")
     evg = ref.evaluator(**kw)
+    evg.set_option("thorough_generic", 1)
     resg = evg.thorough(pairs, codes, wb, ws)
-    monkeypatch.delenv("EPA_TH_GENERIC")
     assert np.max(np.abs(res["lnl"] - resg["lnl"])) < 1e-9
     assert np.max(np.abs(res["pendant_length"] - resg["pendant_length"])) < 1e-9
     assert np.max(np.abs(res["distal_length"] - resg["distal_length"])) < 1e-9
@@ -222,7 +220,7 @@ def test_raxml_blo_local_optimisation(states, rs):
 def test_raxml_blo_tuned_kernels_equal_general_kernel(monkeypatch, states, pinv):
     """--raxml-blo runs on the LOCAL instantiations of k_thorough_dna (register sumtable, 1 - 8 waves per
     pair; with +I since round 5) and k_thorough_aa_mfma (windows up to 192 sites; +I included); the general kernel
-    (EPA_TH_GENERIC=1) is the cross-check.  The window lengths cover every span class of the tuned
+    (option thorough_generic) is the cross-check.  The window lengths cover every span class of the tuned
     kernels and, for 20 states, the hand-over to the general kernel beyond 192 sites."""
     root = synth.random_tree(40, 61)
     rates = synth.gamma_rates(0.5)
@@ -239,9 +237,8 @@ def test_raxml_blo_tuned_kernels_equal_general_kernel(monkeypatch, states, pinv)
     ev = ref.evaluator(raxml_blo=True)
     _, pairs, res = check_against_oracle(ev, o, reads, states)
     tuned_stats = dict(ev.last_stats)
-    monkeypatch.setenv("EPA_TH_GENERIC", "1")
     evg = ref.evaluator(raxml_blo=True)
-    monkeypatch.delenv("EPA_TH_GENERIC")
+    evg.set_option("thorough_generic", 1)
     codes, wb, ws = epa.encode_queries(states, reads, compact=True)
     gen = evg.thorough(pairs, codes, wb, ws)
     assert np.max(np.abs(gen["lnl"] - res["lnl"])) < 1e-8

@@ -219,9 +219,9 @@ def test_preplace_pair_path_bitwise_equals_generic(monkeypatch):
     codes, wb, ws = epa.encode_queries(4, reads)
     assert len(set(wb % 2)) == 2 and len(set(ws % 4)) == 4
     fast = e.preplace(codes, wb, ws)
-    monkeypatch.setenv("EPA_PREPLACE_GENERIC", "1")
+    e.set_option("preplace_generic", 1)
     generic = e.preplace(codes, wb, ws)
-    monkeypatch.delenv("EPA_PREPLACE_GENERIC")
+    e.set_option("preplace_generic", 0)
     assert np.array_equal(fast, generic)  # same association order, bit for bit
     assert np.max(np.abs(fast - o.preplace(reads))) < LNL_TOL
 
@@ -371,40 +371,6 @@ def test_every_span_class_in_one_chunk_incl_half_chunk_tails():
         assert np.max(np.abs(res["pendant_length"] - tp)) < 1e-6 and np.max(np.abs(res["distal_length"] - td)) < 1e-6
         assert pinv_ev.last_stats["rounds"] == o.last_stats["rounds"]
         assert pinv_ev.last_stats["newton_evals"] == o.last_stats["newton_evals"]
-
-
-@pytest.mark.parametrize("switch", ["EPA_PREPLACE_DB", "EPA_PREPLACE_DUO"])
-def test_opt_in_preplacement_loops_are_bit_identical(switch, tmp_path):
-    """The two measured-and-not-adopted branch loops of k_preplace_pairs -- double-buffered slices (round 4, 4 % slower)
-    and two branches per stage (round 5, 5 % slower: DESIGN 4.3) -- stay compiled and selectable; run in a child
-    process (the switches are read once per process) they return the default loop's table bit for bit."""
-    import subprocess
-    import sys
-    script = tmp_path / "child.py"
-    script.write_text(r"""
-import os, sys
-import numpy as np
-sys.path.insert(0, os.environ["EPA_ROOT"]); sys.path.insert(0, os.path.join(os.environ["EPA_ROOT"], "tests"))
-import epa_ng_amd as epa
-from epa_ng_amd import hostlib, synth
-w = synth.dna_workload(40, 600, 3000, 150, (91, 92, 93))
-ref = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"], freqs=w["freqs"], rates=w["rates"])
-ev = ref.evaluator()
-codes, wb, ws = epa.encode_queries(4, w["reads"], compact=True)
-np.save(sys.argv[1], ev.preplace(codes, wb, ws))
-""")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for val in (None, "1"):
-        env = dict(os.environ, EPA_ROOT=root)
-        env.pop("EPA_PREPLACE_DB", None); env.pop("EPA_PREPLACE_DUO", None)
-        if val:
-            env[switch] = val
-        out = tmp_path / ("t_%s.npy" % (val or "0"))
-        r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(np.load(out))
-    assert outs[0].shape[0] == 3000 and np.array_equal(outs[0], outs[1])
 
 
 def test_noise_flat_pair_of_the_round5_hand_run():

@@ -296,7 +296,7 @@ def test_full_size_cfg2_properties():
     for sh in shares:
         assert abs(sh.sum() - 1.0) < 1e-5 and np.all(sh > 0.125 * 0.84) and np.all(sh < 0.125 * 1.16)
     # learning is gated on the launch's MEASURED duration (>= 1 ms), not on what this box is expected to take
-    if os.environ.get("EPA_TH_XCD_BALANCE", "1") != "0" and min(th_ms) >= 1.5:
+    if min(th_ms) >= 1.5:
         assert not np.array_equal(shares[-1], np.full(8, 0.125))
     assert 500.0 < ev.sclk_mhz() < 3000.0                               # the launch stamped its shader clock
     small = hostlib.Reference(w["newick"], w["labels"], w["seqs"], states=4, subst=w["subst"], freqs=w["freqs"],
@@ -1164,7 +1164,7 @@ def test_group_launch_of_small_chunks_equals_per_chunk_launches():
 
 
 def test_queued_thorough_launch_equals_host_launched(monkeypatch):
-    """EPA_QUEUED_THOROUGH=1 (opt-in): the pair list and the Newton kernel are queued behind the selection before the
+    """option queued_thorough (opt-in): the pair list and the Newton kernel are queued behind the selection before the
     host has seen the candidate count, guarded on the device by the read-back block the host checks afterwards
     (launch_thorough_queued).  Same bits as the host-launched order -- for a chunk of one read length (the queued
     kernel runs), for mixed read lengths (the queued kernel must exit, the ordinary per-class launches run), through
@@ -1182,10 +1182,10 @@ def test_queued_thorough_launch_equals_host_launched(monkeypatch):
         mixed.append(r)
     for reads in (one_len, mixed):
         codes, wb, ws = epa.encode_queries(4, reads, compact=True)
-        monkeypatch.delenv("EPA_QUEUED_THOROUGH", raising=False)
+        ev.set_option("queued_thorough", 0)
         p0, r0 = ev.place_chunk(codes, wb, ws, max_span=150)
         st0 = dict(ev.last_stats)
-        monkeypatch.setenv("EPA_QUEUED_THOROUGH", "1")
+        ev.set_option("queued_thorough", 1)
         p1, r1 = ev.place_chunk(codes, wb, ws, max_span=150)
         st1 = dict(ev.last_stats)
         assert len(p0) > len(reads) and np.array_equal(p0, p1) and np.array_equal(r0, r1)
@@ -1196,9 +1196,9 @@ def test_queued_thorough_launch_equals_host_launched(monkeypatch):
         for c in range(len(reads) // Q):
             cc, cb, cs = epa.encode_queries(4, reads[c * Q:(c + 1) * Q], compact=True)
             chunks.append((epa.pack_codes_4bit(cc), cb, cs))
-        monkeypatch.delenv("EPA_QUEUED_THOROUGH")
+        ev.set_option("queued_thorough", 0)
         expect = [ev.place_chunk(*ch, max_span=150) for ch in chunks]
-        monkeypatch.setenv("EPA_QUEUED_THOROUGH", "1")
+        ev.set_option("queued_thorough", 1)
         kw = dict(threshold=0.99999, max_span=150, max_pairs=Q * 64)
         n = len(chunks)
         got = [None] * n
@@ -1225,12 +1225,12 @@ def test_queued_thorough_launch_equals_host_launched(monkeypatch):
         ev.chunk_launch_end(0)
         p, r = ev.chunk_finish(0)
         assert np.array_equal(p, expect[0][0]) and np.array_equal(r, expect[0][1])
-        monkeypatch.delenv("EPA_QUEUED_THOROUGH")
+        ev.set_option("queued_thorough", 0)
 
 
 def test_selection_bitmap_and_sorted_staging_paths_agree(tmp_path):
     """the candidate list comes from a [B][Q] bitmap (default) or, for bitmaps over 64 MB, from
-    staging rows + compaction + a stable device sort (EPA_SELECT_SORT forces that path): same pairs
+    staging rows + compaction + a stable device sort (the option select_sort forces that path): same pairs
     in the same (branch, query) order, same results, for the three selection rules"""
     import subprocess, sys
     script = tmp_path / "sel.py"
@@ -1242,6 +1242,7 @@ def test_selection_bitmap_and_sorted_staging_paths_agree(tmp_path):
         "w = synth.dna_workload(96, 400, 700, 120, (91, 92, 93))\n"
         "ref = hostlib.Reference(w['newick'], w['labels'], w['seqs'], states=4, subst=w['subst'], freqs=w['freqs'], rates=w['rates'])\n"
         "ev = ref.evaluator()\n"
+        "ev.set_option('select_sort', int(sys.argv[2]))\n"
         "codes, wb, ws = epa.encode_queries(4, w['reads'], compact=True)\n"
         "out = {}\n"
         "for mode, param in (('dynamic', 0.0), ('fixed', 0.05), ('baseball', 0.0)):\n"
@@ -1250,10 +1251,9 @@ def test_selection_bitmap_and_sorted_staging_paths_agree(tmp_path):
         "    out[mode + '_p'] = p; out[mode + '_r'] = r\n"
         "np.savez(sys.argv[1], **out)\n" % (REPO, os.path.join(REPO, "tests")))
     outs = []
-    for env_extra, name in (({}, "bitmap.npz"), ({"EPA_SELECT_SORT": "1"}, "sorted.npz")):
-        env = dict(os.environ, **env_extra)
-        r = subprocess.run([sys.executable, str(script), str(tmp_path / name)], capture_output=True, text=True,
-                           timeout=600, env=env)
+    for sort, name in ((0, "bitmap.npz"), (1, "sorted.npz")):
+        r = subprocess.run([sys.executable, str(script), str(tmp_path / name), str(sort)], capture_output=True, text=True,
+                           timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append(np.load(tmp_path / name))
     for k in outs[0].files:
@@ -1264,7 +1264,7 @@ def test_selection_bitmap_and_sorted_staging_paths_agree(tmp_path):
 def test_selection_from_segment_maxima_equals_full_row_selection(states, tips, width, rl, monkeypatch):
     """The fused chunk body selects the dynamic rule's candidates from the per-(query, 64-branch segment) maxima the
     preplacement leaves behind (k_select_seg: only the segments near a row's maximum are read);
-    EPA_SELECT_FULL_ROWS=1 sends the same chunk through the full-row kernel.  Same pairs in the same order, same
+    the option select_full_rows sends the same chunk through the full-row kernel.  Same pairs in the same order, same
     results -- for a tree of 10 segments, one of 22 (20 states), one of a single partial segment, thresholds from
     lax to 1 - 1e-9, and reads with rare ambiguity codes (their rows have no maxima: rebuilt from the row)."""
     if states == 4:
@@ -1290,11 +1290,11 @@ def test_selection_from_segment_maxima_equals_full_row_selection(states, tips, w
     ev = ref.evaluator()
     codes, wb, ws = epa.encode_queries(states, reads, compact=True)
     for thr in (0.9, 0.99999, 1.0 - 1e-9):
-        monkeypatch.delenv("EPA_SELECT_FULL_ROWS", raising=False)
+        ev.set_option("select_full_rows", 0)
         p_seg, r_seg = ev.place_chunk(codes, wb, ws, threshold=thr)
-        monkeypatch.setenv("EPA_SELECT_FULL_ROWS", "1")
+        ev.set_option("select_full_rows", 1)
         p_full, r_full = ev.place_chunk(codes, wb, ws, threshold=thr)
-        monkeypatch.delenv("EPA_SELECT_FULL_ROWS")
+        ev.set_option("select_full_rows", 0)
         assert np.array_equal(p_seg, p_full), thr
         assert np.array_equal(r_seg["lnl"], r_full["lnl"])
     assert len(p_seg) >= len(reads)
