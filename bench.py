@@ -119,6 +119,61 @@ def reference_binary_check(newick, labels, seqs, sample_codes, wb, ws, W, states
         return {"status": "hook error: %r" % (e,)}
 
 
+def cli_e2e_leg(newick, labels, seqs, chunks, W, model):
+    """The drop-in EXECUTABLE end to end: the cfg2 reference and the given reads written
+    once as aligned FASTA and as the reference's binary fasta (.bfast), `epa-ng-amd` run on each with its defaults --
+    everything a user's run does per read besides the device calls is inside: reading / indexing the file, ASCII or
+    4-bit -> wire codes, the chunk pipeline, LWR + filter, jplace text, the write.  reads/s = reads / loop_s (first
+    read -> closed jplace; the one-off reference setup is reported beside it), stage times are busy seconds of stages
+    that overlap on the host's cores."""
+    from epa_ng_amd import hostlib, synth
+    import hashlib
+    exe = hostlib.cli_exe()
+    out = {"host_cores": hostlib.configure_threads()}
+    d = tempfile.mkdtemp(prefix="epa_cli_e2e_")
+    try:
+        with open(os.path.join(d, "ref.tre"), "w") as f:
+            f.write(newick + "\n")
+        with open(os.path.join(d, "ref.fasta"), "w") as f:
+            for l, s_ in zip(labels, seqs):
+                f.write(">%s\n%s\n" % (l, s_))
+        t0 = time.perf_counter()
+        n = synth.write_query_files(os.path.join(d, "q.fasta"), os.path.join(d, "q.bfast"), chunks, W)
+        out["reads"] = n
+        out["write_inputs_s"] = round(time.perf_counter() - t0, 2)
+        digests = {}
+        for kind in ("fasta", "bfast"):
+            od = os.path.join(d, "out_" + kind)
+            os.mkdir(od)
+            best = None
+            for rep in range(2):                       # the second run reads the query file from the page cache
+                r = subprocess.run([exe, "-t", os.path.join(d, "ref.tre"), "-s", os.path.join(d, "ref.fasta"),
+                                    "-q", os.path.join(d, "q." + kind), "-m", model, "-w", od,
+                                    "--stats-json", os.path.join(od, "stats.json")], capture_output=True, text=True, timeout=600)
+                if r.returncode != 0:
+                    raise RuntimeError("epa-ng-amd failed on the %s file: %s" % (kind, (r.stdout + r.stderr)[-400:]))
+                st = json.load(open(os.path.join(od, "stats.json")))
+                if best is None or st["loop_s"] < best["loop_s"]:
+                    best = st
+            h = hashlib.sha256()
+            with open(os.path.join(od, "epa_result.jplace"), "rb") as f:
+                for line in f:
+                    if b'"invocation"' not in line:   # the command line differs by the query file's name
+                        h.update(line)
+            digests[kind] = h.hexdigest()[:16]
+            out[kind] = {"reads_per_s": round(n / best["loop_s"], 1), "reads_per_s_incl_setup": round(n / best["elapsed_s"], 1),
+                         "jplace_bytes": os.path.getsize(os.path.join(od, "epa_result.jplace")),
+                         "query_file_bytes": os.path.getsize(os.path.join(d, "q." + kind)),
+                         "stages_s": {k: round(v, 4) for k, v in best.items() if k.endswith("_s")}}
+        out["jplace_identical"] = digests["fasta"] == digests["bfast"]
+        out["jplace_sha16"] = digests
+        out["note"] = ("epa-ng-amd end to end on %d reads, defaults (chunk 50000), best of two runs; loop_s = first read -> "
+                       "closed jplace; stages are busy seconds of overlapping host stages on host_cores threads" % n)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def sclk_fields(clks, exec_tflops):
     """the shader clock the timed Newton launches really ran at (in-kernel s_memtime over s_memrealtime of a
     wave that lives as long as the launch: epa_dev_last_sclk_mhz) and the kernel's fp64 rate against the
@@ -295,12 +350,17 @@ def main():
         the per-rank times (before the MAX) are kept in rank_elapsed[tag]"""
         n_warm = a.warmup if n_warm is None else n_warm
         n_timed = a.steps if n_timed is None else n_timed
+        region = getattr(loop_body, "region", None)      # deep pipelines: chunks are begun ahead inside [lo, hi) only
+        if region is not None:
+            region[:] = [0, n_warm]
         for i in range(n_warm):
             loop_body(i, False)
         finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        if region is not None:
+            region[:] = [n_warm, n_warm + n_timed]
         t0 = time.perf_counter()
         for i in range(n_warm, n_warm + n_timed):
             loop_body(i, record)
@@ -537,19 +597,107 @@ def main():
 
         return st, step, finish
 
-    st_res, step_resident, fin_resident = make_loop(True, exch)
-    elapsed = timed(step_resident, fin_resident, "resident")
+    # The schedule `value` is measured on (and the CLI's chunk loop runs, host/place.cpp): a DEEP pipeline -- S = A + 2
+    # slots, A chunks begun ahead.  Per step k:  launch_end(k); finish(k - 2); stage(k + A); launch_begin(k + A)  -- chunk
+    # k's Newton kernel is queued while chunk k - 1's still runs and fills its tail wave by wave, the preplacement +
+    # selection chains of chunks k + 1 .. k + A are already queued on their own streams.  Bit-identical rows
+    # (tests/test_gpu_pipeline.py: the five-slot order equals place_chunk).  Per-launch kernel durations overlap in
+    # this order, so the roofline's ms_per_launch / kernel_ms_per_step come from a SERIALISED pass of the two-slot
+    # order above over the same chunks (outside `value`'s clock; the line says so).
+    S_DEEP = int(os.environ.get("EPA_BENCH_SLOTS", "5"))
+    A_DEEP = int(os.environ.get("EPA_BENCH_AHEAD", str(max(1, S_DEEP - 2))))
+    LAG = S_DEEP - A_DEEP                       # finish(k - LAG) right after launch_end(k)
+    assert 1 <= A_DEEP and LAG >= 1
+    bufs_deep = [bufs[0], bufs[1]] + [(torch.empty_like(d_pairs), torch.empty_like(d_res)) for _ in range(S_DEEP - 2)]
+
+    def make_loop_deep(resident, gather):
+        st = {"bytes_up": 0, "bytes_down": 0, "n_of_slot": {}, "begun": set(), "ended": [],
+              "t_stage": 0.0, "t_launch": 0.0, "t_end": 0.0, "t_finish": 0.0}
+        region = [0, 0]
+
+        def begin(j, timed_):
+            slot = j % S_DEEP
+            t = time.perf_counter()
+            if resident:
+                dc, dwb, dws = dev_chunks[j % n_chunks]
+                ev.chunk_stage(slot, dc, dwb, dws)
+            else:
+                _, hb, hs, wire = host_chunks[j % n_chunks]
+                ev.chunk_stage(slot, wire, hb, hs)
+                st["bytes_up"] += (wire.data if isinstance(wire, epa.Packed4) else wire).nbytes + 8 * Q
+            t1 = time.perf_counter()
+            kw = dict(pairs_out=bufs_deep[slot][0], results_out=bufs_deep[slot][1], keep_on_device=True) if (resident or world > 1) else {}
+            kw["host_ordered"] = world == 1
+            ev.chunk_launch_begin(slot, threshold=0.99999, max_span=a.read_len, max_pairs=cap, **kw)
+            if timed_:
+                st["t_stage"] += t1 - t
+                st["t_launch"] += time.perf_counter() - t1
+            st["begun"].add(j)
+
+        def retire(j, timed_):
+            slot = j % S_DEEP
+            t = time.perf_counter()
+            if resident or world > 1:
+                n = ev.chunk_finish_device(slot)
+                if world > 1:
+                    gather.post(bufs_deep[slot][0], bufs_deep[slot][1], n)
+            else:
+                p, r = ev.chunk_finish(slot, copy=False)
+                n = len(p)
+            if timed_:
+                st["t_finish"] += time.perf_counter() - t
+            st["n_of_slot"][slot] = n
+            st["bytes_down"] += n * 32
+
+        def step(i, record):
+            if not Q:
+                if world > 1:
+                    gather.post(d_pairs, d_res, 0)
+                return
+            timed_ = i >= a.warmup and region[0] > 0
+            for j in range(i, min(i + A_DEEP, region[1])):       # steady state: only i + A - 1 is new here ...
+                if j not in st["begun"]:
+                    begin(j, timed_)
+            t = time.perf_counter()
+            ev.chunk_launch_end(i % S_DEEP)
+            if timed_:
+                st["t_end"] += time.perf_counter() - t
+            st["begun"].discard(i)
+            st["ended"].append(i)
+            while len(st["ended"]) > LAG:                         # chunk i - LAG: its Newton kernel is long done
+                retire(st["ended"].pop(0), timed_)
+            j = i + A_DEEP                                        # ... and the chunk A ahead goes in behind launch_end(i)
+            if j < region[1] and j not in st["begun"]:
+                begin(j, timed_)
+
+        step.region = region
+
+        def finish():
+            while st["ended"]:
+                retire(st["ended"].pop(0), False)
+            if world > 1:
+                gather.finish()
+
+        return st, step, finish
+
+    st_res, step_resident, fin_resident = make_loop_deep(True, exch)
+    elapsed = timed(step_resident, fin_resident, "resident", record=False)
     # what the LAST TIMED step left in HBM (outside the clock): the rows the `parity` block checks
     last_i = a.warmup + a.steps - 1
     last_out = None
     if rank == 0 and world == 1 and Q:
-        n_last = st_res["n_of_slot"].get(last_i & 1, 0)
-        last_out = (last_i % n_chunks, bufs[last_i & 1][0][:n_last].cpu().numpy().copy(),
-                    bufs[last_i & 1][1][:n_last].cpu().numpy().copy())
+        n_last = st_res["n_of_slot"].get(last_i % S_DEEP, 0)
+        last_out = (last_i % n_chunks, bufs_deep[last_i % S_DEEP][0][:n_last].cpu().numpy().copy(),
+                    bufs_deep[last_i % S_DEEP][1][:n_last].cpu().numpy().copy())
+    # the serialised pass: the two-slot order, Newton launches never overlap -> per-launch kernel times for the roofline
+    elapsed_serial = None
+    if world == 1:
+        _, step_serial, fin_serial = make_loop(True, None)
+        elapsed_serial = timed(step_serial, fin_serial, "serial", n_warm=1)
 
     # ---------------- loop 2: PCIe inside the step, overlapped on the copy streams
     exch2 = make_gather(True)
-    state, step_pcie, finish_pcie = make_loop(False, exch2)
+    state, step_pcie, finish_pcie = make_loop_deep(False, exch2)
     elapsed_pcie = timed(step_pcie, finish_pcie, "pcie")
 
     # ---------------- the fixed-size job of BASELINE configs[3] (cfg4: 10^7 reads) on these N GPUs:
@@ -861,6 +1009,15 @@ def main():
         except Exception as e:  # noqa: BLE001
             extras["cfg5_noheur"] = {"status": "failed: %r" % (e,)}
 
+    if world == 1 and states == 4 and not a.no_extras and not os.environ.get("EPA_BENCH_NO_CLI"):
+        try:
+            nrd = int(os.environ.get("EPA_BENCH_CLI_READS", "1000000"))
+            use = [(c, b, s_) for c, b, s_, _ in host_chunks[:max(1, -(-nrd // max(Q, 1)))]]
+            model = "GTR{%s}+FU{%s}+G4{%r}" % ("/".join(map(repr, subst)), "/".join(map(repr, freqs)), alpha)
+            extras["cli_e2e"] = cli_e2e_leg(newick, labels, seqs, use, W, model)
+        except Exception as e:  # noqa: BLE001  (a secondary measurement must never take the bench line down)
+            extras["cli_e2e"] = {"status": "failed: %r" % (e,)}
+
     metric = ("query placements/sec (whole node), 512-tip GTR+G4 DNA ref, preplace+thorough" if states == 4
               else "query placements/sec (whole node), AA PROTGTR+G4 ref (cfg3 shape), preplace+thorough")
     pcie = {"value": round(total_reads / elapsed_pcie, 2), "unit": "placements/s",
@@ -878,6 +1035,12 @@ def main():
     out = {"metric": metric,
            "value": round(value, 2), "unit": "placements/s", "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+           "schedule": {"order": "launch_end(k); finish(k-%d); stage(k+%d); launch_begin(k+%d)" % (LAG, A_DEEP, A_DEEP),
+                        "slots": S_DEEP, "chunks_begun_ahead": A_DEEP,
+                        "ms_per_step_serialised_two_slot_order": (round(elapsed_serial / a.steps * 1e3, 3) if elapsed_serial else None),
+                        "note": "value / ms_per_step: the deep pipeline (chunk k's Newton kernel queued into chunk k-1's tail; the "
+                                "order the CLI's chunk loop runs); roofline.ms_per_launch, kernel_ms_per_step, sclk: a serialised "
+                                "pass of the two-slot order over the same chunks, where launches do not overlap"},
            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f64",
            "data": "synthetic",
            "config": {"workload": ("cfg2: %d-tip DNA GTR+G4 ref, W=%d, %d bp reads, dyn-heur 0.99999, "

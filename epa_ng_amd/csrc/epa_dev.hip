@@ -427,11 +427,17 @@ static int encode_impl(uint32_t states, uint32_t sites, uint32_t Q, const char* 
       const char* sq = seqs[q];
       uint32_t lo = 0, hi = sites;
       if (premasking) {  // get_valid_range, src/util/Range.hpp:34-49: only the literal '-'
+        // a short read of a wide alignment is ~90 % leading / trailing gaps: eight characters per compare
+        // (1 M reads x 1500 columns are 1.5 GB of '-' that the byte loop walked twice per chunk)
+        constexpr uint64_t GAPS = 0x2d2d2d2d2d2d2d2dull;
+        while (lo + 8 <= hi) { uint64_t w8; memcpy(&w8, sq + lo, 8); if (w8 != GAPS) break; lo += 8; }
         while (lo < hi && sq[lo] == '-') ++lo;
+        while (hi >= lo + 8) { uint64_t w8; memcpy(&w8, sq + hi - 8, 8); if (w8 != GAPS) break; hi -= 8; }
         while (hi > lo && sq[hi - 1] == '-') --hi;
       }
-      // every character of the row is validated, as the reference does (Lookup_Store.hpp:100-108)
-      for (uint32_t w = 0; w < sites; ++w)
+      // every character of the row is validated, as the reference does (Lookup_Store.hpp:100-108); outside the
+      // window all of them are '-' (just compared), which is valid
+      for (uint32_t w = lo; w < hi; ++w)
         if (map[(unsigned char)sq[w]] < 0) { bad[t] = q; code[t] = EPA_ERR_INVALID_CHAR; return; }
       if (hi == lo) { bad[t] = q; code[t] = EPA_ERR_QUERY_ALL_GAP; return; }
       win_begin[q] = lo;
@@ -536,15 +542,33 @@ extern "C" int epa_dev_set_query_packing(epa_ctx* ctx, int bits) {
 extern "C" int epa_pack_codes_4bit(const uint8_t* codes, uint32_t Q, uint32_t stride, uint8_t* packed) {
   if (!codes || !packed) return EPA_ERR_INVALID_ARG;
   const size_t ps = ((size_t)stride + 1) / 2;
-  for (uint32_t q = 0; q < Q; ++q) {
-    const uint8_t* r = codes + (size_t)q * stride;
-    uint8_t* o = packed + (size_t)q * ps;
-    for (uint32_t p = 0; p < ps; ++p) {
-      const uint8_t hi = r[2 * p], lo = (2 * p + 1 < stride) ? r[2 * p + 1] : 0;
-      if (hi > 15 || lo > 15) return EPA_ERR_INVALID_ARG;
-      o[p] = (uint8_t)((hi << 4) | lo);
+  // rows are independent: the encoder's host threads (an 80 MB pass per million 150 bp reads)
+  const unsigned cap = g_encode_threads.load(std::memory_order_relaxed);
+  const unsigned hw = cap ? cap : std::max(1u, std::thread::hardware_concurrency());
+  const unsigned nt = (unsigned)std::min<uint64_t>(std::min(hw, 32u), std::max<uint64_t>(1, (uint64_t)Q * stride >> 20));
+  std::vector<int> bad(nt, 0);
+  auto work = [&](unsigned t) {
+    const uint32_t q0 = (uint32_t)((uint64_t)Q * t / nt), q1 = (uint32_t)((uint64_t)Q * (t + 1) / nt);
+    unsigned over = 0;
+    for (uint32_t q = q0; q < q1; ++q) {
+      const uint8_t* r = codes + (size_t)q * stride;
+      uint8_t* o = packed + (size_t)q * ps;
+      for (uint32_t p = 0; p < stride / 2; ++p) {
+        const uint8_t hi = r[2 * p], lo = r[2 * p + 1];
+        over |= hi | lo;
+        o[p] = (uint8_t)((hi << 4) | lo);
+      }
+      if (stride & 1) { const uint8_t hi = r[stride - 1]; over |= hi; o[ps - 1] = (uint8_t)(hi << 4); }
     }
+    bad[t] = over > 15;
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
   }
+  for (unsigned t = 0; t < nt; ++t) if (bad[t]) return EPA_ERR_INVALID_ARG;
   return EPA_OK;
 }
 
@@ -1918,6 +1942,7 @@ extern "C" int epa_dev_chunk_launch_end(epa_ctx* ctx, int slot) {
       if (i) mm.state = member_state;
     }
     s->g_n = 0;
+    s->g_left = 0;   // (a failure after the members were marked must not leave the leader refusing chunk_stage for ever)
   };
   auto abandon = [&](int code) {
     (void)hipStreamSynchronize(s->stream);
@@ -1952,9 +1977,10 @@ extern "C" int epa_dev_chunk_launch_end(epa_ctx* ctx, int slot) {
     d_results = s->d_gres;
   }
   if (hipEventRecord(s->ev_done, ctx->stream) != hipSuccess) return abandon(epa_fail(ctx, EPA_ERR_HIP, "hipEventRecord(chunk done)"));
-  EPA_HIP(ctx, hipStreamWaitEvent(ctx->down_stream, s->ev_done, 0));
+  if (hipStreamWaitEvent(ctx->down_stream, s->ev_done, 0) != hipSuccess) return abandon(epa_fail(ctx, EPA_ERR_HIP, "hipStreamWaitEvent(chunk done)"));
   if (gn > 1) {
-    EPA_HIP(ctx, hipMemcpyAsync(s->h_goff, s->d_goff, sizeof(uint32_t) * (EPA_MAX_GROUP + 1), hipMemcpyDeviceToHost, ctx->down_stream));
+    if (hipMemcpyAsync(s->h_goff, s->d_goff, sizeof(uint32_t) * (EPA_MAX_GROUP + 1), hipMemcpyDeviceToHost, ctx->down_stream) != hipSuccess)
+      return abandon(epa_fail(ctx, EPA_ERR_HIP, "hipMemcpyAsync(group offsets)"));
     group_restore_leader(s);
     s->g_left = gn;
     for (int i = 1; i < gn; ++i) {
@@ -1967,21 +1993,21 @@ extern "C" int epa_dev_chunk_launch_end(epa_ctx* ctx, int slot) {
     s->out_pairs = d_pairs;
     s->out_res = d_results;
     // device-resident results are consumed on the caller's stream
-    if (!(s->l_flags & EPA_CHUNK_HOST_ORDERED)) EPA_HIP(ctx, hipStreamWaitEvent(base, s->ev_done, 0));
+    if (!(s->l_flags & EPA_CHUNK_HOST_ORDERED)) if (hipStreamWaitEvent(base, s->ev_done, 0) != hipSuccess) return abandon(epa_fail(ctx, EPA_ERR_HIP, "hipStreamWaitEvent (chunk_launch_end)"));
   } else {
     const size_t off_r = (sizeof(epa_pair) * n + 255) & ~(size_t)255;
     rc = grow_pinned(ctx, &s->h_out, &s->h_out_sz, off_r + sizeof(epa_result) * n);
     if (rc) return abandon(rc);
     if (n) {
-      EPA_HIP(ctx, hipMemcpyAsync(s->h_out, d_pairs, sizeof(epa_pair) * n, hipMemcpyDeviceToHost, ctx->down_stream));
-      EPA_HIP(ctx, hipMemcpyAsync((char*)s->h_out + off_r, d_results, sizeof(epa_result) * n, hipMemcpyDeviceToHost,
-                                  ctx->down_stream));
+      if (hipMemcpyAsync(s->h_out, d_pairs, sizeof(epa_pair) * n, hipMemcpyDeviceToHost, ctx->down_stream) != hipSuccess) return abandon(epa_fail(ctx, EPA_ERR_HIP, "hipMemcpyAsync (chunk_launch_end)"));
+      if (hipMemcpyAsync((char*)s->h_out + off_r, d_results, sizeof(epa_result) * n, hipMemcpyDeviceToHost,
+                                  ctx->down_stream) != hipSuccess) return abandon(epa_fail(ctx, EPA_ERR_HIP, "hipMemcpyAsync (chunk_launch_end)"));
     }
     s->out_pairs = (const epa_pair*)s->h_out;
     s->out_res = (const epa_result*)((char*)s->h_out + off_r);
   }
-  EPA_HIP(ctx, hipMemcpyAsync(s->h_stats, s->d_stats, 128, hipMemcpyDeviceToHost, ctx->down_stream));
-  EPA_HIP(ctx, hipEventRecord(s->ev_down, ctx->down_stream));
+  if (hipMemcpyAsync(s->h_stats, s->d_stats, 128, hipMemcpyDeviceToHost, ctx->down_stream) != hipSuccess) return abandon(epa_fail(ctx, EPA_ERR_HIP, "hipMemcpyAsync (chunk_launch_end)"));
+  if (hipEventRecord(s->ev_down, ctx->down_stream) != hipSuccess) return abandon(epa_fail(ctx, EPA_ERR_HIP, "hipEventRecord (chunk_launch_end)"));
   s->state = 2;
   return EPA_OK;
 }
@@ -2279,6 +2305,7 @@ extern "C" int epa_dev_place_all_rows(epa_ctx* ctx, const uint8_t* q_codes, cons
   unsigned long long* d_n = (unsigned long long*)(out + off_n);
   hipLaunchKernelGGL(k_all_rows, dim3(1), dim3(1024), 0, ctx->stream, (const epa_pair*)out, (const epa_result*)(out + off_r),
                      (const double*)(out + off_l), (const uint32_t*)(out + off_c), Q, filter_max, seq_offset, rows, d_n);
+  EPA_HIP(ctx, hipGetLastError());
   unsigned long long h_n = 0;
   EPA_HIP(ctx, hipMemcpyAsync(&h_n, d_n, sizeof(h_n), hipMemcpyDeviceToHost, ctx->stream));
   EPA_HIP(ctx, hipStreamSynchronize(ctx->stream));

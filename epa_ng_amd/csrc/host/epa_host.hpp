@@ -326,8 +326,14 @@ public:
   // zero-copy variant (mapped files, one sequence line of `sites` characters per record): headers in
   // `out`, pointers into the mapping in `rows`; 0 = not applicable for the next chunk, use read_next()
   size_t read_next_views(MSA& out, std::vector<const char*>& rows, size_t sites, size_t max_seqs);
+  // binary fasta only: the next records go STRAIGHT to the compact 4-bit wire rows the device reads (Encoded_Chunk) --
+  // the file's nibbles are the device's codes (src/io/encoding.hpp:11-134), so there is no ASCII stage at all: window =
+  // first / last non-zero nibble (get_valid_range, src/util/Range.hpp:34-49), row = the window's nibbles re-aligned.
+  // Headers in `out` (empty sequences).  0 = not a mapped bfast file, or its end.
+  size_t read_next_wire(MSA& out, struct Encoded_Chunk& enc, size_t sites, size_t max_seqs, bool premasking);
+  bool is_bfast() const { return bfast_; }
 private:
-  size_t index_records(size_t max_seqs, bool& done);
+  size_t index_records(size_t max_seqs, bool& done, bool predict = false);
   void consume(size_t m);
   bool refill();
   bool open_bfast();                                  // binary fasta (src/io/Binary_Fasta.hpp)?
@@ -342,6 +348,12 @@ private:
   size_t pos_ = 0, len_ = 0, scan_ = 0;  // unparsed region [pos_, len_), record index built up to scan_
   std::vector<size_t> starts_;            // offsets of the '>' of the records found so far
   bool eof_ = false, first_block_ = true;
+  // read_next_views: records of one header line + one sequence line all have the same distance from the end of the
+  // header line to the next record; once learned, the next '>' is LOOKED UP there instead of searched for (the index
+  // was a serial memchr over the whole file: 1.5 GB per million reads of a 1500-column alignment).  Every record found
+  // that way is validated by read_next_views (length, no line break inside); a miss falls back to the search for good.
+  size_t seq_part_ = 0;
+  bool predict_ok_ = true;
   char up_[256];
 };
 void write_jplace(std::ostream& os, const std::vector<Sample>& chunks, const std::string& newick,
@@ -424,6 +436,10 @@ struct Run_Stats {
   double ref_tree_logl = 0;  // of the reference tree, evaluated on the device at branch 0
   double seconds_place = 0, seconds_thorough = 0;  // device calls (fused path: all in seconds_place)
   double seconds_setup = 0, seconds_read = 0, seconds_stage_wait = 0, seconds_post = 0, seconds_write = 0;
+  // finer stages of the chunk loop (busy time of the stage, summed over chunks; the stages run on different threads
+  // and overlap, so they do not add up to seconds_loop = wall time from the first read to the closed jplace)
+  double seconds_encode = 0, seconds_sample = 0, seconds_text = 0, seconds_loop = 0;
+  int host_threads = 0;
 };
 Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const std::string& outdir,
                      const Options& options, const std::string& invocation, int device = 0);

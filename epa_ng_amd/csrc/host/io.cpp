@@ -73,7 +73,86 @@ bool Fasta_Stream::open_bfast() {
   bfast_ = true;
   bfast_offsets_ = std::move(offs);
   bfast_next_ = 0;
+  struct stat sb;   // mapped as well: read_next_wire() takes the records' nibbles straight from the page cache
+  if (::fstat(::fileno(f_), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+    void* m = ::mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, ::fileno(f_), 0);
+    if (m != MAP_FAILED) {
+      map_ = static_cast<const char*>(m);
+      map_len_ = (size_t)sb.st_size;
+    }
+  }
   return true;
+}
+
+size_t Fasta_Stream::read_next_wire(MSA& out, Encoded_Chunk& enc, size_t sites, size_t max_seqs, bool premasking) {
+  configure_host_threads();
+  if (!bfast_ || !map_ || max_seqs == 0 || sites == 0) return 0;
+  const size_t m = std::min(max_seqs, bfast_offsets_.size() - bfast_next_);
+  if (m == 0) return 0;
+  const size_t first = out.size();
+  out.resize(first + m);
+  enc.win_begin.assign(m, 0);
+  enc.win_span.assign(m, 0);
+  std::vector<const unsigned char*> rows(m, nullptr);
+  const size_t nbytes = (sites + 1) / 2;
+  auto u64_at = [&](size_t off) { uint64_t v; std::memcpy(&v, map_ + off, 8); return v; };   // little-endian hosts (x86-64)
+  std::vector<uint8_t> stat(m, 0);   // 1 truncated record, 2 another width than the reference, 3 all gap
+  uint32_t mx = 1;
+#pragma omp parallel for schedule(static) reduction(max : mx)
+  for (long i = 0; i < (long)m; ++i) {
+    const size_t off = bfast_offsets_[bfast_next_ + (size_t)i];
+    if (off + 16 > map_len_) { stat[i] = 1; continue; }
+    const uint64_t hlen = u64_at(off);
+    if (hlen > (1u << 20) || off + 16 + hlen > map_len_) { stat[i] = 1; continue; }
+    out[first + i] = Sequence(std::string(map_ + off + 8, (size_t)hlen), std::string());
+    if (u64_at(off + 8 + hlen) != sites) { stat[i] = 2; continue; }
+    if (off + 16 + hlen + nbytes > map_len_) { stat[i] = 1; continue; }
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(map_ + off + 16 + hlen);
+    rows[i] = p;
+    size_t lo = 0, hi = sites;
+    if (premasking) {   // nibble 0 = '-' (NT_MAP[0]); the padding nibble of an odd row is 0 as well
+      size_t k = 0;
+      while (k + 8 <= nbytes) { uint64_t w; std::memcpy(&w, p + k, 8); if (w) break; k += 8; }
+      while (k < nbytes && p[k] == 0) ++k;
+      lo = std::min(sites, 2 * k + ((k < nbytes && (p[k] >> 4) == 0) ? 1 : 0));
+      size_t e = nbytes;
+      while (e >= k + 8 && e >= 8) { uint64_t w; std::memcpy(&w, p + e - 8, 8); if (w) break; e -= 8; }
+      while (e > k && p[e - 1] == 0) --e;
+      hi = e == 0 ? 0 : std::min(sites, 2 * e - ((p[e - 1] & 15) == 0 ? 1 : 0));
+      if (hi <= lo) { stat[i] = 3; continue; }
+    }
+    enc.win_begin[i] = (uint32_t)lo;
+    enc.win_span[i] = (uint32_t)(hi - lo);
+    mx = std::max(mx, (uint32_t)(hi - lo));
+  }
+  for (size_t i = 0; i < m; ++i) {   // the first offender in file order, with the reference's messages
+    if (stat[i] == 1) throw std::runtime_error{"bfast: truncated sequence"};
+    if (stat[i] == 2) throw std::runtime_error{"Query sequence length not same as reference alignment!"};   // Tiny_Tree.cpp:145-147
+    if (stat[i] == 3)   // Tiny_Tree.cpp:153-156
+      throw std::runtime_error{"Sequence with header '" + out[first + i].header() + "' does not appear to have any non-gap sites!"};
+  }
+  enc.stride = (mx + 15) / 16 * 16;
+  enc.bits = 4;
+  const size_t ps = (enc.stride + 1) / 2;
+  enc.codes.assign(m * ps, 0);
+#pragma omp parallel for schedule(static)
+  for (long i = 0; i < (long)m; ++i) {
+    const unsigned char* p = rows[i];
+    uint8_t* o = enc.codes.data() + (size_t)i * ps;
+    const size_t lo = enc.win_begin[i], n = enc.win_span[i], nb = (n + 1) / 2;
+    if (!(lo & 1)) {
+      std::memcpy(o, p + lo / 2, nb);
+    } else {   // the window starts in a low nibble: shift the nibble stream by one
+      const size_t k0 = lo / 2;
+      for (size_t b = 0; b < nb; ++b) {
+        const unsigned nxt = (k0 + b + 1 < nbytes) ? p[k0 + b + 1] : 0u;
+        o[b] = (uint8_t)(((p[k0 + b] & 15u) << 4) | (nxt >> 4));
+      }
+    }
+    if (n & 1) o[nb - 1] &= 0xf0;   // past the window: '-'
+  }
+  bfast_next_ += m;
+  return m;
 }
 
 size_t Fasta_Stream::read_next_bfast(MSA& out, size_t max_seqs) {
@@ -146,14 +225,31 @@ bool Fasta_Stream::refill() {
 // Extends the index of record starts as far as a chunk of max_seqs needs and returns how many
 // complete records are available (a record is complete once the next one has started, or the file
 // has ended); `done` = nothing is left behind them.
-size_t Fasta_Stream::index_records(size_t max_seqs, bool& done) {
+size_t Fasta_Stream::index_records(size_t max_seqs, bool& done, bool predict) {
   for (;;) {
     const char* base = map_ ? map_ : buf_.data();
     while (scan_ < len_ && starts_.size() <= max_seqs) {
+      if (predict && predict_ok_ && map_ && seq_part_ && !starts_.empty() && starts_.back() + 1 == scan_) {
+        // the record that starts at starts_.back(): end of its header line + the learned length of the rest
+        const size_t b = starts_.back();
+        const char* nl = (const char*)std::memchr(base + b, '\n', std::min<size_t>(len_ - b, 4096));
+        if (nl) {
+          const size_t cand = (size_t)(nl - base) + seq_part_;
+          if (cand < len_ && base[cand] == '>' && base[cand - 1] == '\n') { starts_.push_back(cand); scan_ = cand + 1; continue; }
+          if (cand == len_) { scan_ = len_; break; }   // the last record ends with the file
+        }
+      }
       const char* p = (const char*)std::memchr(base + scan_, '>', len_ - scan_);
       if (!p) { scan_ = len_; break; }
       const size_t o = (size_t)(p - base);
-      if (o == 0 ? first_block_ : base[o - 1] == '\n') starts_.push_back(o);
+      if (o == 0 ? first_block_ : base[o - 1] == '\n') {
+        if (map_ && !starts_.empty()) {   // learn: header end of the previous record -> this record
+          const size_t b = starts_.back();
+          const char* nl = (const char*)std::memchr(base + b, '\n', o - b);
+          if (nl) seq_part_ = o - (size_t)(nl - base);
+        }
+        starts_.push_back(o);
+      }
       scan_ = o + 1;
     }
     done = eof_ && scan_ >= len_;
@@ -218,7 +314,7 @@ size_t Fasta_Stream::read_next_views(MSA& out, std::vector<const char*>& rows, s
   configure_host_threads();
   if (!map_ || bfast_ || max_seqs == 0 || sites == 0) return 0;
   bool done = false;
-  const size_t m = index_records(max_seqs, done);
+  const size_t m = index_records(max_seqs, done, true);
   if (m == 0) return 0;
   const size_t first = out.size();
   out.resize(first + m);
@@ -246,6 +342,12 @@ size_t Fasta_Stream::read_next_views(MSA& out, std::vector<const char*>& rows, s
   if (!ok) {
     out.resize(first);
     rows.clear();
+    if (predict_ok_ && starts_.size() > 1) {
+      // the looked-up record starts cannot be trusted for this file: search from the first record on, from now on
+      predict_ok_ = false;
+      scan_ = starts_[0] + 1;
+      starts_.resize(1);
+    }
     return 0;
   }
   consume(m);

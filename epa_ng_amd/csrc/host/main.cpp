@@ -40,6 +40,7 @@ static void usage() {
       "  --rank R --world N --comm-file F   one process per GPU: rank R places its contiguous slice of the\n"
       "                        queries, results are gathered to rank 0 over RCCL; rank 0 leaves the RCCL id in F\n"
       "                        (defaults: RANK / WORLD_SIZE / LOCAL_RANK / EPA_COMM_FILE of the environment)\n"
+      "  --stats-json FILE     the time breakdown of the run as JSON\n"
       "  --comm-nonce STR      marks this run's id record in F (default: EPA_COMM_NONCE / TORCHELASTIC_RUN_ID); give\n"
       "                        one whenever the launcher can: without it a record is only checked for its age\n"
       "  --comm-probe-seconds S  bound of the handshake every rank runs before placing (default 120)\n"
@@ -53,7 +54,7 @@ int main(int argc, char** argv) {
   const auto start = std::chrono::steady_clock::now();
   std::string invocation;
   for (int i = 0; i < argc; ++i) { invocation += argv[i]; invocation += " "; }
-  std::string tree_file, ref_file, query_file, outdir = "./", model_desc = "GTR+G";
+  std::string tree_file, ref_file, query_file, outdir = "./", model_desc = "GTR+G", stats_json;
   Options opt;
   int device = 0;
   bool device_given = false;
@@ -126,6 +127,7 @@ int main(int argc, char** argv) {
     else if (a == "--comm-self-send") opt.comm_self_send = true;       // test hook
     else if (a == "--host-heuristic") opt.host_heuristic = true;       // diagnostics
     else if (a == "--no-pipeline") opt.no_pipeline = true;
+    else if (a == "--stats-json") stats_json = need(i);
     else if (a == "--redo" || a == "--verbose") {}
     else if (a == "-h" || a == "--help") { usage(); return 0; }
     else { std::cerr << "option " << a << " is outside the placement hot path of this build\n"; return 1; }
@@ -158,6 +160,7 @@ int main(int argc, char** argv) {
     const Model model(model_desc);
     std::cout << "Using model parameters: " << model.to_string() << std::endl;
     const auto t_tree = std::chrono::steady_clock::now();
+    const double secs_parse = std::chrono::duration<double>(t_tree - start).count();   // reference MSA, query-file peek, masks, model
     const Tree tree(ss.str(), ref, model, opt);
     if (tree.rooted_input())
       std::cout << "Rooted reference tree: placements are reported on the "
@@ -181,6 +184,16 @@ int main(int argc, char** argv) {
               << ", device " << st.seconds_place + st.seconds_thorough << ", lwr+filter " << st.seconds_post
               << ", write jplace " << st.seconds_write << "\n"
               << "Elapsed Time: " << secs << "s" << std::endl;
+    if (!stats_json.empty()) {   // the same numbers, machine-readable (bench.py's cli_e2e leg)
+      std::ofstream sj(stats_json);
+      sj << "{\"queries\": " << st.queries << ", \"pairs\": " << st.pairs << ", \"host_threads\": " << st.host_threads
+         << ", \"elapsed_s\": " << secs << ", \"tree_msa_s\": " << secs_tree << ", \"parse_inputs_s\": " << secs_parse
+         << ", \"device_setup_s\": " << st.seconds_setup
+         << ", \"loop_s\": " << st.seconds_loop << ", \"read_index_s\": " << st.seconds_read << ", \"encode_s\": " << st.seconds_encode
+         << ", \"stage_wait_s\": " << st.seconds_stage_wait << ", \"device_calls_s\": " << st.seconds_place + st.seconds_thorough
+         << ", \"build_sample_s\": " << st.seconds_sample << ", \"lwr_filter_s\": " << st.seconds_post
+         << ", \"jplace_text_s\": " << st.seconds_text << ", \"write_s\": " << st.seconds_write << "}\n";
+    }
   } catch (const std::exception& e) {
     std::cerr << e.what() << "\nAborting with a failure." << std::endl;
     return 1;

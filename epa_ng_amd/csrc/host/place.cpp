@@ -340,16 +340,18 @@ void chunk_launch(const Encoded_Chunk& enc, size_t Q, const Tree& tree, Device_E
   dev.pair_capacity() = cap;
 }
 
-size_t chunk_finish(const MSA& chunk, Device_Evaluator& dev, int slot, Sample& sample, size_t seq_id_offset) {
+size_t chunk_finish(const MSA& chunk, Device_Evaluator& dev, int slot, Sample& sample, size_t seq_id_offset, double* secs_sample) {
   const epa_pair* pairs = nullptr;
   const epa_result* res = nullptr;
   uint64_t n = 0;
   const int rc = epa_dev_chunk_finish(dev.ctx(), slot, &pairs, &res, &n, nullptr);
   if (rc == EPA_ERR_NEG_INF) throw std::runtime_error{epa_dev_last_error(dev.ctx())};  // Tiny_Tree.cpp:209-212
   if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
+  const auto t0 = std::chrono::steady_clock::now();
   Work work(n);
   for (size_t i = 0; i < n; ++i) work[i] = Work_Pair{pairs[i].branch_id, pairs[i].seq_id};
   build_sample(work, res, chunk, sample, seq_id_offset);
+  if (secs_sample) *secs_sample = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return n;
 }
 
@@ -507,12 +509,13 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
   const bool premask = options.premasking && msa_info.gap_count() > 0;
   if (devices.empty()) throw std::runtime_error{"no device given"};
   Run_Stats st;
-  configure_host_threads();
+  st.host_threads = configure_host_threads();
   auto ts = clk::now();
   std::vector<std::unique_ptr<Device_Evaluator>> devs;
   for (int d : devices) devs.emplace_back(new Device_Evaluator(tree, options, d));
   st.ref_tree_logl = devs[0]->ref_tree_logl(0);
   st.seconds_setup = std::chrono::duration<double>(clk::now() - ts).count();
+  const auto t_loop = clk::now();
 
   struct Staged { size_t index = 0, offset = 0; MSA chunk; Encoded_Chunk enc; };
   std::mutex mu;
@@ -582,17 +585,23 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
         // one-line records of a mapped file are encoded straight from the mapping (no sequence strings)
         std::vector<const char*> rows;
         const size_t per_chunk = device_chunk;
-        if (!premask) reader.read_next_views(s.chunk, rows, tree.num_sites(), per_chunk);
-        if (rows.empty()) reader.read_next(s.chunk, per_chunk);
+        // binary fasta: the file's nibbles ARE the device's codes -- no ASCII stage (nucleotide data, no column mask)
+        const bool wire = !premask && reader.is_bfast() && tree.model().num_states() == 4 &&
+                          reader.read_next_wire(s.chunk, s.enc, tree.num_sites(), per_chunk, options.premasking) > 0;
+        if (!wire && !premask) reader.read_next_views(s.chunk, rows, tree.num_sites(), per_chunk);
+        if (!wire && rows.empty()) reader.read_next(s.chunk, per_chunk);
         const double rd = std::chrono::duration<double>(clk::now() - r0).count();
         if (s.chunk.empty()) break;
         if (premask) s.chunk = subset_msa(s.chunk, msa_info.gap_mask());
         s.index = index++;
         s.offset = offset;
         offset += s.chunk.size();
-        s.enc = rows.empty() ? encode_chunk(s.chunk, tree, options) : encode_rows(rows, s.chunk, tree, options);
+        const auto e0 = clk::now();
+        if (!wire) s.enc = rows.empty() ? encode_chunk(s.chunk, tree, options) : encode_rows(rows, s.chunk, tree, options);
+        const double en = std::chrono::duration<double>(clk::now() - e0).count();
         std::unique_lock<std::mutex> lk(mu);
         st.seconds_read += rd;
+        st.seconds_encode += en;
         cv_put.wait(lk, [&] { return queue.size() < depth || failure; });
         if (failure) break;
         queue.push_back(std::move(s));
@@ -632,7 +641,7 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
           if (results.size() <= done.index) { results.resize(done.index + 1); ready.resize(done.index + 1, 0); }
           results[done.index] = std::move(text);
           ready[done.index] = 1;
-          st.seconds_write += secs_text;
+          st.seconds_text += secs_text;
           st.queries += done.chunk.size();
           st.pairs += tm.pairs;
           st.seconds_place += tm.place;
@@ -669,11 +678,13 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
         if (have_prev) {
           const auto t1 = clk::now();
           Sample smp;
-          tm.pairs = chunk_finish(prev.chunk, *devs[k], slot ^ 1, smp, prev.offset);
+          double secs_sample = 0;
+          tm.pairs = chunk_finish(prev.chunk, *devs[k], slot ^ 1, smp, prev.offset, &secs_sample);
           const auto t2 = clk::now();
           compute_and_set_lwr(smp);
           filter(smp, options);
-          tm.thorough = std::chrono::duration<double>(t2 - t1).count();
+          { std::lock_guard<std::mutex> lk(mu); st.seconds_sample += secs_sample; }
+          tm.thorough = std::chrono::duration<double>(t2 - t1).count() - secs_sample;
           tm.post = std::chrono::duration<double>(clk::now() - t2).count();
           publish(prev, smp, tm);
         } else if (have_cur) {
@@ -728,6 +739,7 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
   os.flush();
   if (!os) throw std::runtime_error{"writing " + out_path + " failed"};
   st.seconds_write += std::chrono::duration<double>(clk::now() - ts).count();
+  st.seconds_loop = std::chrono::duration<double>(clk::now() - t_loop).count();
   return st;
 }
 

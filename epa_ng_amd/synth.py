@@ -221,3 +221,66 @@ def compact_to_ascii(codes, win_begin, win_span, W, states=4):
         b, n = int(win_begin[q]), int(win_span[q])
         out[q, b:b + n] = cols_of[codes[q, :n]]
     return [row.tobytes().decode() for row in out]
+
+
+def _full_code_rows(codes, win_begin, win_span, W):
+    """compact 4-bit-code rows -> [Q][W] code rows (0 = '-'), vectorised"""
+    Q, stride = codes.shape
+    full = np.zeros((Q, W), np.uint8)
+    cols = win_begin.astype(np.int64)[:, None] + np.arange(stride, dtype=np.int64)[None, :]
+    ok = np.arange(stride)[None, :] < win_span.astype(np.int64)[:, None]
+    rows = np.broadcast_to(np.arange(Q, dtype=np.int64)[:, None], cols.shape)
+    full[rows[ok], cols[ok]] = codes[ok]
+    return full
+
+
+def _headers8(first, n):
+    """n fixed-width labels q0000000 .. as an [n][8] byte matrix"""
+    ids = np.arange(first, first + n, dtype=np.int64)
+    h = np.empty((n, 8), np.uint8)
+    h[:, 0] = ord("q")
+    for k in range(7):
+        h[:, 7 - k] = ord("0") + (ids // 10 ** k) % 10
+    return h
+
+
+def write_query_files(fasta_path, bfast_path, chunks, W):
+    """bench.py's cli_e2e leg: the same nucleotide reads as an aligned FASTA file (one header line + one sequence
+    line of W characters per read) and as the reference's binary fasta (src/io/Binary_Fasta.hpp:
+    "BFAST\\0\\0" | u64 n | u64 mask_len + mask chars | n x (u64 id, u64 offset) | per read: u64 header length,
+    header, u64 sites, ceil(sites / 2) bytes of 4-bit codes, earlier site in the high nibble).
+    chunks: iterable of (codes [Q][stride] uint8, win_begin, win_span).  -> number of reads"""
+    import struct
+    chunks = list(chunks)
+    n = sum(len(c[1]) for c in chunks)
+    lut = np.frombuffer(NT_COLS.encode(), dtype=np.uint8)
+    rec = 8 + 8 + 8 + (W + 1) // 2                      # bfast record: fixed size with 8-byte labels
+    data0 = 7 + 8 + 8 + W + 16 * n
+    first = 0
+    with open(fasta_path, "wb") as ff, open(bfast_path, "wb") as fb:
+        fb.write(b"BFAST\0\0" + struct.pack("<QQ", n, W) + b"0" * W)
+        table = np.empty((n, 2), "<u8")
+        table[:, 0] = np.arange(n)
+        table[:, 1] = data0 + rec * np.arange(n, dtype=np.uint64)
+        fb.write(table.tobytes())
+        for codes, wb, ws in chunks:
+            Q = len(wb)
+            full = _full_code_rows(codes, wb, ws, W)
+            hd = _headers8(first, Q)
+            fa = np.empty((Q, 1 + 8 + 1 + W + 1), np.uint8)
+            fa[:, 0] = ord(">")
+            fa[:, 1:9] = hd
+            fa[:, 9] = ord("\n")
+            fa[:, 10:10 + W] = lut[full]
+            fa[:, 10 + W] = ord("\n")
+            ff.write(fa.tobytes())
+            if W & 1:
+                full = np.concatenate([full, np.zeros((Q, 1), np.uint8)], axis=1)
+            bf = np.empty((Q, rec), np.uint8)
+            bf[:, 0:8] = np.frombuffer(struct.pack("<Q", 8), np.uint8)
+            bf[:, 8:16] = hd
+            bf[:, 16:24] = np.frombuffer(struct.pack("<Q", W), np.uint8)
+            bf[:, 24:] = (full[:, 0::2] << 4) | full[:, 1::2]
+            fb.write(bf.tobytes())
+            first += Q
+    return n

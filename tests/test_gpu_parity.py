@@ -321,10 +321,13 @@ def check_sweep_case(seed):
                        ",".join("%s:%d" % kv for kv in sorted(rep["decisions"].items())) or "-",
                        ev.last_stats["rounds"], rounds_orc))
     assert not rep["unreproduced"], (seed, rep["unreproduced"])
-    if os.environ.get("EPA_SWEEP_NO_BOUNDS"):   # hand runs over NEW random seeds: bimodal configurations are logged, not failed
-        return
+    info = {"pairs": len(pairs), "nflat": nflat, "dflat": dflat, "max_flat": max_flat, "max_dlnl": max_dlnl,
+            "evaluator_max_dlnl": float(ev_d.max())}
+    if os.environ.get("EPA_SWEEP_NO_BOUNDS"):   # runs over NEW random seeds: bimodal configurations are counted, not failed
+        return info
     assert nflat <= max_flat, (seed, nflat, max_flat)
     assert dflat <= max_dlnl, (seed, dflat, max_dlnl)
+    return info
 
 
 @pytest.mark.parametrize("seed", range(N_SWEEP))

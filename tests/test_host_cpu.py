@@ -652,3 +652,27 @@ print("PATH=" + epa.comm_library_path())
     assert run("mapped", {"EPA_RCCL_LIB": str(other)}) == str(other)      # the environment override beats the mapped copy
     assert run("explicit", {"EPA_RCCL_LIB": "/nonexistent/lib.so"}) == str(other)
     assert run("env", {"EPA_RCCL_LIB": "/nonexistent/lib.so"}) == ""      # an explicit choice is final: no silent fallback
+
+
+def test_bench_query_file_writers_roundtrip(tmp_path):
+    """synth.write_query_files (bench.py's cli_e2e leg) writes the same reads as aligned FASTA and as the reference's
+    binary fasta; the product's reader returns identical (label, sequence) records from both, equal to the ASCII
+    expansion of the compact rows; odd widths included"""
+    import subprocess
+    from epa_ng_amd import synth
+    exe = _stream_dump_exe(tmp_path)
+    for W in (300, 301):
+        root = synth.random_tree(12, 5)
+        labels, seqs = synth.simulate_msa(root, W, synth.CFG2_SUBST, synth.CFG2_FREQS, synth.gamma_rates(0.5), 6)
+        chunks = [synth.make_reads_compact(seqs, 400, 61, 0.03, 7 + i, 4) for i in range(2)]
+        fa, bf = tmp_path / ("q%d.fasta" % W), tmp_path / ("q%d.bfast" % W)
+        assert synth.write_query_files(str(fa), str(bf), chunks, W) == 800
+        want = []
+        for c in chunks:
+            want += synth.compact_to_ascii(*c, W, 4)
+        outs = []
+        for f in (fa, bf):
+            out = subprocess.run([str(exe), str(f), "150"], check=True, capture_output=True, text=True).stdout
+            outs.append([tuple(l.split("|")) for l in out.strip().split("\n")])
+        assert outs[0] == outs[1] and len(outs[0]) == 800
+        assert [s for _, s in outs[0]] == want and outs[0][0][0] == "q0000000" and outs[0][799][0] == "q0000799"

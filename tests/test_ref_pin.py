@@ -66,6 +66,41 @@ def test_oracle_equals_the_reference_on_its_bundled_data(case, model, raxml_blo)
         assert abs(tp[i] - rp) < 1e-6 * max(1.0, rp) and abs(td[i] - rd) < 1e-6, (b, q)
 
 
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("case,model,raxml_blo", [("dna8_gtr_g_default", "GTR+G", False),
+                                                  ("dna8_gtr_g_default", "GTR+G", True)])
+def test_device_equals_the_reference_on_its_bundled_data(case, model, raxml_blo):
+    """The PRODUCT against the real reference: the same driver output, diffed against what
+    libepa_dev.so returns through the C-ABI for every (branch, query) pair of the reference's bundled data -- tree lnL,
+    preplacement table, thorough lnL / pendant / distal -- so that `make -C oracle ref && pytest tests/test_ref_pin.py`
+    on a box with libpll and a GPU turns "parity: unpinned" into a statement about the device, not only about the
+    checker.  oracle/_ref/ travels to the GPU box with the snapshot (git-ignored, not gpurun-ignored)."""
+    import epa_ng_amd as epa
+    from epa_ng_amd import hostlib
+    from golden_util import read_fasta
+    g, query, tree_lnl, pre, tho = _run(case, model, ("--raxml-blo",) if raxml_blo else ())
+    labels = [a for a, _ in g["msa"]]
+    seqs = [b for _, b in g["msa"]]
+    ref = hostlib.Reference(g["newick"], labels, seqs, states=g["states"], subst=g["subst"], freqs=g["freqs"],
+                            rates=g["gamma_rates"])
+    ev = ref.evaluator(raxml_blo=raxml_blo)
+    reads = [s for _, s in read_fasta(query)]
+    B = ref.B
+    assert abs(ev.tree_logl(0) - tree_lnl) < 1e-6 * max(1.0, abs(tree_lnl))
+    codes, wb, ws = epa.encode_queries(g["states"], reads, premasking=False)
+    lnl = ev.preplace(codes, wb, ws)
+    assert len(pre) == B * len(reads) and max(abs(lnl[q, b] - v) for (b, q), v in pre.items()) < 1e-6
+    pairs = np.zeros(B * len(reads), epa.PAIR_DTYPE)
+    pairs["branch_id"] = np.repeat(np.arange(B), len(reads))
+    pairs["seq_id"] = np.tile(np.arange(len(reads)), B)
+    res = ev.thorough(pairs, codes, wb, ws)
+    for i, (b, q) in enumerate(zip(pairs["branch_id"], pairs["seq_id"])):
+        rl, rp, rd = tho[(int(b), int(q))]
+        assert abs(res["lnl"][i] - rl) < 1e-6, (b, q, res["lnl"][i], rl)
+        assert abs(res["pendant_length"][i] - rp) < 1e-6 * max(1.0, rp) and abs(res["distal_length"][i] - rd) < 1e-6, (b, q)
+
+
 def test_the_recipe_says_why_it_cannot_run_here():
     """`make -C oracle ref` either builds the driver or stops with the message naming the missing library --
     it never fabricates one"""
