@@ -317,6 +317,9 @@ def main():
     ev.set_stream(torch.cuda.current_stream().cuda_stream)
     if os.environ.get("EPA_BENCH_AA_VALU"):        # A/B: the lane = site VALU kernel for the 20-state windows
         ev.set_option("aa_valu", 1)
+    for kv in filter(None, os.environ.get("EPA_BENCH_OPTS", "").split(",")):   # A/B switches: key=value,... (epa_dev_set_option)
+        k_, v_ = kv.split("=")
+        ev.set_option(k_, int(v_))
     ev.build_lookup()
     torch.cuda.synchronize()
     lookup_ms = ev.kernel_ms("lookup")
@@ -597,7 +600,7 @@ def main():
 
         return st, step, finish
 
-    # The schedule `value` is measured on (and the CLI's chunk loop runs, host/place.cpp): a DEEP pipeline -- S = A + 2
+    # The schedule `value` is measured on: a DEEP pipeline -- S = A + 2
     # slots, A chunks begun ahead.  Per step k:  launch_end(k); finish(k - 2); stage(k + A); launch_begin(k + A)  -- chunk
     # k's Newton kernel is queued while chunk k - 1's still runs and fills its tail wave by wave, the preplacement +
     # selection chains of chunks k + 1 .. k + A are already queued on their own streams.  Bit-identical rows

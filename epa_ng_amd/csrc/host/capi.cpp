@@ -269,4 +269,16 @@ int epa_host_heuristic(const double* lnl, uint32_t Q, uint32_t B, int mode, doub
   });
 }
 
+// test hook: the jplace number formatter on an array of values, one text of `width` bytes per value (NUL-padded)
+int epa_host_format_fixed(const double* v, size_t n, unsigned int precision, char* out, size_t width) {
+  for (size_t i = 0; i < n; ++i) {
+    char buf[512];
+    const size_t len = epa::format_fixed(buf, sizeof(buf), v[i], precision);
+    if (len >= width) return -1;
+    std::memset(out + i * width, 0, width);
+    std::memcpy(out + i * width, buf, len);
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -309,6 +309,9 @@ private:
 // a container that sees 256 CPUs but is limited to 16 crawls with 256 spinning threads).
 // Called once by the entry points; returns the thread count in effect.
 int configure_host_threads();
+// OpenMP team size of the CALLING host thread's stages from now on (0 = all usable CPUs): the chunk loop gives its
+// stager a small team and runs its post-processing threads serially, one whole chunk each
+void set_thread_team(int n);
 // user limit on the host threads (-T/--threads, src/main.cpp:256-258); call before the first host stage
 void set_host_thread_limit(int n);
 
@@ -356,6 +359,8 @@ private:
   bool predict_ok_ = true;
   char up_[256];
 };
+// v in fixed notation with `precision` digits, correctly rounded (= printf %.*f); returns the length written to buf
+size_t format_fixed(char* buf, size_t cap, double v, unsigned int precision);
 void write_jplace(std::ostream& os, const std::vector<Sample>& chunks, const std::string& newick,
                   const std::string& invocation, unsigned int precision,
                   const Rtree_Mapper* mapper = nullptr);

@@ -8,10 +8,12 @@
 #include <ostream>
 
 #include <cctype>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
+#include <omp.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -429,69 +431,102 @@ MSA read_fasta(const std::string& path) {
   return out;
 }
 
+// v in fixed notation with `precision` digits, correctly rounded like printf's %.*f (and the reference's
+// std::fixed << std::setprecision).  std::to_chars does that exactly, at ~80 ns per number; the jplace text of a
+// million reads holds six million of them.  Fast path: |v| x 10^p in 80-bit arithmetic (64-bit mantissa) is within
+// x 2^-63 of the true product, so unless its fraction lies that close to one half the rounded integer is KNOWN to be
+// the correctly rounded one and is printed as an integer with a decimal point; anything near a tie, huge, non-finite
+// or with more than 18 digits goes to std::to_chars.  tests/test_host_cpu.py compares both against printf.
+size_t format_fixed(char* buf, size_t cap, double v, unsigned int precision) {
+  static const long double kPow10[19] = {1e0L, 1e1L, 1e2L, 1e3L, 1e4L, 1e5L, 1e6L, 1e7L, 1e8L, 1e9L, 1e10L, 1e11L, 1e12L,
+                                         1e13L, 1e14L, 1e15L, 1e16L, 1e17L, 1e18L};
+  static const unsigned long long kPow10u[19] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull,
+                                                 100000000ull, 1000000000ull, 10000000000ull, 100000000000ull, 1000000000000ull,
+                                                 10000000000000ull, 100000000000000ull, 1000000000000000ull,
+                                                 10000000000000000ull, 100000000000000000ull, 1000000000000000000ull};
+  if (precision >= 1 && precision <= 18 && cap >= 48 && sizeof(long double) > sizeof(double)) {
+    const long double x = fabsl((long double)v) * kPow10[precision];   // NaN fails the comparison below
+    if (x < 9.0e18L) {
+      unsigned long long n = (unsigned long long)x;          // floor
+      const long double frac = x - (long double)n;           // exact
+      const long double err = x * 2.2e-19L + 1e-30L;         // > x 2^-63: the product's rounding
+      if (fabsl(frac - 0.5L) > err) {
+        n += frac > 0.5L;
+        const unsigned long long ip = n / kPow10u[precision], fp = n % kPow10u[precision];
+        char* p = buf;
+        if (std::signbit(v)) *p++ = '-';
+        p = std::to_chars(p, buf + cap, ip).ptr;
+        *p++ = '.';
+        char* e = p + precision;
+        unsigned long long r = fp;
+        for (char* q = e; q > p;) { *--q = (char)('0' + r % 10); r /= 10; }
+        return (size_t)(e - buf);
+      }
+    }
+  }
+  const auto r = std::to_chars(buf, buf + cap, v, std::chars_format::fixed, (int)precision);
+  if (r.ec == std::errc()) return (size_t)(r.ptr - buf);
+  const int len = std::snprintf(buf, cap, "%.*f", (int)precision, v);
+  return (size_t)std::max(0, std::min(len, (int)cap - 1));
+}
+
 // One chunk of the "placements" array as text (sample_to_jplace_string, src/io/jplace_util.cpp:
 // 60-98): formatted per pquery in parallel with snprintf into per-thread strings, then joined.
 // Numbers are fixed-point with `precision` digits like the reference's stream settings.
 std::string jplace_chunk_text(const Sample& sample, unsigned int precision, const Rtree_Mapper* mapper) {
   const bool remap = mapper && (bool)*mapper;  // placement_to_jplace_string, jplace_util.cpp:20-26
-  configure_host_threads();
+  const int nt_max = std::max(1, configure_host_threads());
   const long n = (long)sample.size();
-  std::vector<std::string> part(n);
-#pragma omp parallel for schedule(static)
-  for (long i = 0; i < n; ++i) {
-    const auto& pq = sample[i];
-    std::string& o = part[i];
-    o.reserve(64 + pq.size() * (40 + 4 * (precision + 8)));
-    o += "    {\"p\": [\n";
-    char buf[512];
-    // fixed notation with `precision` digits = what the reference's stream settings print
-    // (std::fixed << std::setprecision); std::to_chars is correctly rounded like printf's %.*f and
-    // several times faster (the jplace text was the largest host stage of a 3M-read run)
-    auto fixed = [&](double v) {
-      const auto r = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::fixed, (int)precision);
-      if (r.ec == std::errc()) o.append(buf, (size_t)(r.ptr - buf));
-      else {
-        const int len = std::snprintf(buf, sizeof(buf), "%.*f", (int)precision, v);
-        o.append(buf, (size_t)std::max(0, std::min(len, (int)sizeof(buf) - 1)));
+  // one contiguous buffer per thread over a contiguous range of pqueries (no string per pquery: 50 000 small heap
+  // blocks per chunk were a third of this stage), every placement line assembled in a stack buffer with pointer bumps
+  std::vector<std::string> part((size_t)nt_max);
+#pragma omp parallel num_threads(nt_max)
+  {
+    const int t = omp_get_thread_num(), nthr = omp_get_num_threads();
+    const long i0 = n * t / nthr, i1 = n * (t + 1) / nthr;
+    std::string& o = part[(size_t)t];
+    size_t est = 0;
+    for (long i = i0; i < i1; ++i) est += 48 + sample[i].header().size() + sample[i].size() * (24 + 4 * (size_t)(precision + 12));
+    o.reserve(est);
+    char line[1024];
+    for (long i = i0; i < i1; ++i) {
+      const auto& pq = sample[i];
+      o += "    {\"p\": [\n";
+      size_t j = 0;
+      for (const auto& p : pq) {
+        size_t edge = p.branch_id();
+        double distal = p.distal_length();
+        if (remap) {
+          const auto m = mapper->in_rtree((unsigned int)edge, distal);
+          edge = m.first;
+          distal = m.second;
+        }
+        char* w = line;
+        std::memcpy(w, "      [", 7); w += 7;
+        w = std::to_chars(w, line + 64, edge).ptr;
+        const double vals[4] = {p.likelihood(), p.lwr(), distal, p.pendant_length()};
+        for (int k = 0; k < 4; ++k) {
+          *w++ = ','; *w++ = ' ';
+          w += format_fixed(w, (size_t)(line + sizeof(line) - w) - 8, vals[k], precision);
+        }
+        *w++ = ']';
+        if (++j < pq.size()) *w++ = ',';
+        *w++ = '\n';
+        o.append(line, (size_t)(w - line));
       }
-    };
-    size_t j = 0;
-    for (const auto& p : pq) {
-      size_t edge = p.branch_id();
-      double distal = p.distal_length();
-      if (remap) {
-        const auto m = mapper->in_rtree((unsigned int)edge, distal);
-        edge = m.first;
-        distal = m.second;
-      }
-      o += "      [";
-      {
-        const auto r = std::to_chars(buf, buf + sizeof(buf), edge);
-        o.append(buf, (size_t)(r.ptr - buf));
-      }
-      o += ", ";
-      fixed(p.likelihood());
-      o += ", ";
-      fixed(p.lwr());
-      o += ", ";
-      fixed(distal);
-      o += ", ";
-      fixed(p.pendant_length());
-      o += "]";
-      if (++j < pq.size()) o += ",";
+      o += "      ],\n    \"n\": [\"";
+      o += pq.header();
+      o += "\"]\n    }";
+      if (i + 1 < n) o += ",";
       o += "\n";
     }
-    o += "      ],\n    \"n\": [\"";
-    o += pq.header();
-    o += "\"]\n    }";
-    if (i + 1 < n) o += ",";
-    o += "\n";
   }
   size_t total = 0;
-  for (const auto& x : part) total += x.size();
-  std::string out;
-  out.reserve(total);
-  for (const auto& x : part) out += x;
+  std::vector<size_t> at(part.size());
+  for (size_t k = 0; k < part.size(); ++k) { at[k] = total; total += part[k].size(); }
+  std::string out(total, '\0');
+#pragma omp parallel for schedule(static) num_threads(nt_max)
+  for (long k = 0; k < (long)part.size(); ++k) std::memcpy(&out[at[(size_t)k]], part[(size_t)k].data(), part[(size_t)k].size());
   return out;
 }
 

@@ -28,6 +28,12 @@ void set_host_thread_limit(int n) {
   epa_encode_set_threads((unsigned)g_thread_limit);   // the query encoder's std::threads honour -T too
 }
 
+namespace { thread_local int tl_team = 0; }   // set_thread_team: OpenMP team of the calling host thread's stages; 0 = all
+void set_thread_team(int n) {
+  tl_team = n > 0 ? n : 0;
+  configure_host_threads();
+}
+
 int configure_host_threads() {
   static const int n = [] {
     int v = omp_get_max_threads();
@@ -42,8 +48,9 @@ int configure_host_threads() {
     epa_encode_set_threads((unsigned)v);   // affinity mask / cgroup quota apply to the query encoder as well
     return v;
   }();
-  omp_set_num_threads(n);  // per calling thread (the device workers are separate host threads)
-  return n;
+  const int team = tl_team > 0 ? std::min(tl_team, n) : n;
+  omp_set_num_threads(team);  // per calling thread (the device workers are separate host threads)
+  return team;
 }
 
 namespace {
@@ -340,21 +347,6 @@ void chunk_launch(const Encoded_Chunk& enc, size_t Q, const Tree& tree, Device_E
   dev.pair_capacity() = cap;
 }
 
-size_t chunk_finish(const MSA& chunk, Device_Evaluator& dev, int slot, Sample& sample, size_t seq_id_offset, double* secs_sample) {
-  const epa_pair* pairs = nullptr;
-  const epa_result* res = nullptr;
-  uint64_t n = 0;
-  const int rc = epa_dev_chunk_finish(dev.ctx(), slot, &pairs, &res, &n, nullptr);
-  if (rc == EPA_ERR_NEG_INF) throw std::runtime_error{epa_dev_last_error(dev.ctx())};  // Tiny_Tree.cpp:209-212
-  if (rc != EPA_OK) throw_dev(dev.ctx(), rc);
-  const auto t0 = std::chrono::steady_clock::now();
-  Work work(n);
-  for (size_t i = 0; i < n; ++i) work[i] = Work_Pair{pairs[i].branch_id, pairs[i].seq_id};
-  build_sample(work, res, chunk, sample, seq_id_offset);
-  if (secs_sample) *secs_sample = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  return n;
-}
-
 size_t place_all(const MSA& chunk, const Encoded_Chunk& enc, const Tree& tree, Device_Evaluator& dev,
                  Sample& sample, const Options& options, size_t seq_id_offset) {
   const size_t Q = chunk.size(), fm = options.filter_max;
@@ -575,8 +567,95 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
       if (room < device_chunk) device_chunk = std::max<size_t>(std::min<size_t>(options.chunk_size, device_chunk), std::max<size_t>(room, 1));
     }
   }
+  // Post-processing pool.  The reference hands a finished chunk to an asynchronous writer (src/io/jplace_writer.hpp:58-69);
+  // here everything behind the device calls -- pquery building, LWR, filter, jplace text -- leaves the device worker
+  // with the chunk: a few pool threads take WHOLE chunks and run those stages single-threaded, several chunks at a
+  // time.  Round 6 measured the alternative (every stage an OpenMP region over all cores, entered from the stager, the
+  // worker and a writer thread at once): three teams of 16 on 16 cores ran each stage 2 - 3 x slower than alone and the
+  // 1 M-read run got slower, not faster (bench.py cli_e2e: 2.9 -> 2.5 M reads/s).  Text leaves in chunk order.
+  const int host_cores = st.host_threads;
+  const int n_post = std::max(2, std::min(12, host_cores - (int)devices.size() - std::min(6, std::max(2, host_cores / 3))));
+  const int stager_team = std::max(1, std::min(6, host_cores / 3));
+  struct Finished {
+    size_t index = 0, offset = 0;
+    MSA chunk;                      // headers
+    bool have_sample = false;       // the worker already built (and filtered) the sample: text only
+    Sample smp;
+    std::vector<epa_pair> pairs;    // else: the chunk's rows as the device returned them
+    std::vector<epa_result> res;
+  };
+  std::deque<Finished> wq;
+  std::mutex wq_mu;
+  std::condition_variable wq_put, wq_get;
+  bool workers_done = false, writer_failed = false;
+  auto post_thread = [&] {
+    set_thread_team(1);   // this thread's stages run serially: the parallelism is across chunks
+    for (;;) {
+      Finished f;
+      {
+        std::unique_lock<std::mutex> lk(wq_mu);
+        wq_get.wait(lk, [&] { return !wq.empty() || workers_done || writer_failed; });
+        if (writer_failed || wq.empty()) return;
+        f = std::move(wq.front());
+        wq.pop_front();
+        wq_put.notify_all();
+      }
+      try {
+        const auto t0 = clk::now();
+        if (!f.have_sample) {
+          Work work(f.pairs.size());
+          for (size_t i = 0; i < work.size(); ++i) work[i] = Work_Pair{f.pairs[i].branch_id, f.pairs[i].seq_id};
+          build_sample(work, f.res.data(), f.chunk, f.smp, f.offset);
+        }
+        const auto t1 = clk::now();
+        if (!f.have_sample) {
+          compute_and_set_lwr(f.smp);
+          filter(f.smp, options);
+        }
+        const auto t2 = clk::now();
+        std::string text = jplace_chunk_text(f.smp, options.precision, &tree.mapper());
+        const auto t3 = clk::now();
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          if (results.size() <= f.index) { results.resize(f.index + 1); ready.resize(f.index + 1, 0); }
+          results[f.index] = std::move(text);
+          ready[f.index] = 1;
+          st.seconds_sample += std::chrono::duration<double>(t1 - t0).count();
+          st.seconds_post += std::chrono::duration<double>(t2 - t1).count();
+          st.seconds_text += std::chrono::duration<double>(t3 - t2).count();
+        }
+        std::unique_lock<std::mutex> wl(wmu, std::try_to_lock);   // whoever finds the file free writes what is ready, in order
+        if (wl.owns_lock()) drain();
+      } catch (...) {
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          if (!failure) failure = std::current_exception();
+          cv_put.notify_all();
+          cv_get.notify_all();
+        }
+        std::lock_guard<std::mutex> lk(wq_mu);
+        writer_failed = true;
+        wq.clear();
+        wq_put.notify_all();
+        wq_get.notify_all();
+        return;
+      }
+    }
+  };
+  std::vector<std::thread> post_pool;
+  for (int i = 0; i < n_post; ++i) post_pool.emplace_back(post_thread);
+  auto hand_over = [&](Finished&& f) {
+    std::unique_lock<std::mutex> lk(wq_mu);
+    wq_put.wait(lk, [&] { return wq.size() < (size_t)n_post + 2 || writer_failed; });
+    if (writer_failed) return;
+    wq.push_back(std::move(f));
+    wq_get.notify_one();
+  };
+
   std::thread stager([&] {
     try {
+      set_thread_team(stager_team);
+      epa_encode_set_threads((unsigned)stager_team);
       Fasta_Stream reader(query_file);
       size_t index = 0, offset = 0;
       for (;;) {
@@ -632,37 +711,33 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
         cv_put.notify_one();
         return true;
       };
-      auto publish = [&](const Staged& done, Sample& smp, const Chunk_Timing& tm) {
-        const auto tf = clk::now();
-        std::string text = jplace_chunk_text(smp, options.precision, &tree.mapper());
-        const double secs_text = std::chrono::duration<double>(clk::now() - tf).count();
-        {
-          std::lock_guard<std::mutex> lk(mu);
-          if (results.size() <= done.index) { results.resize(done.index + 1); ready.resize(done.index + 1, 0); }
-          results[done.index] = std::move(text);
-          ready[done.index] = 1;
-          st.seconds_text += secs_text;
-          st.queries += done.chunk.size();
-          st.pairs += tm.pairs;
-          st.seconds_place += tm.place;
-          st.seconds_thorough += tm.thorough;
-          st.seconds_post += tm.post;
-        }
-        std::unique_lock<std::mutex> wl(wmu, std::try_to_lock);
-        if (wl.owns_lock()) drain();
+      auto account = [&](size_t queries, const Chunk_Timing& tm) {
+        std::lock_guard<std::mutex> lk(mu);
+        st.queries += queries;
+        st.pairs += tm.pairs;
+        st.seconds_place += tm.place;
+        st.seconds_thorough += tm.thorough;
       };
       if (!pipelined) {
         for (;;) {
           Staged cur;
           if (!take(cur)) return;
           Chunk_Timing tm;
-          Sample smp = process_chunk(cur.chunk, cur.enc, tree, *devs[k], options, cur.offset, tm);
-          publish(cur, smp, tm);
+          Finished f;
+          f.smp = process_chunk(cur.chunk, cur.enc, tree, *devs[k], options, cur.offset, tm);
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            st.seconds_post += tm.post;
+          }
+          account(cur.chunk.size(), tm);
+          f.index = cur.index; f.offset = cur.offset; f.have_sample = true;
+          f.chunk = std::move(cur.chunk);
+          hand_over(std::move(f));
         }
       }
       // two-slot pipeline: launch chunk i (its upload and kernels are queued, the call returns once
-      // the candidate count is known), then finish chunk i-1: its D2H, LWR, filter and jplace text
-      // run while the GPU works on chunk i
+      // the candidate count is known), then finish chunk i-1 and hand its rows to the post-processing pool:
+      // the worker goes straight back to its GPU
       Staged prev;
       bool have_prev = false;
       int slot = 0;
@@ -677,16 +752,21 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
         }
         if (have_prev) {
           const auto t1 = clk::now();
-          Sample smp;
-          double secs_sample = 0;
-          tm.pairs = chunk_finish(prev.chunk, *devs[k], slot ^ 1, smp, prev.offset, &secs_sample);
-          const auto t2 = clk::now();
-          compute_and_set_lwr(smp);
-          filter(smp, options);
-          { std::lock_guard<std::mutex> lk(mu); st.seconds_sample += secs_sample; }
-          tm.thorough = std::chrono::duration<double>(t2 - t1).count() - secs_sample;
-          tm.post = std::chrono::duration<double>(clk::now() - t2).count();
-          publish(prev, smp, tm);
+          Finished f;
+          const epa_pair* pairs = nullptr;
+          const epa_result* res = nullptr;
+          uint64_t n = 0;
+          const int rc = epa_dev_chunk_finish(devs[k]->ctx(), slot ^ 1, &pairs, &res, &n, nullptr);
+          if (rc == EPA_ERR_NEG_INF) throw std::runtime_error{epa_dev_last_error(devs[k]->ctx())};  // Tiny_Tree.cpp:209-212
+          if (rc != EPA_OK) throw_dev(devs[k]->ctx(), rc);
+          f.pairs.assign(pairs, pairs + n);   // the slot's pinned buffer is reused by the chunk after next
+          f.res.assign(res, res + n);
+          tm.pairs = n;
+          tm.thorough = std::chrono::duration<double>(clk::now() - t1).count();
+          account(prev.chunk.size(), tm);
+          f.index = prev.index; f.offset = prev.offset;
+          f.chunk = std::move(prev.chunk);
+          hand_over(std::move(f));
         } else if (have_cur) {
           std::lock_guard<std::mutex> lk(mu);
           st.seconds_place += tm.place;
@@ -723,6 +803,12 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
     cv_put.notify_all();
   }
   stager.join();
+  {
+    std::lock_guard<std::mutex> lk(wq_mu);
+    workers_done = true;
+    wq_get.notify_all();
+  }
+  for (auto& t : post_pool) t.join();
   if (failure) {
     os.close();
     std::remove(out_path.c_str());   // no half-written result file

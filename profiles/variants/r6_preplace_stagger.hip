@@ -443,6 +443,7 @@ constexpr int NB2_ACC = 15;             // branches per work item when partial s
                                         // windows): 15 x 1024 doubles + the 36 KB slice fill the CU's 160 KB
 constexpr int NB2_ACC_S = 14;           // the same for the 20-state site path (43 KB slice)
 constexpr int NB2_BURST = 8;            // single-chunk variants: result rows staged per 64-byte burst
+constexpr int NB2_RING = 12;            // ... with staggered bursts (k_preplace_pairs STAG): a ring of rows, a burst may leave up to 3 branches late
 constexpr uint32_t ZERO_OFF = (PE - 1) * 8;  // (none, none) of the thread's own first row: exact +0.0
 
 // (symbol of site, symbol of site + 1) -> entry of the pair row: the 16 plain pairs first
@@ -728,7 +729,7 @@ __device__ __forceinline__ uint32_t choose_tile(uint32_t ng, uint32_t B, uint32_
 // A/Bs in profiles/r5_preplace_duo_ab.txt, r5_preplace_prio_ab.txt): slices of consecutive branches alternating between
 // two LDS buffers with one barrier per branch (0.966 / 0.949 against 0.930 / 0.910 ms), and two branches staged and
 // gathered between one pair of barriers (1.018 / 1.011 ms) -- the gather phase is bound by the LDS itself.
-template <bool ACC, int SPR, int ROWL>
+template <bool ACC, int SPR, int ROWL, bool STAG = false>
 __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     const double* __restrict__ lookup2, const uint16_t* __restrict__ packed,
     const uint16_t* __restrict__ tails, const uint32_t* __restrict__ win_begin,
@@ -743,6 +744,8 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
   __shared__ uint32_t s_maxspan;
   __shared__ uint32_t s_qi[GQ2];   // query of thread t (burst write-out), ~0 = nothing to write
   constexpr uint32_t BSTR = GQ2 + 4;    // burst staging rows 4 doubles apart in the banks: conflict-free
+  constexpr uint32_t RING = STAG ? NB2_RING : NB2_BURST;
+  static_assert(!STAG || !ACC, "staggered bursts: single-chunk variant only");
   // persistent grid over (group, branch tile) items of class 0, see k_preplace
   const uint32_t ng = status[5];
   const uint32_t NBP = ACC ? NB2_ACC : choose_tile(ng, B, gridDim.x);
@@ -886,7 +889,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
         if (ACC) {
           accs[j * GQ2 + t] = sum;
         } else {
-          accs[(j & 7u) * BSTR + t] = sum;
+          accs[(STAG ? j % RING : (j & 7u)) * BSTR + t] = sum;
           if (segmax) seg.add(segmax, segp, qi, b0 + j, j + 1 == nb, sum);
         }
       }
@@ -897,7 +900,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
     // 8-byte stores spread over the item were evicted sector by sector (1.76 GB written for a
     // 0.41 GB table); 8 stores per lane back to back, each lane its own sector, relied on L2
     // merging them before eviction (1.19 GB for 0.83 GB; 2.15 GB under the XCD-contiguous walk).
-    // Burst kb = branches b0 + 8 kb .. of this item, staged in rows 0 .. 7.
+    // Burst kb = branches b0 + 8 kb .. of this item, staged in rows (8 kb + c) % RING.
     auto emit_burst = [&](uint32_t kb) {
       __builtin_amdgcn_wave_barrier();
       // four lanes per query, 16 bytes (two branches) per lane: a store instruction still hands over whole
@@ -905,7 +908,7 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
       // stores -- the write-out is store-issue bound (in-kernel cycle counters: 3.7k cycles per burst)
       const uint32_t lane = (uint32_t)t & 63u, wbase = (uint32_t)t & ~63u, c4 = lane & 3u;
       const uint32_t ncol = min(8u, nb - 8u * kb), bcol = b0 + 8u * kb + 2u * c4;
-      const uint32_t r0 = 2u * c4, r1 = 2u * c4 + 1u;
+      const uint32_t r0 = STAG ? (8u * kb + 2u * c4) % RING : 2u * c4, r1 = STAG ? (8u * kb + 2u * c4 + 1u) % RING : 2u * c4 + 1u;
 #pragma unroll
       for (uint32_t k = 0; k < 4; ++k) {
         const uint32_t tq = wbase + k * 16 + (lane >> 2);
@@ -919,16 +922,20 @@ __global__ void __launch_bounds__(GQ2, 4) k_preplace_pairs(
       }
       __builtin_amdgcn_wave_barrier();
     };
-    // All sixteen waves issue their bursts behind the same barrier, every eighth branch (535 of a branch's 5200 clocks
-    // with the LDS gather path idle).  Round 6 built the stagger VERDICT round 5 asked for -- a ring of twelve staging
-    // rows, wave w writing its burst (w & 3) branches late, four waves per branch on four of eight branches -- bit-
-    // identical and 5 - 6 % SLOWER (0.956 - 0.972 against 0.906 - 0.912 ms per launch, three interleaved rounds:
-    // profiles/r6_ab_spec_step_stagger.txt; source profiles/variants/r6_preplace_stagger.hip): the late waves arrive
-    // late at that branch's barrier, and the barrier is what the other fifteen wait at.  The kernel is closed here.
+    // STAG: all sixteen waves used to issue their bursts behind the same barrier, every eighth branch: 64 KB per CU
+    // through one write path while the LDS gather path idled (535 of a branch's 5200 clocks).  With four more staging
+    // rows (a ring of 12) wave w writes its burst (w & 3) branches late -- four waves per branch on four of eight
+    // branches -- beside the other waves' gathers.  A wave only ever reads its own 64 columns of the staging rows.
+    const uint32_t stag_d = STAG ? (uint32_t)__builtin_amdgcn_readfirstlane(t >> 6) & 3u : 0u;
     auto flush = [&](uint32_t j) {
       if (ACC) return;
-      if ((j & 7u) == 7u) emit_burst(j >> 3);
-      else if (j + 1 == nb) emit_burst(j >> 3);
+      uint32_t done = 0;   // bursts of this item already written by this wave
+      if (j >= 7u + stag_d) {
+        done = ((j - 7u - stag_d) >> 3) + 1u;
+        if (((j - 7u - stag_d) & 7u) == 0u) emit_burst(done - 1u);
+      }
+      if (j + 1 == nb)
+        for (uint32_t kb = done; 8u * kb < nb; ++kb) emit_burst(kb);
     };
     {
       // The slice of branch j+1 is requested (into registers) before the gathers of branch j start
@@ -1791,8 +1798,15 @@ int launch_preplace(epa_ctx* ctx, const uint8_t* d_codes, const uint32_t* d_begi
     const size_t lds2w = (size_t)((CH + SPREAD_WIDE) / 2) * ROWL_PACKED + sizeof(double) * NB2_BURST * (GQ2 + 4);
     PRE2(false, SPREAD_WIDE, ROWL_PACKED, lds2w);
   } else if (pairs) {
+    const size_t lds_stag = (size_t)TROWS2 * ROWL_NARROW + sizeof(double) * NB2_RING * (GQ2 + 4);
     if (acc) PRE2(true, SPREAD, ROWL_PACKED, lds2);
-    else PRE2(false, SPREAD, ROWL_NARROW, lds2);
+    else if (ctx->opt.preplace_stagger && lds_stag + 4352 <= 163840) {
+      EPA_HIP(ctx, hipFuncSetAttribute((const void*)k_preplace_pairs<false, SPREAD, ROWL_NARROW, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_stag));
+      hipLaunchKernelGGL((k_preplace_pairs<false, SPREAD, ROWL_NARROW, true>), grid2, dim3(GQ2), (uint32_t)lds_stag, ctx->stream, ctx->lookup2,
+                         (const uint16_t*)packed, (const uint16_t*)tails, d_begin, d_span, perm, groups, ctx->W, ctx->B, pitch, NP16, status,
+                         d_lnl, segmax, segp);
+    } else PRE2(false, SPREAD, ROWL_NARROW, lds2);
   }
 #undef PRE2
   if (sites) {

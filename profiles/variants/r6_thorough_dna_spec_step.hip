@@ -307,7 +307,9 @@ __device__ __forceinline__ void cat_inner_pre(const Model& m, const double (&Ap)
 #ifndef TH_STREAM_DEPTH
 #define TH_STREAM_DEPTH 2
 #endif
-
+#ifndef TH_SPEC_STEP
+#define TH_SPEC_STEP 0
+#endif
 
 template <int NCH>
 struct SiteState {
@@ -628,9 +630,21 @@ __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, 
   if (df >= 0.0 && fabs(f) < tol) return rts;
   if (f < 0.0) { xl = rts; xh = x2; } else { xh = rts; xl = x1; }
   for (int i = 1; i <= max_iters; ++i) {
-    // (forming both candidate steps before the branch decision -- the division beside the bracket test instead of behind
-    // it, same bits -- was measured in round 6 and is 1.4 % SLOWER: profiles/r6_ab_spec_step_stagger.txt, source
-    // profiles/variants/r6_thorough_dna_spec_step.hip)
+#if TH_SPEC_STEP
+    // Both candidate steps are formed before the branch decision (the same IEEE operations on the same operands: the
+    // step taken has the bits of the branchy form; the quotient of the step NOT taken may be inf / nan and is dropped).
+    // The decision chain of an evaluation -- bracket test, division, comparisons: ~35 dependent fp64 instructions on
+    // wave-uniform values -- is pure latency for the wave; the division (10 dependent instructions) now runs beside
+    // the bracket test instead of behind it.
+    const double dxn = f / df;
+    const double dxb = 0.5 * (xh - xl);
+    const bool bis = df <= 0.0 || (((rts - xh) * df - f) * ((rts - xl) * df - f) >= 0.0);
+    const double nxt = bis ? xl + dxb : rts - dxn;
+    const bool same = bis ? (xl == nxt) : (rts == nxt);
+    dx = bis ? dxb : dxn;
+    rts = nxt;
+    if (same) return rts;
+#else
     if (df <= 0.0 || (((rts - xh) * df - f) * ((rts - xl) * df - f) >= 0.0)) {
       dx = 0.5 * (xh - xl);
       rts = xl + dx;
@@ -641,6 +655,7 @@ __device__ __forceinline__ double newton(const SiteState<NCH>& st, double* tab, 
       rts -= dx;
       if (temp == rts) return rts;
     }
+#endif
     if (fabs(dx) < tol || i == max_iters) return rts;
     if (rts < x1) rts = x1;
     derivatives<NCH, ZERO0, NW, TAILH, NG>(st, tab, lane, lc, cb, rts, f, df);

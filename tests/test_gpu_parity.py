@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import epa_ng_amd as epa
+from epa_ng_amd import hostlib, synth
 from golden_util import CASES, load_case
 from oracle_lib import Oracle
 

@@ -2,17 +2,20 @@
 
 The 192 configurations of test_gpu_parity.py (seeds 0 .. 191 + the named outliers) are the ones the flat-pair rule
 of tests/sweep_util.py was written against; the builder's hand runs over ~9000 more seeds are builder-box logs.  This
-module makes the DRIVER run 400 further configurations -- seeds 20000 .. 20399, chosen before any of them was ever
-run -- through the same check_sweep_case():
+module makes the DRIVER run further configurations -- seeds 20000 .. 20199, the first half of a range (20000 .. 20399)
+that was fixed before any of its seeds had ever been run; the whole range ran once by hand with this module's rule
+(profiles/r6_sweep_slice_20000_20399.log: 400 configurations, no violation, ONE over the per-configuration bounds: seed
+20210, 16 of 4248 pairs in another local optimum 1.0 lnL away), the suite keeps the half that fits the driver's GPU
+test time (~5 min) -- through the same check_sweep_case():
   1. evaluator parity at the device's own lengths, every pair, 1e-6            (unconditional)
   2. pairs on the oracle's path: lnL to 1e-6                                   (unconditional)
   3a/b. every other pair reproduced by a rounding sibling of the oracle (<= 2^8 ulp, 2^12 for lnL-equal pairs)
         at a named solver decision                                             (unconditional)
   3c. the per-configuration bounds (<= 1 % of the pairs off the oracle's path, each within 1e-4 lnL) cannot be
       asserted seed by seed without naming outliers after the fact -- about one random configuration in 300 is
-      bimodal.  Stated up front instead: at most 1 % of the slice's configurations (4 of 400)
+      bimodal.  Stated up front instead: at most 1 % of the slice's configurations (2 of 200)
       may exceed them, and the last test of the module prints which did.
-Twenty seeds per test item: 20 items of ~30 s."""
+Twenty seeds per test item: 10 items of ~30 s."""
 import os
 
 import pytest
@@ -21,7 +24,7 @@ import test_gpu_parity as T
 
 pytestmark = pytest.mark.gpu
 
-FIRST, COUNT, PER_ITEM = 20000, 400, 20
+FIRST, COUNT, PER_ITEM = 20000, 200, 20
 _seen = {"configs": 0, "over_bounds": []}
 
 

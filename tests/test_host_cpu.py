@@ -676,3 +676,31 @@ def test_bench_query_file_writers_roundtrip(tmp_path):
             outs.append([tuple(l.split("|")) for l in out.strip().split("\n")])
         assert outs[0] == outs[1] and len(outs[0]) == 800
         assert [s for _, s in outs[0]] == want and outs[0][0][0] == "q0000000" and outs[0][799][0] == "q0000799"
+
+
+def test_jplace_number_formatter_equals_printf():
+    """format_fixed (the jplace text's numbers: six million per million reads) takes a fast path through 80-bit
+    arithmetic whenever the rounded integer is provably the correctly rounded one and std::to_chars otherwise; both
+    must print what printf's %.*f prints (= the reference's std::fixed << std::setprecision): random values of the
+    magnitudes a jplace holds, exact and near ties at the last digit, zeros of both signs, huge and non-finite values"""
+    L = hostlib.host_lib()
+    L.epa_host_format_fixed.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_char_p, C.c_size_t]
+    rng = np.random.RandomState(5)
+    vals = [0.0, -0.0, 1e-12, -1e-12, 5e-11, -5e-11, 0.5, 1.5, 2.5, 0.125, 1e22, -1e22, 1e300, float("inf"), float("-inf"),
+            float("nan"), 123456789.123456789, -30123.4567890123, 0.99999999995, 0.99999999994999, 9.5e-11, 4.9999999999e-11]
+    vals += list(-rng.uniform(0, 1e5, 20000))                       # log-likelihoods
+    vals += list(rng.uniform(0, 1, 20000))                          # like-weight ratios
+    vals += list(10.0 ** rng.uniform(-12, 2, 20000))                # branch lengths
+    for p in (1, 6, 10):                                            # ties and near-ties at digit p
+        k = rng.randint(0, 10 ** min(p + 3, 9), 4000).astype(np.float64)
+        base = (k + 0.5) / 10.0 ** p
+        vals += list(base) + list(np.nextafter(base, 0)) + list(np.nextafter(base, 1e9)) + list(-base)
+    v = np.array(vals, np.float64)
+    for p in (1, 6, 10, 15, 18):
+        out = C.create_string_buffer(len(v) * 400)
+        assert L.epa_host_format_fixed(v.ctypes.data, len(v), p, out, 400) == 0
+        raw = out.raw
+        for i, x in enumerate(v):
+            got = raw[i * 400:(i + 1) * 400].split(b"\0", 1)[0].decode()
+            want = "%.*f" % (p, x)
+            assert got == want, (p, repr(float(x)), got, want)
