@@ -331,10 +331,10 @@ size_t Fasta_Stream::read_next_views(MSA& out, std::vector<const char*>& rows, s
     const char* sb = nl + 1;
     const char* se = e;
     while (se > sb && (se[-1] == '\n' || se[-1] == '\r')) --se;
-    bool good = (size_t)(se - sb) == sites;
-    if (good)
-      for (const char* p = sb; p < se; ++p)
-        if ((unsigned char)*p <= ' ') { good = false; break; }   // a second line, or blanks inside the line
+    // exactly `sites` bytes between the header line and the next record: a row with a line break or a blank INSIDE
+    // those bytes is short of real characters -- the encoder, which looks at every one of them, refuses it
+    // ("char is invalid!"), so the bytes are not walked twice
+    const bool good = (size_t)(se - sb) == sites;
     if (!good) { ok = 0; continue; }
     const char* h = nl;
     while (h > b && (h[-1] == '\r' || h[-1] == ' ' || h[-1] == '\t')) --h;

@@ -3,6 +3,8 @@
 // into the C-ABI of libepa_dev.so.  Heuristics, LWR and filters are the reference's host-side
 // set operations (src/core/heuristics.hpp, src/set_manipulators.cpp) on flat arrays.
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -574,16 +576,27 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
   // worker and a writer thread at once): three teams of 16 on 16 cores ran each stage 2 - 3 x slower than alone and the
   // 1 M-read run got slower, not faster (bench.py cli_e2e: 2.9 -> 2.5 M reads/s).  Text leaves in chunk order.
   const int host_cores = st.host_threads;
-  const int n_post = std::max(2, std::min(12, host_cores - (int)devices.size() - std::min(6, std::max(2, host_cores / 3))));
-  const int stager_team = std::max(1, std::min(6, host_cores / 3));
+  // the stager's share of the cores: a FASTA file is 1.5 KB of text per 150 bp read of a 1500-column alignment (gap scan +
+  // encoding: the largest host stage), a binary fasta file needs next to nothing
+  Fasta_Stream reader(query_file);
+  const int stager_team = reader.is_bfast() ? std::max(1, std::min(3, host_cores / 5)) : std::max(1, std::min(8, host_cores / 2));
+  const int n_post = std::max(2, std::min(12, host_cores - (int)devices.size() - stager_team));
+  constexpr int kSlots = 4;   // pipeline slots per device: a finished chunk's pinned rows stay valid for two more chunks
   struct Finished {
     size_t index = 0, offset = 0;
     MSA chunk;                      // headers
     bool have_sample = false;       // the worker already built (and filtered) the sample: text only
     Sample smp;
-    std::vector<epa_pair> pairs;    // else: the chunk's rows as the device returned them
-    std::vector<epa_result> res;
+    const epa_pair* pairs = nullptr;   // else: the chunk's rows in the slot's pinned buffer, as the device returned them
+    const epa_result* res = nullptr;
+    size_t n = 0;
+    std::atomic<int>* slot_busy = nullptr;   // cleared once the rows have been consumed (the worker re-stages the slot then)
   };
+  std::vector<std::unique_ptr<std::atomic<int>[]>> slot_busy;
+  for (size_t d = 0; d < devices.size(); ++d) {
+    slot_busy.emplace_back(new std::atomic<int>[kSlots]);
+    for (int i = 0; i < kSlots; ++i) slot_busy.back()[i].store(0);
+  }
   std::deque<Finished> wq;
   std::mutex wq_mu;
   std::condition_variable wq_put, wq_get;
@@ -603,9 +616,10 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
       try {
         const auto t0 = clk::now();
         if (!f.have_sample) {
-          Work work(f.pairs.size());
+          Work work(f.n);
           for (size_t i = 0; i < work.size(); ++i) work[i] = Work_Pair{f.pairs[i].branch_id, f.pairs[i].seq_id};
-          build_sample(work, f.res.data(), f.chunk, f.smp, f.offset);
+          build_sample(work, f.res, f.chunk, f.smp, f.offset);
+          f.slot_busy->store(0, std::memory_order_release);   // the pinned rows are free again
         }
         const auto t1 = clk::now();
         if (!f.have_sample) {
@@ -633,8 +647,10 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
           cv_put.notify_all();
           cv_get.notify_all();
         }
+        if (f.slot_busy) f.slot_busy->store(0, std::memory_order_release);
         std::lock_guard<std::mutex> lk(wq_mu);
         writer_failed = true;
+        for (auto& q : wq) if (q.slot_busy) q.slot_busy->store(0, std::memory_order_release);
         wq.clear();
         wq_put.notify_all();
         wq_get.notify_all();
@@ -656,7 +672,6 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
     try {
       set_thread_team(stager_team);
       epa_encode_set_threads((unsigned)stager_team);
-      Fasta_Stream reader(query_file);
       size_t index = 0, offset = 0;
       for (;;) {
         Staged s;
@@ -746,6 +761,11 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
         const bool have_cur = take(cur);
         Chunk_Timing tm;
         if (have_cur) {
+          // the slot's pinned result buffer may still be read by a post-processing thread (its chunk before last)
+          while (slot_busy[k][slot].load(std::memory_order_acquire)) {
+            { std::lock_guard<std::mutex> lk(wq_mu); if (writer_failed) return; }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+          }
           const auto t0 = clk::now();
           chunk_launch(cur.enc, cur.chunk.size(), tree, *devs[k], slot, options);
           tm.place = std::chrono::duration<double>(clk::now() - t0).count();
@@ -756,11 +776,13 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
           const epa_pair* pairs = nullptr;
           const epa_result* res = nullptr;
           uint64_t n = 0;
-          const int rc = epa_dev_chunk_finish(devs[k]->ctx(), slot ^ 1, &pairs, &res, &n, nullptr);
+          const int pslot = (slot + kSlots - 1) % kSlots;
+          const int rc = epa_dev_chunk_finish(devs[k]->ctx(), pslot, &pairs, &res, &n, nullptr);
           if (rc == EPA_ERR_NEG_INF) throw std::runtime_error{epa_dev_last_error(devs[k]->ctx())};  // Tiny_Tree.cpp:209-212
           if (rc != EPA_OK) throw_dev(devs[k]->ctx(), rc);
-          f.pairs.assign(pairs, pairs + n);   // the slot's pinned buffer is reused by the chunk after next
-          f.res.assign(res, res + n);
+          f.pairs = pairs; f.res = res; f.n = n;   // read in place: valid until the slot is staged again (guarded by slot_busy)
+          slot_busy[k][pslot].store(1, std::memory_order_release);
+          f.slot_busy = &slot_busy[k][pslot];
           tm.pairs = n;
           tm.thorough = std::chrono::duration<double>(clk::now() - t1).count();
           account(prev.chunk.size(), tm);
@@ -774,7 +796,7 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
         if (!have_cur) break;
         prev = std::move(cur);
         have_prev = true;
-        slot ^= 1;
+        slot = (slot + 1) % kSlots;
       }
     } catch (const std::exception& e) {
       std::lock_guard<std::mutex> lk(mu);
