@@ -72,6 +72,16 @@ struct ThArgsAM {
 // doubles per table: NC * 4 * 6 entries + 8 of padding = 64 B mod 256 B for NC = 4 and 8: the three Newton rows
 // hit different banks
 template <int NC> constexpr int tab_stride() { return NC * 24 + 8; }
+// AAM_PRIVATE_TABLES (round 6): a Newton evaluation used to cost two workgroup barriers -- one behind the table every
+// thread had written one entry of, one behind the per-wave partial sums.  Now every wave writes the whole table for
+// itself (80 / 160 exponentials over 64 lanes = 2 / 3 per lane instead of one, + the three orders' coefficients: ~25
+// vector instructions more per wave) into its own LDS block, ordered by the wave's own LDS queue -- no workgroup
+// barrier -- and the partial sums alternate between two slots, so the ONE remaining barrier per evaluation also covers a
+// wave that is already writing the next evaluation's sums.  Same entries, same products, same summation order: the bits
+// of the two-barrier form (0: that form, for the A/B).
+#ifndef AAM_PRIVATE_TABLES
+#define AAM_PRIVATE_TABLES 1
+#endif
 template <int NC>
 struct SharedM {
   // A-operand tiles of U in the order the products use them, q = 5 t + rt, two tiles interleaved:
@@ -82,6 +92,8 @@ struct SharedM {
   // the five values a lane needs are consecutive (the sixth is padding)
   double tab[4][tab_stride<NC>()];  // [3]: zeros -- the B operand's fourth column in a Newton evaluation
   double bc[24];                   // cross-wave sums: f [0..8), f' [8..16), lnL [16..24)
+  double bc2[2][16];               // AAM_PRIVATE_TABLES: f / f' partial sums, alternating slot per evaluation
+  double ncst[NC * S][4];          // ... per (category, eigen index): lr, w, w lr, (w lr) lr -- the table coefficients
   uint32_t next_pair;              // work-queue hand-out of the workgroup
   double e2t[64];                  // 2^(j/64): table of exp_tab (wave_util.hpp)
 };
@@ -189,6 +201,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
   constexpr int NTHR = 64 * NW;
   constexpr int CS = NC * S;          // component rows of a reference vector
   __shared__ alignas(16) SharedM<NC> sh;
+#if AAM_PRIVATE_TABLES
+  __shared__ alignas(16) double ntab_all[NW][3][tab_stride<NC>()];   // every wave's own Newton table
+#endif
   const ModelDev* __restrict__ m = a.m;
   // wave-uniform values are told to the compiler as such (v_readfirstlane): the pair's ids, window and row
   // pointers then live in SGPRs, the reference rows are loaded as (scalar base)[lane offset] without a 64-bit
@@ -222,6 +237,21 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
       t_c[i] = tslot[i] == 0 ? t_w[i] : (tslot[i] == 1 ? t_w[i] * t_lr[i] : t_w[i] * t_lr[i] * t_lr[i]);
     }
   }
+#if AAM_PRIVATE_TABLES
+  for (int kx = tid; kx < CS; kx += NTHR) {
+    const double lr = m->lam[kx % S] * m->rate[kx / S], w = m->w[kx / S];
+    sh.ncst[kx][0] = lr; sh.ncst[kx][1] = w; sh.ncst[kx][2] = w * lr; sh.ncst[kx][3] = w * lr * lr;
+  }
+  for (int i = tid; i < NW * 3 * tab_stride<NC>(); i += NTHR) (&ntab_all[0][0][0])[i] = 0.0;   // incl. the padding entries
+  constexpr int NE2 = (CS + 63) / 64;
+  int npos[NE2];
+#pragma unroll
+  for (int i = 0; i < NE2; ++i) {
+    const int kx = (lane + 64 * i) % CS;
+    npos[i] = ((kx / S) * 4 + (kx % S) % 4) * 6 + (kx % S) / 4;
+  }
+  int bcpar = 0;
+#endif
   __syncthreads();
 
   uint32_t wrounds = 0, wevals = 0, wreverts = 0;
@@ -481,12 +511,6 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
       }
     };
 
-    // (Round 6 built the ONE-barrier form VERDICT round 5 asked for -- every wave writes the whole Newton table for itself
-    // into its own LDS block, 2 - 3 exponentials per lane instead of one, ordered by the wave's own LDS queue; partial
-    // sums in alternating slots -- parity-green and 5 % SLOWER at cfg3: 20.13 - 20.17 against 19.08 - 19.16 ms per 128.9k
-    // pairs, three interleaved rounds on one box (profiles/r6_aa_one_barrier_ab.txt; source:
-    // profiles/variants/r6_thorough_aa_mfma_private_tables.hip).  Four waves each computing 80 exponentials and
-    // writing 240 entries cost more than the barrier they save; the two-barrier form below stays.)
     // f, f' at proposal t: per tile 20 MFMAs contract the register-resident sumtable (A operand:
     // rows = the four sites of a block) with the Newton tables (B operand: column i = table i,
     // column 3 zeros); D puts l_0, l_1, l_2 of a site in lanes 0, 1, 2 of one quad
@@ -495,6 +519,27 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
 #ifdef AAM_PROFILE
       const long long d0_ = clock64();
 #endif
+#if AAM_PRIVATE_TABLES
+      double* const mytab = &ntab_all[wv][0][0];
+#pragma unroll
+      for (int i = 0; i < NE2; ++i) {
+        const int kx = lane + 64 * i;
+        if (kx < CS) {
+          const double2 c01 = *reinterpret_cast<const double2*>(&sh.ncst[kx][0]);
+          const double2 c23 = *reinterpret_cast<const double2*>(&sh.ncst[kx][2]);
+          const double e = exp_tab(c01.x * t, sh.e2t);
+          mytab[npos[i]] = e * c01.y;
+          mytab[tab_stride<NC>() + npos[i]] = e * c23.x;
+          mytab[2 * tab_stride<NC>() + npos[i]] = e * c23.y;
+        }
+      }
+#ifdef AAM_PROFILE
+      const long long d1_ = clock64();
+#endif
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
 #pragma unroll
       for (int i = 0; i < NE; ++i)
         if (tid + i * NTHR < NENT) sh.tab[tslot[i]][tpos[i]] = exp_tab(t_lr[i] * t, sh.e2t) * t_c[i];
@@ -502,6 +547,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
       const long long d1_ = clock64();
 #endif
       __syncthreads();
+#endif
 #ifdef AAM_PROFILE
       const long long d2_ = clock64();
 #endif
@@ -512,8 +558,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
       double av[NC][NTS];
       {
         const int zt = zero_after(t);
+#if AAM_PRIVATE_TABLES
+        const double* const rowp = row < 3 ? mytab + row * tab_stride<NC>() : &sh.tab[3][0];   // row 3: the zero table
+#else
+        const double* const rowp = &sh.tab[row][0];
+#endif
 #pragma unroll
-        for (int cat = 0; cat < NC; ++cat) lds5(&sh.tab[row][(cat * 4 + kq) * 6 + zt], av[cat]);
+        for (int cat = 0; cat < NC; ++cat) lds5(rowp + (cat * 4 + kq) * 6 + zt, av[cat]);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -541,13 +592,19 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 2) k_thorough_aa_mfma(c
 #endif
       double ft, dft;
       wave_sum2(fl, dfl, ft, dft);
-      if (lane == 0) { sh.bc[wv] = ft; sh.bc[8 + wv] = dft; }
+#if AAM_PRIVATE_TABLES
+      double* const bcp = sh.bc2[bcpar];
+      bcpar ^= 1;
+#else
+      double* const bcp = sh.bc;
+#endif
+      if (lane == 0) { bcp[wv] = ft; bcp[8 + wv] = dft; }
 #ifdef AAM_PROFILE
       const long long d4_ = clock64() + (long long)(ft != 12345.678 ? 0 : 1);
 #endif
-      __syncthreads();   // also: every wave is past its table reads
-      f = sum_waves<NW>(sh.bc);
-      df = sum_waves<NW>(sh.bc + 8);
+      __syncthreads();   // the evaluation's one barrier (two-barrier form: also "every wave is past its table reads")
+      f = sum_waves<NW>(bcp);
+      df = sum_waves<NW>(bcp + 8);
       ++evals;
 #ifdef AAM_PROFILE
       const long long d5_ = clock64() + (long long)(f != 12345.678 ? 0 : 1);
