@@ -72,6 +72,9 @@ def parse():
                    help="with --no-cpu-baseline: still check this many reads of step 0 against the oracle (untimed)")
     p.add_argument("--no-extras", action="store_true",
                    help="skip the secondary measurements (chunk-5000 rate, reference-binary hook)")
+    p.add_argument("--serial-schedule", action="store_true",
+                   help="run every loop in the serialised two-slot order (Newton launches never overlap): the command whose "
+                        "kernel trace must agree with roofline.ms_per_launch (profiles/rN_kernel_trace_stats_serialised.txt)")
     p.add_argument("--workload", choices=["dna", "aa", "cfg5"], default="dna",
                    help="dna = cfg2 (the metric's config); aa = cfg3 shape (use --tips 2000 --width 500 "
                         "--read-len 100), a parity/measurement case, not the headline")
@@ -683,6 +686,11 @@ def main():
 
         return st, step, finish
 
+    if a.serial_schedule:
+        S_DEEP = 2
+
+        def make_loop_deep(resident, gather):          # noqa: F811  (--serial-schedule: the two-slot order everywhere)
+            return make_loop(resident, gather)
     st_res, step_resident, fin_resident = make_loop_deep(True, exch)
     elapsed = timed(step_resident, fin_resident, "resident", record=False)
     # what the LAST TIMED step left in HBM (outside the clock): the rows the `parity` block checks
@@ -1038,8 +1046,9 @@ def main():
     out = {"metric": metric,
            "value": round(value, 2), "unit": "placements/s", "n_gpus": world, "steps": a.steps,
            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
-           "schedule": {"order": "launch_end(k); finish(k-%d); stage(k+%d); launch_begin(k+%d)" % (LAG, A_DEEP, A_DEEP),
-                        "slots": S_DEEP, "chunks_begun_ahead": A_DEEP,
+           "schedule": {"order": ("launch_begin(k); finish(k-1); stage(k+1); launch_end(k)  [--serial-schedule]" if a.serial_schedule else
+                                  "launch_end(k); finish(k-%d); stage(k+%d); launch_begin(k+%d)" % (LAG, A_DEEP, A_DEEP)),
+                        "slots": S_DEEP, "chunks_begun_ahead": 0 if a.serial_schedule else A_DEEP,
                         "ms_per_step_serialised_two_slot_order": (round(elapsed_serial / a.steps * 1e3, 3) if elapsed_serial else None),
                         "note": "value / ms_per_step: the deep pipeline (chunk k's Newton kernel queued into chunk k-1's tail; the "
                                 "order the CLI's chunk loop runs); roofline.ms_per_launch, kernel_ms_per_step, sclk: a serialised "

@@ -14,6 +14,16 @@ cd $R
 python profiles/db_to_txt.py gpurun_out/${tag}_stats/st_results.db > gpurun_out/${tag}_kernel_trace_stats.txt
 python profiles/step_timeline.py gpurun_out/${tag}_stats/st_results.db 12 > gpurun_out/${tag}_step_timeline.txt 2>/dev/null
 head -12 gpurun_out/${tag}_kernel_trace_stats.txt
+# (round 6) the default command runs the DEEP pipeline: kernels of neighbouring chunks overlap on the device and their traced
+# durations include the wait for each other.  roofline.ms_per_launch / kernel_ms_per_step come from the serialised pass;
+# the trace that must agree with them is the same bench in the serialised two-slot order everywhere:
+cd /tmp
+rm -rf $R/gpurun_out/${tag}_stats_serial
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_stats_serial -o st -- \
+  python $R/bench.py --no-cpu-baseline --no-extras --serial-schedule > $R/gpurun_out/${tag}_stats_serial.log 2>&1
+cd $R
+python profiles/db_to_txt.py gpurun_out/${tag}_stats_serial/st_results.db > gpurun_out/${tag}_kernel_trace_stats_serialised.txt
+head -6 gpurun_out/${tag}_kernel_trace_stats_serialised.txt
 bash profiles/run_pmc.sh ${tag} \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" \
   "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" \
