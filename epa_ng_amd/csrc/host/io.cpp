@@ -103,12 +103,12 @@ size_t Fasta_Stream::read_next_wire(MSA& out, Encoded_Chunk& enc, size_t sites, 
 #pragma omp parallel for schedule(static) reduction(max : mx)
   for (long i = 0; i < (long)m; ++i) {
     const size_t off = bfast_offsets_[bfast_next_ + (size_t)i];
-    if (off + 16 > map_len_) { stat[i] = 1; continue; }
+    if (off > map_len_ || map_len_ - off < 16) { stat[i] = 1; continue; }   // (no sums of untrusted 64-bit values)
     const uint64_t hlen = u64_at(off);
-    if (hlen > (1u << 20) || off + 16 + hlen > map_len_) { stat[i] = 1; continue; }
+    if (hlen > (1u << 20) || map_len_ - off < 16 + hlen) { stat[i] = 1; continue; }
     out[first + i] = Sequence(std::string(map_ + off + 8, (size_t)hlen), std::string());
     if (u64_at(off + 8 + hlen) != sites) { stat[i] = 2; continue; }
-    if (off + 16 + hlen + nbytes > map_len_) { stat[i] = 1; continue; }
+    if (map_len_ - off - 16 - hlen < nbytes) { stat[i] = 1; continue; }
     const unsigned char* p = reinterpret_cast<const unsigned char*>(map_ + off + 16 + hlen);
     rows[i] = p;
     size_t lo = 0, hi = sites;

@@ -704,3 +704,81 @@ def test_jplace_number_formatter_equals_printf():
             got = raw[i * 400:(i + 1) * 400].split(b"\0", 1)[0].decode()
             want = "%.*f" % (p, x)
             assert got == want, (p, repr(float(x)), got, want)
+
+
+def test_bfast_records_straight_to_wire_rows(tmp_path):
+    """Fasta_Stream::read_next_wire (round 6): binary-fasta records become the compact 4-bit wire rows WITHOUT an ASCII
+    stage -- window = first / last non-zero nibble, row = the window's nibbles re-aligned (a window that starts in a low
+    nibble shifts the stream by four bits).  Against the ASCII route (epa_encode_queries_compact + epa_pack_codes_4bit)
+    on the same reads: even and odd alignment widths, windows starting on even and odd columns, odd spans, chunked
+    reads; a record of another width and a truncated file are errors with the reference's messages."""
+    import struct
+    import subprocess
+    from epa_ng_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "wire.cpp"
+    src.write_text(r'''
+#include "epa_host.hpp"
+#include <cstdio>
+#include <cstdlib>
+int main(int argc, char** argv) {
+  try {
+    epa::Fasta_Stream in(argv[1]);
+    const size_t sites = std::strtoul(argv[2], nullptr, 10), chunk = std::strtoul(argv[3], nullptr, 10);
+    for (;;) {
+      epa::MSA m;
+      epa::Encoded_Chunk e;
+      const size_t n = in.read_next_wire(m, e, sites, chunk, true);
+      if (!n) break;
+      const size_t ps = (e.stride + 1) / 2;
+      for (size_t i = 0; i < n; ++i) {
+        std::printf("%s %u %u %u %d ", m[i].header().c_str(), e.win_begin[i], e.win_span[i], e.stride, e.bits);
+        for (size_t b = 0; b < ps; ++b) std::printf("%02x", e.codes[i * ps + b]);
+        std::printf("\n");
+      }
+    }
+  } catch (const std::exception& ex) { std::printf("ERROR %s\n", ex.what()); return 3; }
+}
+''')
+    exe = tmp_path / "wire"
+    pkg = os.path.join(root, "epa_ng_amd")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-fopenmp", "-I", os.path.join(root, "include"), "-I", os.path.join(pkg, "csrc", "host"),
+                    str(src), "-o", str(exe), "-L", pkg, "-lepa_host", "-lepa_dev", "-Wl,-rpath," + pkg], check=True)
+    for W in (240, 241):
+        tree = synth.random_tree(10, 3)
+        labels, seqs = synth.simulate_msa(tree, W, synth.CFG2_SUBST, synth.CFG2_FREQS, synth.gamma_rates(0.5), 4)
+        chunks = [synth.make_reads_compact(seqs, 300, rl, 0.03, 50 + rl, 4) for rl in (37, 64)]
+        fa, bf = tmp_path / ("w%d.fasta" % W), tmp_path / ("w%d.bfast" % W)
+        synth.write_query_files(str(fa), str(bf), chunks, W)
+        begins = np.concatenate([c[1] for c in chunks])
+        assert len(set(begins % 2)) == 2                     # windows start on even AND odd columns
+        for chunk in (600, 250):
+            out = subprocess.run([str(exe), str(bf), str(W), str(chunk)], check=True, capture_output=True, text=True).stdout
+            rows = [l.split() for l in out.strip().split("\n")]
+            assert len(rows) == 600
+            k = 0
+            for codes, wb, ws in chunks:
+                for q in range(len(wb)):
+                    h, b, sp, stride, bits, hexrow = rows[k]
+                    assert h == "q%07d" % k and int(b) == wb[q] and int(sp) == ws[q] and int(bits) == 4
+                    stride = int(stride)
+                    assert stride % 16 == 0 and stride >= int(sp)
+                    want = np.zeros(stride, np.uint8)
+                    want[:ws[q]] = codes[q, :ws[q]]
+                    packed = epa.pack_codes_4bit(want[None, :]).data[0]
+                    assert bytes.fromhex(hexrow) == packed.tobytes(), (W, k)
+                    k += 1
+        # another width than the reference alignment / a truncated file
+        r = subprocess.run([str(exe), str(bf), str(W + 2), "100"], capture_output=True, text=True)
+        assert r.returncode == 3 and "Query sequence length not same as reference alignment!" in r.stdout
+        cut = tmp_path / "cut.bfast"
+        cut.write_bytes(bf.read_bytes()[:-40])
+        r = subprocess.run([str(exe), str(cut), str(W), "1000"], capture_output=True, text=True)
+        assert r.returncode == 3 and "truncated" in r.stdout
+    # an all-gap record
+    rec = struct.pack("<Q", 2) + b"g0" + struct.pack("<Q", 6) + bytes(3)
+    blob = b"BFAST\0\0" + struct.pack("<QQ", 1, 6) + b"000000" + struct.pack("<QQ", 0, 7 + 8 + 8 + 6 + 16) + rec
+    gp = tmp_path / "gap.bfast"
+    gp.write_bytes(blob)
+    r = subprocess.run([str(exe), str(gp), "6", "10"], capture_output=True, text=True)
+    assert r.returncode == 3 and "does not appear to have any non-gap sites" in r.stdout and "g0" in r.stdout
