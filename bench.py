@@ -992,7 +992,7 @@ def main():
                                "ms_per_chunk": round(t5g / (ngr * G) * 1e3, 3), "chunks_per_group_launch": G,
                                "rows": rows5,
                                "host_ms_per_chunk": {k_: round(v_ / (ngr * G) * 1e3, 3) for k_, v_ in hostg.items()},
-                               "note": "reference default --chunk-size 5000 (src/util/Options.hpp:20) through the C-ABI: stage / finish per "
+                               "note": "reference default --chunk-size 5000 (src/util/Options.hpp:26) through the C-ABI: stage / finish per "
                                        "5000-read chunk, H2D/D2H inside the clock; epa_dev_chunk_launch_many runs ONE chunk body per four "
                                        "staged chunks (twelve slots, two groups begun ahead); per chunk the same bits as a launch of its own",
                                "per_chunk_launch": per_chunk}

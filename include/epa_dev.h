@@ -382,7 +382,7 @@ int epa_dev_chunk_finish(epa_ctx* ctx, int slot, const epa_pair** pairs, const e
                          uint64_t* n_pairs, epa_thorough_stats* stats);
 
 /*
- * Small chunks (the reference's default --chunk-size is 5000, src/util/Options.hpp:20; the chunk body of
+ * Small chunks (the reference's default --chunk-size is 5000, src/util/Options.hpp:26; the chunk body of
  * src/core/place.cpp:207-246 then runs once per 5000 reads): every launch of the Newton kernel costs a fixed
  * ~0.11 ms, a preplacement over a handful of query groups another ~0.15 ms, and a chunk body is ~23 dispatches.
  * A GROUP LAUNCH runs ONE chunk body -- one preplacement, one selection, one Newton launch -- over the
