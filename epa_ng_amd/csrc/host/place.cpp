@@ -582,9 +582,12 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
   const int stager_team = reader.is_bfast() ? std::max(1, std::min(3, host_cores / 5)) : std::max(1, std::min(8, host_cores / 2));
   const int n_post = std::max(2, std::min(12, host_cores - (int)devices.size() - stager_team));
   constexpr int kSlots = 4;   // pipeline slots per device: a finished chunk's pinned rows stay valid for two more chunks
+  constexpr size_t kParts = 4;   // post-processing jobs per chunk (query ranges): a 50 000-read chunk is ~35 ms of serial work,
+                                 // which is what the run's tail -- and the pool's load balance -- is made of
   struct Finished {
-    size_t index = 0, offset = 0;
-    MSA chunk;                      // headers
+    size_t index = 0, offset = 0;   // index: position of the text in the jplace (chunk index x kParts + part)
+    std::shared_ptr<const MSA> chunk;   // headers (shared by the chunk's parts)
+    size_t q_lo = 0, q_hi = 0;      // this job's queries of the chunk (raw rows only)
     bool have_sample = false;       // the worker already built (and filtered) the sample: text only
     Sample smp;
     const epa_pair* pairs = nullptr;   // else: the chunk's rows in the slot's pinned buffer, as the device returned them
@@ -616,10 +619,17 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
       try {
         const auto t0 = clk::now();
         if (!f.have_sample) {
-          Work work(f.n);
-          for (size_t i = 0; i < work.size(); ++i) work[i] = Work_Pair{f.pairs[i].branch_id, f.pairs[i].seq_id};
-          build_sample(work, f.res, f.chunk, f.smp, f.offset);
-          f.slot_busy->store(0, std::memory_order_release);   // the pinned rows are free again
+          Work work;
+          std::vector<epa_result> res;
+          work.reserve(f.n / kParts + f.n / 16 + 16);
+          res.reserve(f.n / kParts + f.n / 16 + 16);
+          for (size_t i = 0; i < f.n; ++i) {   // branch-major rows: this job's queries keep their order
+            const uint32_t q = f.pairs[i].seq_id;
+            if (q >= f.q_lo && q < f.q_hi) { work.push_back(Work_Pair{f.pairs[i].branch_id, q}); res.push_back(f.res[i]); }
+          }
+          f.slot_busy->fetch_sub(1, std::memory_order_acq_rel);   // the pinned rows are free again once every part has read them
+          f.slot_busy = nullptr;
+          build_sample(work, res.data(), *f.chunk, f.smp, f.offset);
         }
         const auto t1 = clk::now();
         if (!f.have_sample) {
@@ -662,8 +672,8 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
   for (int i = 0; i < n_post; ++i) post_pool.emplace_back(post_thread);
   auto hand_over = [&](Finished&& f) {
     std::unique_lock<std::mutex> lk(wq_mu);
-    wq_put.wait(lk, [&] { return wq.size() < (size_t)n_post + 2 || writer_failed; });
-    if (writer_failed) return;
+    wq_put.wait(lk, [&] { return wq.size() < (size_t)n_post + 2 * kParts || writer_failed; });
+    if (writer_failed) { if (f.slot_busy) f.slot_busy->store(0, std::memory_order_release); return; }
     wq.push_back(std::move(f));
     wq_get.notify_one();
   };
@@ -745,8 +755,13 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
             st.seconds_post += tm.post;
           }
           account(cur.chunk.size(), tm);
-          f.index = cur.index; f.offset = cur.offset; f.have_sample = true;
-          f.chunk = std::move(cur.chunk);
+          f.index = cur.index * kParts; f.offset = cur.offset; f.have_sample = true;
+          f.chunk = std::make_shared<const MSA>(std::move(cur.chunk));
+          {
+            std::lock_guard<std::mutex> lk(mu);   // the other part positions of this chunk stay empty
+            if (results.size() < (cur.index + 1) * kParts) { results.resize((cur.index + 1) * kParts); ready.resize((cur.index + 1) * kParts, 0); }
+            for (size_t pp = 1; pp < kParts; ++pp) ready[cur.index * kParts + pp] = 1;
+          }
           hand_over(std::move(f));
         }
       }
@@ -780,15 +795,22 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
           const int rc = epa_dev_chunk_finish(devs[k]->ctx(), pslot, &pairs, &res, &n, nullptr);
           if (rc == EPA_ERR_NEG_INF) throw std::runtime_error{epa_dev_last_error(devs[k]->ctx())};  // Tiny_Tree.cpp:209-212
           if (rc != EPA_OK) throw_dev(devs[k]->ctx(), rc);
-          f.pairs = pairs; f.res = res; f.n = n;   // read in place: valid until the slot is staged again (guarded by slot_busy)
-          slot_busy[k][pslot].store(1, std::memory_order_release);
-          f.slot_busy = &slot_busy[k][pslot];
           tm.pairs = n;
           tm.thorough = std::chrono::duration<double>(clk::now() - t1).count();
           account(prev.chunk.size(), tm);
-          f.index = prev.index; f.offset = prev.offset;
-          f.chunk = std::move(prev.chunk);
-          hand_over(std::move(f));
+          // rows read in place by kParts jobs: valid until the slot is staged again (guarded by slot_busy = parts still reading)
+          slot_busy[k][pslot].store((int)kParts, std::memory_order_release);
+          const auto headers = std::make_shared<const MSA>(std::move(prev.chunk));
+          const size_t Qp = headers->size();
+          for (size_t pp = 0; pp < kParts; ++pp) {
+            Finished part;
+            part.pairs = pairs; part.res = res; part.n = n;
+            part.slot_busy = &slot_busy[k][pslot];
+            part.index = prev.index * kParts + pp; part.offset = prev.offset;
+            part.chunk = headers;
+            part.q_lo = Qp * pp / kParts; part.q_hi = Qp * (pp + 1) / kParts;
+            hand_over(std::move(part));
+          }
         } else if (have_cur) {
           std::lock_guard<std::mutex> lk(mu);
           st.seconds_place += tm.place;
