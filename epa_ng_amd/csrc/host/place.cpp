@@ -571,8 +571,8 @@ Run_Stats simple_mpi(const Tree& tree, const std::string& query_file, const MSA_
   }
   // Post-processing pool.  The reference hands a finished chunk to an asynchronous writer (src/io/jplace_writer.hpp:58-69);
   // here everything behind the device calls -- pquery building, LWR, filter, jplace text -- leaves the device worker
-  // with the chunk: a few pool threads take WHOLE chunks and run those stages single-threaded, several chunks at a
-  // time.  Round 6 measured the alternative (every stage an OpenMP region over all cores, entered from the stager, the
+  // with the chunk: the pool's threads take a finished chunk in kParts query-range jobs and run those stages
+  // single-threaded, a dozen jobs at a time.  Round 6 measured the alternative (every stage an OpenMP region over all cores, entered from the stager, the
   // worker and a writer thread at once): three teams of 16 on 16 cores ran each stage 2 - 3 x slower than alone and the
   // 1 M-read run got slower, not faster (bench.py cli_e2e: 2.9 -> 2.5 M reads/s).  Text leaves in chunk order.
   const int host_cores = st.host_threads;
